@@ -1,0 +1,198 @@
+/*
+ * smm_hip.h -- C ABI of libsmm_hip.so: the MI355X (gfx950) implementation of the CSR SpMV + Krylov inner
+ * loop behind SMM::ConjugateGradient / SMM::BiCGStab over SMM::CSRMatrix
+ * (vasil-pashov/sparse_matrix_math v0.2.0, include/sparse_matrix_math.h -- cited below as "ref").
+ *
+ * The reference is a header-only C++ template library with no FFI seam, so this header
+ * IS the drop-in boundary: plain pointers and sizes, no C++ / torch types.  Each entry point names the
+ * reference interface it replaces.  include/smm_hip/sparse_matrix_math.h layers the reference's own C++
+ * signatures (SMM::CSRMatrix<T>::rMult, SMM::ConjugateGradient, SMM::BiCGStab, ...) on top of these calls;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns an int shim status: SMM_HIP_OK (0) or a negative SMM_HIP_ERR_* code.  Nothing
+ *     throws.  The reference's own SolverStatus (ref:2010-2014) is returned through *solver_status.
+ *   - `_f32` / `_f64` select T = float / double (the reference's template parameter).  Index arrays are
+ *     int32 exactly as in the reference (ref:1243-1259).
+ *   - functions without `_dev` take HOST pointers, like the reference's API: they copy in, run on the GPU,
+ *     copy out and synchronise before returning.
+ *   - `_dev` functions take DEVICE pointers and a hipStream_t (as void*); they only enqueue work unless they
+ *     must return a value to the host (solvers synchronise the stream before returning their status).
+ *   - there is NO CPU fallback: without a HIP device every call fails with SMM_HIP_ERR_NO_DEVICE.
+ *   - rounding: multiply-adds are a*x+b (two roundings) like the reference's default _smm_fma (ref:28-36);
+ *     a library built with -DSMM_WITH_STD_FMA uses fma(a,x,b) instead.  smm_hip_uses_std_fma() tells which.
+ */
+#ifndef SMM_HIP_H
+#define SMM_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMM_HIP_VERSION_MAJOR 0
+#define SMM_HIP_VERSION_MINOR 1
+
+/* shim status */
+#define SMM_HIP_OK 0
+#define SMM_HIP_ERR_INVALID (-1)   /* bad argument (null pointer, dtype mismatch, negative size, aliasing x==out) */
+#define SMM_HIP_ERR_HIP (-2)       /* HIP runtime failure; text in smm_hip_last_error() */
+#define SMM_HIP_ERR_NO_DEVICE (-3) /* no HIP device / smm_hip_init not possible */
+#define SMM_HIP_ERR_PRECOND (-4)   /* structural failure in a preconditioner (missing / tiny diagonal, empty row): the
+                                      reference's non-zero return of apply()/init() (ref:1668-1693) */
+#define SMM_HIP_ERR_NOMEM (-5)
+
+/* SolverStatus, ref:2010-2014 */
+#define SMM_SOLVER_SUCCESS 0
+#define SMM_SOLVER_DIVERGED 1
+#define SMM_SOLVER_MAX_ITERATIONS_REACHED 2
+
+/* SpMV op: rMult / rMultAdd / rMultSub, ref:1501-1515 */
+#define SMM_OP_ASSIGN 0 /* out = A*x          */
+#define SMM_OP_ADD 1    /* out = lhs + A*x    */
+#define SMM_OP_SUB 2    /* out = lhs - A*x    */
+
+/* Preconditioner kinds.  NONE = IDPreconditioner (ref:1166-1170), SGS = SGSPreconditioner (ref:1173-1186,
+ * SolverPreconditioner::SYMMETRIC_GAUS_SEIDEL ref:1002-1006).  JACOBI is absent from the reference and ILU0 is
+ * declared but unusable there (ref:1189-1212, 1715-1790); both are additions (BASELINE.json north_star).
+ * IC0 = IC0Preconditioner (ref:1216-1235), used by the preconditioned ConjugateGradient overload. */
+#define SMM_PRECOND_NONE 0
+#define SMM_PRECOND_JACOBI 1
+#define SMM_PRECOND_ILU0 2
+#define SMM_PRECOND_SGS 3
+#define SMM_PRECOND_IC0 4
+
+#define SMM_DTYPE_F32 0
+#define SMM_DTYPE_F64 1
+
+/* SpMV kernel families (smm_hip_csr_set_kernel).  AUTO picks from nnz/row. */
+#define SMM_SPMV_AUTO 0
+#define SMM_SPMV_VECTOR 1 /* L lanes of a wavefront per row, wave shuffle reduction */
+#define SMM_SPMV_STREAM 2 /* row blocks staged through LDS with 16-byte coalesced loads, row-sequential sums */
+
+typedef struct smm_hip_csr smm_hip_csr;         /* device-resident CSRMatrix<T> (ref:1243-1259) */
+typedef struct smm_hip_precond smm_hip_precond; /* device-resident preconditioner */
+typedef void* smm_hip_stream;                   /* hipStream_t; NULL = the library's own stream */
+
+/* ---- runtime ------------------------------------------------------------------------------------------- */
+/* Select the HIP device this process uses (one process per GPU) and create the library stream.  Idempotent. */
+int smm_hip_init(int device);
+int smm_hip_shutdown(void);
+/* Text of the last failure on the calling thread ("" if none). */
+const char* smm_hip_last_error(void);
+int smm_hip_uses_std_fma(void);
+/* name: device name (may be NULL), cus: compute units, hbm_bytes: total device memory */
+int smm_hip_device_info(char* name, size_t name_cap, int* cus, size_t* hbm_bytes);
+/* Blocks until everything enqueued on `stream` (NULL = library stream) has finished. */
+int smm_hip_stream_synchronize(smm_hip_stream stream);
+
+/* ---- CSRMatrix<T> (ref:1243-1259; replaces CSRMatrix::init(TripletMatrix) ref:1326-1349 as the way in) ---- */
+/* Copies the three host arrays of a CSRMatrix (values[nnz], positions[nnz] ascending per row, start[rows+1])
+ * to the device.  The host arrays stay owned by the caller. */
+int smm_hip_csr_create_f32(int rows, int cols, const int* start, const int* positions, const float* values, smm_hip_csr** out);
+int smm_hip_csr_create_f64(int rows, int cols, const int* start, const int* positions, const double* values, smm_hip_csr** out);
+/* Wraps arrays that already live in device memory (no copy; the caller keeps them alive and unchanged). */
+int smm_hip_csr_create_dev_f32(int rows, int cols, const int* d_start, const int* d_positions, const float* d_values, smm_hip_csr** out);
+int smm_hip_csr_create_dev_f64(int rows, int cols, const int* d_start, const int* d_positions, const double* d_values, smm_hip_csr** out);
+int smm_hip_csr_destroy(smm_hip_csr* m);
+/* getDenseRowCount / getDenseColCount / getNonZeroCount (ref:1351-1364) + dtype + firstActiveStart (ref:1619-1628) */
+int smm_hip_csr_info(const smm_hip_csr* m, int* rows, int* cols, int* nnz, int* dtype, int* first_active_start);
+/* Force a SpMV kernel family / lanes-per-row (0 = heuristic).  Tuning knob, not needed for correctness. */
+int smm_hip_csr_set_kernel(smm_hip_csr* m, int family, int lanes_per_row);
+int smm_hip_csr_get_kernel(const smm_hip_csr* m, int* family, int* lanes_per_row);
+/* Times the candidate SpMV configurations on this matrix and keeps the fastest. */
+int smm_hip_csr_autotune(smm_hip_csr* m);
+
+/* ---- SpMV: CSRMatrix<T>::rMult / rMultAdd / rMultSub (ref:1458-1515) -------------------------------------- */
+/* out[i] = op(lhs[i], sum_k values[k]*x[positions[k]]); empty rows give op(lhs[i],0) (ref:1479-1483);
+ * out may alias lhs, x must not alias out (ref:1503).  lhs is ignored for SMM_OP_ASSIGN. */
+int smm_hip_spmv_f32(const smm_hip_csr* m, int op, const float* lhs, const float* x, float* out);
+int smm_hip_spmv_f64(const smm_hip_csr* m, int op, const double* lhs, const double* x, double* out);
+int smm_hip_spmv_dev_f32(const smm_hip_csr* m, int op, const float* d_lhs, const float* d_x, float* d_out, smm_hip_stream stream);
+int smm_hip_spmv_dev_f64(const smm_hip_csr* m, int op, const double* d_lhs, const double* d_x, double* d_out, smm_hip_stream stream);
+
+/* ---- reductions: Vector<T>::operator* (ref:305-328), secondNormSquared (ref:296-303) ---------------------- */
+int smm_hip_dot_f32(int n, const float* a, const float* b, float* result);
+int smm_hip_dot_f64(int n, const double* a, const double* b, double* result);
+/* d_result: one T in device memory */
+int smm_hip_dot_dev_f32(int n, const float* d_a, const float* d_b, float* d_result, smm_hip_stream stream);
+int smm_hip_dot_dev_f64(int n, const double* d_a, const double* d_b, double* d_result, smm_hip_stream stream);
+
+/* ---- AXPY-style updates of the solver loops (device pointers; scalars by value) ---------------------------
+ * y = a*x + y_in form used by every update loop of ref:2245-2247, 2263-2267, 2272-2274, 2362-2394:
+ *   smm_hip_axpby_dev: out[i] = _smm_fma(a, x[i], y[i])      (out may alias x or y) */
+int smm_hip_axpy_dev_f32(int n, float a, const float* d_x, const float* d_y, float* d_out, smm_hip_stream stream);
+int smm_hip_axpy_dev_f64(int n, double a, const double* d_x, const double* d_y, double* d_out, smm_hip_stream stream);
+
+/* ---- solvers ------------------------------------------------------------------------------------------------
+ * smm_hip_cg_*  replaces  SolverStatus ConjugateGradient(const CSRMatrix<T>& a, const T* b, const T* x0, T* x,
+ *                                                      int maxIterations, T eps)            (ref:2316-2398)
+ *   maxIterations == -1 means rows (not clamped otherwise); convergence test eps*eps > ||r||^2; when the
+ *   initial residual already passes, x is NOT written (ref:2342-2344).  x may alias x0.
+ *   With M != NULL (kind SMM_PRECOND_IC0) it replaces the IC0 overload (ref:2414-2505).
+ * smm_hip_bicgstab_*  replaces  SolverStatus BiCGStab(const CSRMatrix<T>& a, T* b, T* x, int maxIterations, T eps
+ *                                                   [, const Preconditioner& M])          (ref:2191-2303)
+ *   x is in/out; maxIterations is clamped to rows, -1 means rows; the loop body always runs once; status is
+ *   SUCCESS unless iterations > maxIterations (ref:2277-2282); M == NULL is the IDPreconditioner overload.
+ * Additive outputs (may be NULL; the reference API has no equivalent): iterations = loop passes executed,
+ * resnorm = last ||r||^2 (cg) or ||r|| (bicgstab) the loop computed.
+ */
+int smm_hip_cg_f32(const smm_hip_csr* a, const float* b, const float* x0, float* x, int maxIterations, float eps,
+                   const smm_hip_precond* M, int* solver_status, int* iterations, float* resnorm2);
+int smm_hip_cg_f64(const smm_hip_csr* a, const double* b, const double* x0, double* x, int maxIterations, double eps,
+                   const smm_hip_precond* M, int* solver_status, int* iterations, double* resnorm2);
+int smm_hip_cg_dev_f32(const smm_hip_csr* a, const float* d_b, const float* d_x0, float* d_x, int maxIterations, float eps,
+                       const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm2);
+int smm_hip_cg_dev_f64(const smm_hip_csr* a, const double* d_b, const double* d_x0, double* d_x, int maxIterations, double eps,
+                       const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm2);
+
+int smm_hip_bicgstab_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps,
+                         const smm_hip_precond* M, int* solver_status, int* iterations, float* resnorm);
+int smm_hip_bicgstab_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps,
+                         const smm_hip_precond* M, int* solver_status, int* iterations, double* resnorm);
+int smm_hip_bicgstab_dev_f32(const smm_hip_csr* a, const float* d_b, float* d_x, int maxIterations, float eps,
+                             const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm);
+int smm_hip_bicgstab_dev_f64(const smm_hip_csr* a, const double* d_b, double* d_x, int maxIterations, double eps,
+                             const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm);
+
+/* BiCGSymmetric (ref:2021-2102): same kernels as CG plus the DIVERGED heuristics (ref:2056-2058, 2079-2081) */
+int smm_hip_bicgsymmetric_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, int* solver_status, int* iterations);
+int smm_hip_bicgsymmetric_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps, int* solver_status, int* iterations);
+
+/* ---- preconditioners: `int apply(const T* rhs, T* x) const noexcept` (ref:1173-1235) --------------------------
+ * create: replaces CSRMatrix<T>::getPreconditioner<kind>() (ref:1643-1651) / IC0Preconditioner::init (ref:1798).
+ * The matrix must outlive the preconditioner (the reference holds a const CSRMatrix&).  Structural failures
+ * (missing or |d|<1e-5 diagonal, empty row, non-SPD IC0 pivot) return SMM_HIP_ERR_PRECOND. */
+int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out);
+int smm_hip_precond_destroy(smm_hip_precond* M);
+int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower, int* levels_upper);
+/* x = M^-1 rhs; rhs must not alias x (ref:1667) */
+int smm_hip_precond_apply_f32(const smm_hip_precond* M, const float* rhs, float* x);
+int smm_hip_precond_apply_f64(const smm_hip_precond* M, const double* rhs, double* x);
+int smm_hip_precond_apply_dev_f32(const smm_hip_precond* M, const float* d_rhs, float* d_x, smm_hip_stream stream);
+int smm_hip_precond_apply_dev_f64(const smm_hip_precond* M, const double* d_rhs, double* d_x, smm_hip_stream stream);
+/* copies the factor values (ILU0 / IC0: nnz values on A's pattern; JACOBI: rows diagonal entries) to the host */
+int smm_hip_precond_values_f32(const smm_hip_precond* M, float* out, size_t count);
+int smm_hip_precond_values_f64(const smm_hip_precond* M, double* out, size_t count);
+
+/* ---- synthetic workload generators (BASELINE.json configs; device-side so 5e8-entry matrices need no host
+ *      std::map as in ref:606-618).  d_start[rows+1], d_positions[nnz], d_values[nnz] are DEVICE arrays sized by
+ *      the *_nnz query.  Same laws as sparse_matrix_math_amd.generators (numpy), bit for bit. --------------- */
+long long smm_hip_gen_poisson2d_nnz(int nx, int ny);
+long long smm_hip_gen_stencil3d_nnz(int nx, int ny, int nz);
+long long smm_hip_gen_banded_nnz(int n, int k, unsigned long long seed, int max_offset);
+int smm_hip_gen_poisson2d_dev_f32(int nx, int ny, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
+int smm_hip_gen_poisson2d_dev_f64(int nx, int ny, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
+/* 7-point stencil: diagonal `diag`, lower neighbours `lo`, upper neighbours `hi` (Laplacian: 6,-1,-1;
+ * convection-diffusion stand-in for atmosmodd: 6,-1-c,-1+c) */
+int smm_hip_gen_stencil3d_dev_f32(int nx, int ny, int nz, float diag, float lo, float hi, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
+int smm_hip_gen_stencil3d_dev_f64(int nx, int ny, int nz, double diag, double lo, double hi, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
+/* banded-random symmetric strictly diagonally dominant matrix */
+int smm_hip_gen_banded_dev_f32(int n, int k, unsigned long long seed, int max_offset, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
+int smm_hip_gen_banded_dev_f64(int n, int k, unsigned long long seed, int max_offset, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMM_HIP_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of libsmm_hip.so (the C ABI declared in include/smm_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import of the symbols, and
+if there is no HIP device every call returns SMM_HIP_ERR_NO_DEVICE, which `check` turns into SmmHipError.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SMM_HIP_OK = 0
+SMM_HIP_ERR_INVALID = -1
+SMM_HIP_ERR_HIP = -2
+SMM_HIP_ERR_NO_DEVICE = -3
+SMM_HIP_ERR_PRECOND = -4
+SMM_HIP_ERR_NOMEM = -5
+
+
+class SmmHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libsmm_hip error {code}: {message}")
+        self.code = code
+
+
+def library_path(fma=False):
+    name = "libsmm_hip_fma.so" if fma else "libsmm_hip.so"
+    return os.path.join(_HERE, "lib", name)
+
+
+_P = c_void_p  # opaque handles and device pointers travel as void*
+
+# name -> (restype, argtypes); {T} expands to float/double for the _f32/_f64 twins
+_TYPED = {
+    "smm_hip_csr_create": (c_int, [c_int, c_int, _P, _P, _P, POINTER(_P)]),
+    "smm_hip_csr_create_dev": (c_int, [c_int, c_int, _P, _P, _P, POINTER(_P)]),
+    "smm_hip_spmv": (c_int, [_P, c_int, _P, _P, _P]),
+    "smm_hip_spmv_dev": (c_int, [_P, c_int, _P, _P, _P, _P]),
+    "smm_hip_dot": (c_int, [c_int, _P, _P, _P]),
+    "smm_hip_dot_dev": (c_int, [c_int, _P, _P, _P, _P]),
+    "smm_hip_axpy_dev": (c_int, [c_int, "T", _P, _P, _P, _P]),
+    "smm_hip_cg": (c_int, [_P, _P, _P, _P, c_int, "T", _P, POINTER(c_int), POINTER(c_int), "PT"]),
+    "smm_hip_cg_dev": (c_int, [_P, _P, _P, _P, c_int, "T", _P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
+    "smm_hip_bicgstab": (c_int, [_P, _P, _P, c_int, "T", _P, POINTER(c_int), POINTER(c_int), "PT"]),
+    "smm_hip_bicgstab_dev": (c_int, [_P, _P, _P, c_int, "T", _P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
+    "smm_hip_bicgsymmetric": (c_int, [_P, _P, _P, c_int, "T", POINTER(c_int), POINTER(c_int)]),
+    "smm_hip_precond_apply": (c_int, [_P, _P, _P]),
+    "smm_hip_precond_apply_dev": (c_int, [_P, _P, _P, _P]),
+    "smm_hip_precond_values": (c_int, [_P, _P, c_size_t]),
+    "smm_hip_gen_poisson2d_dev": (c_int, [c_int, c_int, _P, _P, _P, _P]),
+    "smm_hip_gen_stencil3d_dev": (c_int, [c_int, c_int, c_int, "T", "T", "T", _P, _P, _P, _P]),
+    "smm_hip_gen_banded_dev": (c_int, [c_int, c_int, c_ulonglong, c_int, _P, _P, _P, _P]),
+}
+
+_PLAIN = {
+    "smm_hip_init": (c_int, [c_int]),
+    "smm_hip_shutdown": (c_int, []),
+    "smm_hip_last_error": (c_char_p, []),
+    "smm_hip_uses_std_fma": (c_int, []),
+    "smm_hip_device_info": (c_int, [c_char_p, c_size_t, POINTER(c_int), POINTER(c_size_t)]),
+    "smm_hip_stream_synchronize": (c_int, [_P]),
+    "smm_hip_csr_destroy": (c_int, [_P]),
+    "smm_hip_csr_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "smm_hip_csr_set_kernel": (c_int, [_P, c_int, c_int]),
+    "smm_hip_csr_get_kernel": (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
+    "smm_hip_csr_autotune": (c_int, [_P]),
+    "smm_hip_precond_create": (c_int, [_P, c_int, POINTER(_P)]),
+    "smm_hip_precond_destroy": (c_int, [_P]),
+    "smm_hip_precond_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "smm_hip_gen_poisson2d_nnz": (c_longlong, [c_int, c_int]),
+    "smm_hip_gen_stencil3d_nnz": (c_longlong, [c_int, c_int, c_int]),
+    "smm_hip_gen_banded_nnz": (c_longlong, [c_int, c_int, c_ulonglong, c_int]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/smm_hip.h declares (used by the CPU-side export test)."""
+    names = list(_PLAIN)
+    for base in _TYPED:
+        names += [f"{base}_f32", f"{base}_f64"]
+    return names
+
+
+_lib = None
+
+
+def load(fma=False):
+    """Load the shared library (once) and declare the prototypes.  Raises OSError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path(fma)
+    if not os.path.exists(path):
+        raise OSError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  sparse_matrix_math_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _PLAIN.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for base, (res, args) in _TYPED.items():
+        for suf, ct in (("f32", c_float), ("f64", c_double)):
+            fn = getattr(lib, f"{base}_{suf}")
+            fn.restype = res
+            fn.argtypes = [ct if a == "T" else POINTER(ct) if a == "PT" else a for a in args]
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != SMM_HIP_OK:
+        msg = load().smm_hip_last_error().decode("utf-8", "replace")
+        raise SmmHipError(status, msg)

@@ -1,0 +1,197 @@
+// smm_blas1.hip -- streaming reductions and AXPY-style updates (gfx950).
+//
+// dot: Vector<T>::operator* (ref:305-328) / secondNormSquared (ref:296-303).  The reference sums serially (or as
+// a grain-8192 TBB tree); here every lane keeps a private sum over a grid-strided slice (16-byte loads), lanes
+// meet in a wave butterfly (__shfl_xor), waves meet through LDS, and each of the NPART workgroups writes one
+// partial; a one-workgroup kernel adds the partials in a fixed order.  No atomics: results are bitwise
+// reproducible from run to run.  Accumulation is in T, like the reference.
+#include <algorithm>
+
+#include "smm_device.h"
+#include "smm_internal.h"
+
+namespace smm {
+
+constexpr int TPB = 256;
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+	using type = float4;
+	static constexpr int N = 4;
+};
+template <>
+struct Vec16<double> {
+	using type = double2;
+	static constexpr int N = 2;
+};
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void dotPartialsKernel(int n, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ partials,
+                                                         const int* __restrict__ doneFlag) {
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	constexpr int N = Vec16<T>::N;
+	using V = typename Vec16<T>::type;
+	T acc = T(0);
+	const long long tid = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x;
+	const long long nthreads = static_cast<long long>(gridDim.x) * TPB;
+	const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+	if (aligned) {
+		const long long nvec = n / N;
+		const V* av = reinterpret_cast<const V*>(a);
+		const V* bv = reinterpret_cast<const V*>(b);
+		for (long long i = tid; i < nvec; i += nthreads) {
+			const V x = av[i];
+			const V y = bv[i];
+			if constexpr (N == 4) {
+				acc += x.x * y.x;
+				acc += x.y * y.y;
+				acc += x.z * y.z;
+				acc += x.w * y.w;
+			} else {
+				acc += x.x * y.x;
+				acc += x.y * y.y;
+			}
+		}
+		for (long long i = nvec * N + tid; i < n; i += nthreads) acc += a[i] * b[i];
+	} else {
+		for (long long i = tid; i < n; i += nthreads) acc += a[i] * b[i];
+	}
+	const T s = blockSum256(acc, red);
+	if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void sumPartialsKernel(const T* __restrict__ partials, T* __restrict__ result) {
+	__shared__ T red[4];
+	T acc = T(0);
+	for (int i = threadIdx.x; i < NPART; i += TPB) acc += partials[i];
+	const T s = blockSum256(acc, red);
+	if (threadIdx.x == 0) result[0] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void axpyKernel(int n, T alpha, const T* x, const T* y, T* out) {
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		out[i] = smmFma(alpha, x[i], y[i]);
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void copy2Kernel(int n, const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2) {
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const T v = src[i];
+		d1[i] = v;
+		if (d2) d2[i] = v;
+	}
+}
+
+static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, numCUs() * 8LL))); }
+
+template <typename T>
+int launchDotPartials(int n, const T* a, const T* b, T* partials, const int* doneFlag, hipStream_t s) {
+	dotPartialsKernel<T><<<NPART, TPB, 0, s>>>(n, a, b, partials, doneFlag);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int launchSumPartials(const T* partials, T* result, hipStream_t s) {
+	sumPartialsKernel<T><<<1, TPB, 0, s>>>(partials, result);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int launchAxpy(int n, T a, const T* x, const T* y, T* out, hipStream_t s) {
+	if (n <= 0) return SMM_HIP_OK;
+	axpyKernel<T><<<gridFor(n), TPB, 0, s>>>(n, a, x, y, out);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int launchCopy2(int n, const T* src, T* dst1, T* dst2, hipStream_t s) {
+	if (n <= 0) return SMM_HIP_OK;
+	copy2Kernel<T><<<gridFor(n), TPB, 0, s>>>(n, src, dst1, dst2);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+#define SMM_INSTANTIATE(T)                                                                     \
+	template int launchDotPartials<T>(int, const T*, const T*, T*, const int*, hipStream_t);   \
+	template int launchSumPartials<T>(const T*, T*, hipStream_t);                              \
+	template int launchAxpy<T>(int, T, const T*, const T*, T*, hipStream_t);                   \
+	template int launchCopy2<T>(int, const T*, T*, T*, hipStream_t);
+SMM_INSTANTIATE(float)
+SMM_INSTANTIATE(double)
+#undef SMM_INSTANTIATE
+
+template <typename T>
+static int dotDev(int n, const T* a, const T* b, T* d_result, hipStream_t s) {
+	if (n < 0 || !d_result || (n > 0 && (!a || !b))) {
+		setError("dot: bad arguments");
+		return SMM_HIP_ERR_INVALID;
+	}
+	DevBuf<T> partials;
+	SMM_TRY(partials.alloc(NPART));
+	SMM_TRY(launchDotPartials<T>(n, a, b, partials, nullptr, s));
+	SMM_TRY(launchSumPartials<T>(partials, d_result, s));
+	// the partials buffer goes back to the cache when this returns; work enqueued later on the same stream
+	// cannot overtake the two kernels above
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int dotHost(int n, const T* a, const T* b, T* result) {
+	if (n < 0 || !result || (n > 0 && (!a || !b))) {
+		setError("dot: bad arguments");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	hipStream_t s = libStream();
+	DevBuf<T> da, db, dr;
+	SMM_TRY(da.alloc(n));
+	SMM_TRY(dr.alloc(1));
+	if (n) SMM_HIP_TRY(hipMemcpyAsync(da, a, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	const T* pb = da;
+	if (b != a) {
+		SMM_TRY(db.alloc(n));
+		if (n) SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		pb = db;
+	}
+	SMM_TRY(dotDev<T>(n, da, pb, dr, s));
+	SMM_HIP_TRY(hipMemcpyAsync(result, dr, sizeof(T), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
+}
+
+}  // namespace smm
+
+using namespace smm;
+
+extern "C" {
+
+int smm_hip_dot_f32(int n, const float* a, const float* b, float* result) { return dotHost<float>(n, a, b, result); }
+int smm_hip_dot_f64(int n, const double* a, const double* b, double* result) { return dotHost<double>(n, a, b, result); }
+int smm_hip_dot_dev_f32(int n, const float* d_a, const float* d_b, float* d_result, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return dotDev<float>(n, d_a, d_b, d_result, pickStream(stream));
+}
+int smm_hip_dot_dev_f64(int n, const double* d_a, const double* d_b, double* d_result, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return dotDev<double>(n, d_a, d_b, d_result, pickStream(stream));
+}
+
+int smm_hip_axpy_dev_f32(int n, float a, const float* d_x, const float* d_y, float* d_out, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return launchAxpy<float>(n, a, d_x, d_y, d_out, pickStream(stream));
+}
+int smm_hip_axpy_dev_f64(int n, double a, const double* d_x, const double* d_y, double* d_out, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return launchAxpy<double>(n, a, d_x, d_y, d_out, pickStream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// smm_internal.h -- shared declarations of libsmm_hip.so (gfx950 only; no CPU fallback anywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/smm_hip.h"
+
+namespace smm {
+
+// ---------------------------------------------------------------------------------------------------------
+// error plumbing: every C entry point returns an int; HIP failures land in a thread-local message
+// ---------------------------------------------------------------------------------------------------------
+void setError(const char* fmt, ...);
+int hipFail(hipError_t e, const char* what, const char* file, int line);
+
+#define SMM_HIP_TRY(expr)                                             \
+	do {                                                              \
+		hipError_t _e = (expr);                                       \
+		if (_e != hipSuccess) {                                       \
+			return ::smm::hipFail(_e, #expr, __FILE__, __LINE__);     \
+		}                                                             \
+	} while (0)
+
+#define SMM_TRY(expr)              \
+	do {                           \
+		int _s = (expr);           \
+		if (_s != SMM_HIP_OK) {    \
+			return _s;             \
+		}                          \
+	} while (0)
+
+// make sure a device is selected; returns SMM_HIP_ERR_NO_DEVICE when there is none
+int ensureInit();
+hipStream_t libStream();
+inline hipStream_t pickStream(smm_hip_stream s) { return s ? static_cast<hipStream_t>(s) : libStream(); }
+int numCUs();
+
+// caching device allocator (solver temporaries are allocated per call like the reference's SMM::Vector,
+// ref:2336-2339, but hipMalloc is far too slow to sit in that path)
+int devAlloc(void** p, size_t bytes);
+void devFree(void* p);
+void devTrim();
+
+template <typename T>
+struct DevBuf {
+	T* p = nullptr;
+	size_t n = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	~DevBuf() { release(); }
+	int alloc(size_t count) {
+		release();
+		n = count;
+		return devAlloc(reinterpret_cast<void**>(&p), (count ? count : 1) * sizeof(T));
+	}
+	void release() {
+		if (p) devFree(p);
+		p = nullptr;
+		n = 0;
+	}
+	operator T*() const { return p; }
+};
+
+template <typename T>
+constexpr int dtypeOf() { return std::is_same<T, float>::value ? SMM_DTYPE_F32 : SMM_DTYPE_F64; }
+
+}  // namespace smm
+
+// ---------------------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------------------
+struct smm_hip_csr {
+	int rows = 0, cols = 0, nnz = 0, dtype = 0;
+	int firstActiveStart = 0;
+	int* d_start = nullptr;
+	int* d_positions = nullptr;
+	void* d_values = nullptr;
+	bool owns = false;
+	// resolved SpMV configuration
+	int family = SMM_SPMV_VECTOR;
+	int lanes = 4;
+	// STREAM family: row blocks (first row of every block; n_rowblocks+1 entries) staged through LDS
+	int* d_rowblocks = nullptr;
+	int n_rowblocks = 0;
+	int stream_nnz_cap = 0;  // LDS capacity in nonzeros the row blocks were cut for
+};
+
+struct smm_hip_precond {
+	int kind = SMM_PRECOND_NONE;
+	int dtype = 0;
+	const smm_hip_csr* a = nullptr;
+	void* d_values = nullptr;  // JACOBI: diag[rows]; ILU0 / IC0: factor values on A's pattern [nnz]; SGS: null (uses A)
+	size_t n_values = 0;
+	// level schedules of the lower / upper triangular sweeps: rows sorted by level
+	int* d_order_lo = nullptr;
+	int* d_order_up = nullptr;
+	std::vector<int> lvl_ptr_lo, lvl_ptr_up;  // host: level l covers order[lvl_ptr[l] .. lvl_ptr[l+1])
+};
+
+namespace smm {
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel launchers (device pointers, asynchronous on `s`)
+// ---------------------------------------------------------------------------------------------------------
+// Partial-sum slots every fused reduction writes: NPART partials per reduced quantity
+constexpr int NPART = 1024;
+
+// dotMode of the SpMV epilogue: which per-row products are block-reduced into `partials`
+//   0 none; 1: out[i]*w1[i] -> partials[0..NPART); 2: out[i]*out[i] -> partials[0..), out[i]*w1[i] -> partials[NPART..)
+template <typename T>
+int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
+               const int* doneFlag, hipStream_t s);
+
+int buildRowBlocks(smm_hip_csr* m, int nnzCap);
+void chooseSpmvConfig(smm_hip_csr* m);
+
+// partials[0..NPART) = per-block sums of a[i]*b[i]
+template <typename T>
+int launchDotPartials(int n, const T* a, const T* b, T* partials, const int* doneFlag, hipStream_t s);
+// result[0] = sum of partials[0..NPART) in fixed order
+template <typename T>
+int launchSumPartials(const T* partials, T* result, hipStream_t s);
+template <typename T>
+int launchAxpy(int n, T a, const T* x, const T* y, T* out, hipStream_t s);
+template <typename T>
+int launchCopy2(int n, const T* src, T* dst1, T* dst2, hipStream_t s);
+
+// solver drivers (smm_solvers.hip)
+template <typename T>
+int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations, T eps, const smm_hip_precond* M, hipStream_t s,
+          int* status, int* iterations, T* resnorm2);
+template <typename T>
+int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const smm_hip_precond* M, hipStream_t s,
+                int* status, int* iterations, T* resnorm);
+template <typename T>
+int bicgsymmetricDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, hipStream_t s, int* status, int* iterations);
+
+// preconditioner apply (smm_precond.hip); doneFlag may be null
+template <typename T>
+int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* doneFlag, hipStream_t s);
+
+}  // namespace smm

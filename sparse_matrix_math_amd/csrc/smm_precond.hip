@@ -1,0 +1,612 @@
+// smm_precond.hip -- preconditioner apply on gfx950: Jacobi, Symmetric Gauss-Seidel (ref:1658-1713), ILU(0)
+// (declared ref:1189-1212, unusable there), IC(0) (ref:1803-1837).
+//
+// SGS / ILU0 / IC0 apply are two sparse triangular solves on A's own pattern.  The reference walks the rows
+// one after another; here the dependency DAG of each sweep is cut into levels once, at create time (rows of one
+// level depend only on rows of earlier levels), rows are sorted by level, and a sweep runs level by level with
+// one lane per row.  Inside a row the entries are visited in exactly the reference's order, and a row only
+// starts when all rows it reads are final, so the result is bit-identical to the sequential sweep.
+// Runs of small levels are executed by a single 1024-lane workgroup with a workgroup barrier between levels
+// (no launch per level); a large level gets a multi-workgroup launch of its own.
+//
+// Factorisation (ILU0 / IC0) is setup work and runs on the host at create time; only the values it produces
+// live on the device.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "smm_device.h"
+#include "smm_internal.h"
+
+namespace smm {
+
+constexpr int TPB = 256;
+constexpr int SMALL_LEVEL = 1024;  // levels up to this many rows are chained inside one workgroup
+
+enum SweepMode { SGS_LO = 0, SGS_UP = 1, ILU_LO = 2, ILU_UP = 3, IC_LO = 4, IC_UP = 5 };
+
+template <typename T, int MODE>
+__device__ __forceinline__ void solveRow(int row, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
+                                         const T* __restrict__ rhs, T* x) {
+	const int b = start[row];
+	const int e = start[row + 1];
+	if (MODE == SGS_LO) {  // ref:1673-1695
+		int k = b;
+		T lhs = rhs[row];
+		int col = positions[k];
+		T value = vals[k];
+		while (col < row) {
+			lhs = smmFma(-value, x[col], lhs);
+			++k;
+			col = positions[k];
+			value = vals[k];
+		}
+		x[row] = lhs / value;
+	} else if (MODE == SGS_UP) {  // ref:1698-1711
+		int k = e - 1;
+		int col = positions[k];
+		T value = vals[k];
+		T lhs = T(0);
+		while (col > row) {
+			lhs = smmFma(value, x[col], lhs);
+			--k;
+			col = positions[k];
+			value = vals[k];
+		}
+		x[row] = x[row] - lhs / value;
+	} else if (MODE == ILU_LO) {  // L y = rhs, unit diagonal
+		T sum = rhs[row];
+		for (int k = b; k < e && positions[k] < row; ++k) {
+			sum = smmFma(-vals[k], x[positions[k]], sum);
+		}
+		x[row] = sum;
+	} else if (MODE == ILU_UP) {  // U x = y
+		T sum = x[row];
+		int k = e - 1;
+		for (; k >= b && positions[k] > row; --k) {
+			sum = smmFma(-vals[k], x[positions[k]], sum);
+		}
+		x[row] = sum / vals[k];
+	} else if (MODE == IC_LO) {  // ref:1806-1819: sum -= l*x (plain multiply and subtract)
+		T sum = rhs[row];
+		int k = b;
+		int col = positions[k];
+		while (col < row && k < e) {
+			const T prod = vals[k] * x[col];
+			sum = sum - prod;
+			++k;
+			col = positions[k];
+		}
+		x[row] = sum / vals[k];
+	} else {  // IC_UP, ref:1822-1835
+		T sum = x[row];
+		int k = e - 1;
+		int col = positions[k];
+		while (col > row && k >= b) {
+			const T prod = vals[k] * x[col];
+			sum = sum - prod;
+			--k;
+			col = positions[k];
+		}
+		x[row] = sum / vals[k];
+	}
+}
+
+// one large level: rows order[begin .. begin+count)
+template <typename T, int MODE>
+__global__ __launch_bounds__(TPB) void sweepLevelKernel(const int* __restrict__ order, int begin, int count, const int* __restrict__ start,
+                                                        const int* __restrict__ positions, const T* __restrict__ vals, const T* __restrict__ rhs,
+                                                        T* x, const int* __restrict__ doneFlag) {
+	if (doneFlag && *doneFlag) return;
+	const int i = blockIdx.x * TPB + threadIdx.x;
+	if (i < count) {
+		solveRow<T, MODE>(order[begin + i], start, positions, vals, rhs, x);
+	}
+}
+
+// a run of small levels [l0, l1) inside one workgroup; lvlPtr is the device copy of the level pointers
+template <typename T, int MODE>
+__global__ __launch_bounds__(SMALL_LEVEL) void sweepChainKernel(const int* __restrict__ order, const int* __restrict__ lvlPtr, int l0, int l1,
+                                                                const int* __restrict__ start, const int* __restrict__ positions,
+                                                                const T* __restrict__ vals, const T* __restrict__ rhs, T* x,
+                                                                const int* __restrict__ doneFlag) {
+	if (doneFlag && *doneFlag) return;
+	for (int l = l0; l < l1; ++l) {
+		const int begin = lvlPtr[l];
+		const int count = lvlPtr[l + 1] - begin;
+		if (static_cast<int>(threadIdx.x) < count) {
+			solveRow<T, MODE>(order[begin + threadIdx.x], start, positions, vals, rhs, x);
+		}
+		// rows of the next level read x[] written above by other wavefronts of this workgroup
+		__threadfence_block();
+		__syncthreads();
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void jacobiApplyKernel(int n, const T* __restrict__ diag, const T* __restrict__ rhs, T* __restrict__ x,
+                                                         const int* __restrict__ doneFlag) {
+	if (doneFlag && *doneFlag) return;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		x[i] = rhs[i] / diag[i];
+	}
+}
+
+// diag[i] = A_ii; err[0] is set when a diagonal is missing or |d| < 1e-5 (the SGS validity rule, ref:1691-1693)
+template <typename T>
+__global__ __launch_bounds__(TPB) void extractDiagKernel(int rows, const int* __restrict__ start, const int* __restrict__ positions,
+                                                         const T* __restrict__ vals, T* __restrict__ diag, int* __restrict__ err) {
+	for (long long row = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; row < rows; row += static_cast<long long>(gridDim.x) * TPB) {
+		bool found = false;
+		T d = T(0);
+		for (int k = start[row]; k < start[row + 1]; ++k) {
+			if (positions[k] == row) {
+				d = vals[k];
+				found = true;
+				break;
+			}
+		}
+		diag[row] = d;
+		if (!found || (d < T(0) ? -d : d) < T(1e-5)) atomicOr(err, 1);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side analysis
+// ---------------------------------------------------------------------------------------------------------
+struct HostCsr {
+	int rows = 0;
+	std::vector<int> start, positions;
+};
+
+// level sets of the strictly-lower (lower=true) or strictly-upper part of the pattern
+static void buildLevels(const HostCsr& h, bool lower, std::vector<int>& order, std::vector<int>& lvlPtr) {
+	const int n = h.rows;
+	std::vector<int> level(static_cast<size_t>(n), 0);
+	int maxLevel = -1;
+	if (lower) {
+		for (int i = 0; i < n; ++i) {
+			int lv = 0;
+			for (int k = h.start[i]; k < h.start[i + 1] && h.positions[k] < i; ++k) {
+				lv = std::max(lv, level[h.positions[k]] + 1);
+			}
+			level[i] = lv;
+			maxLevel = std::max(maxLevel, lv);
+		}
+	} else {
+		for (int i = n - 1; i >= 0; --i) {
+			int lv = 0;
+			for (int k = h.start[i + 1] - 1; k >= h.start[i] && h.positions[k] > i; --k) {
+				lv = std::max(lv, level[h.positions[k]] + 1);
+			}
+			level[i] = lv;
+			maxLevel = std::max(maxLevel, lv);
+		}
+	}
+	lvlPtr.assign(static_cast<size_t>(maxLevel + 2), 0);
+	for (int i = 0; i < n; ++i) lvlPtr[level[i] + 1]++;
+	for (int l = 0; l <= maxLevel; ++l) lvlPtr[l + 1] += lvlPtr[l];
+	order.resize(static_cast<size_t>(n));
+	std::vector<int> cursor(lvlPtr.begin(), lvlPtr.end() - 1);
+	for (int i = 0; i < n; ++i) order[cursor[level[i]]++] = i;
+}
+
+// every row non-empty, diagonal stored; with checkMagnitude also |d| >= 1e-5 (ref:1666-1693)
+template <typename T>
+static bool diagonalOk(const HostCsr& h, const std::vector<T>& vals, bool checkMagnitude) {
+	for (int i = 0; i < h.rows; ++i) {
+		bool found = false;
+		for (int k = h.start[i]; k < h.start[i + 1]; ++k) {
+			if (h.positions[k] == i) {
+				found = !checkMagnitude || std::fabs(vals[k]) >= T(1e-5);
+				break;
+			}
+		}
+		if (!found) return false;
+	}
+	return true;
+}
+
+// ILU(0), IKJ ordering on A's pattern (Saad, Iterative Methods for Sparse Linear Systems, Alg. 10.4): unit-lower L
+// and U share one value array.  l_ik = a_ik * (1/u_kk) as ref:1767 intends.  false on a missing / tiny pivot.
+template <typename T>
+static bool factorIlu0(const HostCsr& h, std::vector<T>& lu) {
+	const int n = h.rows;
+	std::vector<int> where(static_cast<size_t>(n), -1);
+	std::vector<T> pivotInv(static_cast<size_t>(n));
+	for (int i = 0; i < n; ++i) {
+		const int rb = h.start[i], re = h.start[i + 1];
+		for (int q = rb; q < re; ++q) where[h.positions[q]] = q;
+		int q = rb;
+		for (; q < re && h.positions[q] < i; ++q) {
+			const int k = h.positions[q];
+			const T lik = lu[q] * pivotInv[k];
+			lu[q] = lik;
+			for (int u = h.start[k + 1] - 1; u >= h.start[k] && h.positions[u] > k; --u) {
+				const int target = where[h.positions[u]];
+				if (target != -1) lu[target] -= lik * lu[u];
+			}
+		}
+		const bool ok = q < re && h.positions[q] == i && std::fabs(lu[q]) >= T(1e-6);
+		if (ok) pivotInv[i] = T(1.0) / lu[q];
+		for (int c = rb; c < re; ++c) where[h.positions[c]] = -1;
+		if (!ok) return false;
+	}
+	return true;
+}
+
+// IC(0): A ~ L L^T with L's values stored at A's lower positions and mirrored into the upper ones, column by
+// column like ref:1839-1928 (the rows j>i that hold column i are the columns >i of row i for a symmetric pattern).
+template <typename T>
+static bool factorIc0(const HostCsr& h, const std::vector<T>& a, std::vector<T>& ic) {
+	const int n = h.rows;
+	std::vector<int> filled(static_cast<size_t>(n), 0);
+	std::vector<int> where(static_cast<size_t>(n), -1);
+	for (int i = 0; i < n; ++i) {
+		const int rb = h.start[i], re = h.start[i + 1];
+		if (rb == re) return false;
+		for (int q = rb; q < re; ++q) where[h.positions[q]] = q;
+		T acc = T(0);
+		int dq = rb;
+		while (dq < re && h.positions[dq] < i) {
+			acc += ic[dq] * ic[dq];
+			++dq;
+		}
+		if (dq >= re || h.positions[dq] != i) return false;
+		const T under = a[dq] - acc;
+		if (!(under > T(0))) return false;
+		const T d = std::sqrt(under);
+		ic[rb + filled[i]] = d;
+		filled[i]++;
+		const T dinv = T(1) / d;
+		for (int q = dq + 1; q < re; ++q) {
+			const int j = h.positions[q];
+			const int jb = h.start[j], je = h.start[j + 1];
+			const int slot = jb + filled[j];
+			if (slot >= je || h.positions[slot] != i) continue;
+			T sum = T(0);
+			int k = jb;
+			while (k < je && h.positions[k] < i) {
+				const int mine = where[h.positions[k]];
+				if (mine != -1) sum += ic[mine] * ic[k];
+				++k;
+			}
+			const T lji = (a[k] - sum) * dinv;
+			ic[k] = lji;
+			ic[rb + filled[i]] = lji;
+			filled[i]++;
+			filled[j]++;
+		}
+		for (int q = rb; q < re; ++q) where[h.positions[q]] = -1;
+	}
+	return true;
+}
+
+struct SweepPlan {
+	// launch groups: chains of small levels, or single large levels
+	struct Group {
+		int l0, l1;
+		bool chain;
+	};
+	std::vector<Group> groups;
+	int* d_lvlPtr = nullptr;
+};
+
+static void planGroups(const std::vector<int>& lvlPtr, std::vector<SweepPlan::Group>& groups) {
+	const int nl = static_cast<int>(lvlPtr.size()) - 1;
+	int l = 0;
+	while (l < nl) {
+		const int sz = lvlPtr[l + 1] - lvlPtr[l];
+		if (sz > SMALL_LEVEL) {
+			groups.push_back({l, l + 1, false});
+			++l;
+		} else {
+			int e = l + 1;
+			while (e < nl && lvlPtr[e + 1] - lvlPtr[e] <= SMALL_LEVEL) ++e;
+			groups.push_back({l, e, true});
+			l = e;
+		}
+	}
+}
+
+}  // namespace smm
+
+// the level pointers and launch groups ride along behind the public handle
+struct smm_precond_plan {
+	smm::SweepPlan lo, up;
+};
+
+namespace smm {
+
+static std::mutex g_planMutex;
+static std::vector<std::pair<const smm_hip_precond*, smm_precond_plan*>> g_plans;
+
+static smm_precond_plan* planOf(const smm_hip_precond* M) {
+	std::lock_guard<std::mutex> lock(g_planMutex);
+	for (auto& kv : g_plans) {
+		if (kv.first == M) return kv.second;
+	}
+	return nullptr;
+}
+
+template <typename T, int MODE>
+static int runSweep(const smm_hip_precond* M, const SweepPlan& plan, const int* d_order, const std::vector<int>& lvlPtr, const T* vals, const T* rhs,
+                    T* x, const int* doneFlag, hipStream_t s) {
+	const smm_hip_csr* a = M->a;
+	for (const auto& g : plan.groups) {
+		if (g.chain) {
+			sweepChainKernel<T, MODE><<<1, SMALL_LEVEL, 0, s>>>(d_order, plan.d_lvlPtr, g.l0, g.l1, a->d_start, a->d_positions, vals, rhs, x, doneFlag);
+		} else {
+			const int begin = lvlPtr[g.l0];
+			const int count = lvlPtr[g.l1] - begin;
+			sweepLevelKernel<T, MODE><<<(count + TPB - 1) / TPB, TPB, 0, s>>>(d_order, begin, count, a->d_start, a->d_positions, vals, rhs, x, doneFlag);
+		}
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* doneFlag, hipStream_t s) {
+	if (!M || M->dtype != dtypeOf<T>()) {
+		setError("precond_apply: null handle or dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const int n = M->a->rows;
+	if (n == 0) return SMM_HIP_OK;
+	if (!rhs || !x || rhs == x) {  // assert(rhs != x), ref:1667
+		setError("precond_apply: null vector or rhs aliases x");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (M->kind == SMM_PRECOND_JACOBI) {
+		const int grid = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
+		jacobiApplyKernel<T><<<grid, TPB, 0, s>>>(n, static_cast<const T*>(M->d_values), rhs, x, doneFlag);
+		SMM_HIP_TRY(hipGetLastError());
+		return SMM_HIP_OK;
+	}
+	const smm_precond_plan* plan = planOf(M);
+	if (!plan) {
+		setError("precond_apply: preconditioner has no sweep plan");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const T* aVals = static_cast<const T*>(M->a->d_values);
+	const T* fVals = static_cast<const T*>(M->d_values);
+	switch (M->kind) {
+	case SMM_PRECOND_SGS:
+		SMM_TRY((runSweep<T, SGS_LO>(M, plan->lo, M->d_order_lo, M->lvl_ptr_lo, aVals, rhs, x, doneFlag, s)));
+		SMM_TRY((runSweep<T, SGS_UP>(M, plan->up, M->d_order_up, M->lvl_ptr_up, aVals, rhs, x, doneFlag, s)));
+		return SMM_HIP_OK;
+	case SMM_PRECOND_ILU0:
+		SMM_TRY((runSweep<T, ILU_LO>(M, plan->lo, M->d_order_lo, M->lvl_ptr_lo, fVals, rhs, x, doneFlag, s)));
+		SMM_TRY((runSweep<T, ILU_UP>(M, plan->up, M->d_order_up, M->lvl_ptr_up, fVals, rhs, x, doneFlag, s)));
+		return SMM_HIP_OK;
+	case SMM_PRECOND_IC0:
+		SMM_TRY((runSweep<T, IC_LO>(M, plan->lo, M->d_order_lo, M->lvl_ptr_lo, fVals, rhs, x, doneFlag, s)));
+		SMM_TRY((runSweep<T, IC_UP>(M, plan->up, M->d_order_up, M->lvl_ptr_up, fVals, rhs, x, doneFlag, s)));
+		return SMM_HIP_OK;
+	default:
+		setError("precond_apply: kind %d has no apply", M->kind);
+		return SMM_HIP_ERR_INVALID;
+	}
+}
+
+template int precondApplyDev<float>(const smm_hip_precond*, const float*, float*, const int*, hipStream_t);
+template int precondApplyDev<double>(const smm_hip_precond*, const double*, double*, const int*, hipStream_t);
+
+static int uploadInts(const std::vector<int>& v, int** d, hipStream_t s) {
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(d), std::max<size_t>(1, v.size()) * sizeof(int)));
+	if (!v.empty()) SMM_HIP_TRY(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s));
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int createTyped(const smm_hip_csr* a, int kind, smm_hip_precond* M) {
+	hipStream_t s = libStream();
+	const int n = a->rows;
+	if (kind == SMM_PRECOND_JACOBI) {
+		SMM_TRY(devAlloc(&M->d_values, static_cast<size_t>(std::max(1, n)) * sizeof(T)));
+		M->n_values = static_cast<size_t>(n);
+		DevBuf<int> err;
+		SMM_TRY(err.alloc(1));
+		SMM_HIP_TRY(hipMemsetAsync(err, 0, sizeof(int), s));
+		if (n) {
+			const int grid = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
+			extractDiagKernel<T><<<grid, TPB, 0, s>>>(n, a->d_start, a->d_positions, static_cast<const T*>(a->d_values), static_cast<T*>(M->d_values), err);
+		}
+		int herr = 0;
+		SMM_HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		if (herr) {
+			setError("jacobi: missing or |d|<1e-5 diagonal entry");
+			return SMM_HIP_ERR_PRECOND;
+		}
+		return SMM_HIP_OK;
+	}
+	// SGS / ILU0 / IC0: analysis on the host
+	if (a->rows != a->cols) {
+		setError("preconditioner needs a square matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a->firstActiveStart != 0 && n > 0) {  // ref:1666-1670, 1737-1739
+		setError("preconditioner: matrix has leading empty rows (firstActiveStart != 0)");
+		return SMM_HIP_ERR_PRECOND;
+	}
+	HostCsr h;
+	h.rows = n;
+	h.start.resize(static_cast<size_t>(n) + 1);
+	h.positions.resize(static_cast<size_t>(a->nnz));
+	std::vector<T> vals(static_cast<size_t>(a->nnz));
+	SMM_HIP_TRY(hipMemcpyAsync(h.start.data(), a->d_start, h.start.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+	if (a->nnz) {
+		SMM_HIP_TRY(hipMemcpyAsync(h.positions.data(), a->d_positions, h.positions.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipMemcpyAsync(vals.data(), a->d_values, vals.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+	}
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (!diagonalOk<T>(h, vals, kind == SMM_PRECOND_SGS)) {
+		setError("preconditioner: empty row, missing diagonal or |d|<1e-5");
+		return SMM_HIP_ERR_PRECOND;
+	}
+	if (kind == SMM_PRECOND_ILU0) {
+		std::vector<T> lu(vals);
+		if (!factorIlu0<T>(h, lu)) {
+			setError("ilu0: zero / missing pivot (reordering would be needed, ref:1741-1746)");
+			return SMM_HIP_ERR_PRECOND;
+		}
+		SMM_TRY(devAlloc(&M->d_values, std::max<size_t>(1, lu.size()) * sizeof(T)));
+		M->n_values = lu.size();
+		if (!lu.empty()) SMM_HIP_TRY(hipMemcpyAsync(M->d_values, lu.data(), lu.size() * sizeof(T), hipMemcpyHostToDevice, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	} else if (kind == SMM_PRECOND_IC0) {
+		std::vector<T> ic(vals.size(), T(0));
+		if (!factorIc0<T>(h, vals, ic)) {
+			setError("ic0: matrix is not symmetric positive definite on its pattern (ref:1871-1878)");
+			return SMM_HIP_ERR_PRECOND;
+		}
+		SMM_TRY(devAlloc(&M->d_values, std::max<size_t>(1, ic.size()) * sizeof(T)));
+		M->n_values = ic.size();
+		if (!ic.empty()) SMM_HIP_TRY(hipMemcpyAsync(M->d_values, ic.data(), ic.size() * sizeof(T), hipMemcpyHostToDevice, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
+	std::vector<int> orderLo, orderUp;
+	buildLevels(h, true, orderLo, M->lvl_ptr_lo);
+	buildLevels(h, false, orderUp, M->lvl_ptr_up);
+	SMM_TRY(uploadInts(orderLo, &M->d_order_lo, s));
+	SMM_TRY(uploadInts(orderUp, &M->d_order_up, s));
+	auto* plan = new smm_precond_plan();
+	planGroups(M->lvl_ptr_lo, plan->lo.groups);
+	planGroups(M->lvl_ptr_up, plan->up.groups);
+	int st = uploadInts(M->lvl_ptr_lo, &plan->lo.d_lvlPtr, s);
+	if (st == SMM_HIP_OK) st = uploadInts(M->lvl_ptr_up, &plan->up.d_lvlPtr, s);
+	if (st != SMM_HIP_OK) {
+		delete plan;
+		return st;
+	}
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	std::lock_guard<std::mutex> lock(g_planMutex);
+	g_plans.emplace_back(M, plan);
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int applyHost(const smm_hip_precond* M, const T* rhs, T* x) {
+	if (!M) {
+		setError("precond_apply: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	const int n = M->a->rows;
+	if (n > 0 && (!rhs || !x || rhs == x)) {
+		setError("precond_apply: null vector or rhs aliases x");
+		return SMM_HIP_ERR_INVALID;
+	}
+	hipStream_t s = libStream();
+	DevBuf<T> dr, dx;
+	SMM_TRY(dr.alloc(n));
+	SMM_TRY(dx.alloc(n));
+	if (n) SMM_HIP_TRY(hipMemcpyAsync(dr, rhs, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	SMM_TRY(precondApplyDev<T>(M, dr, dx, nullptr, s));
+	if (n) SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int valuesHost(const smm_hip_precond* M, T* out, size_t count) {
+	if (!M || M->dtype != dtypeOf<T>() || !out) {
+		setError("precond_values: null handle / dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (!M->d_values || count > M->n_values) {
+		setError("precond_values: this preconditioner holds %zu values", M->n_values);
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	hipStream_t s = libStream();
+	if (count) SMM_HIP_TRY(hipMemcpyAsync(out, M->d_values, count * sizeof(T), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
+}
+
+}  // namespace smm
+
+using namespace smm;
+
+extern "C" {
+
+int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out) {
+	if (!a || !out) {
+		setError("precond_create: null argument");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*out = nullptr;
+	if (kind < SMM_PRECOND_NONE || kind > SMM_PRECOND_IC0) {
+		setError("precond_create: unknown kind %d", kind);
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	auto* M = new smm_hip_precond();
+	M->kind = kind;
+	M->dtype = a->dtype;
+	M->a = a;
+	int st = SMM_HIP_OK;
+	if (kind != SMM_PRECOND_NONE) {
+		st = a->dtype == SMM_DTYPE_F32 ? createTyped<float>(a, kind, M) : createTyped<double>(a, kind, M);
+	}
+	if (st != SMM_HIP_OK) {
+		smm_hip_precond_destroy(M);
+		return st;
+	}
+	*out = M;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_destroy(smm_hip_precond* M) {
+	if (!M) return SMM_HIP_OK;
+	smm_precond_plan* plan = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(g_planMutex);
+		for (size_t i = 0; i < g_plans.size(); ++i) {
+			if (g_plans[i].first == M) {
+				plan = g_plans[i].second;
+				g_plans.erase(g_plans.begin() + static_cast<long>(i));
+				break;
+			}
+		}
+	}
+	if (plan) {
+		devFree(plan->lo.d_lvlPtr);
+		devFree(plan->up.d_lvlPtr);
+		delete plan;
+	}
+	devFree(M->d_values);
+	devFree(M->d_order_lo);
+	devFree(M->d_order_up);
+	delete M;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower, int* levels_upper) {
+	if (!M) {
+		setError("precond_info: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (kind) *kind = M->kind;
+	if (levels_lower) *levels_lower = M->lvl_ptr_lo.empty() ? 0 : static_cast<int>(M->lvl_ptr_lo.size()) - 1;
+	if (levels_upper) *levels_upper = M->lvl_ptr_up.empty() ? 0 : static_cast<int>(M->lvl_ptr_up.size()) - 1;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_apply_f32(const smm_hip_precond* M, const float* rhs, float* x) { return applyHost<float>(M, rhs, x); }
+int smm_hip_precond_apply_f64(const smm_hip_precond* M, const double* rhs, double* x) { return applyHost<double>(M, rhs, x); }
+int smm_hip_precond_apply_dev_f32(const smm_hip_precond* M, const float* d_rhs, float* d_x, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return precondApplyDev<float>(M, d_rhs, d_x, nullptr, pickStream(stream));
+}
+int smm_hip_precond_apply_dev_f64(const smm_hip_precond* M, const double* d_rhs, double* d_x, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return precondApplyDev<double>(M, d_rhs, d_x, nullptr, pickStream(stream));
+}
+int smm_hip_precond_values_f32(const smm_hip_precond* M, float* out, size_t count) { return valuesHost<float>(M, out, count); }
+int smm_hip_precond_values_f64(const smm_hip_precond* M, double* out, size_t count) { return valuesHost<double>(M, out, count); }
+
+}  // extern "C"

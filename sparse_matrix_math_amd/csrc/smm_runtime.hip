@@ -1,0 +1,298 @@
+// smm_runtime.hip -- device selection, error text, library stream, caching allocator, CSR handles.
+#include <cstdarg>
+#include <map>
+
+#include "smm_internal.h"
+
+namespace smm {
+
+static thread_local std::string g_lastError;
+static std::mutex g_mutex;
+static bool g_inited = false;
+static int g_device = -1;
+static int g_cus = 0;
+static hipStream_t g_stream = nullptr;
+
+void setError(const char* fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_lastError = buf;
+}
+
+int hipFail(hipError_t e, const char* what, const char* file, int line) {
+	setError("HIP error %d (%s) at %s:%d in `%s`", static_cast<int>(e), hipGetErrorString(e), file, line, what);
+	return e == hipErrorOutOfMemory ? SMM_HIP_ERR_NOMEM : SMM_HIP_ERR_HIP;
+}
+
+static int initLocked(int device) {
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		setError("no HIP device available (hipGetDeviceCount -> %d, count %d); libsmm_hip has no CPU fallback", static_cast<int>(e), count);
+		return SMM_HIP_ERR_NO_DEVICE;
+	}
+	if (device < 0 || device >= count) {
+		setError("device %d out of range (0..%d)", device, count - 1);
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (g_inited && device == g_device) {
+		return SMM_HIP_OK;
+	}
+	SMM_HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	SMM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+	g_cus = prop.multiProcessorCount;
+	if (g_stream) {
+		hipStreamDestroy(g_stream);
+		g_stream = nullptr;
+	}
+	SMM_HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+	g_device = device;
+	g_inited = true;
+	return SMM_HIP_OK;
+}
+
+int ensureInit() {
+	std::lock_guard<std::mutex> lock(g_mutex);
+	if (g_inited) {
+		// another thread / torch may have switched the current device
+		hipError_t e = hipSetDevice(g_device);
+		if (e != hipSuccess) return hipFail(e, "hipSetDevice", __FILE__, __LINE__);
+		return SMM_HIP_OK;
+	}
+	int dev = 0;
+	if (const char* env = getenv("SMM_HIP_DEVICE")) dev = atoi(env);
+	return initLocked(dev);
+}
+
+hipStream_t libStream() { return g_stream; }
+int numCUs() { return g_cus > 0 ? g_cus : 256; }
+
+// ---- caching allocator: free blocks keyed by size, reused exactly --------------------------------------
+static std::mutex g_allocMutex;
+static std::multimap<size_t, void*> g_free;
+static std::map<void*, size_t> g_live;
+
+int devAlloc(void** p, size_t bytes) {
+	bytes = (bytes + 255) & ~static_cast<size_t>(255);
+	{
+		std::lock_guard<std::mutex> lock(g_allocMutex);
+		auto it = g_free.find(bytes);
+		if (it != g_free.end()) {
+			*p = it->second;
+			g_free.erase(it);
+			g_live[*p] = bytes;
+			return SMM_HIP_OK;
+		}
+	}
+	hipError_t e = hipMalloc(p, bytes);
+	if (e == hipErrorOutOfMemory) {
+		devTrim();
+		e = hipMalloc(p, bytes);
+	}
+	if (e != hipSuccess) {
+		*p = nullptr;
+		return hipFail(e, "hipMalloc", __FILE__, __LINE__);
+	}
+	std::lock_guard<std::mutex> lock(g_allocMutex);
+	g_live[*p] = bytes;
+	return SMM_HIP_OK;
+}
+
+void devFree(void* p) {
+	if (!p) return;
+	std::lock_guard<std::mutex> lock(g_allocMutex);
+	auto it = g_live.find(p);
+	if (it == g_live.end()) {
+		hipFree(p);
+		return;
+	}
+	g_free.emplace(it->second, p);
+	g_live.erase(it);
+}
+
+void devTrim() {
+	std::lock_guard<std::mutex> lock(g_allocMutex);
+	for (auto& kv : g_free) hipFree(kv.second);
+	g_free.clear();
+}
+
+// number of leading rows without entries = firstActiveStart (ref:1619-1628): start[] is non-decreasing, so
+// it is the count of i in [0,rows) with start[i+1] == 0
+__global__ void countLeadingEmpty(int rows, const int* __restrict__ start, int* __restrict__ out) {
+	int local = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+		local += start[i + 1] == 0 ? 1 : 0;
+	}
+	if (local) atomicAdd(out, local);
+}
+
+static int finishCsr(smm_hip_csr* m) {
+	hipStream_t s = libStream();
+	int* d_cnt = nullptr;
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_cnt), sizeof(int)));
+	SMM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), s));
+	int nnz = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&nnz, m->d_start + m->rows, sizeof(int), hipMemcpyDeviceToHost, s));
+	if (m->rows > 0) {
+		const int grid = std::min(1024, (m->rows + 255) / 256);
+		countLeadingEmpty<<<grid, 256, 0, s>>>(m->rows, m->d_start, d_cnt);
+	}
+	int first = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&first, d_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	devFree(d_cnt);
+	m->nnz = nnz;
+	m->firstActiveStart = first;
+	chooseSpmvConfig(m);
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int csrCreate(int rows, int cols, const int* start, const int* positions, const T* values, bool onDevice, smm_hip_csr** out) {
+	if (!out) {
+		setError("csr_create: out is null");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*out = nullptr;
+	if (rows < 0 || cols < 0 || !start) {
+		setError("csr_create: bad shape or null start");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	auto* m = new smm_hip_csr();
+	m->rows = rows;
+	m->cols = cols;
+	m->dtype = dtypeOf<T>();
+	if (onDevice) {
+		m->d_start = const_cast<int*>(start);
+		m->d_positions = const_cast<int*>(positions);
+		m->d_values = const_cast<T*>(values);
+		m->owns = false;
+	} else {
+		const int nnz = start[rows];
+		if (nnz < 0 || (nnz > 0 && (!positions || !values))) {
+			delete m;
+			setError("csr_create: start[rows] negative or null positions/values");
+			return SMM_HIP_ERR_INVALID;
+		}
+		m->owns = true;
+		int st = devAlloc(reinterpret_cast<void**>(&m->d_start), (static_cast<size_t>(rows) + 1) * sizeof(int));
+		if (st == SMM_HIP_OK) st = devAlloc(reinterpret_cast<void**>(&m->d_positions), static_cast<size_t>(nnz ? nnz : 1) * sizeof(int));
+		if (st == SMM_HIP_OK) st = devAlloc(&m->d_values, static_cast<size_t>(nnz ? nnz : 1) * sizeof(T));
+		if (st != SMM_HIP_OK) {
+			smm_hip_csr_destroy(m);
+			return st;
+		}
+		hipStream_t s = libStream();
+		hipError_t e = hipMemcpyAsync(m->d_start, start, (static_cast<size_t>(rows) + 1) * sizeof(int), hipMemcpyHostToDevice, s);
+		if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->d_positions, positions, static_cast<size_t>(nnz) * sizeof(int), hipMemcpyHostToDevice, s);
+		if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->d_values, values, static_cast<size_t>(nnz) * sizeof(T), hipMemcpyHostToDevice, s);
+		if (e == hipSuccess) e = hipStreamSynchronize(s);
+		if (e != hipSuccess) {
+			smm_hip_csr_destroy(m);
+			return hipFail(e, "csr upload", __FILE__, __LINE__);
+		}
+	}
+	const int st = finishCsr(m);
+	if (st != SMM_HIP_OK) {
+		smm_hip_csr_destroy(m);
+		return st;
+	}
+	*out = m;
+	return SMM_HIP_OK;
+}
+
+}  // namespace smm
+
+using namespace smm;
+
+extern "C" {
+
+int smm_hip_init(int device) {
+	std::lock_guard<std::mutex> lock(g_mutex);
+	return initLocked(device);
+}
+
+int smm_hip_shutdown(void) {
+	std::lock_guard<std::mutex> lock(g_mutex);
+	if (!g_inited) return SMM_HIP_OK;
+	hipDeviceSynchronize();
+	devTrim();
+	if (g_stream) hipStreamDestroy(g_stream);
+	g_stream = nullptr;
+	g_inited = false;
+	g_device = -1;
+	return SMM_HIP_OK;
+}
+
+const char* smm_hip_last_error(void) { return g_lastError.c_str(); }
+
+int smm_hip_uses_std_fma(void) {
+#ifdef SMM_WITH_STD_FMA
+	return 1;
+#else
+	return 0;
+#endif
+}
+
+int smm_hip_device_info(char* name, size_t name_cap, int* cus, size_t* hbm_bytes) {
+	SMM_TRY(ensureInit());
+	hipDeviceProp_t prop;
+	SMM_HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+	if (name && name_cap) {
+		snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+	}
+	if (cus) *cus = prop.multiProcessorCount;
+	if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_stream_synchronize(smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	SMM_HIP_TRY(hipStreamSynchronize(pickStream(stream)));
+	return SMM_HIP_OK;
+}
+
+int smm_hip_csr_create_f32(int rows, int cols, const int* start, const int* positions, const float* values, smm_hip_csr** out) {
+	return csrCreate<float>(rows, cols, start, positions, values, false, out);
+}
+int smm_hip_csr_create_f64(int rows, int cols, const int* start, const int* positions, const double* values, smm_hip_csr** out) {
+	return csrCreate<double>(rows, cols, start, positions, values, false, out);
+}
+int smm_hip_csr_create_dev_f32(int rows, int cols, const int* d_start, const int* d_positions, const float* d_values, smm_hip_csr** out) {
+	return csrCreate<float>(rows, cols, d_start, d_positions, d_values, true, out);
+}
+int smm_hip_csr_create_dev_f64(int rows, int cols, const int* d_start, const int* d_positions, const double* d_values, smm_hip_csr** out) {
+	return csrCreate<double>(rows, cols, d_start, d_positions, d_values, true, out);
+}
+
+int smm_hip_csr_destroy(smm_hip_csr* m) {
+	if (!m) return SMM_HIP_OK;
+	if (m->owns) {
+		devFree(m->d_start);
+		devFree(m->d_positions);
+		devFree(m->d_values);
+	}
+	devFree(m->d_rowblocks);
+	delete m;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_csr_info(const smm_hip_csr* m, int* rows, int* cols, int* nnz, int* dtype, int* first_active_start) {
+	if (!m) {
+		setError("csr_info: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (rows) *rows = m->rows;
+	if (cols) *cols = m->cols;
+	if (nnz) *nnz = m->nnz;
+	if (dtype) *dtype = m->dtype;
+	if (first_active_start) *first_active_start = m->firstActiveStart;
+	return SMM_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,775 @@
+// smm_solvers.hip -- device-resident Krylov loops: ConjugateGradient (ref:2316-2398, IC0 overload ref:2414-2505),
+// BiCGStab (ref:2191-2303), BiCGSymmetric (ref:2021-2102).
+//
+// Design (MI355X-first, not a translation of the CPU loop):
+//   * every vector and every scalar (alpha, beta, omega, ||r||^2, the convergence flag, the iteration count)
+//     lives in HBM; the host only enqueues kernels.  No per-iteration host round trip: the host peeks at the
+//     `done` flag through a pinned mailbox every few iterations, and every kernel of the loop starts by testing
+//     the flag, so iterations enqueued past convergence are no-ops and x / iterations / status are exactly
+//     those of the iteration at which the reference would have returned.
+//   * the dot products that follow an SpMV are fused into the SpMV epilogue (p.Ap; ap.r0; as.as + as.s), the
+//     ||r||^2 and r.r0 sums are fused into the x/r update, exactly the fusions the reference's serial loops
+//     do (ref:2371-2375, 2263-2267) plus the SpMV ones.  Partial sums are combined in a fixed order.
+//   * update loops keep the reference's expression shapes (_smm_fma nesting), so given the same scalars they
+//     are bit-identical to the CPU loops.
+#include <algorithm>
+#include <cmath>
+
+#include "smm_device.h"
+#include "smm_internal.h"
+
+namespace smm {
+
+constexpr int TPB = 256;
+
+template <typename T>
+struct Scal {
+	T rr;       // CG: residualNormSquared / rz for PCG ; BiCGStab: rr0
+	T denom;    // p.Ap / ap.r0
+	T alpha;
+	T beta;
+	T omega;
+	T res;      // CG: last ||r||^2 ; BiCGStab: last ||r||
+	T rrOld;    // BiCGSymmetric rSquare before the update
+	T epsv;
+	int done;
+	int iters;
+	int status;
+	int pad;
+};
+
+template <typename T>
+__device__ __forceinline__ T sumParts(const T* __restrict__ partials, T* red) {
+	T acc = T(0);
+	for (int i = threadIdx.x; i < NPART; i += TPB) acc += partials[i];
+	return blockSum256(acc, red);
+}
+
+// ---- scalar stages (one workgroup each) ----------------------------------------------------------------
+// CG start: rr = r.r ; if eps^2 > rr -> done, SUCCESS, x untouched (ref:2341-2344)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgInitScal(const T* __restrict__ partials, Scal<T>* sc, T eps, int pcg, const T* __restrict__ partials2) {
+	__shared__ T red[4];
+	const T rr = sumParts(partials, red);
+	T rz = T(0);
+	if (pcg) rz = sumParts(partials2, red);
+	if (threadIdx.x == 0) {
+		sc->rr = pcg ? rz : rr;
+		sc->res = rr;
+		sc->iters = 0;
+		sc->status = SMM_SOLVER_MAX_ITERATIONS_REACHED;
+		sc->done = 0;
+		if (eps * eps > rr) {
+			sc->done = 1;
+			sc->status = SMM_SOLVER_SUCCESS;
+		}
+	}
+}
+
+// alpha = rr / (Ap.p)  (ref:2354-2358)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgAlphaScal(const T* __restrict__ partials, Scal<T>* sc) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T pAp = sumParts(partials, red);
+	if (threadIdx.x == 0) {
+		sc->denom = pAp;
+		sc->alpha = sc->rr / pAp;
+	}
+}
+
+// after the x/r update: convergence test, beta (ref:2377-2382); for PCG partials hold r.r and partials2 r.z (ref:2483-2488)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgBetaScal(const T* __restrict__ partials, const T* __restrict__ partials2, Scal<T>* sc, T eps, int pcg) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T rrNew = sumParts(partials, red);
+	T rzNew = T(0);
+	if (pcg) rzNew = sumParts(partials2, red);
+	if (threadIdx.x == 0) {
+		sc->iters += 1;
+		sc->res = rrNew;
+		if (eps * eps > rrNew) {
+			sc->done = 1;
+			sc->status = SMM_SOLVER_SUCCESS;
+		} else if (pcg) {
+			sc->beta = rzNew / sc->rr;
+			sc->rr = rzNew;
+		} else {
+			sc->beta = rrNew / sc->rr;
+			sc->rr = rrNew;
+		}
+	}
+}
+
+// ---- vector stages -------------------------------------------------------------------------------------
+// x = alpha p + xcur ; r = -alpha Ap + r ; partial ||r||^2   (ref:2371-2375)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ p, const T* __restrict__ Ap,
+                                                  const T* xcur, T* x, T* __restrict__ r, T* __restrict__ partials, int wantNorm) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T alpha = sc->alpha;
+	T acc = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		x[i] = smmFma(alpha, p[i], xcur[i]);
+		const T ri = smmFma(-alpha, Ap[i], r[i]);
+		r[i] = ri;
+		acc += ri * ri;
+	}
+	if (wantNorm) {
+		const T s = blockSum256(acc, red);
+		if (threadIdx.x == 0) partials[blockIdx.x] = s;
+	}
+}
+
+// p = beta p + z   (ref:2391-2393 with z = r; ref:2497-2499 with z = M^-1 r)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgUpdateP(int n, const Scal<T>* __restrict__ sc, T* __restrict__ p, const T* __restrict__ z) {
+	if (sc->done) return;
+	const T beta = sc->beta;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		p[i] = smmFma(beta, p[i], z[i]);
+	}
+}
+
+// two dot products that share an operand: partials = a.a, partials2 = a.b
+template <typename T>
+__global__ __launch_bounds__(TPB) void dot2Partials(int n, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ partials,
+                                                    T* __restrict__ partials2, const int* __restrict__ doneFlag) {
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	T acc0 = T(0), acc1 = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const T ai = a[i];
+		acc0 += ai * ai;
+		acc1 += ai * b[i];
+	}
+	const T s0 = blockSum256(acc0, red);
+	const T s1 = blockSum256(acc1, red);
+	if (threadIdx.x == 0) {
+		partials[blockIdx.x] = s0;
+		partials2[blockIdx.x] = s1;
+	}
+}
+
+// ---- BiCGStab stages -----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgInitScal(const T* __restrict__ partials, Scal<T>* sc) {
+	__shared__ T red[4];
+	const T rr0 = sumParts(partials, red);  // ref:2231
+	if (threadIdx.x == 0) {
+		sc->rr = rr0;
+		sc->res = T(0);
+		sc->iters = 0;
+		sc->done = 0;
+		sc->status = SMM_SOLVER_SUCCESS;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgAlphaScal(const T* __restrict__ partials, Scal<T>* sc) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T denom = sumParts(partials, red);  // ap.r0, ref:2243
+	if (threadIdx.x == 0) {
+		sc->denom = denom;
+		sc->alpha = sc->rr / denom;  // ref:2244
+	}
+}
+
+// s = -alpha ap + r   (ref:2245-2247)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgUpdateS(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ ap, const T* __restrict__ r,
+                                                   T* __restrict__ sv) {
+	if (sc->done) return;
+	const T alpha = sc->alpha;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		sv[i] = smmFma(-alpha, ap[i], r[i]);
+	}
+}
+
+// omega = (as.s) / (as.as)   (ref:2259-2261); partials = as.as, partials2 = as.s
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgOmegaScal(const T* __restrict__ partials, const T* __restrict__ partials2, Scal<T>* sc) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T asas = sumParts(partials, red);
+	const T ass = sumParts(partials2, red);
+	if (threadIdx.x == 0) {
+		sc->omega = ass / asas;
+	}
+}
+
+// x = alpha p + (omega s + x) ; r = -omega as + s ; partial ||r||^2 and r.r0   (ref:2263-2269)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ p, const T* __restrict__ sv,
+                                                    const T* __restrict__ as, const T* __restrict__ r0, T* __restrict__ x, T* __restrict__ r,
+                                                    T* __restrict__ partials, T* __restrict__ partials2) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T alpha = sc->alpha;
+	const T omega = sc->omega;
+	T acc0 = T(0), acc1 = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const T si = sv[i];
+		x[i] = smmFma(alpha, p[i], smmFma(omega, si, x[i]));
+		const T ri = smmFma(-omega, as[i], si);
+		r[i] = ri;
+		acc0 += ri * ri;
+		acc1 += ri * r0[i];
+	}
+	const T s0 = blockSum256(acc0, red);
+	const T s1 = blockSum256(acc1, red);
+	if (threadIdx.x == 0) {
+		partials[blockIdx.x] = s0;
+		partials2[blockIdx.x] = s1;
+	}
+}
+
+// resL2Norm, beta, loop condition (ref:2268-2277)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgBetaScal(const T* __restrict__ partials, const T* __restrict__ partials2, Scal<T>* sc, T eps) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T rr = sumParts(partials, red);
+	const T newRR0 = sumParts(partials2, red);
+	if (threadIdx.x == 0) {
+		const T res = sizeof(T) == 4 ? static_cast<T>(__fsqrt_rn(static_cast<float>(rr))) : static_cast<T>(__dsqrt_rn(static_cast<double>(rr)));
+		sc->res = res;
+		sc->beta = (newRR0 * sc->alpha) / (sc->rr * sc->omega);  // ref:2271
+		sc->rr = newRR0;
+		sc->iters += 1;
+		if (!(res > eps)) sc->done = 1;  // while (resL2Norm > eps ...), NaN leaves the loop (ref:2277)
+	}
+}
+
+// p = beta (-omega ap + p) + r   (ref:2272-2274)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgUpdateP(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ ap, const T* __restrict__ r,
+                                                   T* __restrict__ p) {
+	if (sc->done) return;
+	const T beta = sc->beta;
+	const T omega = sc->omega;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		p[i] = smmFma(beta, smmFma(-omega, ap[i], p[i]), r[i]);
+	}
+}
+
+// ---- BiCGSymmetric stages (ref:2021-2102) ----------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(TPB) void bsymInitScal(const T* __restrict__ partials, Scal<T>* sc) {
+	__shared__ T red[4];
+	const T rr = sumParts(partials, red);  // ref:2043
+	if (threadIdx.x == 0) {
+		sc->rr = rr;
+		sc->iters = 0;
+		sc->done = 0;
+		sc->status = SMM_SOLVER_SUCCESS;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bsymAlphaScal(const T* __restrict__ partials, Scal<T>* sc, T eps) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T denom = sumParts(partials, red);
+	if (threadIdx.x == 0) {
+		if (eps > (denom < T(0) ? -denom : denom) && sc->rr > T(1)) {  // ref:2056-2058
+			sc->done = 1;
+			sc->status = SMM_SOLVER_DIVERGED;
+		} else {
+			sc->alpha = sc->rr / denom;
+		}
+	}
+}
+
+// x += alpha p ; r -= alpha ap  (ref:2068-2071: plain += / -= forms, not _smm_fma)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bsymUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ p, const T* __restrict__ ap,
+                                                    T* __restrict__ x, T* __restrict__ r, T* __restrict__ partials) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T alpha = sc->alpha;
+	T acc = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const T pa = alpha * p[i];
+		x[i] = x[i] + pa;
+		const T qa = alpha * ap[i];
+		const T ri = r[i] - qa;
+		r[i] = ri;
+		acc += ri * ri;
+	}
+	const T s = blockSum256(acc, red);
+	if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bsymBetaScal(const T* __restrict__ partials, Scal<T>* sc, T eps) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T newRR = sumParts(partials, red);  // ref:2075
+	if (threadIdx.x == 0) {
+		if (newRR > T(1) && sc->rr < eps) {  // ref:2079-2081
+			sc->done = 1;
+			sc->status = SMM_SOLVER_DIVERGED;
+		} else {
+			sc->beta = newRR / sc->rr;
+			sc->rr = newRR;
+			sc->iters += 1;
+			if (!(newRR > eps * eps)) sc->done = 1;  // ref:2096
+		}
+	}
+}
+
+// p = r + beta p  (ref:2090-2092)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bsymUpdateP(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ r, T* __restrict__ p) {
+	if (sc->done) return;
+	const T beta = sc->beta;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const T bp = beta * p[i];
+		p[i] = r[i] + bp;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------------------------------------
+static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, NPART))); }
+
+// Polls the device `done` flag without stalling the queue: every `interval` iterations the flag is copied into a
+// pinned mailbox behind an event; the host reads mailboxes whose event has completed and waits only when more
+// than two are outstanding.
+struct DonePoller {
+	static constexpr int SLOTS = 4;
+	int* mailbox = nullptr;
+	hipEvent_t ev[SLOTS] = {};
+	bool pending[SLOTS] = {};
+	int head = 0, count = 0;
+	hipStream_t s = nullptr;
+	int init(hipStream_t stream) {
+		s = stream;
+		SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&mailbox), SLOTS * sizeof(int), hipHostMallocDefault));
+		for (int i = 0; i < SLOTS; ++i) {
+			mailbox[i] = 0;
+			SMM_HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+		}
+		return SMM_HIP_OK;
+	}
+	~DonePoller() {
+		for (int i = 0; i < SLOTS; ++i) {
+			if (ev[i]) hipEventDestroy(ev[i]);
+		}
+		if (mailbox) hipHostFree(mailbox);
+	}
+	// returns 1 when a completed check saw done, 0 otherwise, <0 on error
+	int post(const int* d_done) {
+		int seen = 0;
+		if (count == SLOTS - 1) seen = drain(true);
+		if (seen) return seen;
+		const int slot = (head + count) % SLOTS;
+		SMM_HIP_TRY(hipMemcpyAsync(&mailbox[slot], d_done, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipEventRecord(ev[slot], s));
+		pending[slot] = true;
+		++count;
+		return drain(false);
+	}
+	int drain(bool block) {
+		while (count > 0) {
+			if (block && count >= 2) {
+				SMM_HIP_TRY(hipEventSynchronize(ev[head]));
+			} else {
+				const hipError_t q = hipEventQuery(ev[head]);
+				if (q == hipErrorNotReady) return 0;
+				if (q != hipSuccess) return hipFail(q, "hipEventQuery", __FILE__, __LINE__);
+			}
+			const int v = mailbox[head];
+			pending[head] = false;
+			head = (head + 1) % SLOTS;
+			--count;
+			if (v) return 1;
+		}
+		return 0;
+	}
+};
+
+static int checkInterval(int it) { return std::max(4, std::min(64, it / 4)); }
+
+template <typename T>
+static int readScal(const Scal<T>* d_sc, Scal<T>* h, hipStream_t s) {
+	SMM_HIP_TRY(hipMemcpyAsync(h, d_sc, sizeof(Scal<T>), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations, T eps, const smm_hip_precond* M, hipStream_t s, int* status,
+          int* iterations, T* resnorm2) {
+	if (!a || a->dtype != dtypeOf<T>()) {
+		setError("cg: null matrix or dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a->rows != a->cols) {
+		setError("cg: matrix must be square");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const int pcg = M != nullptr;
+	if (pcg && (M->kind != SMM_PRECOND_IC0 || M->a != a)) {
+		// the reference only has the IC0 overload (ref:2414-2422)
+		setError("cg: preconditioner must be an IC0 preconditioner created for this matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const int n = a->rows;
+	if (n > 0 && (!b || !x0 || !x)) {
+		setError("cg: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	DevBuf<T> r, p, Ap, z, parts, parts2;
+	DevBuf<Scal<T>> sc;
+	SMM_TRY(r.alloc(n));
+	SMM_TRY(p.alloc(n));
+	SMM_TRY(Ap.alloc(n));
+	if (pcg) SMM_TRY(z.alloc(n));
+	SMM_TRY(parts.alloc(2 * NPART));
+	SMM_TRY(parts2.alloc(NPART));
+	SMM_TRY(sc.alloc(1));
+	const int g = gridFor(n);
+
+	SMM_TRY(launchSpmv<T>(a, SMM_OP_SUB, b, x0, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
+	if (pcg) {
+		SMM_TRY(precondApplyDev<T>(M, r, z, nullptr, s));           // z = M^-1 r, ref:2441
+		SMM_TRY(launchCopy2<T>(n, z, p, nullptr, s));               // p = z, ref:2447
+		SMM_TRY(launchDotPartials<T>(n, r, r, parts, nullptr, s));  // ||r||^2
+		SMM_TRY(launchDotPartials<T>(n, r, z, parts2, nullptr, s)); // r.z
+	} else {
+		SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));               // p = r, ref:2340
+		SMM_TRY(launchDotPartials<T>(n, r, r, parts, nullptr, s));  // ref:2341
+	}
+	cgInitScal<T><<<1, TPB, 0, s>>>(parts, sc, eps, pcg, parts2);
+	if (maxIterations == -1) maxIterations = n;  // ref:2345-2347 (no clamp otherwise)
+
+	DonePoller poller;
+	SMM_TRY(poller.init(s));
+	int seenDone = 0;
+	int nextCheck = 0;
+	const int* doneFlag = &sc.p->done;
+	for (int i = 0; i < maxIterations && !seenDone; ++i) {
+		if (i == nextCheck) {
+			seenDone = poller.post(doneFlag);
+			if (seenDone < 0) return seenDone;
+			if (seenDone) break;
+			nextCheck = i + checkInterval(i);
+		}
+		// Ap = A p with the p.Ap partial sums fused into the epilogue (ref:2353-2354)
+		SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, Ap, 1, p, parts, doneFlag, s));
+		cgAlphaScal<T><<<1, TPB, 0, s>>>(parts, sc);
+		const T* xcur = i == 0 ? x0 : x;  // ref:2351, 2395
+		// NPART workgroups: every partial slot is (re)written each iteration, idle workgroups write 0
+		cgUpdateXR<T><<<NPART, TPB, 0, s>>>(n, sc, p, Ap, xcur, x, r, parts, pcg ? 0 : 1);
+		if (pcg) {
+			SMM_TRY(precondApplyDev<T>(M, r, z, doneFlag, s));         // ref:2482
+			dot2Partials<T><<<NPART, TPB, 0, s>>>(n, r, z, parts, parts2, doneFlag);  // r.r and r.z, ref:2483-2484
+			cgBetaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc, eps, 1);
+			cgUpdateP<T><<<g, TPB, 0, s>>>(n, sc, p, z);
+		} else {
+			cgBetaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc, eps, 0);
+			cgUpdateP<T><<<g, TPB, 0, s>>>(n, sc, p, r);
+		}
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	Scal<T> h;
+	SMM_TRY(readScal<T>(sc, &h, s));
+	if (status) *status = h.status;
+	if (iterations) *iterations = h.iters;
+	if (resnorm2) *resnorm2 = h.res;
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const smm_hip_precond* M, hipStream_t s, int* status,
+                int* iterations, T* resnorm) {
+	if (!a || a->dtype != dtypeOf<T>()) {
+		setError("bicgstab: null matrix or dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a->rows != a->cols) {
+		setError("bicgstab: matrix must be square");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const bool precondition = M != nullptr && M->kind != SMM_PRECOND_NONE;  // ref:2209
+	if (precondition && (M->a != a || M->kind == SMM_PRECOND_IC0)) {
+		setError("bicgstab: preconditioner must be JACOBI / ILU0 / SGS created for this matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const int n = a->rows;
+	if (n > 0 && (!b || !x)) {
+		setError("bicgstab: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	maxIterations = std::min(maxIterations, n);  // ref:2200
+	if (maxIterations == -1) maxIterations = n;  // ref:2201-2203
+	DevBuf<T> r, r0, p, ap, sv, as, scratch, parts, parts2;
+	DevBuf<Scal<T>> sc;
+	SMM_TRY(r.alloc(n));
+	SMM_TRY(r0.alloc(n));
+	SMM_TRY(p.alloc(n));
+	SMM_TRY(ap.alloc(n));
+	SMM_TRY(sv.alloc(n));
+	SMM_TRY(as.alloc(n));
+	if (precondition) SMM_TRY(scratch.alloc(n));
+	SMM_TRY(parts.alloc(2 * NPART));
+	SMM_TRY(parts2.alloc(NPART));
+	SMM_TRY(sc.alloc(1));
+	const int g = NPART;  // update kernels that write partials use the full partial grid
+
+	if (precondition) {
+		SMM_TRY(launchSpmv<T>(a, SMM_OP_SUB, b, x, scratch, 0, nullptr, nullptr, nullptr, s));  // ref:2215
+		SMM_TRY(precondApplyDev<T>(M, scratch, r, nullptr, s));                                  // ref:2217-2224
+	} else {
+		SMM_TRY(launchSpmv<T>(a, SMM_OP_SUB, b, x, r, 0, nullptr, nullptr, nullptr, s));
+	}
+	SMM_TRY(launchCopy2<T>(n, r, r0, p, s));                     // ref:2225-2226
+	SMM_TRY(launchDotPartials<T>(n, r, r0, parts, nullptr, s));  // ref:2231
+	bicgInitScal<T><<<1, TPB, 0, s>>>(parts, sc);
+
+	DonePoller poller;
+	SMM_TRY(poller.init(s));
+	const int* doneFlag = &sc.p->done;
+	const int planned = std::max(1, maxIterations);  // do { } while: the body always runs once (ref:2232, 2277)
+	int nextCheck = 1;
+	for (int i = 0; i < planned; ++i) {
+		if (i == nextCheck) {
+			const int seen = poller.post(doneFlag);
+			if (seen < 0) return seen;
+			if (seen) break;
+			nextCheck = i + checkInterval(i);
+		}
+		if (precondition) {
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
+			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));                                          // ref:2235
+			SMM_TRY(launchDotPartials<T>(n, ap, r0, parts, doneFlag, s));                                      // ref:2243
+		} else {
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, ap, 1, r0, parts, doneFlag, s));  // ref:2240 + 2243 fused
+		}
+		bicgAlphaScal<T><<<1, TPB, 0, s>>>(parts, sc);
+		bicgUpdateS<T><<<gridFor(n), TPB, 0, s>>>(n, sc, ap, r, sv);
+		if (precondition) {
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
+			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));                                           // ref:2251
+			dot2Partials<T><<<NPART, TPB, 0, s>>>(n, as, sv, parts, parts2, doneFlag);                          // ref:2259, 2261
+			bicgOmegaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc);
+		} else {
+			// as = A s with as.as -> parts[0..NPART) and as.s -> parts[NPART..2 NPART) fused (ref:2256-2261)
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, as, 2, sv, parts, doneFlag, s));
+			bicgOmegaScal<T><<<1, TPB, 0, s>>>(parts, parts.p + NPART, sc);
+		}
+		bicgUpdateXR<T><<<g, TPB, 0, s>>>(n, sc, p, sv, as, r0, x, r, parts, parts2);
+		bicgBetaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc, eps);
+		bicgUpdateP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, ap, r, p);
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	Scal<T> h;
+	SMM_TRY(readScal<T>(sc, &h, s));
+	if (status) *status = h.iters > maxIterations ? SMM_SOLVER_MAX_ITERATIONS_REACHED : SMM_SOLVER_SUCCESS;  // ref:2279-2282
+	if (iterations) *iterations = h.iters;
+	if (resnorm) *resnorm = h.res;
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int bicgsymmetricDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, hipStream_t s, int* status, int* iterations) {
+	if (!a || a->dtype != dtypeOf<T>()) {
+		setError("bicgsymmetric: null matrix or dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a->rows != a->cols) {
+		setError("bicgsymmetric: matrix must be square");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const int n = a->rows;
+	maxIterations = std::min(maxIterations, n);  // ref:2030-2033
+	if (maxIterations == -1) maxIterations = n;
+	DevBuf<T> r, p, ap, parts;
+	DevBuf<Scal<T>> sc;
+	SMM_TRY(r.alloc(n));
+	SMM_TRY(p.alloc(n));
+	SMM_TRY(ap.alloc(n));
+	SMM_TRY(parts.alloc(2 * NPART));
+	SMM_TRY(sc.alloc(1));
+	SMM_TRY(launchSpmv<T>(a, SMM_OP_SUB, b, x, r, 0, nullptr, nullptr, nullptr, s));  // ref:2036
+	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));
+	SMM_TRY(launchDotPartials<T>(n, r, r, parts, nullptr, s));
+	bsymInitScal<T><<<1, TPB, 0, s>>>(parts, sc);
+	DonePoller poller;
+	SMM_TRY(poller.init(s));
+	const int* doneFlag = &sc.p->done;
+	const int planned = std::max(1, maxIterations);
+	int nextCheck = 1;
+	for (int i = 0; i < planned; ++i) {
+		if (i == nextCheck) {
+			const int seen = poller.post(doneFlag);
+			if (seen < 0) return seen;
+			if (seen) break;
+			nextCheck = i + checkInterval(i);
+		}
+		SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, ap, 1, p, parts, doneFlag, s));  // ref:2048-2049
+		bsymAlphaScal<T><<<1, TPB, 0, s>>>(parts, sc, eps);
+		bsymUpdateXR<T><<<NPART, TPB, 0, s>>>(n, sc, p, ap, x, r, parts);
+		bsymBetaScal<T><<<1, TPB, 0, s>>>(parts, sc, eps);
+		bsymUpdateP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, r, p);
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	Scal<T> h;
+	SMM_TRY(readScal<T>(sc, &h, s));
+	int st = h.status;
+	if (st == SMM_SOLVER_SUCCESS && h.iters > maxIterations) st = SMM_SOLVER_MAX_ITERATIONS_REACHED;  // ref:2098-2100
+	if (status) *status = st;
+	if (iterations) *iterations = h.iters;
+	return SMM_HIP_OK;
+}
+
+// ---- host-pointer wrappers: the reference's calling convention -----------------------------------------
+template <typename T>
+static int cgHost(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations, T eps, const smm_hip_precond* M, int* status,
+                  int* iterations, T* resnorm2) {
+	if (!a) {
+		setError("cg: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	const int n = a->rows;
+	if (n > 0 && (!b || !x0 || !x)) {
+		setError("cg: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	hipStream_t s = libStream();
+	DevBuf<T> db, dx0, dx;
+	SMM_TRY(db.alloc(n));
+	SMM_TRY(dx0.alloc(n));
+	SMM_TRY(dx.alloc(n));
+	if (n) {
+		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_HIP_TRY(hipMemcpyAsync(dx0, x0, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		// x is only written once the loop runs (ref:2342-2344): start the device copy from the caller's x
+		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	}
+	int it = 0;
+	SMM_TRY(cgDev<T>(a, db, dx0, dx, maxIterations, eps, M, s, status, &it, resnorm2));
+	if (iterations) *iterations = it;
+	if (n && it > 0) {
+		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int bicgstabHost(const smm_hip_csr* a, T* b, T* x, int maxIterations, T eps, const smm_hip_precond* M, int* status, int* iterations,
+                        T* resnorm) {
+	if (!a) {
+		setError("bicgstab: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	const int n = a->rows;
+	if (n > 0 && (!b || !x)) {
+		setError("bicgstab: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	hipStream_t s = libStream();
+	DevBuf<T> db, dx;
+	SMM_TRY(db.alloc(n));
+	SMM_TRY(dx.alloc(n));
+	if (n) {
+		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	}
+	SMM_TRY(bicgstabDev<T>(a, db, dx, maxIterations, eps, M, s, status, iterations, resnorm));
+	if (n) {
+		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int bicgsymmetricHost(const smm_hip_csr* a, T* b, T* x, int maxIterations, T eps, int* status, int* iterations) {
+	if (!a) {
+		setError("bicgsymmetric: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	const int n = a->rows;
+	if (n > 0 && (!b || !x)) {
+		setError("bicgsymmetric: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	hipStream_t s = libStream();
+	DevBuf<T> db, dx;
+	SMM_TRY(db.alloc(n));
+	SMM_TRY(dx.alloc(n));
+	if (n) {
+		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	}
+	SMM_TRY(bicgsymmetricDev<T>(a, db, dx, maxIterations, eps, s, status, iterations));
+	if (n) {
+		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
+	return SMM_HIP_OK;
+}
+
+}  // namespace smm
+
+using namespace smm;
+
+extern "C" {
+
+int smm_hip_cg_f32(const smm_hip_csr* a, const float* b, const float* x0, float* x, int maxIterations, float eps, const smm_hip_precond* M,
+                   int* solver_status, int* iterations, float* resnorm2) {
+	return cgHost<float>(a, b, x0, x, maxIterations, eps, M, solver_status, iterations, resnorm2);
+}
+int smm_hip_cg_f64(const smm_hip_csr* a, const double* b, const double* x0, double* x, int maxIterations, double eps, const smm_hip_precond* M,
+                   int* solver_status, int* iterations, double* resnorm2) {
+	return cgHost<double>(a, b, x0, x, maxIterations, eps, M, solver_status, iterations, resnorm2);
+}
+int smm_hip_cg_dev_f32(const smm_hip_csr* a, const float* d_b, const float* d_x0, float* d_x, int maxIterations, float eps,
+                       const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm2) {
+	SMM_TRY(ensureInit());
+	return cgDev<float>(a, d_b, d_x0, d_x, maxIterations, eps, M, pickStream(stream), solver_status, iterations, resnorm2);
+}
+int smm_hip_cg_dev_f64(const smm_hip_csr* a, const double* d_b, const double* d_x0, double* d_x, int maxIterations, double eps,
+                       const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm2) {
+	SMM_TRY(ensureInit());
+	return cgDev<double>(a, d_b, d_x0, d_x, maxIterations, eps, M, pickStream(stream), solver_status, iterations, resnorm2);
+}
+
+int smm_hip_bicgstab_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, const smm_hip_precond* M, int* solver_status,
+                         int* iterations, float* resnorm) {
+	return bicgstabHost<float>(a, b, x, maxIterations, eps, M, solver_status, iterations, resnorm);
+}
+int smm_hip_bicgstab_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps, const smm_hip_precond* M, int* solver_status,
+                         int* iterations, double* resnorm) {
+	return bicgstabHost<double>(a, b, x, maxIterations, eps, M, solver_status, iterations, resnorm);
+}
+int smm_hip_bicgstab_dev_f32(const smm_hip_csr* a, const float* d_b, float* d_x, int maxIterations, float eps, const smm_hip_precond* M,
+                             smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm) {
+	SMM_TRY(ensureInit());
+	return bicgstabDev<float>(a, d_b, d_x, maxIterations, eps, M, pickStream(stream), solver_status, iterations, resnorm);
+}
+int smm_hip_bicgstab_dev_f64(const smm_hip_csr* a, const double* d_b, double* d_x, int maxIterations, double eps, const smm_hip_precond* M,
+                             smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm) {
+	SMM_TRY(ensureInit());
+	return bicgstabDev<double>(a, d_b, d_x, maxIterations, eps, M, pickStream(stream), solver_status, iterations, resnorm);
+}
+
+int smm_hip_bicgsymmetric_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, int* solver_status, int* iterations) {
+	return bicgsymmetricHost<float>(a, b, x, maxIterations, eps, solver_status, iterations);
+}
+int smm_hip_bicgsymmetric_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps, int* solver_status, int* iterations) {
+	return bicgsymmetricHost<double>(a, b, x, maxIterations, eps, solver_status, iterations);
+}
+
+}  // extern "C"

@@ -1,0 +1,320 @@
+"""Host-side mirror of the reference's public API for the hot path, on top of the C ABI (include/smm_hip.h).
+
+Names, argument order and error behaviour follow include/sparse_matrix_math.h of vasil-pashov/sparse_matrix_math:
+CSRMatrix.rMult / rMultAdd / rMultSub (ref:1501-1515), getPreconditioner (ref:1643-1651), ConjugateGradient
+(ref:2316-2398, IC0 overload ref:2414-2505), BiCGStab (ref:2191-2303), BiCGSymmetric (ref:2021-2102), SolverStatus
+(ref:2010-2014), SolverPreconditioner (ref:1002-1006).  Vectors are numpy arrays in host memory, like the
+reference's raw T* arguments; the `*_dev` helpers take device pointers (ints or objects with .data_ptr()) for
+callers that keep their data in HBM (bench.py, the multi-GPU driver).
+
+Everything here runs on the GPU through libsmm_hip.so.  There is no CPU implementation in this package.
+"""
+import ctypes
+import enum
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class SolverStatus(enum.IntEnum):  # ref:2010-2014
+    SUCCESS = 0
+    DIVERGED = 1
+    MAX_ITERATIONS_REACHED = 2
+
+
+class SolverPreconditioner(enum.IntEnum):
+    """ref:1002-1006 has NONE, SYMMETRIC_GAUS_SEIDEL (sic) and ILU0; JACOBI and IC0 are additions.  Values are the
+    SMM_PRECOND_* codes of the C ABI."""
+    NONE = 0
+    JACOBI = 1
+    ILU0 = 2
+    SYMMETRIC_GAUS_SEIDEL = 3
+    IC0 = 4
+
+
+OP_ASSIGN, OP_ADD, OP_SUB = 0, 1, 2
+SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM = 0, 1, 2
+
+_SUFFIX = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
+_CT = {"f32": ctypes.c_float, "f64": ctypes.c_double}
+
+
+def _suffix(dtype):
+    try:
+        return _SUFFIX[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError(f"only float32 and float64 are supported (the reference's float/double), got {dtype}")
+
+
+def _fn(base, suf):
+    return getattr(_lib.load(), f"{base}_{suf}")
+
+
+def _host(a, dtype, name, n=None, writable=False):
+    if not isinstance(a, np.ndarray) or a.dtype != np.dtype(dtype) or not a.flags.c_contiguous:
+        raise TypeError(f"{name} must be a C-contiguous numpy array of {np.dtype(dtype)}")
+    if writable and not a.flags.writeable:
+        raise TypeError(f"{name} must be writable")
+    if n is not None and a.size < n:
+        raise ValueError(f"{name} has {a.size} elements, needs {n}")
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _dptr(t):
+    """device pointer from an int, None, or anything with .data_ptr() (torch tensors)"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if hasattr(t, "data_ptr"):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(int(t))
+
+
+def init(device=0):
+    check(_lib.load().smm_hip_init(int(device)))
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    cus = ctypes.c_int()
+    mem = ctypes.c_size_t()
+    check(_lib.load().smm_hip_device_info(name, 256, ctypes.byref(cus), ctypes.byref(mem)))
+    return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+
+def uses_std_fma():
+    return bool(_lib.load().smm_hip_uses_std_fma())
+
+
+def synchronize(stream=None):
+    check(_lib.load().smm_hip_stream_synchronize(_dptr(stream)))
+
+
+class Preconditioner:
+    """`int apply(const T* rhs, T* x) const` (ref:1173-1235).  Created by CSRMatrix.getPreconditioner."""
+
+    def __init__(self, matrix, kind):
+        self.matrix = matrix  # keeps the matrix alive (the reference holds a const CSRMatrix&)
+        self.kind = SolverPreconditioner(kind)
+        self._h = ctypes.c_void_p()
+        check(_lib.load().smm_hip_precond_create(matrix._h, int(kind), ctypes.byref(self._h)))
+
+    def apply(self, rhs, x):
+        suf = self.matrix._suf
+        n = self.matrix.rows
+        check(_fn("smm_hip_precond_apply", suf)(self._h, _host(rhs, self.matrix.dtype, "rhs", n), _host(x, self.matrix.dtype, "x", n, True)))
+        return 0
+
+    def apply_dev(self, d_rhs, d_x, stream=None):
+        check(_fn("smm_hip_precond_apply_dev", self.matrix._suf)(self._h, _dptr(d_rhs), _dptr(d_x), _dptr(stream)))
+
+    def values(self):
+        """factor values: diag (JACOBI) or the ILU0 / IC0 values on A's pattern"""
+        count = self.matrix.rows if self.kind == SolverPreconditioner.JACOBI else self.matrix.nnz
+        out = np.empty(count, dtype=self.matrix.dtype)
+        check(_fn("smm_hip_precond_values", self.matrix._suf)(self._h, _host(out, self.matrix.dtype, "out"), count))
+        return out
+
+    def levels(self):
+        kind, lo, up = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(_lib.load().smm_hip_precond_info(self._h, ctypes.byref(kind), ctypes.byref(lo), ctypes.byref(up)))
+        return lo.value, up.value
+
+    def close(self):
+        if self._h:
+            _lib.load().smm_hip_precond_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CSRMatrix:
+    """Device-resident CSRMatrix<T> with the reference's layout (ref:1243-1259): values[nnz], positions[nnz]
+    (ascending per row), start[rows+1]."""
+
+    def __init__(self, rows, cols, start, positions, values):
+        values = np.ascontiguousarray(values)
+        self.dtype = values.dtype
+        self._suf = _suffix(self.dtype)
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        positions = np.ascontiguousarray(positions, dtype=np.int32)
+        if start.size != rows + 1:
+            raise ValueError("start must have rows+1 entries")
+        if positions.size < start[-1] or values.size < start[-1]:
+            raise ValueError("positions/values shorter than start[rows]")
+        self._h = ctypes.c_void_p()
+        self._keep = None
+        check(_fn("smm_hip_csr_create", self._suf)(int(rows), int(cols), _host(start, np.int32, "start"), _host(positions, np.int32, "positions"),
+                                                   _host(values, self.dtype, "values"), ctypes.byref(self._h)))
+        self._read_info()
+
+    @classmethod
+    def from_device(cls, rows, cols, d_start, d_positions, d_values, dtype):
+        """Wrap arrays already in HBM (no copy).  The arrays are kept referenced by the returned object."""
+        self = cls.__new__(cls)
+        self.dtype = np.dtype(dtype)
+        self._suf = _suffix(self.dtype)
+        self._h = ctypes.c_void_p()
+        self._keep = (d_start, d_positions, d_values)
+        check(_fn("smm_hip_csr_create_dev", self._suf)(int(rows), int(cols), _dptr(d_start), _dptr(d_positions), _dptr(d_values), ctypes.byref(self._h)))
+        self._read_info()
+        return self
+
+    def _read_info(self):
+        r, c, n, d, f = (ctypes.c_int() for _ in range(5))
+        check(_lib.load().smm_hip_csr_info(self._h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(n), ctypes.byref(d), ctypes.byref(f)))
+        self.rows, self.cols, self.nnz, self.first_active_start = r.value, c.value, n.value, f.value
+
+    # reference getters (ref:1351-1364)
+    def getDenseRowCount(self):
+        return self.rows
+
+    def getDenseColCount(self):
+        return self.cols
+
+    def getNonZeroCount(self):
+        return self.nnz
+
+    def set_kernel(self, family=SPMV_AUTO, lanes_per_row=0):
+        check(_lib.load().smm_hip_csr_set_kernel(self._h, int(family), int(lanes_per_row)))
+
+    def get_kernel(self):
+        fam, lanes = ctypes.c_int(), ctypes.c_int()
+        check(_lib.load().smm_hip_csr_get_kernel(self._h, ctypes.byref(fam), ctypes.byref(lanes)))
+        return fam.value, lanes.value
+
+    def autotune(self):
+        check(_lib.load().smm_hip_csr_autotune(self._h))
+        return self.get_kernel()
+
+    def _spmv(self, op, lhs, mult, out):
+        fn = _fn("smm_hip_spmv", self._suf)
+        plhs = _host(lhs, self.dtype, "lhs", self.rows) if op != OP_ASSIGN else ctypes.c_void_p(0)
+        check(fn(self._h, op, plhs, _host(mult, self.dtype, "mult", self.cols), _host(out, self.dtype, "out", self.rows, True)))
+
+    def rMult(self, mult, res):  # ref:1501-1505
+        self._spmv(OP_ASSIGN, None, mult, res)
+
+    def rMultAdd(self, lhs, mult, out):  # ref:1507-1510
+        self._spmv(OP_ADD, lhs, mult, out)
+
+    def rMultSub(self, lhs, mult, out):  # ref:1512-1515
+        self._spmv(OP_SUB, lhs, mult, out)
+
+    def spmv_dev(self, op, d_lhs, d_x, d_out, stream=None):
+        check(_fn("smm_hip_spmv_dev", self._suf)(self._h, int(op), _dptr(d_lhs), _dptr(d_x), _dptr(d_out), _dptr(stream)))
+
+    def getPreconditioner(self, kind):  # ref:1643-1651
+        return Preconditioner(self, kind)
+
+    def close(self):
+        if self._h:
+            _lib.load().smm_hip_csr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dot(a, b):
+    """Vector<T>::operator* (ref:305-328)"""
+    suf = _suffix(a.dtype)
+    out = _CT[suf]()
+    n = a.size
+    check(_fn("smm_hip_dot", suf)(n, _host(a, a.dtype, "a"), _host(b, a.dtype, "b", n), ctypes.byref(out)))
+    return a.dtype.type(out.value)
+
+
+def dot_dev(n, d_a, d_b, d_result, dtype, stream=None):
+    check(_fn("smm_hip_dot_dev", _suffix(dtype))(int(n), _dptr(d_a), _dptr(d_b), _dptr(d_result), _dptr(stream)))
+
+
+def _mh(M):
+    return M._h if M is not None else ctypes.c_void_p(0)
+
+
+def ConjugateGradient(a, b, x0, x, maxIterations, eps, M=None, info=None):
+    """ref:2316-2398 (M = IC0 preconditioner: ref:2414-2505).  x may be x0.  Returns SolverStatus; `info`, when a
+    dict, receives iterations and resnorm2."""
+    suf = a._suf
+    st, it, res = ctypes.c_int(), ctypes.c_int(), _CT[suf]()
+    check(_fn("smm_hip_cg", suf)(a._h, _host(b, a.dtype, "b", a.rows), _host(x0, a.dtype, "x0", a.rows), _host(x, a.dtype, "x", a.rows, True),
+                                 int(maxIterations), a.dtype.type(eps), _mh(M), ctypes.byref(st), ctypes.byref(it), ctypes.byref(res)))
+    if info is not None:
+        info.update(iterations=it.value, resnorm2=res.value)
+    return SolverStatus(st.value)
+
+
+def BiCGStab(a, b, x, maxIterations, eps, M=None, info=None):
+    """ref:2191-2303.  x is the initial guess and receives the result."""
+    suf = a._suf
+    st, it, res = ctypes.c_int(), ctypes.c_int(), _CT[suf]()
+    check(_fn("smm_hip_bicgstab", suf)(a._h, _host(b, a.dtype, "b", a.rows), _host(x, a.dtype, "x", a.rows, True), int(maxIterations),
+                                       a.dtype.type(eps), _mh(M), ctypes.byref(st), ctypes.byref(it), ctypes.byref(res)))
+    if info is not None:
+        info.update(iterations=it.value, resnorm=res.value)
+    return SolverStatus(st.value)
+
+
+def BiCGSymmetric(a, b, x, maxIterations, eps, info=None):
+    """ref:2021-2102"""
+    suf = a._suf
+    st, it = ctypes.c_int(), ctypes.c_int()
+    check(_fn("smm_hip_bicgsymmetric", suf)(a._h, _host(b, a.dtype, "b", a.rows), _host(x, a.dtype, "x", a.rows, True), int(maxIterations),
+                                            a.dtype.type(eps), ctypes.byref(st), ctypes.byref(it)))
+    if info is not None:
+        info.update(iterations=it.value)
+    return SolverStatus(st.value)
+
+
+def cg_dev(a, d_b, d_x0, d_x, maxIterations, eps, M=None, stream=None):
+    """device-pointer CG; returns (SolverStatus, iterations, resnorm2).  Synchronises `stream`."""
+    suf = a._suf
+    st, it, res = ctypes.c_int(), ctypes.c_int(), _CT[suf]()
+    check(_fn("smm_hip_cg_dev", suf)(a._h, _dptr(d_b), _dptr(d_x0), _dptr(d_x), int(maxIterations), a.dtype.type(eps), _mh(M), _dptr(stream),
+                                     ctypes.byref(st), ctypes.byref(it), ctypes.byref(res)))
+    return SolverStatus(st.value), it.value, res.value
+
+
+def bicgstab_dev(a, d_b, d_x, maxIterations, eps, M=None, stream=None):
+    """device-pointer BiCGStab; returns (SolverStatus, iterations, resnorm).  Synchronises `stream`."""
+    suf = a._suf
+    st, it, res = ctypes.c_int(), ctypes.c_int(), _CT[suf]()
+    check(_fn("smm_hip_bicgstab_dev", suf)(a._h, _dptr(d_b), _dptr(d_x), int(maxIterations), a.dtype.type(eps), _mh(M), _dptr(stream),
+                                           ctypes.byref(st), ctypes.byref(it), ctypes.byref(res)))
+    return SolverStatus(st.value), it.value, res.value
+
+
+# ---- device-side generators (csrc/smm_gen.hip) ------------------------------------------------------------
+def gen_banded_nnz(n, k=25, seed=0x5EED, max_offset=1 << 20):
+    return int(_lib.load().smm_hip_gen_banded_nnz(int(n), int(k), int(seed), int(max_offset)))
+
+
+def gen_poisson2d_nnz(nx, ny):
+    return int(_lib.load().smm_hip_gen_poisson2d_nnz(int(nx), int(ny)))
+
+
+def gen_stencil3d_nnz(nx, ny, nz):
+    return int(_lib.load().smm_hip_gen_stencil3d_nnz(int(nx), int(ny), int(nz)))
+
+
+def gen_banded_dev(n, k, seed, max_offset, d_start, d_positions, d_values, dtype, stream=None):
+    check(_fn("smm_hip_gen_banded_dev", _suffix(dtype))(int(n), int(k), int(seed), int(max_offset), _dptr(d_start), _dptr(d_positions), _dptr(d_values), _dptr(stream)))
+
+
+def gen_poisson2d_dev(nx, ny, d_start, d_positions, d_values, dtype, stream=None):
+    check(_fn("smm_hip_gen_poisson2d_dev", _suffix(dtype))(int(nx), int(ny), _dptr(d_start), _dptr(d_positions), _dptr(d_values), _dptr(stream)))
+
+
+def gen_stencil3d_dev(nx, ny, nz, diag, lo, hi, d_start, d_positions, d_values, dtype, stream=None):
+    t = np.dtype(dtype).type
+    check(_fn("smm_hip_gen_stencil3d_dev", _suffix(dtype))(int(nx), int(ny), int(nz), t(diag), t(lo), t(hi), _dptr(d_start), _dptr(d_positions),
+                                                            _dptr(d_values), _dptr(stream)))
