@@ -1,0 +1,190 @@
+"""GPU parity of the SpMV / dot kernels through the C ABI (libsmm_hip.so) against the oracle and against the committed
+outputs of the real reference."""
+import numpy as np
+import pytest
+from conftest import KAT_CASES, kat_matrix
+from test_oracle import gen_matrices, spmv_vectors
+
+from oracle.oracle import OP_ADD, OP_ASSIGN, OP_SUB
+from sparse_matrix_math_amd import generators as gen
+
+pytestmark = pytest.mark.gpu
+DTYPES = [np.float32, np.float64]
+# (family, lanes): STREAM with 1 lane is the default for short rows and sums in the reference's order
+CONFIGS = [(2, 1), (2, 2), (2, 4), (2, 16), (1, 1), (1, 4), (1, 64)]
+
+
+def bound(csr, x, dtype, lhs=None):
+    """per-row rounding bound for a re-ordered sum: c * eps * sum |a_k x_k| (+ |lhs|)"""
+    start, pos, val = csr
+    rows = len(start) - 1
+    mag = np.zeros(rows)
+    np.add.at(mag, np.repeat(np.arange(rows), np.diff(start)), np.abs(val.astype(np.float64) * x[pos].astype(np.float64)))
+    if lhs is not None:
+        mag = mag + np.abs(lhs)
+    lens = np.maximum(np.diff(start), 1)
+    return (lens + 2) * np.finfo(dtype).eps * mag + np.finfo(dtype).tiny
+
+
+def make(smm, csr, cols=None):
+    rows = len(csr[0]) - 1
+    return smm.CSRMatrix(rows, rows if cols is None else cols, *csr)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_known_answers(smm, dtype):
+    """test/cpp/csr.cpp:259-522 through the HIP kernel: empty last row, in place and out of place, lhs untouched"""
+    csr = kat_matrix(dtype)
+    A = smm.CSRMatrix(5, 4, *csr)
+    for family, lanes in CONFIGS:
+        A.set_kernel(family, lanes)
+        for mult, lhs, add_ref, sub_ref in KAT_CASES:
+            x = np.array(mult, dtype=dtype)
+            l = np.array(lhs, dtype=dtype)
+            out = np.full(5, 77, dtype=dtype)
+            A.rMultAdd(l, x, out)
+            np.testing.assert_allclose(out, np.array(add_ref, dtype=dtype), rtol=1e-6)
+            np.testing.assert_array_equal(l, np.array(lhs, dtype=dtype))
+            A.rMultSub(l, x, out)
+            np.testing.assert_allclose(out, np.array(sub_ref, dtype=dtype), rtol=1e-6, atol=1e-6)
+            inpl = l.copy()
+            A.rMultAdd(inpl, x, inpl)
+            np.testing.assert_allclose(inpl, np.array(add_ref, dtype=dtype), rtol=1e-6)
+            inpl = l.copy()
+            A.rMultSub(inpl, x, inpl)
+            np.testing.assert_allclose(inpl, np.array(sub_ref, dtype=dtype), rtol=1e-6, atol=1e-6)
+    # A == 0 (csr.cpp:278-290, 390-415)
+    E = smm.CSRMatrix(5, 4, np.zeros(6, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=dtype))
+    l = np.array([5, 6, 7, 8, 9], dtype=dtype)
+    out = np.zeros(5, dtype=dtype)
+    E.rMultAdd(l, np.array([1, 2, 3, 4], dtype=dtype), out)
+    np.testing.assert_array_equal(out, l)
+    E.rMultSub(l, np.array([1, 2, 3, 4], dtype=dtype), out)
+    np.testing.assert_array_equal(out, l)
+    E.rMult(np.array([1, 2, 3, 4], dtype=dtype), out)
+    np.testing.assert_array_equal(out, 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_matches_reference_outputs(smm, golden, oracle, dtype):
+    """the committed outputs of the real reference: bit-identical with the row-sequential kernels, within the
+    re-ordering bound with several lanes per row"""
+    dn = np.dtype(dtype).name
+    for mname, csr in gen_matrices(dtype).items():
+        rows = len(csr[0]) - 1
+        A = make(smm, csr)
+        x, lhs = spmv_vectors(rows, dtype)
+        want = {OP_ASSIGN: golden[f"gen/{mname}/{dn}/spmv/assign"], OP_ADD: golden[f"gen/{mname}/{dn}/spmv/add"], OP_SUB: golden[f"gen/{mname}/{dn}/spmv/sub"]}
+        for family, lanes in CONFIGS:
+            A.set_kernel(family, lanes)
+            for op, ref in want.items():
+                out = np.zeros(rows, dtype=dtype)
+                {OP_ASSIGN: lambda: A.rMult(x, out), OP_ADD: lambda: A.rMultAdd(lhs, x, out), OP_SUB: lambda: A.rMultSub(lhs, x, out)}[op]()
+                if lanes == 1:
+                    np.testing.assert_array_equal(out, ref, err_msg=f"{mname} family {family} op {op}")
+                else:
+                    assert np.all(np.abs(out.astype(np.float64) - ref) <= bound(csr, x, dtype, lhs if op else None)), (mname, family, lanes, op)
+        assert abs(float(smm.dot(x, lhs)) - float(golden[f"gen/{mname}/{dn}/dot"])) <= rows * np.finfo(dtype).eps * float(np.abs(x * lhs).sum())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ragged_and_long_rows(smm, oracle, dtype):
+    """row lengths from 0 to far beyond one LDS block (long-row path), rectangular, leading/trailing empty rows"""
+    rng = np.random.default_rng(42)
+    rows, cols = 700, 9000
+    lens = rng.integers(0, 60, size=rows)
+    lens[5] = 5000  # longer than the 2048-entry LDS block
+    lens[300] = 2049
+    lens[301] = 2048
+    lens[:3] = 0
+    lens[-4:] = 0
+    start = np.zeros(rows + 1, dtype=np.int32)
+    np.cumsum(lens, out=start[1:])
+    pos = np.concatenate([np.sort(rng.choice(cols, size=n, replace=False)) for n in lens]).astype(np.int32)
+    val = rng.uniform(-1, 1, start[-1]).astype(dtype)
+    csr = (start, pos, val)
+    x = rng.uniform(-1, 1, cols).astype(dtype)
+    lhs = rng.uniform(-1, 1, rows).astype(dtype)
+    A = smm.CSRMatrix(rows, cols, *csr)
+    assert A.first_active_start == 3
+    ref = oracle.spmv(csr, OP_SUB, lhs, x)
+    for family, lanes in CONFIGS + [(0, 0)]:
+        A.set_kernel(family, lanes)
+        out = np.zeros(rows, dtype=dtype)
+        A.rMultSub(lhs, x, out)
+        assert np.all(np.abs(out.astype(np.float64) - ref) <= bound(csr, x, dtype, lhs)), (family, lanes)
+        if lanes == 1 and family == 1:
+            np.testing.assert_array_equal(out, ref)
+
+
+def test_argument_errors(smm):
+    csr = gen.poisson2d(8)
+    A = make(smm, csr)
+    x = np.ones(64)
+    with pytest.raises(smm.SmmHipError):  # x must not alias out (ref:1503)
+        A.rMult(x, x)
+    with pytest.raises(TypeError):
+        A.rMult(np.ones(64, dtype=np.float32), np.ones(64))
+    with pytest.raises(smm.SmmHipError):
+        A.set_kernel(2, 3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dot_sizes(smm, oracle, dtype):
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 63, 64, 257, 4099, 1_000_003):
+        a = rng.uniform(-1, 1, n).astype(dtype)
+        b = rng.uniform(-1, 1, n).astype(dtype)
+        exact = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+        got = float(smm.dot(a, b))
+        tol = 8 * np.finfo(dtype).eps * float(np.abs(a.astype(np.float64) * b).sum()) * max(1.0, np.log2(max(n, 2)))
+        assert abs(got - exact) <= tol + 1e-300, n
+        # the reference's serial sum is (much) further from the exact value than it is from ours
+        assert abs(got - float(oracle.dot(a, b))) <= n * np.finfo(dtype).eps * float(np.abs(a * b).sum()) + 1e-300
+        assert float(smm.dot(a, b)) == got  # bitwise reproducible
+
+
+@pytest.mark.parametrize("dtype,n,k", [(np.float32, 2_000_000, 25), (np.float64, 1_000_000, 8)])
+def test_full_size_properties(smm, dtype, n, k):
+    """size-independent checks at sizes the CPU oracle is too slow for in a test: A*1 == row sums, linearity,
+    lanes-per-row variants agree, device generator == numpy generator"""
+    import torch
+
+    dev = torch.device("cuda:0")
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    nnz = smm.host.gen_banded_nnz(n, k, 0x5EED, 1 << 20)
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=tdt, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    smm.host.gen_banded_dev(n, k, 0x5EED, 1 << 20, d_start, d_pos, d_val, dtype, stream)
+    torch.cuda.synchronize()
+    assert int(d_start[-1]) == nnz
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, dtype)
+    ones = torch.ones(n, dtype=tdt, device=dev)
+    y = torch.empty(n, dtype=tdt, device=dev)
+    A.spmv_dev(0, None, ones, y, stream)
+    torch.cuda.synchronize()
+    # row sums: diagonal is 1 + sum|offdiag| and off-diagonals are negative -> A*1 == 1 up to rounding
+    assert float((y - 1).abs().max()) <= 64 * np.finfo(dtype).eps * 60
+    g = torch.Generator(device=dev).manual_seed(1)
+    u = torch.rand(n, dtype=tdt, device=dev, generator=g) - 0.5
+    v = torch.rand(n, dtype=tdt, device=dev, generator=g) - 0.5
+    yu, yv, yuv = (torch.empty(n, dtype=tdt, device=dev) for _ in range(3))
+    A.spmv_dev(0, None, u, yu, stream)
+    A.spmv_dev(0, None, v, yv, stream)
+    A.spmv_dev(0, None, u + 2 * v, yuv, stream)
+    torch.cuda.synchronize()
+    assert float((yuv - (yu + 2 * yv)).abs().max()) <= 1e3 * np.finfo(dtype).eps
+    base = yu.clone()
+    for family, lanes in ((2, 1), (2, 4), (1, 8), (1, 64)):
+        A.set_kernel(family, lanes)
+        A.spmv_dev(0, None, u, yu, stream)
+        torch.cuda.synchronize()
+        assert float((yu - base).abs().max()) <= 1e3 * np.finfo(dtype).eps, (family, lanes)
+    # rMultSub with out aliasing lhs on the device path
+    A.set_kernel(0, 0)
+    w = v.clone()
+    A.spmv_dev(2, w, u, w, stream)
+    torch.cuda.synchronize()
+    assert float((w - (v - base)).abs().max()) <= 1e3 * np.finfo(dtype).eps
