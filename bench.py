@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline: CSR SpMV GB/s (% of HBM peak) + BiCGStab iterations/s on the 10M-row, ~51 nnz/row
+banded-random SPD matrix (config 3), fp32, on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one BiCGStab iteration (ref:2232-2277: 2 SpMV + 5 reductions + 3 vector updates) with every operand already
+resident in HBM.  The timed region is one smm_hip_bicgstab_dev call with maxIterations = K and eps = 0 (it cannot stop
+early), bracketed by a barrier and a device synchronise on both sides; it includes the loop's set-up (r = b - A x, r0 = p = r,
+one dot).  Rank 0 prints ONE JSON line.  N > 1: rows are range-partitioned across the ranks (strong scaling, the matrix is
+the same 10M-row matrix), see sparse_matrix_math_amd/distributed.py.
+
+roofline: the dominant kernel is the SpMV; `achieved` = algorithmic bytes of one SpMV launch
+(B_spmv = nnz*(s+4) + (rows+1)*4 + cols*s + rows*s; the fused-dot launches also read one or two more
+vectors, which are NOT counted) divided by the average launch duration measured with HIP events inside the timed region.
+cpu_baseline: the OpenMP port of the same loop (oracle/, kind "port") on this host's cores, a bounded number of
+iterations of the very same matrix copied back from the GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
+METRIC = "CSR SpMV GB/s (% HBM peak) + BiCGStab iters/sec, 10M rows, 1/2/4/8 GPU"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--band-k", type=int, default=25, help="offsets per side: 2k+1 nonzeros per interior row")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--max-offset", type=int, default=1 << 20)
+    ap.add_argument("--diag-shift", type=float, default=0.01,
+                    help="A[i][i] = shift + sum|offdiag|: condition number ~ 50/shift.  SURVEY's law (1.0) converges to fp32 round-off in "
+                         "~25 iterations, after which the recursive residual underflows and the loop breaks down; 0.01 keeps 200 iterations honest")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables it")
+    ap.add_argument("--spmv-family", type=int, default=0)
+    ap.add_argument("--spmv-lanes", type=int, default=0)
+    ap.add_argument("--autotune", action="store_true")
+    return ap.parse_args()
+
+
+def spmv_bytes(rows, cols, nnz, s):
+    return nnz * (s + 4) + (rows + 1) * 4 + cols * s + rows * s
+
+
+def load_traffic(args):
+    """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json), if they match"""
+    path = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("rows") == args.rows and t.get("dtype") == args.dtype and t.get("band_k") == args.band_k:
+            return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def host_cores():
+    """threads for the CPU baseline: the affinity mask, clipped by the cgroup CPU quota and by the GPU box's CPU share
+    (16 host cores per GPU); SMM_BENCH_CPU_THREADS overrides"""
+    if os.environ.get("SMM_BENCH_CPU_THREADS"):
+        return max(1, int(os.environ["SMM_BENCH_CPU_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
+    import numpy as np
+
+    from oracle.oracle import Oracle
+
+    oracle = Oracle()
+    cores = host_cores()
+    oracle.set_threads(cores)
+    csr = (start, positions, values)
+    x0 = np.zeros(len(b), dtype=np_dtype)
+    t0 = time.perf_counter()
+    oracle.bicgstab(csr, b, x0, 1, 0.0, omp=True)  # also warms the page cache / first touch
+    one = time.perf_counter() - t0
+    iters = int(max(2, min(200, budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    st, _, it, _ = oracle.bicgstab(csr, b, x0, iters, 0.0, omp=True)
+    dt = time.perf_counter() - t0
+    return {
+        "value": it / dt,
+        "unit": "iterations/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{it} BiCGStab iterations of the same {len(b)}-row matrix (OpenMP port of the reference loop, {dt:.1f} s)",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import sparse_matrix_math_amd as smm
+    from sparse_matrix_math_amd import host
+
+    smm.init(local_rank)
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    t_dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    s_bytes = 4 if args.dtype == "f32" else 8
+    n = args.rows
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if world > 1:
+        from sparse_matrix_math_amd import distributed as dsm
+
+        result = dsm.bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype)
+    else:
+        nnz = host.gen_banded_nnz(n, args.band_k, args.seed, args.max_offset)
+        d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+        d_val = torch.empty(nnz, dtype=t_dtype, device=dev)
+        host.gen_banded_dev(n, args.band_k, args.seed, args.max_offset, d_start, d_pos, d_val, np_dtype, stream, diag_shift=args.diag_shift)
+        A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np_dtype)
+        if args.autotune:
+            A.autotune()
+        elif args.spmv_family or args.spmv_lanes:
+            A.set_kernel(args.spmv_family or 2, args.spmv_lanes)
+        family, lanes = A.get_kernel()
+        # b = A * x_true with x_true uniform in [0.5, 1.5).  (The reference's test convention b = A*1 is degenerate on this
+        # matrix: every row sums to diag_shift, so 1 is an eigenvector and any Krylov method converges in one step.)
+        x_true = torch.rand(n, dtype=t_dtype, device=dev, generator=torch.Generator(device=dev).manual_seed(args.seed)) + 0.5
+        b = torch.empty(n, dtype=t_dtype, device=dev)
+        A.spmv_dev(0, None, x_true, b, stream)
+        x = torch.zeros(n, dtype=t_dtype, device=dev)
+        torch.cuda.synchronize()
+
+        # warmup: W untimed iterations
+        if args.warmup > 0:
+            host.bicgstab_dev(A, b, x, args.warmup, 0.0, None, stream)
+        x.zero_()
+        host.profile_enable(True)
+        host.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        status, iters, resnorm = host.bicgstab_dev(A, b, x, args.steps, 0.0, None, stream)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        spmv_ms, spmv_launches = host.profile_read(reset=True)
+        host.profile_enable(False)
+        if iters != args.steps or not np.isfinite(resnorm):
+            raise SystemExit(f"BiCGStab ran {iters} of {args.steps} iterations (resnorm {resnorm}): the timed region is invalid")
+        err = float(((x - x_true).abs() / x_true).max())
+        b_spmv = spmv_bytes(n, n, nnz, s_bytes)
+        spmv_avg_s = spmv_ms * 1e-3 / max(spmv_launches, 1)
+        achieved = b_spmv / spmv_avg_s / 1e9
+        result = {
+            "elapsed": elapsed,
+            "iters": iters,
+            "nnz": nnz,
+            "resnorm": float(resnorm),
+            "max_rel_err_vs_x_true": err,
+            "spmv_kernel": {"family": family, "lanes_per_row": lanes},
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": load_traffic(args),
+                "kernel": "spmvStreamKernel" if family == 2 else "spmvVectorKernel",
+                "algorithmic_bytes_per_launch": b_spmv,
+                "avg_launch_ms": spmv_avg_s * 1e3,
+                "launches": spmv_launches,
+            },
+        }
+        if args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(args, np_dtype, d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy(),
+                                                  b.cpu().numpy(), args.cpu_seconds)
+
+    if world > 1:
+        t = torch.tensor([result["elapsed"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        result["elapsed"] = float(t.item())
+    if rank == 0:
+        elapsed = result.pop("elapsed")
+        iters = result.pop("iters")
+        line = {
+            "metric": METRIC,
+            "value": iters / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / iters * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[2]: banded-random symmetric diagonally dominant CSR, BiCGStab, b = A*1, x0 = 0, eps = 0 (fixed iterations)",
+                "rows": n,
+                "nnz": result.pop("nnz"),
+                "band_offsets_per_side": args.band_k,
+                "diag_shift": args.diag_shift,
+                "seed": hex(args.seed),
+                "partition": f"rows/{args.gpus}",
+            },
+        }
+        line.update(result)
+        if "roofline" in line:
+            line["spmv_gbps"] = line["roofline"]["achieved"]
+            line["spmv_pct_hbm_peak"] = 100.0 * line["roofline"]["frac"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

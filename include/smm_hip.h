@@ -16,8 +16,10 @@
  *     int32 exactly as in the reference (ref:1243-1259).
  *   - functions without `_dev` take HOST pointers, like the reference's API: they copy in, run on the GPU,
  *     copy out and synchronise before returning.
- *   - `_dev` functions take DEVICE pointers and a hipStream_t (as void*); they only enqueue work unless they
- *     must return a value to the host (solvers synchronise the stream before returning their status).
+ *   - `_dev` functions take DEVICE pointers and a hipStream_t (as void*, NULL = the null stream); they only enqueue
+ *     work unless they must return a value to the host (solvers synchronise the stream before returning their
+ *     status).  Temporaries are recycled in stream order: drive one matrix from one stream at a time.
+ *     Host-pointer functions run on a private non-blocking stream of the library.
  *   - there is NO CPU fallback: without a HIP device every call fails with SMM_HIP_ERR_NO_DEVICE.
  *   - rounding: multiply-adds are a*x+b (two roundings) like the reference's default _smm_fma (ref:28-36);
  *     a library built with -DSMM_WITH_STD_FMA uses fma(a,x,b) instead.  smm_hip_uses_std_fma() tells which.
@@ -73,7 +75,7 @@ extern "C" {
 
 typedef struct smm_hip_csr smm_hip_csr;         /* device-resident CSRMatrix<T> (ref:1243-1259) */
 typedef struct smm_hip_precond smm_hip_precond; /* device-resident preconditioner */
-typedef void* smm_hip_stream;                   /* hipStream_t; NULL = the library's own stream */
+typedef void* smm_hip_stream;                   /* hipStream_t with HIP's own meaning: NULL = the null (default) stream */
 
 /* ---- runtime ------------------------------------------------------------------------------------------- */
 /* Select the HIP device this process uses (one process per GPU) and create the library stream.  Idempotent. */
@@ -84,8 +86,15 @@ const char* smm_hip_last_error(void);
 int smm_hip_uses_std_fma(void);
 /* name: device name (may be NULL), cus: compute units, hbm_bytes: total device memory */
 int smm_hip_device_info(char* name, size_t name_cap, int* cus, size_t* hbm_bytes);
-/* Blocks until everything enqueued on `stream` (NULL = library stream) has finished. */
+/* Blocks until everything enqueued on `stream` has finished. */
 int smm_hip_stream_synchronize(smm_hip_stream stream);
+
+/* ---- live kernel timing (bench.py roofline) ------------------------------------------------------------------
+ * When enabled every SpMV launch -- standalone or inside a solver loop -- is bracketed by a pair of HIP events on the
+ * stream it is launched on.  smm_hip_profile_read waits for the recorded events, returns the summed SpMV kernel time
+ * in milliseconds and the number of launches since the last reset, and optionally resets the tally. */
+int smm_hip_profile_enable(int on);
+int smm_hip_profile_read(double* spmv_ms, long long* spmv_launches, int reset);
 
 /* ---- CSRMatrix<T> (ref:1243-1259; replaces CSRMatrix::init(TripletMatrix) ref:1326-1349 as the way in) ---- */
 /* Copies the three host arrays of a CSRMatrix (values[nnz], positions[nnz] ascending per row, start[rows+1])
@@ -188,9 +197,10 @@ int smm_hip_gen_poisson2d_dev_f64(int nx, int ny, int* d_start, int* d_positions
  * convection-diffusion stand-in for atmosmodd: 6,-1-c,-1+c) */
 int smm_hip_gen_stencil3d_dev_f32(int nx, int ny, int nz, float diag, float lo, float hi, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
 int smm_hip_gen_stencil3d_dev_f64(int nx, int ny, int nz, double diag, double lo, double hi, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
-/* banded-random symmetric strictly diagonally dominant matrix */
-int smm_hip_gen_banded_dev_f32(int n, int k, unsigned long long seed, int max_offset, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
-int smm_hip_gen_banded_dev_f64(int n, int k, unsigned long long seed, int max_offset, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
+/* banded-random symmetric strictly diagonally dominant matrix: A[i][i] = diag_shift +
+ * sum|offdiag| (SURVEY's law is diag_shift = 1; A*1 = diag_shift*1, so 1/diag_shift sets the condition number) */
+int smm_hip_gen_banded_dev_f32(int n, int k, unsigned long long seed, int max_offset, float diag_shift, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
+int smm_hip_gen_banded_dev_f64(int n, int k, unsigned long long seed, int max_offset, double diag_shift, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
 
 #ifdef __cplusplus
 }

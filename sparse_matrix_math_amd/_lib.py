@@ -49,7 +49,7 @@ _TYPED = {
     "smm_hip_precond_values": (c_int, [_P, _P, c_size_t]),
     "smm_hip_gen_poisson2d_dev": (c_int, [c_int, c_int, _P, _P, _P, _P]),
     "smm_hip_gen_stencil3d_dev": (c_int, [c_int, c_int, c_int, "T", "T", "T", _P, _P, _P, _P]),
-    "smm_hip_gen_banded_dev": (c_int, [c_int, c_int, c_ulonglong, c_int, _P, _P, _P, _P]),
+    "smm_hip_gen_banded_dev": (c_int, [c_int, c_int, c_ulonglong, c_int, "T", _P, _P, _P, _P]),
 }
 
 _PLAIN = {
@@ -59,6 +59,8 @@ _PLAIN = {
     "smm_hip_uses_std_fma": (c_int, []),
     "smm_hip_device_info": (c_int, [c_char_p, c_size_t, POINTER(c_int), POINTER(c_size_t)]),
     "smm_hip_stream_synchronize": (c_int, [_P]),
+    "smm_hip_profile_enable": (c_int, [c_int]),
+    "smm_hip_profile_read": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),
     "smm_hip_csr_destroy": (c_int, [_P]),
     "smm_hip_csr_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "smm_hip_csr_set_kernel": (c_int, [_P, c_int, c_int]),
@@ -84,6 +86,23 @@ def exported_symbols():
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both own the GPU, so when torch is installed its copy is loaded first: libsmm_hip.so's
+    NEEDED libamdhip64.so.7 then binds to it by SONAME, whichever of the two is imported first.  Without torch (or with
+    SMM_HIP_SYSTEM_RUNTIME=1) the library uses the system ROCm runtime."""
+    if os.environ.get("SMM_HIP_SYSTEM_RUNTIME"):
+        return
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load(fma=False):
     """Load the shared library (once) and declare the prototypes.  Raises OSError when it has not been built."""
     global _lib
@@ -95,6 +114,7 @@ def load(fma=False):
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  sparse_matrix_math_amd has no CPU fallback."
         )
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(path)
     for name, (res, args) in _PLAIN.items():
         fn = getattr(lib, name)

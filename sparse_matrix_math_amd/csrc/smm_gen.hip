@@ -52,7 +52,7 @@ __device__ __forceinline__ T bandValue(unsigned long long seed, int r, int k) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void genBandedKernel(int n, BandOffsets o, unsigned long long seed, int* __restrict__ start,
+__global__ __launch_bounds__(TPB) void genBandedKernel(int n, BandOffsets o, unsigned long long seed, T diagShift, int* __restrict__ start,
                                                        int* __restrict__ positions, T* __restrict__ values) {
 	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i <= n; i += static_cast<long long>(gridDim.x) * TPB) {
 		long long s = i;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(TPB) void genBandedKernel(int n, BandOffsets o, uns
 		if (i == n) continue;
 		const int row = static_cast<int>(i);
 		long long w = s;
-		T diag = T(1);
+		T diag = diagShift;
 		for (int k = o.k - 1; k >= 0; --k) {  // columns row - d_k, ascending
 			const int j = row - o.d[k];
 			if (j >= 0) {
@@ -145,7 +145,7 @@ static int genGrid(long long n) { return static_cast<int>(std::max<long long>(1,
 static bool fitsInt(long long v) { return v >= 0 && v <= 2147483647LL; }
 
 template <typename T>
-static int genBanded(int n, int k, unsigned long long seed, int maxOffset, int* d_start, int* d_positions, T* d_values, smm_hip_stream stream) {
+static int genBanded(int n, int k, unsigned long long seed, int maxOffset, T diagShift, int* d_start, int* d_positions, T* d_values, smm_hip_stream stream) {
 	SMM_TRY(ensureInit());
 	if (n < 0 || k < 0 || !d_start || (n > 0 && (!d_positions || !d_values))) {
 		setError("gen_banded: bad arguments");
@@ -156,7 +156,7 @@ static int genBanded(int n, int k, unsigned long long seed, int maxOffset, int* 
 		return SMM_HIP_ERR_INVALID;
 	}
 	const BandOffsets o = drawOffsets(n, k, seed, maxOffset);
-	genBandedKernel<T><<<genGrid(n), TPB, 0, pickStream(stream)>>>(n, o, seed, d_start, d_positions, d_values);
+	genBandedKernel<T><<<genGrid(n), TPB, 0, pickStream(stream)>>>(n, o, seed, diagShift, d_start, d_positions, d_values);
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
 }
@@ -220,11 +220,11 @@ int smm_hip_gen_stencil3d_dev_f32(int nx, int ny, int nz, float diag, float lo, 
 int smm_hip_gen_stencil3d_dev_f64(int nx, int ny, int nz, double diag, double lo, double hi, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream) {
 	return genStencil3d<double>(nx, ny, nz, diag, lo, hi, d_start, d_positions, d_values, stream);
 }
-int smm_hip_gen_banded_dev_f32(int n, int k, unsigned long long seed, int max_offset, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream) {
-	return genBanded<float>(n, k, seed, max_offset, d_start, d_positions, d_values, stream);
+int smm_hip_gen_banded_dev_f32(int n, int k, unsigned long long seed, int max_offset, float diag_shift, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream) {
+	return genBanded<float>(n, k, seed, max_offset, diag_shift, d_start, d_positions, d_values, stream);
 }
-int smm_hip_gen_banded_dev_f64(int n, int k, unsigned long long seed, int max_offset, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream) {
-	return genBanded<double>(n, k, seed, max_offset, d_start, d_positions, d_values, stream);
+int smm_hip_gen_banded_dev_f64(int n, int k, unsigned long long seed, int max_offset, double diag_shift, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream) {
+	return genBanded<double>(n, k, seed, max_offset, diag_shift, d_start, d_positions, d_values, stream);
 }
 
 }  // extern "C"

@@ -40,7 +40,9 @@ int hipFail(hipError_t e, const char* what, const char* file, int line);
 // make sure a device is selected; returns SMM_HIP_ERR_NO_DEVICE when there is none
 int ensureInit();
 hipStream_t libStream();
-inline hipStream_t pickStream(smm_hip_stream s) { return s ? static_cast<hipStream_t>(s) : libStream(); }
+// `_dev` entry points follow plain HIP semantics: the handle is a hipStream_t and NULL is the null (default) stream --
+// which is also what torch.cuda.current_stream().cuda_stream is for PyTorch's default stream
+inline hipStream_t pickStream(smm_hip_stream s) { return static_cast<hipStream_t>(s); }
 int numCUs();
 
 // caching device allocator (solver temporaries are allocated per call like the reference's SMM::Vector,
@@ -91,7 +93,8 @@ struct smm_hip_csr {
 	// STREAM family: row blocks (first row of every block; n_rowblocks+1 entries) staged through LDS
 	int* d_rowblocks = nullptr;
 	int n_rowblocks = 0;
-	int stream_nnz_cap = 0;  // LDS capacity in nonzeros the row blocks were cut for
+	int stream_nnz_cap = 0;  // nonzeros / rows per tile the row blocks were cut for
+	int stream_max_rows = 0;
 };
 
 struct smm_hip_precond {
@@ -112,7 +115,7 @@ namespace smm {
 // kernel launchers (device pointers, asynchronous on `s`)
 // ---------------------------------------------------------------------------------------------------------
 // Partial-sum slots every fused reduction writes: NPART partials per reduced quantity
-constexpr int NPART = 1024;
+constexpr int NPART = 2048;  // 256 CUs x 8 resident workgroups of 256 lanes
 
 // dotMode of the SpMV epilogue: which per-row products are block-reduced into `partials`
 //   0 none; 1: out[i]*w1[i] -> partials[0..NPART); 2: out[i]*out[i] -> partials[0..), out[i]*w1[i] -> partials[NPART..)
@@ -120,7 +123,11 @@ template <typename T>
 int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
                const int* doneFlag, hipStream_t s);
 
-int buildRowBlocks(smm_hip_csr* m, int nnzCap);
+// live event timing of SpMV launches (smm_hip_profile_*): begin returns a slot or -1 when profiling is off
+int profBegin(hipStream_t s);
+void profEnd(int slot, hipStream_t s);
+
+int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows);
 void chooseSpmvConfig(smm_hip_csr* m);
 
 // partials[0..NPART) = per-block sums of a[i]*b[i]

@@ -120,6 +120,31 @@ void devTrim() {
 	g_free.clear();
 }
 
+// ---- live SpMV timing -------------------------------------------------------------------------------------
+static std::mutex g_profMutex;
+static bool g_profOn = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_profEvents;  // pool, reused after reset
+static size_t g_profUsed = 0;
+
+int profBegin(hipStream_t s) {
+	std::lock_guard<std::mutex> lock(g_profMutex);
+	if (!g_profOn) return -1;
+	if (g_profUsed == g_profEvents.size()) {
+		hipEvent_t a, b;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+		g_profEvents.emplace_back(a, b);
+	}
+	const int slot = static_cast<int>(g_profUsed++);
+	(void)hipEventRecord(g_profEvents[slot].first, s);
+	return slot;
+}
+
+void profEnd(int slot, hipStream_t s) {
+	if (slot < 0) return;
+	std::lock_guard<std::mutex> lock(g_profMutex);
+	(void)hipEventRecord(g_profEvents[slot].second, s);
+}
+
 // number of leading rows without entries = firstActiveStart (ref:1619-1628): start[] is non-decreasing, so
 // it is the count of i in [0,rows) with start[i+1] == 0
 __global__ void countLeadingEmpty(int rows, const int* __restrict__ start, int* __restrict__ out) {
@@ -254,6 +279,28 @@ int smm_hip_device_info(char* name, size_t name_cap, int* cus, size_t* hbm_bytes
 int smm_hip_stream_synchronize(smm_hip_stream stream) {
 	SMM_TRY(ensureInit());
 	SMM_HIP_TRY(hipStreamSynchronize(pickStream(stream)));
+	return SMM_HIP_OK;
+}
+
+int smm_hip_profile_enable(int on) {
+	std::lock_guard<std::mutex> lock(g_profMutex);
+	g_profOn = on != 0;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_profile_read(double* spmv_ms, long long* spmv_launches, int reset) {
+	SMM_TRY(ensureInit());
+	std::lock_guard<std::mutex> lock(g_profMutex);
+	double total = 0.0;
+	for (size_t i = 0; i < g_profUsed; ++i) {
+		SMM_HIP_TRY(hipEventSynchronize(g_profEvents[i].second));
+		float ms = 0.f;
+		SMM_HIP_TRY(hipEventElapsedTime(&ms, g_profEvents[i].first, g_profEvents[i].second));
+		total += ms;
+	}
+	if (spmv_ms) *spmv_ms = total;
+	if (spmv_launches) *spmv_launches = static_cast<long long>(g_profUsed);
+	if (reset) g_profUsed = 0;
 	return SMM_HIP_OK;
 }
 

@@ -30,6 +30,17 @@ namespace smm {
 
 constexpr int TPB = 256;  // threads per workgroup = 4 wavefronts
 
+// values[] / positions[] are read exactly once per SpMV: stream them with the non-temporal policy so they do not push
+// x[] (re-read ~nnz/row times) out of L2 / Infinity Cache.  SMM_SPMV_NO_NT builds use plain loads (A/B measurements).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+#ifdef SMM_SPMV_NO_NT
+#define NT_LOAD(p) (*(p))
+#else
+#define NT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+
 template <typename T>
 __device__ __forceinline__ T applyOp(int op, const T* __restrict__ lhs, int row, T dot) {
 	if (op == SMM_OP_ASSIGN) return dot;
@@ -87,125 +98,280 @@ __global__ __launch_bounds__(TPB) void spmvVectorKernel(int rows, const int* __r
 // ---------------------------------------------------------------------------------------------------------
 // STREAM family
 // ---------------------------------------------------------------------------------------------------------
+// A "row tile" is a run of at most TPB / L whole rows holding at most cap - 3 nonzeros; it is the unit of work of one
+// workgroup.  (A row longer than that is a tile of its own and is summed straight from HBM.)  cap = 1024 * nv is chosen
+// per matrix from the mean row length so that a tile of TPB / L average rows fits; LDS is sized at launch accordingly.
 template <typename T>
 struct StreamCfg {
-	// nonzeros staged per row block: 16 KiB of LDS for the two arrays (fp32) / 24 KiB (fp64) -> 8 / 6 workgroups
-	// per CU, i.e. every CU keeps > 100 KiB of coalesced loads in flight while other workgroups compute
-	static constexpr int CAP = 2048;
+	static constexpr int PIECE = 4 * TPB;                   // nonzeros staged per pass: one 16-byte load per lane and array
+	static constexpr int NVMAX = sizeof(T) == 4 ? 4 : 2;    // passes a lane can hold in registers one tile ahead
+	static constexpr int PAD = 16;                          // slack a gather batch may read past its piece
 };
 
-// element index i of the staged block -> LDS slot.  A skew of one slot per 32 keeps power-of-two row lengths
-// off a single bank when adjacent lanes walk adjacent rows.
-__device__ __forceinline__ int ldsSlot(int i) { return i + (i >> 5); }
+// One lane's slice of a staged tile, held in registers between the load (issued one tile ahead) and the LDS store
+template <typename T>
+struct Staged;
+template <>
+struct Staged<float> {
+	i32x4 p[StreamCfg<float>::NVMAX];
+	f32x4 v[StreamCfg<float>::NVMAX];
+};
+template <>
+struct Staged<double> {
+	i32x4 p[StreamCfg<double>::NVMAX];
+	f64x2 v[2 * StreamCfg<double>::NVMAX];
+};
 
+// issue the loads of positions[a0 .. n1) / values[a0 .. n1) (16-byte aligned start a0) -- no wait here.  The caller
+// guarantees a0 + cap <= nnzTotal rounded down to 4, i.e. the 16-byte pieces never run past the arrays.
+template <typename T>
+__device__ __forceinline__ void stageLoad(Staged<T>& r, int t, int nv, int a0, int n1, const int* __restrict__ positions,
+                                          const T* __restrict__ values) {
+#pragma unroll
+	for (int v = 0; v < StreamCfg<T>::NVMAX; ++v) {
+		const int i = a0 + 4 * (t + v * TPB);
+		if (v < nv && i < n1) {
+			r.p[v] = NT_LOAD(reinterpret_cast<const i32x4*>(positions + i));
+			if constexpr (sizeof(T) == 4) {
+				r.v[v] = NT_LOAD(reinterpret_cast<const f32x4*>(values + i));
+			} else {
+				r.v[2 * v] = NT_LOAD(reinterpret_cast<const f64x2*>(values + i));
+				r.v[2 * v + 1] = NT_LOAD(reinterpret_cast<const f64x2*>(values + i + 2));
+			}
+		}
+	}
+}
+
+// registers -> LDS.  positions are stored as BYTE offsets into x (col * sizeof(T)) so that a gather is one
+// scalar-base + 32-bit-offset load with no address arithmetic.
+template <typename T>
+__device__ __forceinline__ void stageStore(const Staged<T>& r, int t, int nv, int a0, int n1, unsigned* sOff, T* sVal) {
+#pragma unroll
+	for (int v = 0; v < StreamCfg<T>::NVMAX; ++v) {
+		const int li = 4 * (t + v * TPB);
+		if (v < nv && a0 + li < n1) {
+			*reinterpret_cast<i32x4*>(sOff + li) = r.p[v] * static_cast<int>(sizeof(T));
+			if constexpr (sizeof(T) == 4) {
+				*reinterpret_cast<f32x4*>(sVal + li) = r.v[v];
+			} else {
+				*reinterpret_cast<f64x2*>(sVal + li) = r.v[2 * v];
+				*reinterpret_cast<f64x2*>(sVal + li + 2) = r.v[2 * v + 1];
+			}
+		}
+	}
+}
+
+// value of lane `j` (wave-uniform j) broadcast to every lane
+__device__ __forceinline__ float readLane(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+__device__ __forceinline__ double readLane(double v, int j) {
+	const long long bits = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_readlane(static_cast<int>(bits), j);
+	const int hi = __builtin_amdgcn_readlane(static_cast<int>(bits >> 32), j);
+	return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
+
+template <typename T>
+__device__ __forceinline__ T gatherX(const T* __restrict__ x, unsigned byteOffset) {
+	return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + byteOffset);
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smmDynLds[];
+
+// rowBlocks holds {first row, start[first row]} per tile (nTiles + 1 entries, the last one {rows, nnz}).
+//
+// Per tile: (1) the tile's positions[] / values[] slice, fetched one tile ahead with 16-byte coalesced loads into
+// registers, is stored to LDS (positions as byte offsets into x); (2) lane (row, piece) walks its piece of its row out of
+// LDS in batches of 8 independent x[] gathers, rows run fastest across the lanes of a wavefront so the gathers of banded
+// matrices are coalesced; (3) the L pieces of a row meet through wave shuffles, left to right.  Two workgroup barriers per
+// tile (LDS ready / LDS free); the HBM stream of tile i+1 is in flight during (2) of tile i.
 template <typename T, int L>
-__global__ __launch_bounds__(TPB) void spmvStreamKernel(int nBlocks, const int* __restrict__ rowBlocks, const int* __restrict__ start,
+__global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
                                                         const int* __restrict__ positions, const T* __restrict__ values, int op, const T* lhs,
                                                         const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
                                                         T* __restrict__ partials, const int* __restrict__ doneFlag) {
-	constexpr int CAP = StreamCfg<T>::CAP;
-	constexpr int SLOTS = CAP + 4 + ((CAP + 4) >> 5) + 1;
-	__shared__ int sPos[SLOTS];
-	__shared__ T sVal[SLOTS];
-	__shared__ T sPart[TPB];
-	__shared__ T red[4];
+	using Cfg = StreamCfg<T>;
+	constexpr int GATHER = 8;
+	constexpr int LW = L > WAVE ? WAVE : L;  // lanes per row
+	constexpr int RW = WAVE / LW;            // rows per wavefront
+	constexpr int RT = RW * (TPB / WAVE);    // rows per tile
+	// LDS carve-up (sized by the host): sVal[cap + PAD] | sOff[cap + PAD] | sStart[RT + 1] | red[4]
+	T* sVal = reinterpret_cast<T*>(smmDynLds);
+	unsigned* sOff = reinterpret_cast<unsigned*>(sVal + cap + Cfg::PAD);
+	int* sStart = reinterpret_cast<int*>(sOff + cap + Cfg::PAD);
+	T* red = reinterpret_cast<T*>(sStart + RT + 4);
 	if (doneFlag && *doneFlag) return;
 
 	const int t = threadIdx.x;
-	constexpr int R = TPB / L;  // rows summed per pass
-	const int rowLocal = t % R;
-	const int piece = t / R;
+	const int lane = t & (WAVE - 1);
+	const int rowInWave = lane % RW;
+	const int piece = lane / RW;
+	const int rl = (t >> 6) * RW + rowInWave;  // this lane's row within the tile
+	const int nv = cap / Cfg::PIECE;
 	T acc0 = T(0), acc1 = T(0);
 
-	for (int blk = blockIdx.x; blk < nBlocks; blk += gridDim.x) {
-		const int r0 = rowBlocks[blk];
-		const int r1 = rowBlocks[blk + 1];
-		const int n0 = start[r0];
-		const int n1 = start[r1];
-		if (n1 - n0 > CAP) {
-			// a single row longer than the LDS block (r1 == r0 + 1 by construction): stream it straight from HBM
-			T dot = T(0);
-			for (int k = n0 + t; k < n1; k += TPB) {
-				dot = smmFma(values[k], x[positions[k]], dot);
-			}
-			dot = blockSum256(dot, red);
-			if (t == 0) {
-				const T o = applyOp(op, lhs, r0, dot);
-				out[r0] = o;
-				if (dotMode == 2) acc0 += o * o;
-				if (dotMode) acc1 += o * w1[r0];
-			}
-			continue;
+	// every slot must always hold a valid byte offset: a batch of GATHER entries may run past the end of its piece and
+	// the x[] loads of those extra entries are issued (their products are discarded)
+	for (int i = t; i < cap + Cfg::PAD; i += TPB) {
+		sOff[i] = 0u;
+		sVal[i] = T(0);
+	}
+
+	// XCD-aware work split: workgroups b, b+8, b+16, ... share an XCD (and its L2), so each of the 8 groups owns one
+	// contiguous eighth of the tiles and walks it with consecutive tiles resident together -- the x[] cache lines that
+	// neighbouring tiles share are then served by that XCD's L2 instead of being fetched once per XCD.
+	// (Placement only affects speed: any blockIdx -> XCD mapping gives the same result.)
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int xcdGroup = blockIdx.x % nGroups;
+	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;  // workgroups in this group
+	const int perGroup = (nTiles + nGroups - 1) / nGroups;
+	const int tileEnd = min(nTiles, (xcdGroup + 1) * perGroup);
+	// tiles that end within `cap` entries of the end of the arrays are not staged (their 16-byte pieces could run past the
+	// arrays); like over-long rows they are summed straight from HBM
+	const int stageLimit = (rowBlocks[nTiles].y & ~3) - cap;
+	int tile = xcdGroup * perGroup + blockIdx.x / nGroups;
+
+	// software pipeline: the 16-byte loads of tile i+1 are issued (into registers) before tile i is summed out of LDS;
+	// the tile descriptors are fetched one step further ahead
+	Staged<T> regs;
+	int ps = 0;
+	int2 m0 = make_int2(0, 0), m1 = make_int2(0, 0), nm0 = make_int2(0, 0), nm1 = make_int2(0, 0);
+	if (tile < tileEnd) {
+		m0 = rowBlocks[tile];
+		m1 = rowBlocks[tile + 1];
+		if (tile + groupSlots < tileEnd) {
+			nm0 = rowBlocks[tile + groupSlots];
+			nm1 = rowBlocks[tile + groupSlots + 1];
 		}
-		// ---- stage positions[n0,n1) and values[n0,n1) into LDS, 16 bytes per lane per load ----
+		if (m1.y - m0.y <= cap - 3 && (m0.y & ~3) <= stageLimit) {
+			stageLoad<T>(regs, t, nv, m0.y & ~3, m1.y, positions, values);
+			if (t < m1.x - m0.x) ps = start[m0.x + t];
+		}
+	}
+	__syncthreads();  // LDS initialised
+	while (tile < tileEnd) {
+		const int r0 = m0.x, n0 = m0.y, r1 = m1.x, n1 = m1.y;
+		const int nrows = r1 - r0;
 		const int a0 = n0 & ~3;  // 16-byte aligned element index for both arrays (fp64: 32-byte aligned)
-		for (int i = a0 + 4 * t; i < n1; i += 4 * TPB) {
-			const int li = i - a0;
-			if (i + 3 < n1) {
-				const int4 p = *reinterpret_cast<const int4*>(positions + i);
-				sPos[ldsSlot(li)] = p.x;
-				sPos[ldsSlot(li + 1)] = p.y;
-				sPos[ldsSlot(li + 2)] = p.z;
-				sPos[ldsSlot(li + 3)] = p.w;
-				if constexpr (sizeof(T) == 4) {
-					const float4 v = *reinterpret_cast<const float4*>(values + i);
-					sVal[ldsSlot(li)] = v.x;
-					sVal[ldsSlot(li + 1)] = v.y;
-					sVal[ldsSlot(li + 2)] = v.z;
-					sVal[ldsSlot(li + 3)] = v.w;
-				} else {
-					const double2 v0 = *reinterpret_cast<const double2*>(values + i);
-					const double2 v1 = *reinterpret_cast<const double2*>(values + i + 2);
-					sVal[ldsSlot(li)] = v0.x;
-					sVal[ldsSlot(li + 1)] = v0.y;
-					sVal[ldsSlot(li + 2)] = v1.x;
-					sVal[ldsSlot(li + 3)] = v1.y;
-				}
-			} else {
-				for (int j = 0; j < 4 && i + j < n1; ++j) {
-					sPos[ldsSlot(li + j)] = positions[i + j];
-					sVal[ldsSlot(li + j)] = values[i + j];
-				}
-			}
+		const bool direct = n1 - n0 > cap - 3 || a0 > stageLimit;
+		if (!direct) {
+			stageStore<T>(regs, t, nv, a0, n1, sOff, sVal);
+			if (t < nrows) sStart[t] = ps - a0;
+			if (t == 0) sStart[nrows] = n1 - a0;
 		}
 		__syncthreads();
-		// ---- row sums from LDS: thread -> (row, piece), row-fastest so that the x gather is coalesced ----
-		for (int rb = r0; rb < r1; rb += R) {
-			const int row = rb + rowLocal;
-			T dot = T(0);
-			if (row < r1) {
-				const int b = start[row] - a0;
-				const int e = start[row + 1] - a0;
-				int kb = b, ke = e;
-				if (L > 1) {
-					const int chunk = (e - b + L - 1) / L;
-					kb = b + piece * chunk;
-					ke = min(e, kb + chunk);
+		// ---- prefetch this workgroup's next tile ----
+		const int ntile = tile + groupSlots;
+		const int2 m0n = nm0, m1n = nm1;
+		if (ntile < tileEnd) {
+			if (m1n.y - m0n.y <= cap - 3 && (m0n.y & ~3) <= stageLimit) {
+				stageLoad<T>(regs, t, nv, m0n.y & ~3, m1n.y, positions, values);
+				if (t < m1n.x - m0n.x) ps = start[m0n.x + t];
+			}
+			if (ntile + groupSlots < tileEnd) {
+				nm0 = rowBlocks[ntile + groupSlots];
+				nm1 = rowBlocks[ntile + groupSlots + 1];
+			}
+		}
+		if (direct && nrows == 1) {
+			// an over-long row: wavefront 0 streams it straight from HBM
+			if (t < WAVE) {
+				T dot = T(0);
+				if constexpr (LW == 1) {
+					// one-lane-per-row configurations promise the reference's left-to-right order (ref:1484-1489): the
+					// wavefront fetches 64 entries at a time and folds them in lane order (every lane forms the same sum)
+					for (int k0 = n0; k0 < n1; k0 += WAVE) {
+						const int k = k0 + lane;
+						const bool ok = k < n1;
+						const T v = ok ? values[k] : T(0);
+						const T xx = ok ? x[positions[k]] : T(0);
+						const int cnt = min(WAVE, n1 - k0);
+						for (int j = 0; j < cnt; ++j) {
+							dot = smmFma(readLane(v, j), readLane(xx, j), dot);
+						}
+					}
+				} else {
+					for (int k = n0 + lane; k < n1; k += WAVE) {
+						dot = smmFma(values[k], x[positions[k]], dot);
+					}
+					dot = groupSum<WAVE>(dot);
 				}
-				for (int k = kb; k < ke; ++k) {
-					const int s = ldsSlot(k);
-					dot = smmFma(sVal[s], x[sPos[s]], dot);
+				if (lane == 0) {
+					const T o = applyOp(op, lhs, r0, dot);
+					out[r0] = o;
+					if (dotMode == 2) acc0 += o * o;
+					if (dotMode) acc1 += o * w1[r0];
 				}
 			}
-			if (L > 1) {
-				sPart[t] = dot;
-				__syncthreads();
-				if (piece == 0 && row < r1) {
+		} else if (direct) {
+			// one of the last tiles of the matrix: one lane per row, left to right, straight from HBM
+			if (t < nrows) {
+				const int row = r0 + t;
+				const int e = start[row + 1];
+				T dot = T(0);
+				for (int k = start[row]; k < e; ++k) {
+					dot = smmFma(values[k], x[positions[k]], dot);
+				}
+				const T o = applyOp(op, lhs, row, dot);
+				out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		} else {
+			// ---- row sums from LDS: lane -> (row, piece), rows fastest across lanes so that the x gather is coalesced ----
+			T dot = T(0);
+			if (rl < nrows) {
+				const int b = sStart[rl];
+				const int e = sStart[rl + 1];
+				int kb = b, ke = e;
+				if (LW > 1) {
+					const int piecelen = (e - b + LW - 1) / LW;
+					kb = b + piece * piecelen;
+					ke = min(e, kb + piecelen);
+				}
+				// batches of GATHER entries: the x[] gathers of a batch are all issued before the first multiply-add, so a lane
+				// keeps GATHER independent loads in flight; the sum itself stays strictly left to right.  Entries past the end
+				// of the piece are loaded too (valid offsets, see above) but never added.
+				for (int k = kb; k < ke; k += GATHER) {
+					const int nvalid = ke - k;
+					unsigned off[GATHER];
+					T xv[GATHER], vv[GATHER];
 #pragma unroll
-					for (int q = 1; q < L; ++q) {
-						dot += sPart[q * R + rowLocal];
+					for (int u = 0; u < GATHER; ++u) {
+						off[u] = sOff[k + u];
+						vv[u] = sVal[k + u];
+					}
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						xv[u] = gatherX<T>(x, off[u]);
+					}
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						const T next = smmFma(vv[u], xv[u], dot);
+						dot = u < nvalid ? next : dot;
 					}
 				}
-				__syncthreads();
 			}
-			if (piece == 0 && row < r1) {
+			if (LW > 1) {
+				// pieces of one row sit RW lanes apart in the same wavefront; add them left to right: ((p0 + p1) + p2) + ...
+				T total = dot;
+#pragma unroll
+				for (int q = 1; q < LW; ++q) {
+					total += __shfl(dot, rowInWave + q * RW, WAVE);
+				}
+				dot = total;
+			}
+			if (piece == 0 && rl < nrows) {
+				const int row = r0 + rl;
 				const T o = applyOp(op, lhs, row, dot);
 				out[row] = o;
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
 			}
 		}
-		__syncthreads();  // LDS is restaged by the next row block
+		__syncthreads();  // every lane is done with the LDS copy of this tile
+		tile = ntile;
+		m0 = m0n;
+		m1 = m1n;
 	}
 	if (dotMode) {
 		if (dotMode == 2) {
@@ -220,36 +386,47 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nBlocks, const int* 
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-// Cut rows into blocks of <= cap nonzeros and <= TPB rows; a row longer than cap gets a block of its own.
-int buildRowBlocks(smm_hip_csr* m, int cap) {
+// Cut rows into tiles of <= capNnz nonzeros and <= maxRows rows; a row longer than capNnz gets a tile of its own.
+int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows) {
 	std::vector<int> hs(static_cast<size_t>(m->rows) + 1);
 	hipStream_t s = libStream();
 	SMM_HIP_TRY(hipMemcpyAsync(hs.data(), m->d_start, hs.size() * sizeof(int), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	std::vector<int> rb;
-	rb.reserve(static_cast<size_t>(m->nnz / cap + m->rows / TPB + 2));
+	std::vector<int> rb;  // pairs {first row, start[first row]}
+	rb.reserve(2 * static_cast<size_t>(m->nnz / capNnz + m->rows / maxRows + 2));
 	int r = 0;
 	const int rows = m->rows;
 	while (r < rows) {
 		rb.push_back(r);
+		rb.push_back(hs[r]);
 		const int base = hs[r];
-		int e = r + 1;  // always take at least one row
-		const int limitRow = std::min(rows, r + TPB);
-		while (e < limitRow && hs[e + 1] - base <= cap) ++e;
-		if (hs[e] - base > cap) {
-			// first row alone exceeds the cap: e == r + 1, long-row path
-		}
+		int e = r + 1;  // always take at least one row (alone it may exceed capNnz: over-long row)
+		const int limitRow = std::min(rows, r + maxRows);
+		while (e < limitRow && hs[e + 1] - base <= capNnz) ++e;
 		r = e;
 	}
 	rb.push_back(rows);
+	rb.push_back(hs[rows]);
 	devFree(m->d_rowblocks);
 	m->d_rowblocks = nullptr;
-	m->n_rowblocks = static_cast<int>(rb.size()) - 1;
-	m->stream_nnz_cap = cap;
+	m->n_rowblocks = static_cast<int>(rb.size() / 2) - 1;
+	m->stream_nnz_cap = capNnz;
+	m->stream_max_rows = maxRows;
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(&m->d_rowblocks), rb.size() * sizeof(int)));
 	SMM_HIP_TRY(hipMemcpyAsync(m->d_rowblocks, rb.data(), rb.size() * sizeof(int), hipMemcpyHostToDevice, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
 	return SMM_HIP_OK;
+}
+
+// LDS capacity (nonzeros) of a tile of TPB / lanes average rows, in staging passes of 1024
+template <typename T>
+static int streamCap(const smm_hip_csr* m, int lanes) {
+	const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0;
+	const int rowsPerTile = TPB / std::min(lanes, WAVE);
+	const double want = avg * rowsPerTile * 1.04 + 3;
+	int nv = static_cast<int>((want + StreamCfg<T>::PIECE - 1) / StreamCfg<T>::PIECE);
+	nv = std::max(1, std::min(nv, StreamCfg<T>::NVMAX));
+	return nv * StreamCfg<T>::PIECE;
 }
 
 static int lanesForAvg(double avg, int family) {
@@ -293,7 +470,9 @@ static void launchVector(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 template <typename T, int L>
 static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {
-	spmvStreamKernel<T, L><<<grid, TPB, 0, s>>>(m->n_rowblocks, m->d_rowblocks, m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
+	const int cap = m->stream_nnz_cap + 3;
+	const size_t lds = static_cast<size_t>(cap + StreamCfg<T>::PAD) * (sizeof(T) + 4) + (TPB + 8) * sizeof(int) + 4 * sizeof(T) + 16;
+	spmvStreamKernel<T, L><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
 	                                            op, lhs, x, out, dotMode, w1, partials, doneFlag);
 }
 
@@ -322,10 +501,14 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	}
 	if (m->rows == 0 && !dotMode) return SMM_HIP_OK;
 	int family = m->family;
-	if (family == SMM_SPMV_STREAM && !m->d_rowblocks) {
-		SMM_TRY(buildRowBlocks(const_cast<smm_hip_csr*>(m), StreamCfg<T>::CAP));
-	}
 	const int L = m->lanes;
+	if (family == SMM_SPMV_STREAM) {
+		const int capNnz = streamCap<T>(m, L) - 3;
+		const int maxRows = TPB / std::min(L, WAVE);
+		if (!m->d_rowblocks || m->stream_nnz_cap != capNnz || m->stream_max_rows != maxRows) {
+			SMM_TRY(buildRowBlocks(const_cast<smm_hip_csr*>(m), capNnz, maxRows));
+		}
+	}
 	int grid;
 	if (dotMode) {
 		grid = NPART;  // fixed number of partial sums
@@ -345,11 +528,13 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	case 32: FN<T, 32>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break; \
 	default: FN<T, 64>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break; \
 	}
+	const int profSlot = profBegin(s);
 	if (family == SMM_SPMV_STREAM) {
 		SMM_DISPATCH_L(launchStream)
 	} else {
 		SMM_DISPATCH_L(launchVector)
 	}
+	profEnd(profSlot, s);
 #undef SMM_DISPATCH_L
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;

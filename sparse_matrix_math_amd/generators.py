@@ -46,11 +46,13 @@ def _band_value(seed, r, k, dtype):
     return -(dtype(0.02) + scaled)
 
 
-def banded_random_spd(n, k=25, seed=0x5EED, max_offset=1 << 20, dtype=np.float32):
+def banded_random_spd(n, k=25, seed=0x5EED, max_offset=1 << 20, dtype=np.float32, diag_shift=1.0):
     """Banded-random symmetric strictly diagonally dominant (hence SPD) matrix, ~2k+1 nonzeros per row.
 
     For every row i and offset d_k: A[i][i-d_k] and A[i][i+d_k] (when inside the matrix) hold
-    -(0.02+0.98u(hash(min(i,j),k))); A[i][i] = 1 + sum |offdiag| accumulated in ascending column order.
+    -(0.02+0.98u(hash(min(i,j),k))); A[i][i] = diag_shift + sum |offdiag| accumulated in ascending column order
+    (diag_shift = 1 is SURVEY.md's law).  Every row sums to diag_shift, so the all-ones vector is the eigenvector of
+    the smallest eigenvalue diag_shift and the condition number is at most (diag_shift + 2 sum|offdiag|) / diag_shift.
     """
     dtype = np.dtype(dtype).type
     offs = band_offsets(n, k, seed, max_offset)
@@ -60,7 +62,7 @@ def banded_random_spd(n, k=25, seed=0x5EED, max_offset=1 << 20, dtype=np.float32
     cols = np.empty((n, width), dtype=np.int64)
     vals = np.zeros((n, width), dtype=dtype)
     valid = np.zeros((n, width), dtype=bool)
-    diag = np.full(n, dtype(1))
+    diag = np.full(n, dtype(diag_shift))
     slot = 0
     for kk in range(K - 1, -1, -1):  # columns i - d_k ascending
         j = rows - offs[kk]

@@ -91,6 +91,17 @@ def synchronize(stream=None):
     check(_lib.load().smm_hip_stream_synchronize(_dptr(stream)))
 
 
+def profile_enable(on=True):
+    check(_lib.load().smm_hip_profile_enable(1 if on else 0))
+
+
+def profile_read(reset=True):
+    """(summed SpMV kernel milliseconds, launches) measured with HIP events on the launch stream"""
+    ms, n = ctypes.c_double(), ctypes.c_longlong()
+    check(_lib.load().smm_hip_profile_read(ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
+    return ms.value, n.value
+
+
 class Preconditioner:
     """`int apply(const T* rhs, T* x) const` (ref:1173-1235).  Created by CSRMatrix.getPreconditioner."""
 
@@ -306,8 +317,8 @@ def gen_stencil3d_nnz(nx, ny, nz):
     return int(_lib.load().smm_hip_gen_stencil3d_nnz(int(nx), int(ny), int(nz)))
 
 
-def gen_banded_dev(n, k, seed, max_offset, d_start, d_positions, d_values, dtype, stream=None):
-    check(_fn("smm_hip_gen_banded_dev", _suffix(dtype))(int(n), int(k), int(seed), int(max_offset), _dptr(d_start), _dptr(d_positions), _dptr(d_values), _dptr(stream)))
+def gen_banded_dev(n, k, seed, max_offset, d_start, d_positions, d_values, dtype, stream=None, diag_shift=1.0):
+    check(_fn("smm_hip_gen_banded_dev", _suffix(dtype))(int(n), int(k), int(seed), int(max_offset), np.dtype(dtype).type(diag_shift), _dptr(d_start), _dptr(d_positions), _dptr(d_values), _dptr(stream)))
 
 
 def gen_poisson2d_dev(nx, ny, d_start, d_positions, d_values, dtype, stream=None):

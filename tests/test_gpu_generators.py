@@ -7,7 +7,7 @@ from sparse_matrix_math_amd import generators as gen
 pytestmark = pytest.mark.gpu
 
 
-def run_dev(smm, kind, args, dtype, nnz, rows):
+def run_dev(smm, kind, args, dtype, nnz, rows, **kw):
     import torch
 
     dev = torch.device("cuda:0")
@@ -16,16 +16,17 @@ def run_dev(smm, kind, args, dtype, nnz, rows):
     d_pos = torch.full((max(nnz, 1),), -1, dtype=torch.int32, device=dev)
     d_val = torch.zeros(max(nnz, 1), dtype=tdt, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    getattr(smm.host, f"gen_{kind}_dev")(*args, d_start, d_pos, d_val, dtype, stream)
+    getattr(smm.host, f"gen_{kind}_dev")(*args, d_start, d_pos, d_val, dtype, stream, **kw)
     torch.cuda.synchronize()
     return d_start.cpu().numpy(), d_pos.cpu().numpy()[:nnz], d_val.cpu().numpy()[:nnz]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_banded(smm, dtype):
-    for n, k, seed, mo in ((2000, 25, 0x5EED, 1 << 20), (50000, 25, 0x5EED, 1 << 20), (10, 25, 1, 1 << 20), (500, 3, 7, 50), (1, 5, 3, 100)):
-        want = gen.banded_random_spd(n, k, seed, mo, dtype)
-        got = run_dev(smm, "banded", (n, k, seed, mo), dtype, len(want[1]), n)
+    for n, k, seed, mo, shift in ((2000, 25, 0x5EED, 1 << 20, 1.0), (50000, 25, 0x5EED, 1 << 20, 0.01), (10, 25, 1, 1 << 20, 1.0), (500, 3, 7, 50, 0.5),
+                                  (1, 5, 3, 100, 1.0)):
+        want = gen.banded_random_spd(n, k, seed, mo, dtype, shift)
+        got = run_dev(smm, "banded", (n, k, seed, mo), dtype, len(want[1]), n, diag_shift=shift)
         for w, g in zip(want, got):
             np.testing.assert_array_equal(g, w)
 

@@ -2,7 +2,7 @@
 sweeps of the reference / oracle."""
 import numpy as np
 import pytest
-from test_oracle import gen_matrices
+from test_oracle import gen_matrices, spmv_vectors
 
 from sparse_matrix_math_amd import generators as gen
 
@@ -25,7 +25,7 @@ def test_sgs_apply_bit_identical_to_reference(smm, golden, dtype):
         rows = len(csr[0]) - 1
         A = make(smm, csr)
         M = A.getPreconditioner(smm.SolverPreconditioner.SYMMETRIC_GAUS_SEIDEL)
-        lhs = np.random.default_rng(1234).uniform(-1, 1, (2, rows)).astype(dtype)[1]
+        lhs = spmv_vectors(rows, dtype)[1]
         x = np.zeros(rows, dtype=dtype)
         assert M.apply(lhs, x) == 0
         np.testing.assert_array_equal(x, golden[f"gen/{mname}/{dn}/sgs_apply/x"], err_msg=mname)
@@ -53,7 +53,7 @@ def test_ic0_matches_reference(smm, golden, dtype):
         A = make(smm, csr)
         M = A.getPreconditioner(P.IC0)
         np.testing.assert_array_equal(M.values(), golden[f"gen/{mname}/{dn}/ic0/values"])
-        lhs = np.random.default_rng(1234).uniform(-1, 1, (2, rows)).astype(dtype)[1]
+        lhs = spmv_vectors(rows, dtype)[1]
         x = np.zeros(rows, dtype=dtype)
         M.apply(lhs, x)
         np.testing.assert_array_equal(x, golden[f"gen/{mname}/{dn}/ic0/x"])

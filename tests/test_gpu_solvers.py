@@ -132,7 +132,7 @@ def test_edge_semantics(smm, golden, dtype):
     # a 0x0 system
     E = smm.CSRMatrix(0, 0, np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=dtype))
     z = np.zeros(0, dtype=dtype)
-    assert int(smm.ConjugateGradient(E, z, z, z, -1, 1e-6)) == 2  # eps^2 > 0 is false for rr == 0 ... loop does not run
+    assert int(smm.ConjugateGradient(E, z, z, z, -1, 1e-6)) == 0  # eps^2 > ||r||^2 == 0: SUCCESS before the loop (ref:2342)
     # wrong preconditioner kinds are rejected
     with pytest.raises(smm.SmmHipError):
         smm.ConjugateGradient(A, b, ones, x, 1, 0.0, A.getPreconditioner(smm.SolverPreconditioner.JACOBI))
