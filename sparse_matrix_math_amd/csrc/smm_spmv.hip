@@ -432,11 +432,12 @@ static int streamCap(const smm_hip_csr* m, int lanes) {
 static int lanesForAvg(double avg, int family) {
 	if (family == SMM_SPMV_STREAM) {
 		// pieces of ~12-16 entries per lane; L == 1 keeps the reference's summation order bit for bit
+		// measured on MI355X (tools/spmv_sweep.py): ~25 entries per lane is the sweet spot
 		if (avg <= 24) return 1;
-		if (avg <= 40) return 2;
-		if (avg <= 96) return 4;
-		if (avg <= 192) return 8;
-		if (avg <= 384) return 16;
+		if (avg <= 64) return 2;
+		if (avg <= 128) return 4;
+		if (avg <= 256) return 8;
+		if (avg <= 512) return 16;
 		return 32;
 	}
 	int l = 1;
