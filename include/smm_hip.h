@@ -185,6 +185,48 @@ int smm_hip_precond_apply_dev_f64(const smm_hip_precond* M, const double* d_rhs,
 int smm_hip_precond_values_f32(const smm_hip_precond* M, float* out, size_t count);
 int smm_hip_precond_values_f64(const smm_hip_precond* M, double* out, size_t count);
 
+/* ---- stage-wise BiCGStab for row-partitioned multi-GPU solves (one process per GPU) -------------------------------
+ * The loop of ref:2191-2283 cut at its global reductions.  Each rank owns rows [row_begin, row_end) of A and the matching
+ * slices of every vector.  Between a *_LOCAL stage and the following *_APPLY stage the caller all-reduces (sum) the first
+ * 1 or 2 scalars of the workspace's `sums` buffer across ranks (RCCL); before each SpMV it exchanges the x-vector halo.
+ * Every stage only enqueues kernels; all scalars of the recurrence stay on the device.
+ *
+ *   r = b - A x  (caller, SpMV)                       INIT_LOCAL  -> all-reduce sums[0]   -> INIT_APPLY
+ *   ap = A p  with dot_mode 1, w1 = r0 (caller)       ALPHA_LOCAL -> all-reduce sums[0]   -> ALPHA_APPLY  (alpha, s)
+ *   as = A s  with dot_mode 2, w1 = s  (caller)       OMEGA_LOCAL -> all-reduce sums[0:2] -> OMEGA_APPLY  (omega, x, r)
+ *                                                                 -> all-reduce sums[0:2] -> BETA_APPLY   (res, beta, p)
+ */
+#define SMM_STAGE_INIT_LOCAL 1
+#define SMM_STAGE_INIT_APPLY 2
+#define SMM_STAGE_ALPHA_LOCAL 3
+#define SMM_STAGE_ALPHA_APPLY 4
+#define SMM_STAGE_OMEGA_LOCAL 5
+#define SMM_STAGE_OMEGA_APPLY 6
+#define SMM_STAGE_BETA_APPLY 7
+typedef struct smm_hip_bicgstab_ws smm_hip_bicgstab_ws;
+/* number of partial sums per reduced quantity a fused SpMV writes (d_partials holds 2x this many T) */
+int smm_hip_partials_count(void);
+/* SpMV with the dot products of the fresh out[] fused into the epilogue: dot_mode 0 none; 1: out.w1 -> partials[0..P);
+ * 2: out.out -> partials[0..P) and out.w1 -> partials[P..2P), P = smm_hip_partials_count() */
+int smm_hip_spmv_fused_dev_f32(const smm_hip_csr* m, int op, const float* d_lhs, const float* d_x, float* d_out, int dot_mode,
+                               const float* d_w1, float* d_partials, smm_hip_stream stream);
+int smm_hip_spmv_fused_dev_f64(const smm_hip_csr* m, int op, const double* d_lhs, const double* d_x, double* d_out, int dot_mode,
+                               const double* d_w1, double* d_partials, smm_hip_stream stream);
+/* workspace for n local rows: owns r, r0, ap, as, the partial-sum buffer, `sums` (4 scalars) and the recurrence state */
+int smm_hip_bicgstab_ws_create_f32(int n, smm_hip_bicgstab_ws** out);
+int smm_hip_bicgstab_ws_create_f64(int n, smm_hip_bicgstab_ws** out);
+int smm_hip_bicgstab_ws_destroy(smm_hip_bicgstab_ws* ws);
+/* p and s live in the caller's halo-extended buffers (they are SpMV inputs): bind the owned slices.  d_sums (optional,
+ * >= 4 scalars) replaces the workspace's own `sums` buffer, e.g. with memory the caller's collective library can see. */
+int smm_hip_bicgstab_ws_bind(smm_hip_bicgstab_ws* ws, void* d_p, void* d_s, void* d_sums);
+int smm_hip_bicgstab_ws_pointers(const smm_hip_bicgstab_ws* ws, void** d_r, void** d_r0, void** d_ap, void** d_as, void** d_partials,
+                                 void** d_sums);
+int smm_hip_bicgstab_ws_stage_f32(smm_hip_bicgstab_ws* ws, int stage, float* d_x, float eps, smm_hip_stream stream);
+int smm_hip_bicgstab_ws_stage_f64(smm_hip_bicgstab_ws* ws, int stage, double* d_x, double eps, smm_hip_stream stream);
+/* synchronises `stream` and returns the loop state: done flag, iterations executed, last ||r|| */
+int smm_hip_bicgstab_ws_result_f32(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* done, int* iterations, float* resnorm);
+int smm_hip_bicgstab_ws_result_f64(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* done, int* iterations, double* resnorm);
+
 /* ---- synthetic workload generators (BASELINE.json configs; device-side so 5e8-entry matrices need no host
  *      std::map as in ref:606-618).  d_start[rows+1], d_positions[nnz], d_values[nnz] are DEVICE arrays sized by
  *      the *_nnz query.  Same laws as sparse_matrix_math_amd.generators (numpy), bit for bit. --------------- */
@@ -201,6 +243,14 @@ int smm_hip_gen_stencil3d_dev_f64(int nx, int ny, int nz, double diag, double lo
  * sum|offdiag| (SURVEY's law is diag_shift = 1; A*1 = diag_shift*1, so 1/diag_shift sets the condition number) */
 int smm_hip_gen_banded_dev_f32(int n, int k, unsigned long long seed, int max_offset, float diag_shift, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
 int smm_hip_gen_banded_dev_f64(int n, int k, unsigned long long seed, int max_offset, double diag_shift, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
+/* rows [row_begin, row_end) only -- what one rank of a row-partitioned run owns: d_start[row_end - row_begin + 1] is local
+ * (d_start[0] == 0), d_positions hold GLOBAL columns.  smm_hip_gen_banded_row_start(row) is start[row] of the full matrix
+ * in closed form, so the local nnz is row_start(row_end) - row_start(row_begin). */
+long long smm_hip_gen_banded_row_start(int n, int k, unsigned long long seed, int max_offset, int row);
+int smm_hip_gen_banded_rows_dev_f32(int n, int k, unsigned long long seed, int max_offset, float diag_shift, int row_begin, int row_end,
+                                    int* d_start, int* d_positions, float* d_values, smm_hip_stream stream);
+int smm_hip_gen_banded_rows_dev_f64(int n, int k, unsigned long long seed, int max_offset, double diag_shift, int row_begin, int row_end,
+                                    int* d_start, int* d_positions, double* d_values, smm_hip_stream stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,11 @@ _TYPED = {
     "smm_hip_gen_poisson2d_dev": (c_int, [c_int, c_int, _P, _P, _P, _P]),
     "smm_hip_gen_stencil3d_dev": (c_int, [c_int, c_int, c_int, "T", "T", "T", _P, _P, _P, _P]),
     "smm_hip_gen_banded_dev": (c_int, [c_int, c_int, c_ulonglong, c_int, "T", _P, _P, _P, _P]),
+    "smm_hip_gen_banded_rows_dev": (c_int, [c_int, c_int, c_ulonglong, c_int, "T", c_int, c_int, _P, _P, _P, _P]),
+    "smm_hip_spmv_fused_dev": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    "smm_hip_bicgstab_ws_create": (c_int, [c_int, POINTER(_P)]),
+    "smm_hip_bicgstab_ws_stage": (c_int, [_P, c_int, _P, "T", _P]),
+    "smm_hip_bicgstab_ws_result": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
 }
 
 _PLAIN = {
@@ -72,6 +77,11 @@ _PLAIN = {
     "smm_hip_gen_poisson2d_nnz": (c_longlong, [c_int, c_int]),
     "smm_hip_gen_stencil3d_nnz": (c_longlong, [c_int, c_int, c_int]),
     "smm_hip_gen_banded_nnz": (c_longlong, [c_int, c_int, c_ulonglong, c_int]),
+    "smm_hip_gen_banded_row_start": (c_longlong, [c_int, c_int, c_ulonglong, c_int, c_int]),
+    "smm_hip_partials_count": (c_int, []),
+    "smm_hip_bicgstab_ws_destroy": (c_int, [_P]),
+    "smm_hip_bicgstab_ws_bind": (c_int, [_P, _P, _P, _P]),
+    "smm_hip_bicgstab_ws_pointers": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P)]),
 }
 
 

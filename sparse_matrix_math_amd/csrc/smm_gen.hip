@@ -51,17 +51,26 @@ __device__ __forceinline__ T bandValue(unsigned long long seed, int r, int k) {
 	return -(T(0.02) + scaled);
 }
 
+__device__ __host__ inline long long bandStart(long long i, long long n, const BandOffsets& o) {
+	long long s = i;
+	for (int k = 0; k < o.k; ++k) {
+		const long long left = i - o.d[k];
+		const long long cap = n - o.d[k];
+		s += left > 0 ? left : 0;
+		s += i < (cap > 0 ? cap : 0) ? i : (cap > 0 ? cap : 0);
+	}
+	return s;
+}
+
+// rows [rowBegin, rowEnd) of the n x n matrix: start[] is local (start[0] == 0), positions[] are global columns
 template <typename T>
-__global__ __launch_bounds__(TPB) void genBandedKernel(int n, BandOffsets o, unsigned long long seed, T diagShift, int* __restrict__ start,
-                                                       int* __restrict__ positions, T* __restrict__ values) {
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i <= n; i += static_cast<long long>(gridDim.x) * TPB) {
-		long long s = i;
-		for (int k = 0; k < o.k; ++k) {
-			s += max(0LL, i - o.d[k]);
-			s += min(i, max(0LL, static_cast<long long>(n) - o.d[k]));
-		}
-		start[i] = static_cast<int>(s);
-		if (i == n) continue;
+__global__ __launch_bounds__(TPB) void genBandedKernel(int n, BandOffsets o, unsigned long long seed, T diagShift, int rowBegin, int rowEnd,
+                                                       int* __restrict__ start, int* __restrict__ positions, T* __restrict__ values) {
+	const long long base = bandStart(rowBegin, n, o);
+	for (long long i = rowBegin + static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i <= rowEnd; i += static_cast<long long>(gridDim.x) * TPB) {
+		const long long s = bandStart(i, n, o) - base;
+		start[i - rowBegin] = static_cast<int>(s);
+		if (i == rowEnd) continue;
 		const int row = static_cast<int>(i);
 		long long w = s;
 		T diag = diagShift;
@@ -145,18 +154,19 @@ static int genGrid(long long n) { return static_cast<int>(std::max<long long>(1,
 static bool fitsInt(long long v) { return v >= 0 && v <= 2147483647LL; }
 
 template <typename T>
-static int genBanded(int n, int k, unsigned long long seed, int maxOffset, T diagShift, int* d_start, int* d_positions, T* d_values, smm_hip_stream stream) {
+static int genBanded(int n, int k, unsigned long long seed, int maxOffset, T diagShift, int rowBegin, int rowEnd, int* d_start, int* d_positions,
+                     T* d_values, smm_hip_stream stream) {
 	SMM_TRY(ensureInit());
-	if (n < 0 || k < 0 || !d_start || (n > 0 && (!d_positions || !d_values))) {
+	if (n < 0 || k < 0 || rowBegin < 0 || rowEnd < rowBegin || rowEnd > n || !d_start || (rowEnd > rowBegin && (!d_positions || !d_values))) {
 		setError("gen_banded: bad arguments");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if (!fitsInt(smm_hip_gen_banded_nnz(n, k, seed, maxOffset))) {
+	if (!fitsInt(smm_hip_gen_banded_row_start(n, k, seed, maxOffset, rowEnd) - smm_hip_gen_banded_row_start(n, k, seed, maxOffset, rowBegin))) {
 		setError("gen_banded: nnz exceeds int32 (the reference's index type, ref:1251-1257)");
 		return SMM_HIP_ERR_INVALID;
 	}
 	const BandOffsets o = drawOffsets(n, k, seed, maxOffset);
-	genBandedKernel<T><<<genGrid(n), TPB, 0, pickStream(stream)>>>(n, o, seed, diagShift, d_start, d_positions, d_values);
+	genBandedKernel<T><<<genGrid(rowEnd - rowBegin), TPB, 0, pickStream(stream)>>>(n, o, seed, diagShift, rowBegin, rowEnd, d_start, d_positions, d_values);
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
 }
@@ -201,6 +211,11 @@ long long smm_hip_gen_stencil3d_nnz(int nx, int ny, int nz) {
 	return 7 * n - 2LL * nx * ny - 2LL * ny * nz - 2LL * nx * nz;
 }
 
+long long smm_hip_gen_banded_row_start(int n, int k, unsigned long long seed, int max_offset, int row) {
+	const BandOffsets o = drawOffsets(n, k, seed, max_offset);
+	return bandStart(row, n, o);
+}
+
 long long smm_hip_gen_banded_nnz(int n, int k, unsigned long long seed, int max_offset) {
 	const BandOffsets o = drawOffsets(n, k, seed, max_offset);
 	long long nnz = n;
@@ -221,10 +236,19 @@ int smm_hip_gen_stencil3d_dev_f64(int nx, int ny, int nz, double diag, double lo
 	return genStencil3d<double>(nx, ny, nz, diag, lo, hi, d_start, d_positions, d_values, stream);
 }
 int smm_hip_gen_banded_dev_f32(int n, int k, unsigned long long seed, int max_offset, float diag_shift, int* d_start, int* d_positions, float* d_values, smm_hip_stream stream) {
-	return genBanded<float>(n, k, seed, max_offset, diag_shift, d_start, d_positions, d_values, stream);
+	return genBanded<float>(n, k, seed, max_offset, diag_shift, 0, n, d_start, d_positions, d_values, stream);
 }
 int smm_hip_gen_banded_dev_f64(int n, int k, unsigned long long seed, int max_offset, double diag_shift, int* d_start, int* d_positions, double* d_values, smm_hip_stream stream) {
-	return genBanded<double>(n, k, seed, max_offset, diag_shift, d_start, d_positions, d_values, stream);
+	return genBanded<double>(n, k, seed, max_offset, diag_shift, 0, n, d_start, d_positions, d_values, stream);
+}
+
+int smm_hip_gen_banded_rows_dev_f32(int n, int k, unsigned long long seed, int max_offset, float diag_shift, int row_begin, int row_end, int* d_start,
+                                    int* d_positions, float* d_values, smm_hip_stream stream) {
+	return genBanded<float>(n, k, seed, max_offset, diag_shift, row_begin, row_end, d_start, d_positions, d_values, stream);
+}
+int smm_hip_gen_banded_rows_dev_f64(int n, int k, unsigned long long seed, int max_offset, double diag_shift, int row_begin, int row_end, int* d_start,
+                                    int* d_positions, double* d_values, smm_hip_stream stream) {
+	return genBanded<double>(n, k, seed, max_offset, diag_shift, row_begin, row_end, d_start, d_positions, d_values, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,337 @@
+"""Row-partitioned multi-GPU BiCGStab: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+The reference is a single-process CPU library (no collectives); this is the MI355X-native scale-out
+of its BiCGStab loop (ref:2191-2283):
+
+  * rank g owns a contiguous range of rows [bounds[g], bounds[g+1]) of A, balanced by nonzeros, and the matching slices of
+    every vector;
+  * before each SpMV the x-vector HALO is exchanged point to point: a rank needs x only on the column range its rows touch
+    ([cmin, cmax]); the parts of that range owned by other ranks are received straight into a halo-extended buffer
+    [left halo | owned | right halo] (`batch_isend_irecv`).  For a banded / stencil matrix that is a few MB from one or two
+    neighbours; for a matrix with global coupling it degenerates into an all-gather built from the same primitives;
+  * the local rows are split once into A_loc (columns this rank owns) and A_rem (halo columns): A_loc p runs while the halo
+    is in flight, A_rem p is added when it has landed (rMultAdd in place), with the dot products fused into that last launch;
+  * the scalars of the recurrence are completed with an all-reduce of 1-2 numbers at the three reduction points of an
+    iteration; every scalar stays in HBM (csrc/smm_stepwise.hip), the host never reads one inside the loop.
+
+The driver (`DistBiCGStab`) is written against two small interfaces -- local kernels (`ops`) and collectives (`comm`) -- so
+the partition / halo / staging logic is exercised on CPU by tests/test_distributed_gloo.py (gloo, world_size 2) with
+stand-in local kernels.  The product implementation of `ops` is `HipOps` (libsmm_hip.so); there is no CPU implementation
+in this package.
+"""
+import ctypes
+
+import numpy as np
+
+STAGE_INIT_LOCAL, STAGE_INIT_APPLY, STAGE_ALPHA_LOCAL, STAGE_ALPHA_APPLY, STAGE_OMEGA_LOCAL, STAGE_OMEGA_APPLY, STAGE_BETA_APPLY = range(1, 8)
+OP_ASSIGN, OP_ADD, OP_SUB = 0, 1, 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# partition and halo plan (pure Python: no device, no communication)
+# ---------------------------------------------------------------------------------------------------------------------
+def partition_rows_by_nnz(row_start, n, world):
+    """bounds[0..world]: contiguous row ranges with ~equal nonzeros.  row_start(i) = start[i] of the full matrix."""
+    total = row_start(n)
+    bounds = [0]
+    for g in range(1, world):
+        target = total * g // world
+        lo, hi = bounds[-1], n
+        while lo < hi:  # smallest row with row_start(row) >= target
+            mid = (lo + hi) // 2
+            if row_start(mid) >= target:
+                hi = mid
+            else:
+                lo = mid + 1
+        bounds.append(lo)
+    bounds.append(n)
+    return bounds
+
+
+def plan_halo(bounds, needs, rank):
+    """needs[q] = (cmin, cmax_exclusive) column range rank q's rows touch.  Returns (sends, recvs): lists of
+    (peer, lo, hi) global column ranges this rank sends from its owned slice / receives into its halo."""
+    own_lo, own_hi = bounds[rank], bounds[rank + 1]
+    recvs, sends = [], []
+    for q in range(len(bounds) - 1):
+        if q == rank:
+            continue
+        lo, hi = max(needs[rank][0], bounds[q]), min(needs[rank][1], bounds[q + 1])
+        if lo < hi:
+            recvs.append((q, lo, hi))
+        lo, hi = max(needs[q][0], own_lo), min(needs[q][1], own_hi)
+        if lo < hi:
+            sends.append((q, lo, hi))
+    return sends, recvs
+
+
+def split_local_remote(torch, start, positions, values, own_lo, own_hi, cmin):
+    """Split the local rows into A_loc (global column in [own_lo, own_hi), renumbered from own_lo) and A_rem (all other
+    columns, renumbered from cmin, the first column of the halo-extended buffer).  Order inside a row is preserved."""
+    nloc = start.numel() - 1
+    lens = (start[1:] - start[:-1]).to(torch.int64)
+    rows_of = torch.repeat_interleave(torch.arange(nloc, device=start.device, dtype=torch.int64), lens)
+    is_loc = (positions >= own_lo) & (positions < own_hi)
+    out = []
+    for mask, shift in ((is_loc, own_lo), (~is_loc, cmin)):
+        counts = torch.bincount(rows_of[mask], minlength=nloc)
+        st = torch.zeros(nloc + 1, dtype=torch.int32, device=start.device)
+        st[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        out.append((st, (positions[mask] - shift).to(torch.int32).contiguous(), values[mask].contiguous()))
+    return out[0], out[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# collectives
+# ---------------------------------------------------------------------------------------------------------------------
+class TorchComm:
+    """torch.distributed: "nccl" (RCCL over xGMI) on the GPUs, "gloo" in the CPU tests"""
+
+    def __init__(self, dist, group=None):
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather_pairs(self, a, b, torch, device):
+        mine = torch.tensor([a, b], dtype=torch.int64, device=device)
+        if self.world == 1:
+            return [(a, b)]
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine, group=self.group)
+        return [(int(t[0]), int(t[1])) for t in out]
+
+    def exchange(self, ext, cmin, sends, recvs):
+        """start the halo exchange of `ext` (the halo-extended vector whose element 0 is global column cmin); returns a
+        list of requests to wait on"""
+        if not sends and not recvs:
+            return []
+        ops = []
+        for q, lo, hi in recvs:
+            ops.append(self.dist.P2POp(self.dist.irecv, ext[lo - cmin:hi - cmin], q, self.group))
+        for q, lo, hi in sends:
+            ops.append(self.dist.P2POp(self.dist.isend, ext[lo - cmin:hi - cmin], q, self.group))
+        return self.dist.batch_isend_irecv(ops)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the loop
+# ---------------------------------------------------------------------------------------------------------------------
+class DistBiCGStab:
+    """BiCGStab (ref:2191-2283) on a row-partitioned matrix.
+
+    ops must provide:  spmv(which, op, lhs, x, out, dot_mode, w1)  with which in {"loc", "rem"};  stage(stage, x, eps);
+    result() -> (done, iterations, resnorm);  attributes p_ext, s_ext, x_ext (halo-extended vectors), r, ap, as_, r0
+    (handles understood by spmv), sums (tensor of >= 2 scalars the collectives reduce), own_offset, n_local.
+    """
+
+    def __init__(self, ops, comm, cmin, sends, recvs):
+        self.ops, self.comm = ops, comm
+        self.cmin, self.sends, self.recvs = cmin, sends, recvs
+
+    def _matvec(self, ext, own_view, out, op_first, lhs_first, dot_mode, w1):
+        """out = op(lhs, A ext): A_loc on the owned slice while the halo is in flight, then A_rem added in place with the
+        dot products fused into that launch"""
+        reqs = self.comm.exchange(ext, self.cmin, self.sends, self.recvs)
+        self.ops.spmv("loc", op_first, lhs_first, own_view, out, 0, None)
+        for r in reqs:
+            r.wait()
+        second = OP_SUB if op_first == OP_SUB else OP_ADD
+        self.ops.spmv("rem", second, out, ext, out, dot_mode, w1)
+
+    def solve(self, b, x_own, max_iterations, eps, check_every=8):
+        """x_own: this rank's slice of x (in/out).  Returns (status, iterations, resnorm) -- identical on every rank."""
+        ops, comm = self.ops, self.comm
+        n_global = ops.n_global
+        max_iterations = min(max_iterations, n_global)  # ref:2200
+        if max_iterations == -1:
+            max_iterations = n_global  # ref:2201-2203
+        # r = b - A x (ref:2215)
+        ops.copy_into_ext(ops.x_ext, x_own)
+        self._matvec(ops.x_ext, ops.own(ops.x_ext), ops.r, OP_SUB, b, 0, None)
+        ops.stage(STAGE_INIT_LOCAL, x_own, eps)  # r0 = p = r, local r.r0
+        comm.all_reduce_sum(ops.sums[:1])
+        ops.stage(STAGE_INIT_APPLY, x_own, eps)
+        planned = max(1, max_iterations)  # do { } while: the body always runs once (ref:2232, 2277)
+        done = 0
+        for it in range(planned):
+            if it and it % check_every == 0:
+                done, _, _ = ops.result()
+                if done:
+                    break
+            self._matvec(ops.p_ext, ops.own(ops.p_ext), ops.ap, OP_ASSIGN, None, 1, ops.r0)  # ap = A p, local ap.r0
+            ops.stage(STAGE_ALPHA_LOCAL, x_own, eps)
+            comm.all_reduce_sum(ops.sums[:1])
+            ops.stage(STAGE_ALPHA_APPLY, x_own, eps)  # alpha, s
+            self._matvec(ops.s_ext, ops.own(ops.s_ext), ops.as_, OP_ASSIGN, None, 2, ops.own(ops.s_ext))  # as = A s, as.as, as.s
+            ops.stage(STAGE_OMEGA_LOCAL, x_own, eps)
+            comm.all_reduce_sum(ops.sums[:2])
+            ops.stage(STAGE_OMEGA_APPLY, x_own, eps)  # omega, x, r, local ||r||^2 and r.r0
+            comm.all_reduce_sum(ops.sums[:2])
+            ops.stage(STAGE_BETA_APPLY, x_own, eps)  # res, beta, p
+        done, iterations, resnorm = ops.result()
+        status = 2 if iterations > max_iterations else 0  # ref:2279-2282
+        return status, iterations, resnorm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# product implementation of the local kernels: libsmm_hip.so
+# ---------------------------------------------------------------------------------------------------------------------
+class HipOps:
+    """Local kernels on one MI355X through the C ABI (csrc/smm_stepwise.hip, smm_spmv.hip).  Vectors are torch tensors
+    (device memory management only); all launches go to torch's current stream so RCCL and the kernels are ordered."""
+
+    def __init__(self, torch, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, np_dtype, device):
+        from . import _lib, host
+
+        self.torch, self.host, self.lib = torch, host, _lib.load()
+        self.check = _lib.check
+        self.np_dtype = np.dtype(np_dtype)
+        self.suf = host._suffix(np_dtype)
+        tdt = torch.float32 if self.np_dtype == np.float32 else torch.float64
+        self.n_global, self.n_local = n_global, own_hi - own_lo
+        self.own_offset = own_lo - cmin
+        ext_len = max(1, cmax_excl - cmin)
+        self.A_loc = host.CSRMatrix.from_device(self.n_local, self.n_local, *loc, np_dtype)
+        self.A_rem = host.CSRMatrix.from_device(self.n_local, ext_len, *rem, np_dtype)
+        self.x_ext = torch.zeros(ext_len, dtype=tdt, device=device)
+        self.p_ext = torch.zeros(ext_len, dtype=tdt, device=device)
+        self.s_ext = torch.zeros(ext_len, dtype=tdt, device=device)
+        self.sums = torch.zeros(4, dtype=tdt, device=device)
+        self.ws = ctypes.c_void_p()
+        self.check(getattr(self.lib, f"smm_hip_bicgstab_ws_create_{self.suf}")(self.n_local, ctypes.byref(self.ws)))
+        self.check(self.lib.smm_hip_bicgstab_ws_bind(self.ws, host._dptr(self.own(self.p_ext)), host._dptr(self.own(self.s_ext)), host._dptr(self.sums)))
+        ptrs = [ctypes.c_void_p() for _ in range(6)]
+        self.check(self.lib.smm_hip_bicgstab_ws_pointers(self.ws, *[ctypes.byref(p) for p in ptrs]))
+        self.r, self.r0, self.ap, self.as_, self.partials, _ = (p.value for p in ptrs)
+        self._spmv = getattr(self.lib, f"smm_hip_spmv_fused_dev_{self.suf}")
+        self._stage = getattr(self.lib, f"smm_hip_bicgstab_ws_stage_{self.suf}")
+        self._result = getattr(self.lib, f"smm_hip_bicgstab_ws_result_{self.suf}")
+
+    def own(self, ext):
+        return ext[self.own_offset:self.own_offset + self.n_local]
+
+    def copy_into_ext(self, ext, own_values):
+        self.own(ext).copy_(own_values)
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def spmv(self, which, op, lhs, x, out, dot_mode, w1):
+        A = self.A_loc if which == "loc" else self.A_rem
+        d = self.host._dptr
+        self.check(self._spmv(A._h, op, d(lhs), d(x), d(out), dot_mode, d(w1), d(self.partials), self._stream()))
+
+    def stage(self, stage, x_own, eps):
+        self.check(self._stage(self.ws, stage, self.host._dptr(x_own), self.np_dtype.type(eps), self._stream()))
+
+    def result(self):
+        done, it = ctypes.c_int(), ctypes.c_int()
+        res = (ctypes.c_float if self.suf == "f32" else ctypes.c_double)()
+        self.check(self._result(self.ws, self._stream(), ctypes.byref(done), ctypes.byref(it), ctypes.byref(res)))
+        return done.value, it.value, res.value
+
+    def close(self):
+        if self.ws:
+            self.lib.smm_hip_bicgstab_ws_destroy(self.ws)
+            self.ws = ctypes.c_void_p()
+
+
+def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np_dtype, device, group=None):
+    """start/positions/values: this rank's rows (local start[], GLOBAL columns) as device tensors.  Collective."""
+    comm = TorchComm(dist, group)
+    rank = comm.rank
+    own_lo, own_hi = bounds[rank], bounds[rank + 1]
+    if positions.numel():
+        cmin = min(int(positions.min()), own_lo)
+        cmax_excl = max(int(positions.max()) + 1, own_hi)
+    else:
+        cmin, cmax_excl = own_lo, own_hi
+    needs = comm.all_gather_pairs(cmin, cmax_excl, torch, device)
+    sends, recvs = plan_halo(bounds, needs, rank)
+    loc, rem = split_local_remote(torch, start, positions, values, own_lo, own_hi, cmin)
+    ops = HipOps(torch, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, np_dtype, device)
+    solver = DistBiCGStab(ops, comm, cmin, sends, recvs)
+    solver.halo_elements = sum(hi - lo for _, lo, hi in recvs)
+    return solver
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py leg for N > 1: the same 10M-row banded matrix, rows split over the ranks (strong scaling)
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from . import host
+
+    n = args.rows
+    stream = torch.cuda.current_stream().cuda_stream
+    row_start = lambda i: host_gen_row_start(args, i)  # noqa: E731
+    bounds = partition_rows_by_nnz(row_start, n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    nnz_local = row_start(hi) - row_start(lo)
+    d_start = torch.empty(hi - lo + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz_local, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz_local, dtype=t_dtype, device=dev)
+    host.gen_banded_rows_dev(n, args.band_k, args.seed, args.max_offset, args.diag_shift, lo, hi, d_start, d_pos, d_val, np_dtype, stream)
+    torch.cuda.synchronize()
+    solver = build_hip_solver(torch, dist, d_start, d_pos, d_val, bounds, n, np_dtype, dev)
+    del d_pos, d_val
+    ops = solver.ops
+    # b = A x_true, x_true uniform in [0.5, 1.5) generated per rank from (seed, rank)
+    x_true = torch.rand(hi - lo, dtype=t_dtype, device=dev, generator=torch.Generator(device=dev).manual_seed(args.seed + rank)) + 0.5
+    b = torch.empty(hi - lo, dtype=t_dtype, device=dev)
+    ops.copy_into_ext(ops.x_ext, x_true)
+    solver._matvec(ops.x_ext, ops.own(ops.x_ext), b, OP_ASSIGN, None, 0, None)
+    x = torch.zeros(hi - lo, dtype=t_dtype, device=dev)
+
+    def run(total):
+        done, last = 0, None
+        while done < total:
+            it = min(args.iters_per_solve, total - done)
+            x.zero_()
+            status, iters, resnorm = solver.solve(b, x, it, 0.0, check_every=1 << 30)
+            if iters != it or not np.isfinite(resnorm) or resnorm <= 0:
+                raise SystemExit(f"rank {rank}: BiCGStab ran {iters} of {it} iterations (resnorm {resnorm}): the timed region is invalid")
+            done += iters
+            last = resnorm
+        return done, last
+
+    if args.warmup > 0:
+        run(args.warmup)
+    host.profile_enable(True)
+    host.profile_read(reset=True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters, resnorm = run(args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    spmv_ms, spmv_launches = host.profile_read(reset=True)
+    host.profile_enable(False)
+    err = ((x - x_true).abs() / x_true).max().reshape(1)
+    dist.all_reduce(err, op=dist.ReduceOp.MAX)
+    nnz_total = row_start(n)
+    return {
+        "elapsed": elapsed,
+        "iters": iters,
+        "nnz": nnz_total,
+        "resnorm": float(resnorm),
+        "max_rel_err_vs_x_true": float(err.item()),
+        "per_rank": {"rows": hi - lo, "nnz": nnz_local, "halo_elements": solver.halo_elements,
+                     "spmv_launch_ms_rank0": spmv_ms / max(spmv_launches, 1), "spmv_launches_rank0": spmv_launches},
+    }
+
+
+def host_gen_row_start(args, row):
+    from . import _lib
+
+    return int(_lib.load().smm_hip_gen_banded_row_start(int(args.rows), int(args.band_k), int(args.seed), int(args.max_offset), int(row)))

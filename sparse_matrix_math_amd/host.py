@@ -321,6 +321,18 @@ def gen_banded_dev(n, k, seed, max_offset, d_start, d_positions, d_values, dtype
     check(_fn("smm_hip_gen_banded_dev", _suffix(dtype))(int(n), int(k), int(seed), int(max_offset), np.dtype(dtype).type(diag_shift), _dptr(d_start), _dptr(d_positions), _dptr(d_values), _dptr(stream)))
 
 
+def gen_banded_row_start(n, k, seed, max_offset, row):
+    """start[row] of the full banded matrix in closed form (no device needed)"""
+    return int(_lib.load().smm_hip_gen_banded_row_start(int(n), int(k), int(seed), int(max_offset), int(row)))
+
+
+def gen_banded_rows_dev(n, k, seed, max_offset, diag_shift, row_begin, row_end, d_start, d_positions, d_values, dtype, stream=None):
+    """rows [row_begin, row_end) of the banded matrix: local start[], GLOBAL columns (what one rank owns)"""
+    check(_fn("smm_hip_gen_banded_rows_dev", _suffix(dtype))(int(n), int(k), int(seed), int(max_offset), np.dtype(dtype).type(diag_shift),
+                                                               int(row_begin), int(row_end), _dptr(d_start), _dptr(d_positions), _dptr(d_values),
+                                                               _dptr(stream)))
+
+
 def gen_poisson2d_dev(nx, ny, d_start, d_positions, d_values, dtype, stream=None):
     check(_fn("smm_hip_gen_poisson2d_dev", _suffix(dtype))(int(nx), int(ny), _dptr(d_start), _dptr(d_positions), _dptr(d_values), _dptr(stream)))
 

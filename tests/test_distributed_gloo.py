@@ -1,0 +1,125 @@
+"""The N > 1 path on CPU: partition, halo plan and the staged BiCGStab driver of sparse_matrix_math_amd/distributed.py under
+torch.distributed gloo with world_size 2 (and 3), local kernels replaced by the numpy stand-in of tests/dist_helpers.py.
+The result must agree with the single-process oracle to rounding, with identical iteration counts."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from sparse_matrix_math_amd import generators as gen
+from sparse_matrix_math_amd.distributed import partition_rows_by_nnz, plan_halo
+
+
+def test_partition_and_halo_plan():
+    start = gen.poisson2d(10)[0]
+    bounds = partition_rows_by_nnz(lambda i: int(start[i]), 100, 3)
+    assert bounds[0] == 0 and bounds[-1] == 100 and bounds == sorted(bounds)
+    per = [int(start[bounds[g + 1]] - start[bounds[g]]) for g in range(3)]
+    assert max(per) - min(per) <= 10
+    # rank g touches [own - 10, own + 10): halos only from direct neighbours
+    needs = [(max(0, bounds[g] - 10), min(100, bounds[g + 1] + 10)) for g in range(3)]
+    sends, recvs = plan_halo(bounds, needs, 1)
+    assert recvs == [(0, bounds[1] - 10, bounds[1]), (2, bounds[2], bounds[2] + 10)]
+    assert sends == [(0, bounds[1], bounds[1] + 10), (2, bounds[2] - 10, bounds[2])]
+    s0, r0 = plan_halo(bounds, needs, 0)
+    assert r0 == [(1, bounds[1], bounds[1] + 10)] and s0 == [(1, bounds[1] - 10, bounds[1])]
+    # a rank that needs everything receives every other rank's whole slice
+    needs[2] = (0, 100)
+    _, r2 = plan_halo(bounds, needs, 2)
+    assert r2 == [(0, 0, bounds[1]), (1, bounds[1], bounds[2])]
+    assert partition_rows_by_nnz(lambda i: int(start[i]), 100, 1) == [0, 100]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, dtype_name, max_it, eps, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from dist_helpers import NumpyOps
+    from oracle.oracle import Oracle
+    from sparse_matrix_math_amd.distributed import DistBiCGStab, TorchComm, partition_rows_by_nnz, plan_halo, split_local_remote
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dtype = np.dtype(dtype_name).type
+        csr = _case(case, dtype)
+        start, pos, val = csr
+        n = len(start) - 1
+        b_full = gen.row_sums(start, val) if case != "banded" else _rand_rhs(csr, dtype)
+        bounds = partition_rows_by_nnz(lambda i: int(start[i]), n, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        lstart = torch.from_numpy((start[lo:hi + 1] - start[lo]).astype(np.int32))
+        lpos = torch.from_numpy(pos[start[lo]:start[hi]].copy())
+        lval = torch.from_numpy(val[start[lo]:start[hi]].copy())
+        comm = TorchComm(dist)
+        cmin = min(int(lpos.min()), lo) if lpos.numel() else lo
+        cmax = max(int(lpos.max()) + 1, hi) if lpos.numel() else hi
+        needs = comm.all_gather_pairs(cmin, cmax, torch, "cpu")
+        sends, recvs = plan_halo(bounds, needs, rank)
+        loc, rem = split_local_remote(torch, lstart, lpos, lval, lo, hi, cmin)
+        ops = NumpyOps(torch, Oracle(), loc, rem, n, lo, hi, cmin, cmax, dtype)
+        solver = DistBiCGStab(ops, comm, cmin, sends, recvs)
+        x = torch.zeros(hi - lo, dtype=torch.float32 if dtype == np.float32 else torch.float64)
+        status, iters, res = solver.solve(torch.from_numpy(b_full[lo:hi].copy()), x, max_it, eps, check_every=3)
+        np.save(os.path.join(out_dir, f"x_{rank}.npy"), x.numpy())
+        np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([status, iters, res, lo, hi], dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def _case(case, dtype):
+    if case == "poisson":
+        return gen.poisson2d(24, dtype=dtype)
+    if case == "convdiff":
+        return gen.convdiff3d(9, 0.3, dtype=dtype)
+    if case == "banded":
+        return gen.banded_random_spd(3000, k=12, seed=4, max_offset=900, dtype=dtype)
+    if case == "global":  # couples every rank with every other: the halo degenerates into an all-gather
+        return gen.random_rows(240, 240, 4, 12, seed=5, dtype=dtype, diag_dominant=True)
+    raise ValueError(case)
+
+
+def _rand_rhs(csr, dtype):
+    from oracle.oracle import Oracle
+
+    x_true = np.random.default_rng(11).uniform(0.5, 1.5, len(csr[0]) - 1).astype(dtype)
+    return Oracle().spmv(csr, 0, None, x_true)
+
+
+@pytest.mark.parametrize("world,case,dtype,max_it,eps", [
+    (2, "poisson", np.float64, -1, 1e-9),
+    (2, "convdiff", np.float32, 7, 1e-30),
+    (2, "banded", np.float64, 12, 1e-30),
+    (3, "global", np.float64, -1, 1e-10),
+    (2, "poisson", np.float64, 0, 1e-9),
+])
+def test_gloo_bicgstab_matches_single_process(tmp_path, oracle, world, case, dtype, max_it, eps):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, np.dtype(dtype).name, max_it, eps, str(tmp_path)), nprocs=world, join=True)
+    csr = _case(case, dtype)
+    n = len(csr[0]) - 1
+    b = gen.row_sums(csr[0], csr[2]) if case != "banded" else _rand_rhs(csr, dtype)
+    st_ref, x_ref, it_ref, res_ref = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), max_it, eps)
+    x = np.zeros(n, dtype=dtype)
+    metas = [np.load(tmp_path / f"meta_{r}.npy") for r in range(world)]
+    for r, m in enumerate(metas):
+        x[int(m[3]):int(m[4])] = np.load(tmp_path / f"x_{r}.npy")
+        assert int(m[0]) == st_ref and (m[:3] == metas[0][:3]).all()  # same status / iterations / residual on every rank
+    iters = int(metas[0][1])
+    if max_it in (-1,):
+        assert abs(iters - it_ref) <= max(1, it_ref // 10)
+        np.testing.assert_allclose(x, 1.0, rtol=1e-6)
+    else:
+        assert iters == it_ref
+    tol = 2e-4 if dtype == np.float32 else 1e-9
+    assert float(np.max(np.abs(x - x_ref))) <= tol * max(1.0, float(np.max(np.abs(x_ref))))
