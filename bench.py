@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--spmv-family", type=int, default=0)
     ap.add_argument("--spmv-lanes", type=int, default=0)
     ap.add_argument("--autotune", action="store_true")
+    ap.add_argument("--dist", action="store_true", help="take the row-partitioned multi-GPU code path even with one rank")
     return ap.parse_args()
 
 
@@ -124,9 +125,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import sparse_matrix_math_amd as smm
     from sparse_matrix_math_amd import host
@@ -138,7 +141,7 @@ def main():
     n = args.rows
     stream = torch.cuda.current_stream().cuda_stream
 
-    if world > 1:
+    if use_dist:
         from sparse_matrix_math_amd import distributed as dsm
 
         result = dsm.bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype)
@@ -217,7 +220,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, np_dtype, d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy(),
                                                   b.cpu().numpy(), args.cpu_seconds)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([result["elapsed"]], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         result["elapsed"] = float(t.item())
@@ -238,7 +241,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "configs[2]: banded-random symmetric diagonally dominant CSR, BiCGStab, b = A*1, x0 = 0, eps = 0 (fixed iterations)",
+                "workload": "configs[2]: banded-random symmetric diagonally dominant CSR, 10M rows ~49 nnz/row, BiCGStab, b = A*x_true, x0 = 0, eps = 0 (fixed iterations)",
                 "rows": n,
                 "nnz": result.pop("nnz"),
                 "band_offsets_per_side": args.band_k,
@@ -253,7 +256,7 @@ def main():
             line["spmv_gbps"] = line["roofline"]["achieved"]
             line["spmv_pct_hbm_peak"] = 100.0 * line["roofline"]["frac"]
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,497 @@
+// smm_hip/sparse_matrix_math.h -- the reference's C++ API for the hot path, re-implemented on top of the C ABI of
+// libsmm_hip.so (include/smm_hip.h).  A program written against vasil-pashov/sparse_matrix_math's
+// include/sparse_matrix_math.h ("ref" below) that only uses
+//
+//     SMM::Vector, SMM::TripletMatrix, SMM::CSRMatrix (init / rMult / rMultAdd / rMultSub / getters / iteration /
+//     getPreconditioner), SMM::SolverStatus, SMM::SolverPreconditioner, SMM::ConjugateGradient (plain and IC0),
+//     SMM::BiCGStab (plain and preconditioned), SMM::BiCGSymmetric, SMM::loadMatrix
+//
+// compiles against this header unchanged and runs those calls on an MI355X: same names, same argument order and meaning,
+// same return values (SolverStatus; int != 0 on failure for init / apply).  Matrix assembly (TripletMatrix, CSR arrays)
+// stays on the host exactly as in the reference; the CSR arrays are mirrored to the GPU the first time a hot-path call
+// needs them.  Nothing here computes on the CPU: every rMult* / solver / apply call goes through libsmm_hip.so and fails
+// (returns non-zero / SolverStatus::DIVERGED with smm_hip_last_error() set) when no GPU is present.
+//
+// Written from the documented behaviour of the reference; no reference source is reproduced here.
+// Additions the reference lacks: CSRMatrix::init(rows, cols, start, positions, values) (raw CSR arrays, ref can only be
+// filled through a std::map), JacobiPreconditioner, a working ILU0Preconditioner, Matrix Market `general` matrices.
+#pragma once
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../smm_hip.h"
+
+#define SMM_MAJOR_VERSION 0
+#define SMM_MINOR_VERSION 2
+#define SMM_PATCH_VERSION 0
+
+namespace SMM {
+
+// ---- C ABI dispatch on T ------------------------------------------------------------------------------------------
+namespace detail {
+template <typename T>
+struct Abi;
+template <>
+struct Abi<float> {
+	static int create(int r, int c, const int* s, const int* p, const float* v, smm_hip_csr** o) { return smm_hip_csr_create_f32(r, c, s, p, v, o); }
+	static int spmv(const smm_hip_csr* m, int op, const float* l, const float* x, float* o) { return smm_hip_spmv_f32(m, op, l, x, o); }
+	static int dot(int n, const float* a, const float* b, float* r) { return smm_hip_dot_f32(n, a, b, r); }
+	static int cg(const smm_hip_csr* a, const float* b, const float* x0, float* x, int it, float eps, const smm_hip_precond* M, int* st) {
+		return smm_hip_cg_f32(a, b, x0, x, it, eps, M, st, nullptr, nullptr);
+	}
+	static int bicgstab(const smm_hip_csr* a, float* b, float* x, int it, float eps, const smm_hip_precond* M, int* st) {
+		return smm_hip_bicgstab_f32(a, b, x, it, eps, M, st, nullptr, nullptr);
+	}
+	static int bicgsym(const smm_hip_csr* a, float* b, float* x, int it, float eps, int* st) { return smm_hip_bicgsymmetric_f32(a, b, x, it, eps, st, nullptr); }
+	static int apply(const smm_hip_precond* M, const float* r, float* x) { return smm_hip_precond_apply_f32(M, r, x); }
+};
+template <>
+struct Abi<double> {
+	static int create(int r, int c, const int* s, const int* p, const double* v, smm_hip_csr** o) { return smm_hip_csr_create_f64(r, c, s, p, v, o); }
+	static int spmv(const smm_hip_csr* m, int op, const double* l, const double* x, double* o) { return smm_hip_spmv_f64(m, op, l, x, o); }
+	static int dot(int n, const double* a, const double* b, double* r) { return smm_hip_dot_f64(n, a, b, r); }
+	static int cg(const smm_hip_csr* a, const double* b, const double* x0, double* x, int it, double eps, const smm_hip_precond* M, int* st) {
+		return smm_hip_cg_f64(a, b, x0, x, it, eps, M, st, nullptr, nullptr);
+	}
+	static int bicgstab(const smm_hip_csr* a, double* b, double* x, int it, double eps, const smm_hip_precond* M, int* st) {
+		return smm_hip_bicgstab_f64(a, b, x, it, eps, M, st, nullptr, nullptr);
+	}
+	static int bicgsym(const smm_hip_csr* a, double* b, double* x, int it, double eps, int* st) { return smm_hip_bicgsymmetric_f64(a, b, x, it, eps, st, nullptr); }
+	static int apply(const smm_hip_precond* M, const double* r, double* x) { return smm_hip_precond_apply_f64(M, r, x); }
+};
+}  // namespace detail
+
+// ---- Vector<T> (ref:42-381): host buffer that decays to T*, dot product and norms on the GPU ---------------------------
+template <typename T>
+class Vector {
+public:
+	using Iterator = T*;
+	using ConstIterator = const T*;
+	Vector() noexcept = default;
+	explicit Vector(const int size) noexcept : buf(static_cast<size_t>(size > 0 ? size : 0)) {}
+	Vector(const int size, const T val) noexcept : buf(static_cast<size_t>(size > 0 ? size : 0), val) {}
+	Vector(std::initializer_list<T> l) : buf(l) {}
+	void init(const int size) { buf.assign(static_cast<size_t>(size), T()); }
+	void init(const int size, const T val) { buf.assign(static_cast<size_t>(size), val); }
+	int getSize() const noexcept { return static_cast<int>(buf.size()); }
+	operator T*() noexcept { return buf.data(); }
+	operator const T*() const noexcept { return buf.data(); }
+	T& operator[](const int i) { return buf[static_cast<size_t>(i)]; }
+	const T& operator[](const int i) const { return buf[static_cast<size_t>(i)]; }
+	Iterator begin() noexcept { return buf.data(); }
+	Iterator end() noexcept { return buf.data() + buf.size(); }
+	ConstIterator begin() const noexcept { return buf.data(); }
+	ConstIterator end() const noexcept { return buf.data() + buf.size(); }
+	void fill(const T v) { std::fill(buf.begin(), buf.end(), v); }
+	Vector& operator+=(const Vector& o) {
+		for (size_t i = 0; i < buf.size(); ++i) buf[i] += o.buf[i];
+		return *this;
+	}
+	Vector& operator-=(const Vector& o) {
+		for (size_t i = 0; i < buf.size(); ++i) buf[i] -= o.buf[i];
+		return *this;
+	}
+	// dot product (ref:305-328) and norms (ref:287-303) -- reductions of the hot path, computed on the GPU
+	const T operator*(const Vector& o) const {
+		T r = T(0);
+		detail::Abi<T>::dot(getSize(), buf.data(), o.buf.data(), &r);
+		return r;
+	}
+	T secondNormSquared() const { return (*this) * (*this); }
+	T secondNorm() const { return std::sqrt(secondNormSquared()); }
+
+private:
+	std::vector<T> buf;
+};
+
+// ---- TripletMatrix<T> (ref:383-684): ordered COO assembly; duplicates are summed ---------------------------------------
+template <typename T>
+class TripletEl {
+public:
+	TripletEl(int r, int c, T v) : row(r), col(c), value(v) {}
+	int getRow() const noexcept { return row; }
+	int getCol() const noexcept { return col; }
+	T getValue() const noexcept { return value; }
+
+private:
+	int row, col;
+	T value;
+};
+
+template <typename T>
+class TripletMatrix {
+public:
+	TripletMatrix() noexcept = default;
+	TripletMatrix(int rows, int cols) noexcept : denseRowCount(rows), denseColCount(cols) {}
+	TripletMatrix(int rows, int cols, int /*numTriplets*/) noexcept : denseRowCount(rows), denseColCount(cols) {}
+	void init(int rows, int cols, int /*numTriplets*/ = 0) {
+		denseRowCount = rows;
+		denseColCount = cols;
+		data.clear();
+	}
+	int getNonZeroCount() const noexcept { return static_cast<int>(data.size()); }
+	int getDenseRowCount() const noexcept { return denseRowCount; }
+	int getDenseColCount() const noexcept { return denseColCount; }
+	// entries with the same (row, col) add up (ref:612-617)
+	void addEntry(int row, int col, T value) { data[key(row, col)] += value; }
+	T getValue(int row, int col) const {
+		auto it = data.find(key(row, col));
+		return it == data.end() ? T(0) : it->second;
+	}
+	bool updateEntry(int row, int col, T value) {
+		auto it = data.find(key(row, col));
+		if (it == data.end()) return false;
+		it->second = value;
+		return true;
+	}
+	// row-major, column-ascending traversal
+	template <typename F>
+	void forEach(F&& f) const {
+		for (const auto& kv : data) f(static_cast<int>(kv.first >> 32), static_cast<int>(kv.first & 0xFFFFFFFFu), kv.second);
+	}
+
+private:
+	static uint64_t key(int row, int col) { return (static_cast<uint64_t>(static_cast<uint32_t>(row)) << 32) | static_cast<uint32_t>(col); }
+	std::map<uint64_t, T> data;
+	int denseRowCount = 0, denseColCount = 0;
+};
+
+enum class SolverPreconditioner { NONE, SYMMETRIC_GAUS_SEIDEL, ILU0, JACOBI /* addition */ };  // ref:1002-1006
+enum class SolverStatus { SUCCESS = 0, DIVERGED, MAX_ITERATIONS_REACHED };                       // ref:2010-2014
+
+// ---- CSRMatrix<T> (ref:1010-1641) -------------------------------------------------------------------------------------------
+template <typename T>
+class CSRMatrix {
+public:
+	using value_type = T;
+
+	class ConstElement {
+	public:
+		ConstElement(const CSRMatrix* m, int row, int idx) : m(m), row(row), idx(idx) {}
+		int getRow() const noexcept { return row; }
+		int getCol() const noexcept { return m->positions[idx]; }
+		T getValue() const noexcept { return m->values[idx]; }
+
+	private:
+		const CSRMatrix* m;
+		int row, idx;
+	};
+	// forward iterator over all stored elements in row-major order (what the reference's tests use: `for (const auto& el : m)`)
+	class ConstIterator {
+	public:
+		ConstIterator(const CSRMatrix* m, int row, int idx) : m(m), row(row), idx(idx) { skipEmpty(); }
+		ConstElement operator*() const { return ConstElement(m, row, idx); }
+		ConstIterator& operator++() {
+			++idx;
+			skipEmpty();
+			return *this;
+		}
+		bool operator!=(const ConstIterator& o) const { return idx != o.idx; }
+		bool operator==(const ConstIterator& o) const { return idx == o.idx; }
+
+	private:
+		void skipEmpty() {
+			while (row < m->denseRowCount && idx >= m->start[row + 1]) ++row;
+		}
+		const CSRMatrix* m;
+		int row, idx;
+	};
+
+	// Every preconditioner wraps a device-side smm_hip_precond; `int apply(const T* rhs, T* x) const` as in ref:1173-1235.
+	class PreconditionerBase {
+	public:
+		PreconditionerBase(const PreconditionerBase&) = delete;
+		PreconditionerBase& operator=(const PreconditionerBase&) = delete;
+		PreconditionerBase(PreconditionerBase&& o) noexcept : m(o.m), kind(o.kind), h(o.h) { o.h = nullptr; }
+		~PreconditionerBase() { smm_hip_precond_destroy(h); }
+		// non-zero on structural failure (missing / tiny diagonal, empty row, non-SPD pivot), like ref:1668-1693
+		int init() const noexcept {
+			if (h) return 0;
+			const smm_hip_csr* dev = m->device();
+			if (!dev) return 1;
+			return smm_hip_precond_create(dev, kind, &h) == SMM_HIP_OK ? 0 : 1;
+		}
+		int apply(const T* rhs, T* x) const noexcept {
+			if (init()) return 1;
+			return detail::Abi<T>::apply(h, rhs, x) == SMM_HIP_OK ? 0 : 1;
+		}
+		const smm_hip_precond* handle() const noexcept { return init() ? nullptr : h; }
+
+	protected:
+		PreconditionerBase(const CSRMatrix& m, int kind) noexcept : m(&m), kind(kind) {}
+		const CSRMatrix* m;
+		int kind;
+		mutable smm_hip_precond* h = nullptr;
+	};
+	class IDPreconditioner {  // ref:1166-1170
+	public:
+		int apply(const T*, T*) const noexcept { return 0; }
+		const smm_hip_precond* handle() const noexcept { return nullptr; }
+	};
+	class SGSPreconditioner : public PreconditionerBase {  // ref:1173-1186
+	public:
+		SGSPreconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_SGS) {}
+		SGSPreconditioner(SGSPreconditioner&&) noexcept = default;
+	};
+	class JacobiPreconditioner : public PreconditionerBase {  // addition
+	public:
+		JacobiPreconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_JACOBI) {}
+		JacobiPreconditioner(JacobiPreconditioner&&) noexcept = default;
+	};
+	class ILU0Preconditioner : public PreconditionerBase {  // ref:1189-1212 (declared there, not usable)
+	public:
+		ILU0Preconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_ILU0) {}
+		ILU0Preconditioner(ILU0Preconditioner&&) noexcept = default;
+		int validate() noexcept { return this->init(); }
+	};
+	class IC0Preconditioner : public PreconditionerBase {  // ref:1216-1235
+	public:
+		IC0Preconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_IC0) {}
+		IC0Preconditioner(IC0Preconditioner&&) noexcept = default;
+	};
+
+	CSRMatrix() noexcept = default;
+	CSRMatrix(const TripletMatrix<T>& triplet) noexcept { init(triplet); }
+	CSRMatrix(const CSRMatrix&) = delete;
+	CSRMatrix& operator=(const CSRMatrix&) = delete;
+	CSRMatrix(CSRMatrix&& o) noexcept { *this = std::move(o); }
+	CSRMatrix& operator=(CSRMatrix&& o) noexcept {
+		release();
+		values = std::move(o.values);
+		positions = std::move(o.positions);
+		start = std::move(o.start);
+		denseRowCount = o.denseRowCount;
+		denseColCount = o.denseColCount;
+		firstActiveStart = o.firstActiveStart;
+		dev = o.dev;
+		o.dev = nullptr;
+		return *this;
+	}
+	~CSRMatrix() { release(); }
+
+	// ref:1326-1349 / 1606-1641: count per row, prefix sum, scatter in map order (row-major, columns ascending)
+	int init(const TripletMatrix<T>& triplet) noexcept {
+		release();
+		denseRowCount = triplet.getDenseRowCount();
+		denseColCount = triplet.getDenseColCount();
+		const int nnz = triplet.getNonZeroCount();
+		values.reset(new T[nnz > 0 ? nnz : 1]);
+		positions.reset(new int[nnz > 0 ? nnz : 1]);
+		start.reset(new int[denseRowCount + 1]());
+		triplet.forEach([&](int r, int, T) { start[r + 1]++; });
+		for (int i = 0; i < denseRowCount; ++i) start[i + 1] += start[i];
+		int k = 0;
+		triplet.forEach([&](int, int c, T v) {
+			positions[k] = c;
+			values[k] = v;
+			++k;
+		});
+		computeFirstActive();
+		return 0;
+	}
+	// addition: adopt raw CSR arrays (copied); columns must ascend inside each row
+	int init(int rows, int cols, const int* startIn, const int* positionsIn, const T* valuesIn) noexcept {
+		release();
+		denseRowCount = rows;
+		denseColCount = cols;
+		const int nnz = startIn[rows];
+		values.reset(new T[nnz > 0 ? nnz : 1]);
+		positions.reset(new int[nnz > 0 ? nnz : 1]);
+		start.reset(new int[rows + 1]);
+		std::copy(startIn, startIn + rows + 1, start.get());
+		std::copy(positionsIn, positionsIn + nnz, positions.get());
+		std::copy(valuesIn, valuesIn + nnz, values.get());
+		computeFirstActive();
+		return 0;
+	}
+	int getNonZeroCount() const noexcept { return start ? start[denseRowCount] : 0; }
+	int getDenseRowCount() const noexcept { return denseRowCount; }
+	int getDenseColCount() const noexcept { return denseColCount; }
+	ConstIterator begin() const noexcept { return ConstIterator(this, 0, 0); }
+	ConstIterator end() const noexcept { return ConstIterator(this, denseRowCount, getNonZeroCount()); }
+	T getValue(int row, int col) const noexcept {
+		const int* b = positions.get() + start[row];
+		const int* e = positions.get() + start[row + 1];
+		const int* it = std::lower_bound(b, e, col);
+		return it != e && *it == col ? values[it - positions.get()] : T(0);
+	}
+
+	// ---- the hot path: out = op(lhs, A * mult) on the GPU (ref:1458-1515) ----
+	void rMult(const T* const mult, T* const res) const noexcept { spmv(SMM_OP_ASSIGN, nullptr, mult, res); }
+	void rMultAdd(const T* const lhs, const T* const mult, T* const out) const noexcept { spmv(SMM_OP_ADD, lhs, mult, out); }
+	void rMultSub(const T* const lhs, const T* const mult, T* const out) const noexcept { spmv(SMM_OP_SUB, lhs, mult, out); }
+
+	template <SolverPreconditioner precond>
+	decltype(auto) getPreconditioner() const noexcept {  // ref:1643-1651
+		if constexpr (precond == SolverPreconditioner::NONE) {
+			return IDPreconditioner();
+		} else if constexpr (precond == SolverPreconditioner::SYMMETRIC_GAUS_SEIDEL) {
+			return SGSPreconditioner(*this);
+		} else if constexpr (precond == SolverPreconditioner::ILU0) {
+			return ILU0Preconditioner(*this);
+		} else {
+			return JacobiPreconditioner(*this);
+		}
+	}
+
+	// device mirror of the three arrays, created on first use; nullptr when there is no GPU
+	const smm_hip_csr* device() const noexcept {
+		if (!dev && start) {
+			if (detail::Abi<T>::create(denseRowCount, denseColCount, start.get(), positions.get(), values.get(), &dev) != SMM_HIP_OK) dev = nullptr;
+		}
+		return dev;
+	}
+	// call after editing values/positions in place through the raw accessors below
+	void invalidateDevice() noexcept {
+		smm_hip_csr_destroy(dev);
+		dev = nullptr;
+	}
+	const T* rawValues() const noexcept { return values.get(); }
+	const int* rawPositions() const noexcept { return positions.get(); }
+	const int* rawStart() const noexcept { return start.get(); }
+
+private:
+	void spmv(int op, const T* lhs, const T* mult, T* out) const noexcept {
+		const smm_hip_csr* d = device();
+		if (d) detail::Abi<T>::spmv(d, op, lhs, mult, out);
+	}
+	void computeFirstActive() noexcept {  // ref:1619-1628
+		firstActiveStart = denseRowCount;
+		for (int i = 0; i < denseRowCount; ++i) {
+			if (start[i + 1] != 0) {
+				firstActiveStart = i;
+				break;
+			}
+		}
+	}
+	void release() noexcept {
+		smm_hip_csr_destroy(dev);
+		dev = nullptr;
+	}
+	// the reference's layout (ref:1243-1259)
+	std::unique_ptr<T[]> values;
+	std::unique_ptr<int[]> positions;
+	std::unique_ptr<int[]> start;
+	int denseRowCount = 0;
+	int denseColCount = 0;
+	int firstActiveStart = 0;
+	mutable smm_hip_csr* dev = nullptr;
+};
+
+// ---- solvers ---------------------------------------------------------------------------------------------------------------
+namespace detail {
+inline SolverStatus toStatus(int abi, int solver) {
+	if (abi != SMM_HIP_OK) return SolverStatus::DIVERGED;  // no GPU / HIP failure: text in smm_hip_last_error()
+	return static_cast<SolverStatus>(solver);
+}
+}  // namespace detail
+
+// ref:2316-2398
+template <typename T>
+inline SolverStatus ConjugateGradient(const CSRMatrix<T>& a, const T* const b, const T* const x0, T* const x, int maxIterations, T eps) {
+	int st = 0;
+	const smm_hip_csr* d = a.device();
+	return detail::toStatus(d ? detail::Abi<T>::cg(d, b, x0, x, maxIterations, eps, nullptr, &st) : SMM_HIP_ERR_NO_DEVICE, st);
+}
+
+// ref:2414-2505
+template <typename T>
+inline SolverStatus ConjugateGradient(const CSRMatrix<T>& a, const T* const b, const T* const x0, T* const x, int maxIterations, T eps,
+                                      const typename CSRMatrix<T>::IC0Preconditioner& M) {
+	int st = 0;
+	const smm_hip_csr* d = a.device();
+	const smm_hip_precond* h = M.handle();
+	return detail::toStatus(d && h ? detail::Abi<T>::cg(d, b, x0, x, maxIterations, eps, h, &st) : SMM_HIP_ERR_NO_DEVICE, st);
+}
+
+// ref:2191-2283.  Preconditioner must be one of CSRMatrix<T>'s preconditioner classes (they live on the GPU); an arbitrary
+// host type with an apply() member cannot run inside the device-resident loop.
+template <typename Preconditioner, typename T>
+inline SolverStatus BiCGStab(const CSRMatrix<T>& a, T* b, T* x, int maxIterations, T eps, const Preconditioner& preconditioner) {
+	static_assert(std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value ||
+	                  std::is_base_of<typename CSRMatrix<T>::PreconditionerBase, Preconditioner>::value,
+	              "BiCGStab on the GPU needs one of CSRMatrix<T>'s preconditioner classes");
+	int st = 0;
+	const smm_hip_csr* d = a.device();
+	const smm_hip_precond* h = preconditioner.handle();
+	constexpr bool precondition = !std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value;
+	if (!d || (precondition && !h)) return SolverStatus::DIVERGED;
+	return detail::toStatus(detail::Abi<T>::bicgstab(d, b, x, maxIterations, eps, h, &st), st);
+}
+
+// ref:2294-2303
+template <typename T>
+inline SolverStatus BiCGStab(const CSRMatrix<T>& a, T* b, T* x, int maxIterations, T eps) {
+	return BiCGStab(a, b, x, maxIterations, eps, typename CSRMatrix<T>::IDPreconditioner());
+}
+
+// ref:2021-2102
+template <typename T>
+inline SolverStatus BiCGSymmetric(const CSRMatrix<T>& a, T* b, T* x, int maxIterations, T eps) {
+	int st = 0;
+	const smm_hip_csr* d = a.device();
+	return detail::toStatus(d ? detail::Abi<T>::bicgsym(d, b, x, maxIterations, eps, &st) : SMM_HIP_ERR_NO_DEVICE, st);
+}
+
+// ---- Matrix Market loader (ref:2507-2669 reads `coordinate real|integer symmetric` only; `general` and `pattern` are additions) ----
+enum class MatrixLoadStatus { SUCCESS = 0, FAILED_TO_OPEN_FILE, FAILED_TO_OPEN_FILE_UNKNOWN_FORMAT, PARSE_ERROR_INVALID_FILE, PARSE_ERROR_UNSUPPORTED_FORMAT };
+
+template <typename T>
+inline MatrixLoadStatus loadMatrix(const char* path, TripletMatrix<T>& out) {
+	std::ifstream in(path);
+	if (!in) return MatrixLoadStatus::FAILED_TO_OPEN_FILE;
+	std::string line;
+	if (!std::getline(in, line)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
+	std::transform(line.begin(), line.end(), line.begin(), [](unsigned char c) { return static_cast<char>(std::tolower(c)); });
+	std::istringstream hdr(line);
+	std::string banner, object, format, field, symmetry;
+	hdr >> banner >> object >> format >> field >> symmetry;
+	if (banner != "%%matrixmarket") return MatrixLoadStatus::FAILED_TO_OPEN_FILE_UNKNOWN_FORMAT;
+	if (object != "matrix" || format != "coordinate") return MatrixLoadStatus::PARSE_ERROR_UNSUPPORTED_FORMAT;
+	const bool pattern = field == "pattern";
+	if (!pattern && field != "real" && field != "integer" && field != "double") return MatrixLoadStatus::PARSE_ERROR_UNSUPPORTED_FORMAT;
+	const bool symmetric = symmetry == "symmetric";
+	if (!symmetric && symmetry != "general") return MatrixLoadStatus::PARSE_ERROR_UNSUPPORTED_FORMAT;
+	while (std::getline(in, line) && (line.empty() || line[0] == '%')) {
+	}
+	int rows = 0, cols = 0;
+	long long entries = 0;
+	{
+		std::istringstream sz(line);
+		if (!(sz >> rows >> cols >> entries)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
+	}
+	out.init(rows, cols);
+	for (long long e = 0; e < entries; ++e) {
+		int r = 0, c = 0;
+		double v = 1.0;
+		if (!(in >> r >> c)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
+		if (!pattern && !(in >> v)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
+		if (r < 1 || c < 1 || r > rows || c > cols) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
+		out.addEntry(r - 1, c - 1, static_cast<T>(v));
+		if (symmetric && r != c) out.addEntry(c - 1, r - 1, static_cast<T>(v));  // mirror the off-diagonals, ref:2598-2601
+	}
+	return MatrixLoadStatus::SUCCESS;
+}
+
+template <typename T>
+inline MatrixLoadStatus loadMatrix(const char* path, CSRMatrix<T>& out) {
+	TripletMatrix<T> triplet;
+	const MatrixLoadStatus st = loadMatrix(path, triplet);
+	if (st != MatrixLoadStatus::SUCCESS) return st;
+	return out.init(triplet) == 0 ? MatrixLoadStatus::SUCCESS : MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
+}
+
+}  // namespace SMM

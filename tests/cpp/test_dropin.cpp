@@ -1,0 +1,246 @@
+// test_dropin.cpp -- the reference's own hot-path tests, compiled against include/smm_hip/sparse_matrix_math.h instead of
+// the reference header: same calls (SMM::TripletMatrix / CSRMatrix::init / rMultAdd / rMultSub / ConjugateGradient / BiCGStab /
+// getPreconditioner / IC0Preconditioner), same known answers (test/cpp/csr.cpp:259-522, test/cpp/cg.cpp:28-60) and the
+// same solver convention (rhs = row sums, x0 = 0, maxIterations = -1, eps = l2Eps<T>, every x_i == 1 within infEps<T>,
+// test/include/test_common.h:13-50).  The reference's mesh assets are replaced by generated SPD matrices.
+// Needs a GPU at run time (the library has no CPU path); exits non-zero on the first failed check.
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "smm_hip/sparse_matrix_math.h"
+
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond)                                                                   \
+	do {                                                                              \
+		++g_checks;                                                                   \
+		if (!(cond)) {                                                                \
+			++g_failed;                                                               \
+			std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);             \
+		}                                                                             \
+	} while (0)
+
+template <typename T>
+static bool approx(T ref, T got, double eps) {
+	return std::fabs(static_cast<double>(ref) - static_cast<double>(got)) <= eps * std::max(1.0, std::fabs(static_cast<double>(ref)));
+}
+
+template <typename T>
+constexpr T l2Eps() { return std::is_same<T, float>::value ? T(1e-4) : T(1e-8); }
+template <typename T>
+constexpr double infEps() { return std::is_same<T, float>::value ? 1e-4 : 1e-8; }
+
+template <typename T>
+static SMM::Vector<T> sumColumsPerRow(const SMM::CSRMatrix<T>& m) {  // test/include/test_common.h:13-21
+	SMM::Vector<T> v(m.getDenseRowCount(), 0);
+	for (const auto& el : m) {
+		v[el.getRow()] += el.getValue();
+	}
+	return v;
+}
+
+template <typename T>
+static void fillKat(SMM::CSRMatrix<T>& m) {  // test/cpp/csr.cpp:263-275
+	SMM::TripletMatrix<T> triplet(5, 4, 10);
+	triplet.addEntry(0, 0, 4.5);
+	triplet.addEntry(0, 2, 3.2);
+	triplet.addEntry(1, 0, 3.1);
+	triplet.addEntry(1, 1, 2.9);
+	triplet.addEntry(1, 3, 0.9);
+	triplet.addEntry(2, 1, 1.7);
+	triplet.addEntry(2, 2, 3.0);
+	triplet.addEntry(3, 0, 3.5);
+	triplet.addEntry(3, 1, 0.4);
+	triplet.addEntry(3, 3, 1.0);
+	m.init(triplet);
+}
+
+template <typename T>
+static void testVectorOps() {
+	SMM::CSRMatrix<T> m;
+	fillKat(m);
+	CHECK(m.getNonZeroCount() == 10 && m.getDenseRowCount() == 5 && m.getDenseColCount() == 4);
+	{  // A * x + b, A != 0, x != 0, b == 0 (csr.cpp:311-329)
+		T mult[5] = {1, 2, 3, 4, 5};
+		T add[5] = {};
+		const T resRef[5] = {T(14.1), T(12.5), T(12.4), T(8.3), 0};
+		T res[5] = {};
+		m.rMultAdd(add, mult, res);
+		for (int i = 0; i < 5; ++i) CHECK(approx(resRef[i], res[i], 1e-6));
+		m.rMultAdd(add, mult, add);  // in place
+		for (int i = 0; i < 5; ++i) CHECK(approx(resRef[i], add[i], 1e-6));
+	}
+	{  // A * x + b, all non-zero (csr.cpp:351-369)
+		T mult[5] = {1, 0, 3, 4};
+		T add[5] = {5, 6, 7, 8, 10};
+		const T resRef[5] = {T(19.1), T(12.7), T(16.), T(15.5), 10};
+		T res[5] = {};
+		m.rMultAdd(add, mult, res);
+		for (int i = 0; i < 5; ++i) CHECK(approx(resRef[i], res[i], 1e-6));
+		m.rMultAdd(add, mult, add);
+		for (int i = 0; i < 5; ++i) CHECK(approx(resRef[i], add[i], 1e-6));
+	}
+	{  // b - A * x (csr.cpp:497-521): out of place leaves `sub` untouched
+		T mult[5] = {1, 0, 3, 4};
+		T sub[5] = {5, 6, 7, 8, 10};
+		const T resRef[5] = {T(-9.1), T(-0.7), T(-2.), T(0.5), 10};
+		T res[5] = {};
+		m.rMultSub(sub, mult, res);
+		for (int i = 0; i < 5; ++i) CHECK(approx(resRef[i], res[i], 1e-6));
+		CHECK(sub[0] == 5 && sub[1] == 6 && sub[2] == 7 && sub[3] == 8 && sub[4] == 10);
+		m.rMultSub(sub, mult, sub);
+		for (int i = 0; i < 5; ++i) CHECK(approx(resRef[i], sub[i], 1e-6));
+	}
+	{  // A == 0 (csr.cpp:278-290)
+		T mult[5] = {1, 2, 3, 4, 5};
+		T add[5] = {5, 6, 7, 8, 9};
+		T res[5] = {};
+		SMM::TripletMatrix<T> emptyTriplet(5, 4, 10);
+		SMM::CSRMatrix<T> emptyMatrix(emptyTriplet);
+		emptyMatrix.rMultAdd(add, mult, res);
+		for (int i = 0; i < 5; ++i) CHECK(res[i] == add[i]);
+	}
+	{  // Vector dot product / norms (ref:287-328)
+		SMM::Vector<T> a(1000, 2), b(1000, 3);
+		CHECK(approx(T(6000), a * b, 1e-6));
+		CHECK(approx(T(4000), a.secondNormSquared(), 1e-6));
+	}
+}
+
+// 2-D 5-point Laplacian assembled through the TripletMatrix, like a user of the reference would
+template <typename T>
+static void poisson(int n, SMM::CSRMatrix<T>& m) {
+	SMM::TripletMatrix<T> t(n * n, n * n);
+	for (int y = 0; y < n; ++y) {
+		for (int x = 0; x < n; ++x) {
+			const int i = y * n + x;
+			t.addEntry(i, i, 4);
+			if (x > 0) t.addEntry(i, i - 1, -1);
+			if (x < n - 1) t.addEntry(i, i + 1, -1);
+			if (y > 0) t.addEntry(i, i - n, -1);
+			if (y < n - 1) t.addEntry(i, i + n, -1);
+		}
+	}
+	m.init(t);
+}
+
+template <typename T>
+static void testSolvers() {
+	for (int n : {7, 24}) {
+		SMM::CSRMatrix<T> m;
+		poisson(n, m);
+		SMM::Vector<T> rhs = sumColumsPerRow(m);
+		{  // test/cpp/cg.cpp:7-26
+			SMM::Vector<T> x(m.getDenseRowCount(), 0);
+			CHECK(SMM::ConjugateGradient<T>(m, rhs, x, x, -1, l2Eps<T>()) == SMM::SolverStatus::SUCCESS);
+			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
+		}
+		{  // test/cpp/bicgstab.cpp:124-143
+			SMM::Vector<T> x(m.getDenseRowCount(), 0);
+			CHECK(SMM::BiCGStab<T>(m, rhs, x, -1, l2Eps<T>()) == SMM::SolverStatus::SUCCESS);
+			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
+		}
+		{  // test/cpp/bicgstab.cpp:145-167
+			SMM::Vector<T> x(m.getDenseRowCount(), 0);
+			using SGSPreconditioner = typename SMM::CSRMatrix<T>::SGSPreconditioner;
+			const SGSPreconditioner& M = m.template getPreconditioner<SMM::SolverPreconditioner::SYMMETRIC_GAUS_SEIDEL>();
+			CHECK((SMM::BiCGStab<SGSPreconditioner, T>(m, rhs, x, -1, l2Eps<T>(), M)) == SMM::SolverStatus::SUCCESS);
+			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
+		}
+		{  // the two preconditioners the reference lacks
+			SMM::Vector<T> x(m.getDenseRowCount(), 0);
+			auto J = m.template getPreconditioner<SMM::SolverPreconditioner::JACOBI>();
+			CHECK(SMM::BiCGStab(m, static_cast<T*>(rhs), static_cast<T*>(x), -1, l2Eps<T>(), J) == SMM::SolverStatus::SUCCESS);
+			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
+			x.fill(0);
+			auto I = m.template getPreconditioner<SMM::SolverPreconditioner::ILU0>();
+			CHECK(I.validate() == 0);
+			CHECK(SMM::BiCGStab(m, static_cast<T*>(rhs), static_cast<T*>(x), -1, l2Eps<T>(), I) == SMM::SolverStatus::SUCCESS);
+			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
+		}
+		{  // test/cpp/cg.cpp:62-84
+			SMM::Vector<T> x(m.getDenseRowCount(), 0);
+			typename SMM::CSRMatrix<T>::IC0Preconditioner M(m);
+			CHECK(M.init() == 0);
+			CHECK(SMM::ConjugateGradient<T>(m, rhs, x, x, -1, l2Eps<T>(), M) == SMM::SolverStatus::SUCCESS);
+			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
+		}
+		{  // test/cpp/bicgsymmetric.cpp:7-26
+			SMM::Vector<T> x(m.getDenseRowCount(), 0);
+			CHECK(SMM::BiCGSymmetric<T>(m, rhs, x, -1, l2Eps<T>()) == SMM::SolverStatus::SUCCESS);
+			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
+		}
+		{  // status quirks (ref:2342-2347, 2277-2282)
+			SMM::Vector<T> x(m.getDenseRowCount(), 0);
+			CHECK(SMM::ConjugateGradient<T>(m, rhs, x, x, 0, l2Eps<T>()) == SMM::SolverStatus::MAX_ITERATIONS_REACHED);
+			CHECK(SMM::BiCGStab<T>(m, rhs, x, 0, l2Eps<T>()) == SMM::SolverStatus::MAX_ITERATIONS_REACHED);
+		}
+	}
+}
+
+template <typename T>
+static void testIC0KnownAnswer() {  // test/cpp/cg.cpp:28-60
+	const int size = 5;
+	SMM::TripletMatrix<T> triplet(size, size);
+	triplet.addEntry(0, 3, 4);
+	triplet.addEntry(0, 0, 10);
+	triplet.addEntry(1, 1, 9);
+	triplet.addEntry(1, 4, 5);
+	triplet.addEntry(2, 2, 12);
+	triplet.addEntry(3, 0, 4);
+	triplet.addEntry(3, 3, 15);
+	triplet.addEntry(3, 4, 7);
+	triplet.addEntry(4, 1, 5);
+	triplet.addEntry(4, 3, 7);
+	triplet.addEntry(4, 4, 8);
+	SMM::CSRMatrix<T> m;
+	m.init(triplet);
+	typename SMM::CSRMatrix<T>::IC0Preconditioner ic0(m);
+	CHECK(ic0.init() == 0);
+	T rhs[size];
+	std::fill_n(rhs, size, T(1));
+	T res[size];
+	const T resRef[size] = {T(0.0995763), T(0.0646186), T(0.0833333), T(0.0010593), T(0.0836864)};
+	CHECK(ic0.apply(rhs, res) == 0);
+	for (int i = 0; i < size; ++i) CHECK(approx(resRef[i], res[i], 1e-4));
+}
+
+static void testLoader() {  // test/cpp/csr.cpp:787-866 shape: a symmetric coordinate file mirrors its off-diagonals
+	const std::string path = "/tmp/smm_hip_dropin_test.mtx";
+	{
+		std::ofstream f(path);
+		f << "%%MatrixMarket matrix coordinate real symmetric\n% comment\n3 3 4\n1 1 2.0\n2 1 -1.0\n2 2 2.0\n3 3 2.0\n";
+	}
+	SMM::CSRMatrix<double> m;
+	CHECK(SMM::loadMatrix(path.c_str(), m) == SMM::MatrixLoadStatus::SUCCESS);
+	CHECK(m.getNonZeroCount() == 5 && m.getValue(0, 1) == -1.0 && m.getValue(1, 0) == -1.0 && m.getValue(2, 2) == 2.0);
+	{
+		std::ofstream f(path);
+		f << "%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 4.0\n1 2 1.0\n2 2 3.0\n";
+	}
+	SMM::CSRMatrix<double> g;
+	CHECK(SMM::loadMatrix(path.c_str(), g) == SMM::MatrixLoadStatus::SUCCESS);
+	CHECK(g.getNonZeroCount() == 3 && g.getValue(0, 1) == 1.0 && g.getValue(1, 0) == 0.0);
+	double b[2] = {5, 3}, x[2] = {0, 0};
+	CHECK(SMM::BiCGStab<double>(g, b, x, -1, 1e-12) == SMM::SolverStatus::SUCCESS);
+	CHECK(approx(1.0, x[0], 1e-9) && approx(1.0, x[1], 1e-9));
+	CHECK(SMM::loadMatrix("/nonexistent/file.mtx", g) == SMM::MatrixLoadStatus::FAILED_TO_OPEN_FILE);
+}
+
+int main() {
+	if (smm_hip_init(0) != SMM_HIP_OK) {
+		std::printf("no GPU: %s\n", smm_hip_last_error());
+		return 77;
+	}
+	testVectorOps<float>();
+	testVectorOps<double>();
+	testSolvers<float>();
+	testSolvers<double>();
+	testIC0KnownAnswer<float>();
+	testIC0KnownAnswer<double>();
+	testLoader();
+	std::printf("%d checks, %d failed\n", g_checks, g_failed);
+	return g_failed ? 1 : 0;
+}
