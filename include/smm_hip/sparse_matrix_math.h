@@ -404,7 +404,8 @@ template <typename T>
 inline SolverStatus ConjugateGradient(const CSRMatrix<T>& a, const T* const b, const T* const x0, T* const x, int maxIterations, T eps) {
 	int st = 0;
 	const smm_hip_csr* d = a.device();
-	return detail::toStatus(d ? detail::Abi<T>::cg(d, b, x0, x, maxIterations, eps, nullptr, &st) : SMM_HIP_ERR_NO_DEVICE, st);
+	const int rc = d ? detail::Abi<T>::cg(d, b, x0, x, maxIterations, eps, nullptr, &st) : SMM_HIP_ERR_NO_DEVICE;
+	return detail::toStatus(rc, st);
 }
 
 // ref:2414-2505
@@ -414,7 +415,8 @@ inline SolverStatus ConjugateGradient(const CSRMatrix<T>& a, const T* const b, c
 	int st = 0;
 	const smm_hip_csr* d = a.device();
 	const smm_hip_precond* h = M.handle();
-	return detail::toStatus(d && h ? detail::Abi<T>::cg(d, b, x0, x, maxIterations, eps, h, &st) : SMM_HIP_ERR_NO_DEVICE, st);
+	const int rc = d && h ? detail::Abi<T>::cg(d, b, x0, x, maxIterations, eps, h, &st) : SMM_HIP_ERR_NO_DEVICE;
+	return detail::toStatus(rc, st);
 }
 
 // ref:2191-2283.  Preconditioner must be one of CSRMatrix<T>'s preconditioner classes (they live on the GPU); an arbitrary
@@ -429,7 +431,8 @@ inline SolverStatus BiCGStab(const CSRMatrix<T>& a, T* b, T* x, int maxIteration
 	const smm_hip_precond* h = preconditioner.handle();
 	constexpr bool precondition = !std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value;
 	if (!d || (precondition && !h)) return SolverStatus::DIVERGED;
-	return detail::toStatus(detail::Abi<T>::bicgstab(d, b, x, maxIterations, eps, h, &st), st);
+	const int rc = detail::Abi<T>::bicgstab(d, b, x, maxIterations, eps, h, &st);
+	return detail::toStatus(rc, st);
 }
 
 // ref:2294-2303
@@ -443,7 +446,8 @@ template <typename T>
 inline SolverStatus BiCGSymmetric(const CSRMatrix<T>& a, T* b, T* x, int maxIterations, T eps) {
 	int st = 0;
 	const smm_hip_csr* d = a.device();
-	return detail::toStatus(d ? detail::Abi<T>::bicgsym(d, b, x, maxIterations, eps, &st) : SMM_HIP_ERR_NO_DEVICE, st);
+	const int rc = d ? detail::Abi<T>::bicgsym(d, b, x, maxIterations, eps, &st) : SMM_HIP_ERR_NO_DEVICE;
+	return detail::toStatus(rc, st);
 }
 
 // ---- Matrix Market loader (ref:2507-2669 reads `coordinate real|integer symmetric` only; `general` and `pattern` are additions) ----
