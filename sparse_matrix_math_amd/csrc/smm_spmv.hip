@@ -331,7 +331,25 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, con
 				// batches of GATHER entries: the x[] gathers of a batch are all issued before the first multiply-add, so a lane
 				// keeps GATHER independent loads in flight; the sum itself stays strictly left to right.  Entries past the end
 				// of the piece are loaded too (valid offsets, see above) but never added.
-				for (int k = kb; k < ke; k += GATHER) {
+				int k = kb;
+				for (; k + GATHER <= ke; k += GATHER) {  // full batches: no predication at all
+					unsigned off[GATHER];
+					T xv[GATHER], vv[GATHER];
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						off[u] = sOff[k + u];
+						vv[u] = sVal[k + u];
+					}
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						xv[u] = gatherX<T>(x, off[u]);
+					}
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						dot = smmFma(vv[u], xv[u], dot);
+					}
+				}
+				if (k < ke) {  // last, partial batch
 					const int nvalid = ke - k;
 					unsigned off[GATHER];
 					T xv[GATHER], vv[GATHER];
@@ -380,6 +398,11 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, con
 		}
 		const T s1 = blockSum256(acc1, red);
 		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		// consumers always add NPART slots per quantity: clear the ones no workgroup of this (smaller) grid owns
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
 	}
 }
 
@@ -425,6 +448,7 @@ static int streamCap(const smm_hip_csr* m, int lanes) {
 	const int rowsPerTile = TPB / std::min(lanes, WAVE);
 	const double want = avg * rowsPerTile * 1.04 + 3;
 	int nv = static_cast<int>((want + StreamCfg<T>::PIECE - 1) / StreamCfg<T>::PIECE);
+	if (const char* env = getenv("SMM_HIP_STREAM_NV")) nv = atoi(env);  // tuning override (tools/spmv_sweep.py)
 	nv = std::max(1, std::min(nv, StreamCfg<T>::NVMAX));
 	return nv * StreamCfg<T>::PIECE;
 }
@@ -473,6 +497,11 @@ static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, c
                          const int* doneFlag, hipStream_t s) {
 	const int cap = m->stream_nnz_cap + 3;
 	const size_t lds = static_cast<size_t>(cap + StreamCfg<T>::PAD) * (sizeof(T) + 4) + (TPB + 8) * sizeof(int) + 4 * sizeof(T) + 16;
+	// persistent grid = exactly the workgroups that are resident together (a larger grid would run in two uneven rounds)
+	int perCU = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvStreamKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
+	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	grid = std::max(1, std::min(std::min(m->n_rowblocks, numCUs() * perCU), NPART));
 	spmvStreamKernel<T, L><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
 	                                            op, lhs, x, out, dotMode, w1, partials, doneFlag);
 }

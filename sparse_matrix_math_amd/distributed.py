@@ -136,6 +136,9 @@ class DistBiCGStab:
     def _matvec(self, ext, own_view, out, op_first, lhs_first, dot_mode, w1):
         """out = op(lhs, A ext): A_loc on the owned slice while the halo is in flight, then A_rem added in place with the
         dot products fused into that launch"""
+        if getattr(self.ops, "rem_empty", False) and not self.sends and not self.recvs:
+            self.ops.spmv("loc", op_first, lhs_first, own_view, out, dot_mode, w1)  # nothing lives on another rank
+            return
         reqs = self.comm.exchange(ext, self.cmin, self.sends, self.recvs)
         self.ops.spmv("loc", op_first, lhs_first, own_view, out, 0, None)
         for r in reqs:
@@ -150,11 +153,16 @@ class DistBiCGStab:
         max_iterations = min(max_iterations, n_global)  # ref:2200
         if max_iterations == -1:
             max_iterations = n_global  # ref:2201-2203
+        if hasattr(ops, "begin_solve"):
+            ops.begin_solve()
+        # views used every iteration, made once (the loop below is host-side latency critical at 8 GPUs)
+        sums1, sums2 = ops.sums[:1], ops.sums[:2]
+        x_view, p_own, s_own = ops.own(ops.x_ext), ops.own(ops.p_ext), ops.own(ops.s_ext)
         # r = b - A x (ref:2215)
         ops.copy_into_ext(ops.x_ext, x_own)
-        self._matvec(ops.x_ext, ops.own(ops.x_ext), ops.r, OP_SUB, b, 0, None)
+        self._matvec(ops.x_ext, x_view, ops.r, OP_SUB, b, 0, None)
         ops.stage(STAGE_INIT_LOCAL, x_own, eps)  # r0 = p = r, local r.r0
-        comm.all_reduce_sum(ops.sums[:1])
+        comm.all_reduce_sum(sums1)
         ops.stage(STAGE_INIT_APPLY, x_own, eps)
         planned = max(1, max_iterations)  # do { } while: the body always runs once (ref:2232, 2277)
         done = 0
@@ -163,15 +171,15 @@ class DistBiCGStab:
                 done, _, _ = ops.result()
                 if done:
                     break
-            self._matvec(ops.p_ext, ops.own(ops.p_ext), ops.ap, OP_ASSIGN, None, 1, ops.r0)  # ap = A p, local ap.r0
+            self._matvec(ops.p_ext, p_own, ops.ap, OP_ASSIGN, None, 1, ops.r0)  # ap = A p, local ap.r0
             ops.stage(STAGE_ALPHA_LOCAL, x_own, eps)
-            comm.all_reduce_sum(ops.sums[:1])
+            comm.all_reduce_sum(sums1)
             ops.stage(STAGE_ALPHA_APPLY, x_own, eps)  # alpha, s
-            self._matvec(ops.s_ext, ops.own(ops.s_ext), ops.as_, OP_ASSIGN, None, 2, ops.own(ops.s_ext))  # as = A s, as.as, as.s
+            self._matvec(ops.s_ext, s_own, ops.as_, OP_ASSIGN, None, 2, s_own)  # as = A s, as.as, as.s
             ops.stage(STAGE_OMEGA_LOCAL, x_own, eps)
-            comm.all_reduce_sum(ops.sums[:2])
+            comm.all_reduce_sum(sums2)
             ops.stage(STAGE_OMEGA_APPLY, x_own, eps)  # omega, x, r, local ||r||^2 and r.r0
-            comm.all_reduce_sum(ops.sums[:2])
+            comm.all_reduce_sum(sums2)
             ops.stage(STAGE_BETA_APPLY, x_own, eps)  # res, beta, p
         done, iterations, resnorm = ops.result()
         status = 2 if iterations > max_iterations else 0  # ref:2279-2282
@@ -202,6 +210,8 @@ class HipOps:
         self.p_ext = torch.zeros(ext_len, dtype=tdt, device=device)
         self.s_ext = torch.zeros(ext_len, dtype=tdt, device=device)
         self.sums = torch.zeros(4, dtype=tdt, device=device)
+        self.rem_empty = self.A_rem.nnz == 0
+        self._cached_stream = None
         self.ws = ctypes.c_void_p()
         self.check(getattr(self.lib, f"smm_hip_bicgstab_ws_create_{self.suf}")(self.n_local, ctypes.byref(self.ws)))
         self.check(self.lib.smm_hip_bicgstab_ws_bind(self.ws, host._dptr(self.own(self.p_ext)), host._dptr(self.own(self.s_ext)), host._dptr(self.sums)))
@@ -218,8 +228,11 @@ class HipOps:
     def copy_into_ext(self, ext, own_values):
         self.own(ext).copy_(own_values)
 
+    def begin_solve(self):
+        self._cached_stream = ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
     def _stream(self):
-        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        return self._cached_stream if self._cached_stream is not None else ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
 
     def spmv(self, which, op, lhs, x, out, dot_mode, w1):
         A = self.A_loc if which == "loc" else self.A_rem
