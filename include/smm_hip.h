@@ -227,6 +227,21 @@ int smm_hip_bicgstab_ws_stage_f64(smm_hip_bicgstab_ws* ws, int stage, double* d_
 int smm_hip_bicgstab_ws_result_f32(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* done, int* iterations, float* resnorm);
 int smm_hip_bicgstab_ws_result_f64(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* done, int* iterations, double* resnorm);
 
+/* ConjugateGradient (ref:2316-2398) in the same stage-wise form, on the same workspace type (r, ap and the bound p are used):
+ *   r = b - A x0 (caller)                          CG_INIT_LOCAL  -> all-reduce sums[0] -> CG_INIT_APPLY  (early exit test)
+ *   Ap = A p with dot_mode 1, w1 = p (caller)      CG_ALPHA_LOCAL -> all-reduce sums[0] -> CG_ALPHA_APPLY (alpha, x, r, local ||r||^2)
+ *                                                                 -> all-reduce sums[0] -> CG_BETA_APPLY  (test, beta, p)
+ * d_xcur is x0 on the first iteration and x afterwards (ref:2351, 2395); x is only written once the loop runs. */
+#define SMM_CG_STAGE_INIT_LOCAL 1
+#define SMM_CG_STAGE_INIT_APPLY 2
+#define SMM_CG_STAGE_ALPHA_LOCAL 3
+#define SMM_CG_STAGE_ALPHA_APPLY 4
+#define SMM_CG_STAGE_BETA_APPLY 5
+int smm_hip_cg_ws_stage_f32(smm_hip_bicgstab_ws* ws, int stage, const float* d_xcur, float* d_x, float eps, smm_hip_stream stream);
+int smm_hip_cg_ws_stage_f64(smm_hip_bicgstab_ws* ws, int stage, const double* d_xcur, double* d_x, double eps, smm_hip_stream stream);
+/* synchronises `stream`; SolverStatus of the stage-wise CG (iterations / ||r||^2 / done come from smm_hip_bicgstab_ws_result_*) */
+int smm_hip_cg_ws_status(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* solver_status);
+
 /* ---- synthetic workload generators (BASELINE.json configs; device-side so 5e8-entry matrices need no host
  *      std::map as in ref:606-618).  d_start[rows+1], d_positions[nnz], d_values[nnz] are DEVICE arrays sized by
  *      the *_nnz query.  Same laws as sparse_matrix_math_amd.generators (numpy), bit for bit. --------------- */

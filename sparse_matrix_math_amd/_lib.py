@@ -54,6 +54,7 @@ _TYPED = {
     "smm_hip_spmv_fused_dev": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "smm_hip_bicgstab_ws_create": (c_int, [c_int, POINTER(_P)]),
     "smm_hip_bicgstab_ws_stage": (c_int, [_P, c_int, _P, "T", _P]),
+    "smm_hip_cg_ws_stage": (c_int, [_P, c_int, _P, _P, "T", _P]),
     "smm_hip_bicgstab_ws_result": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
 }
 
@@ -80,6 +81,7 @@ _PLAIN = {
     "smm_hip_gen_banded_row_start": (c_longlong, [c_int, c_int, c_ulonglong, c_int, c_int]),
     "smm_hip_partials_count": (c_int, []),
     "smm_hip_bicgstab_ws_destroy": (c_int, [_P]),
+    "smm_hip_cg_ws_status": (c_int, [_P, _P, POINTER(c_int)]),
     "smm_hip_bicgstab_ws_bind": (c_int, [_P, _P, _P, _P]),
     "smm_hip_bicgstab_ws_pointers": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P)]),
 }

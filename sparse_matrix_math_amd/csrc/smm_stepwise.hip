@@ -232,6 +232,126 @@ static int wsStage(smm_hip_bicgstab_ws* ws, int stage, T* x, T eps, hipStream_t 
 	return SMM_HIP_OK;
 }
 
+// ---- ConjugateGradient (ref:2316-2398) in stages: the workspace's r, ap and the bound p are used; c[0] = residualNormSquared,
+//      c[1] = alpha, c[3] = beta, c[4] = last ||r||^2; f[0] done, f[1] iterations, f[2] SolverStatus ------------------------------
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgStepInit(int n, const T* __restrict__ r, T* __restrict__ p, T* __restrict__ partials) {
+	__shared__ T red[4];
+	T acc = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const T v = r[i];
+		p[i] = v;      // ref:2340
+		acc += v * v;  // ref:2341
+	}
+	const T s = blockSum256(acc, red);
+	if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ void cgStepCoefInit(const T* __restrict__ sums, StepState<T>* st, T eps) {
+	st->c[0] = sums[0];
+	st->c[4] = sums[0];
+	st->f[1] = 0;
+	st->f[0] = 0;
+	st->f[2] = SMM_SOLVER_MAX_ITERATIONS_REACHED;
+	if (eps * eps > sums[0]) {  // ref:2342-2344: x stays untouched
+		st->f[0] = 1;
+		st->f[2] = SMM_SOLVER_SUCCESS;
+	}
+}
+
+template <typename T>
+__global__ void cgStepCoefAlpha(const T* __restrict__ sums, StepState<T>* st) {
+	if (st->f[0]) return;
+	st->c[1] = st->c[0] / sums[0];  // alpha = rr / (Ap.p), ref:2354-2358
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgStepUpdateXR(int n, const StepState<T>* __restrict__ st, const T* __restrict__ p, const T* __restrict__ Ap,
+                                                      const T* xcur, T* x, T* __restrict__ r, T* __restrict__ partials) {
+	__shared__ T red[4];
+	if (st->f[0]) return;
+	const T alpha = st->c[1];
+	T acc = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		x[i] = smmFma(alpha, p[i], xcur[i]);  // ref:2372
+		const T ri = smmFma(-alpha, Ap[i], r[i]);
+		r[i] = ri;
+		acc += ri * ri;
+	}
+	const T s = blockSum256(acc, red);
+	if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ void cgStepCoefBeta(const T* __restrict__ sums, StepState<T>* st, T eps) {
+	if (st->f[0]) return;
+	const T rrNew = sums[0];
+	st->f[1] += 1;
+	st->c[4] = rrNew;
+	if (eps * eps > rrNew) {  // ref:2377-2379
+		st->f[0] = 1;
+		st->f[2] = SMM_SOLVER_SUCCESS;
+	} else {
+		st->c[3] = rrNew / st->c[0];  // ref:2381
+		st->c[0] = rrNew;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgStepUpdateP(int n, const StepState<T>* __restrict__ st, const T* __restrict__ r, T* __restrict__ p) {
+	if (st->f[0]) return;
+	const T beta = st->c[3];
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		p[i] = smmFma(beta, p[i], r[i]);  // ref:2391-2393
+	}
+}
+
+template <typename T>
+static int cgWsStage(smm_hip_bicgstab_ws* ws, int stage, const T* xcur, T* x, T eps, hipStream_t s) {
+	const int n = ws->n;
+	T* r = static_cast<T*>(ws->r);
+	T* ap = static_cast<T*>(ws->ap);
+	T* p = static_cast<T*>(ws->p);
+	T* parts = static_cast<T*>(ws->partials);
+	T* sums = static_cast<T*>(ws->sums);
+	auto* st = static_cast<StepState<T>*>(ws->state);
+	if (!p) {
+		setError("cg_ws_stage: p not bound");
+		return SMM_HIP_ERR_INVALID;
+	}
+	switch (stage) {
+	case SMM_CG_STAGE_INIT_LOCAL:
+		cgStepInit<T><<<NPART, TPB, 0, s>>>(n, r, p, parts);
+		stepSums<T><<<1, TPB, 0, s>>>(parts, 1, sums, st, 0);
+		break;
+	case SMM_CG_STAGE_INIT_APPLY:
+		cgStepCoefInit<T><<<1, 1, 0, s>>>(sums, st, eps);
+		break;
+	case SMM_CG_STAGE_ALPHA_LOCAL:
+		stepSums<T><<<1, TPB, 0, s>>>(parts, 1, sums, st, 1);
+		break;
+	case SMM_CG_STAGE_ALPHA_APPLY:
+		if ((!x || !xcur) && n > 0) {
+			setError("cg_ws_stage: x is null");
+			return SMM_HIP_ERR_INVALID;
+		}
+		cgStepCoefAlpha<T><<<1, 1, 0, s>>>(sums, st);
+		cgStepUpdateXR<T><<<NPART, TPB, 0, s>>>(n, st, p, ap, xcur, x, r, parts);
+		stepSums<T><<<1, TPB, 0, s>>>(parts, 1, sums, st, 1);
+		break;
+	case SMM_CG_STAGE_BETA_APPLY:
+		cgStepCoefBeta<T><<<1, 1, 0, s>>>(sums, st, eps);
+		cgStepUpdateP<T><<<gridFor(n), TPB, 0, s>>>(n, st, r, p);
+		break;
+	default:
+		setError("cg_ws_stage: unknown stage %d", stage);
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
 template <typename T>
 static int wsResult(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* done, int* iterations, T* resnorm) {
 	StepState<T> h;
@@ -349,6 +469,37 @@ int smm_hip_bicgstab_ws_result_f64(const smm_hip_bicgstab_ws* ws, smm_hip_stream
 	}
 	SMM_TRY(ensureInit());
 	return wsResult<double>(ws, stream, done, iterations, resnorm);
+}
+
+int smm_hip_cg_ws_stage_f32(smm_hip_bicgstab_ws* ws, int stage, const float* d_xcur, float* d_x, float eps, smm_hip_stream stream) {
+	if (!ws || ws->dtype != SMM_DTYPE_F32) {
+		setError("cg_ws_stage: null workspace or dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	return cgWsStage<float>(ws, stage, d_xcur, d_x, eps, pickStream(stream));
+}
+int smm_hip_cg_ws_stage_f64(smm_hip_bicgstab_ws* ws, int stage, const double* d_xcur, double* d_x, double eps, smm_hip_stream stream) {
+	if (!ws || ws->dtype != SMM_DTYPE_F64) {
+		setError("cg_ws_stage: null workspace or dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	return cgWsStage<double>(ws, stage, d_xcur, d_x, eps, pickStream(stream));
+}
+
+int smm_hip_cg_ws_status(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* solver_status) {
+	if (!ws || !solver_status) {
+		setError("cg_ws_status: null argument");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	// f[] sits behind 8 scalars of the workspace's dtype
+	const size_t off = (ws->dtype == SMM_DTYPE_F32 ? sizeof(float) : sizeof(double)) * 8 + 2 * sizeof(int);
+	hipStream_t s = pickStream(stream);
+	SMM_HIP_TRY(hipMemcpyAsync(solver_status, static_cast<const char*>(ws->state) + off, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
 }
 
 }  // extern "C"

@@ -186,6 +186,42 @@ class DistBiCGStab:
         return status, iterations, resnorm
 
 
+CG_INIT_LOCAL, CG_INIT_APPLY, CG_ALPHA_LOCAL, CG_ALPHA_APPLY, CG_BETA_APPLY = range(1, 6)
+
+
+class DistCG(DistBiCGStab):
+    """ConjugateGradient (ref:2316-2398) on a row-partitioned matrix (BASELINE config 4: CG with the dot products completed by
+    an RCCL all-reduce).  ops additionally provides cg_stage(stage, xcur, x, eps) and cg_status()."""
+
+    def solve(self, b, x0_own, x_own, max_iterations, eps, check_every=8):
+        """x0_own: initial guess; x_own: result (may be the same tensor).  Returns (status, iterations, resnorm2)."""
+        ops, comm = self.ops, self.comm
+        if hasattr(ops, "begin_solve"):
+            ops.begin_solve()
+        if max_iterations == -1:
+            max_iterations = ops.n_global  # ref:2345-2347 (no clamp otherwise)
+        sums1 = ops.sums[:1]
+        x_view, p_own = ops.own(ops.x_ext), ops.own(ops.p_ext)
+        ops.copy_into_ext(ops.x_ext, x0_own)
+        self._matvec(ops.x_ext, x_view, ops.r, OP_SUB, b, 0, None)  # r = b - A x0, ref:2337
+        ops.cg_stage(CG_INIT_LOCAL, x0_own, x_own, eps)  # p = r, local r.r
+        comm.all_reduce_sum(sums1)
+        ops.cg_stage(CG_INIT_APPLY, x0_own, x_own, eps)  # eps^2 > ||r||^2 -> done, x untouched (ref:2342-2344)
+        for it in range(max(0, max_iterations)):
+            if it % check_every == 0:
+                done, _, _ = ops.result()
+                if done:
+                    break
+            self._matvec(ops.p_ext, p_own, ops.ap, OP_ASSIGN, None, 1, p_own)  # Ap = A p, local p.Ap
+            ops.cg_stage(CG_ALPHA_LOCAL, x0_own, x_own, eps)
+            comm.all_reduce_sum(sums1)
+            ops.cg_stage(CG_ALPHA_APPLY, x0_own if it == 0 else x_own, x_own, eps)  # alpha, x, r, local ||r||^2 (ref:2351, 2395)
+            comm.all_reduce_sum(sums1)
+            ops.cg_stage(CG_BETA_APPLY, x0_own, x_own, eps)  # test, beta, p
+        _, iterations, resnorm2 = ops.result()
+        return ops.cg_status(), iterations, resnorm2
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # product implementation of the local kernels: libsmm_hip.so
 # ---------------------------------------------------------------------------------------------------------------------
@@ -221,6 +257,7 @@ class HipOps:
         self._spmv = getattr(self.lib, f"smm_hip_spmv_fused_dev_{self.suf}")
         self._stage = getattr(self.lib, f"smm_hip_bicgstab_ws_stage_{self.suf}")
         self._result = getattr(self.lib, f"smm_hip_bicgstab_ws_result_{self.suf}")
+        self._cg_stage = getattr(self.lib, f"smm_hip_cg_ws_stage_{self.suf}")
 
     def own(self, ext):
         return ext[self.own_offset:self.own_offset + self.n_local]
@@ -242,6 +279,15 @@ class HipOps:
     def stage(self, stage, x_own, eps):
         self.check(self._stage(self.ws, stage, self.host._dptr(x_own), self.np_dtype.type(eps), self._stream()))
 
+    def cg_stage(self, stage, xcur_own, x_own, eps):
+        d = self.host._dptr
+        self.check(self._cg_stage(self.ws, stage, d(xcur_own), d(x_own), self.np_dtype.type(eps), self._stream()))
+
+    def cg_status(self):
+        st = ctypes.c_int()
+        self.check(self.lib.smm_hip_cg_ws_status(self.ws, self._stream(), ctypes.byref(st)))
+        return st.value
+
     def result(self):
         done, it = ctypes.c_int(), ctypes.c_int()
         res = (ctypes.c_float if self.suf == "f32" else ctypes.c_double)()
@@ -254,8 +300,9 @@ class HipOps:
             self.ws = ctypes.c_void_p()
 
 
-def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np_dtype, device, group=None):
-    """start/positions/values: this rank's rows (local start[], GLOBAL columns) as device tensors.  Collective."""
+def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np_dtype, device, group=None, solver="bicgstab"):
+    """start/positions/values: this rank's rows (local start[], GLOBAL columns) as device tensors.  Collective.
+    solver: "bicgstab" (DistBiCGStab) or "cg" (DistCG)."""
     comm = TorchComm(dist, group)
     rank = comm.rank
     own_lo, own_hi = bounds[rank], bounds[rank + 1]
@@ -268,7 +315,7 @@ def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np
     sends, recvs = plan_halo(bounds, needs, rank)
     loc, rem = split_local_remote(torch, start, positions, values, own_lo, own_hi, cmin)
     ops = HipOps(torch, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, np_dtype, device)
-    solver = DistBiCGStab(ops, comm, cmin, sends, recvs)
+    solver = (DistCG if solver == "cg" else DistBiCGStab)(ops, comm, cmin, sends, recvs)
     solver.halo_elements = sum(hi - lo for _, lo, hi in recvs)
     return solver
 

@@ -79,6 +79,40 @@ class NumpyOps:
                 return
             p[:] = t(self.c["beta"]) * (-t(self.c["omega"]) * ap + p) + r
 
+    def cg_stage(self, stage, xcur_own, x_own, eps):
+        t = self.dtype.type
+        r, ap = self.r.numpy(), self.ap.numpy()
+        p, sums = self.own(self.p_ext).numpy(), self.sums.numpy()
+        if stage == 1:  # CG_INIT_LOCAL
+            p[:] = r
+            sums[0] = np.dot(r, r)
+        elif stage == 2:  # CG_INIT_APPLY
+            self.c["rr0"] = self.c["res"] = sums[0]
+            self.iters, self.done, self.status = 0, 0, 2
+            if t(eps) * t(eps) > sums[0]:
+                self.done, self.status = 1, 0
+        elif self.done:
+            return
+        elif stage == 3:  # CG_ALPHA_LOCAL
+            sums[0] = self.partial[0]
+        elif stage == 4:  # CG_ALPHA_APPLY
+            a = t(self.c["rr0"]) / sums[0]
+            x_own.numpy()[:] = a * p + xcur_own.numpy()
+            r[:] = -a * ap + r
+            sums[0] = np.dot(r, r)
+        elif stage == 5:  # CG_BETA_APPLY
+            self.iters += 1
+            self.c["res"] = sums[0]
+            if t(eps) * t(eps) > sums[0]:
+                self.done, self.status = 1, 0
+                return
+            beta = sums[0] / t(self.c["rr0"])
+            self.c["rr0"] = sums[0]
+            p[:] = beta * p + r
+
+    def cg_status(self):
+        return self.status
+
     def result(self):
         return self.done, self.iters, float(self.c["res"])
 

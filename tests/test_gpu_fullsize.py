@@ -1,0 +1,99 @@
+"""BASELINE.json configurations at their FULL sizes on one MI355X, checked through size-independent properties (the CPU oracle
+is too slow here): config 3 (10M rows x ~49 nnz, fp32, BiCGStab) and config 4's matrix (3-D Laplacian 512^3 = 134M rows, fp64, CG)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_10m_rows_bicgstab(smm):
+    import torch
+
+    from sparse_matrix_math_amd import host
+
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    n, k, seed, mo = 10_000_000, 25, 0x5EED, 1 << 20
+    nnz = host.gen_banded_nnz(n, k, seed, mo)
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    host.gen_banded_dev(n, k, seed, mo, d_start, d_pos, d_val, np.float32, stream)
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np.float32)
+    assert A.nnz == nnz == 484552446
+    ones = torch.ones(n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(ones)
+    A.spmv_dev(0, None, ones, y, stream)
+    torch.cuda.synchronize()
+    assert float((y - 1).abs().max()) < 1e-4  # every row sums to diag_shift = 1
+    g = torch.Generator(device=dev).manual_seed(5)
+    u = torch.rand(n, dtype=torch.float32, device=dev, generator=g) - 0.5
+    v = torch.rand(n, dtype=torch.float32, device=dev, generator=g) - 0.5
+    au, av = torch.empty_like(u), torch.empty_like(u)
+    A.spmv_dev(0, None, u, au, stream)
+    A.spmv_dev(0, None, v, av, stream)
+    torch.cuda.synchronize()
+    lhs, rhs = float(torch.dot(au.double(), v.double())), float(torch.dot(u.double(), av.double()))
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)  # symmetric: (A u).v == u.(A v)
+    assert float(torch.dot(au.double(), u.double())) > 0  # positive definite
+    x_true = torch.rand(n, dtype=torch.float32, device=dev, generator=g) + 0.5
+    b = torch.empty_like(u)
+    A.spmv_dev(0, None, x_true, b, stream)
+    x = torch.zeros_like(u)
+    status, iters, res = host.bicgstab_dev(A, b, x, 25, 0.0, None, stream)
+    assert int(status) == 0 and iters == 25 and np.isfinite(res)
+    assert float(((x - x_true).abs() / x_true).max()) < 2e-5  # solves A x = b
+    r = b.clone()
+    A.spmv_dev(2, r, x, r, stream)  # r = b - A x, in place (rMultSub)
+    torch.cuda.synchronize()
+    assert float(r.norm()) <= 1e-5 * float(b.norm())
+    # a lanes-per-row variant agrees with the default kernel to rounding
+    A.set_kernel(2, 1)
+    y1 = torch.empty_like(u)
+    A.spmv_dev(0, None, u, y1, stream)
+    torch.cuda.synchronize()
+    assert float((y1 - au).abs().max()) <= 1e-4
+
+
+def test_config4_laplacian_512_cg(smm):
+    import torch
+
+    from sparse_matrix_math_amd import host
+
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    N = 512
+    n = N ** 3
+    nnz = host.gen_stencil3d_nnz(N, N, N)
+    assert n == 134217728 and nnz == 937951232  # config 4
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    host.gen_stencil3d_dev(N, N, N, 6.0, -1.0, -1.0, d_start, d_pos, d_val, np.float64, stream)
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np.float64)
+    ones = torch.ones(n, dtype=torch.float64, device=dev)
+    b = torch.empty_like(ones)
+    A.spmv_dev(0, None, ones, b, stream)  # b = A 1: zero in the interior, > 0 on the boundary
+    torch.cuda.synchronize()
+    assert int(d_start[-1]) == nnz
+    assert float(b.min()) == 0.0 and float(b.max()) == 3.0 and abs(float(b.sum()) - 6.0 * N * N) < 1e-6
+    x = torch.zeros_like(ones)
+    status, iters, res2 = host.cg_dev(A, b, x, x, 100, 0.0, None, stream)
+    assert int(status) == 2 and iters == 100  # MAX_ITERATIONS_REACHED after exactly 100 iterations
+    r = b.clone()
+    A.spmv_dev(2, r, x, r, stream)
+    torch.cuda.synchronize()
+    true_res2 = float(torch.dot(r, r))
+    assert abs(true_res2 - res2) <= 1e-8 * max(true_res2, res2) + 1e-12  # recursive residual == true residual
+    assert res2 < float(torch.dot(b, b))  # and it went down
+    # CG minimises the A-norm of the error monotonically: 20 more iterations from x must not increase it
+    def err_energy(xx):
+        e = xx - ones
+        ae = torch.empty_like(e)
+        A.spmv_dev(0, None, e, ae, stream)
+        torch.cuda.synchronize()
+        return float(torch.dot(e, ae))
+    e100 = err_energy(x)
+    x2 = x.clone()
+    host.cg_dev(A, b, x2, x2, 20, 0.0, None, stream)
+    assert err_energy(x2) < e100 < err_energy(torch.zeros_like(ones))
