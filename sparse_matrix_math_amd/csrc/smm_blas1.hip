@@ -135,12 +135,17 @@ static int dotDev(int n, const T* a, const T* b, T* d_result, hipStream_t s) {
 		setError("dot: bad arguments");
 		return SMM_HIP_ERR_INVALID;
 	}
-	DevBuf<T> partials;
-	SMM_TRY(partials.alloc(NPART));
+	// one persistent partial-sum buffer per scalar type: this entry point only enqueues, so a buffer handed back to the
+	// allocator here could be given to another stream while these two kernels are still pending.  (Callers drive the
+	// `_dev` entry points from one stream at a time, see include/smm_hip.h.)
+	static T* partials = nullptr;
+	static std::mutex mu;
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		if (!partials) SMM_TRY(devAlloc(reinterpret_cast<void**>(&partials), NPART * sizeof(T)));
+	}
 	SMM_TRY(launchDotPartials<T>(n, a, b, partials, nullptr, s));
 	SMM_TRY(launchSumPartials<T>(partials, d_result, s));
-	// the partials buffer goes back to the cache when this returns; work enqueued later on the same stream
-	// cannot overtake the two kernels above
 	return SMM_HIP_OK;
 }
 

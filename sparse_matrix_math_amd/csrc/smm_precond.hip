@@ -402,6 +402,7 @@ static int uploadInts(const std::vector<int>& v, int** d, hipStream_t s) {
 template <typename T>
 static int createTyped(const smm_hip_csr* a, int kind, smm_hip_precond* M) {
 	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipDeviceSynchronize());  // the matrix may still be being written on a caller's stream
 	const int n = a->rows;
 	if (kind == SMM_PRECOND_JACOBI) {
 		SMM_TRY(devAlloc(&M->d_values, static_cast<size_t>(std::max(1, n)) * sizeof(T)));

@@ -157,6 +157,9 @@ __global__ void countLeadingEmpty(int rows, const int* __restrict__ start, int* 
 
 static int finishCsr(smm_hip_csr* m) {
 	hipStream_t s = libStream();
+	// device arrays handed in by the caller may still be being written on one of the caller's streams; the library's own
+	// (non-blocking) stream is not ordered behind those, so set-up paths that read them wait for the whole device first
+	SMM_HIP_TRY(hipDeviceSynchronize());
 	int* d_cnt = nullptr;
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_cnt), sizeof(int)));
 	SMM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), s));

@@ -413,6 +413,7 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, con
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows) {
 	std::vector<int> hs(static_cast<size_t>(m->rows) + 1);
 	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipDeviceSynchronize());  // start[] may have been produced on a caller's stream (see finishCsr)
 	SMM_HIP_TRY(hipMemcpyAsync(hs.data(), m->d_start, hs.size() * sizeof(int), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
 	std::vector<int> rb;  // pairs {first row, start[first row]}
@@ -674,6 +675,7 @@ int smm_hip_csr_autotune(smm_hip_csr* m) {
 	SMM_TRY(ensureInit());
 	if (m->rows == 0 || m->nnz == 0) return SMM_HIP_OK;
 	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipDeviceSynchronize());  // the matrix may still be being written on a caller's stream
 	const size_t esz = m->dtype == SMM_DTYPE_F32 ? 4 : 8;
 	void *dx = nullptr, *dy = nullptr;
 	SMM_TRY(devAlloc(&dx, esz * static_cast<size_t>(m->cols ? m->cols : 1)));
