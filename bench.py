@@ -255,6 +255,10 @@ def main():
         if "roofline" in line:
             line["spmv_gbps"] = line["roofline"]["achieved"]
             line["spmv_pct_hbm_peak"] = 100.0 * line["roofline"]["frac"]
+            if line["roofline"].get("traffic"):
+                # measured HBM-side bytes (PMC, profiles/spmv_traffic.json) over the live launch time: how hard the memory system
+                # is actually driven -- the gap to `achieved` is x[] cache lines re-fetched from beyond L2
+                line["roofline"]["traffic_gbps"] = line["roofline"]["traffic"] / (line["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
         print(json.dumps(line))
     if use_dist:
         dist.barrier()

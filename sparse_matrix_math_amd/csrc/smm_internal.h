@@ -95,6 +95,7 @@ struct smm_hip_csr {
 	int n_rowblocks = 0;
 	int stream_nnz_cap = 0;  // nonzeros / rows per tile the row blocks were cut for
 	int stream_max_rows = 0;
+	std::mutex tileMutex;  // the tile table is built lazily by the first SpMV; concurrent solves on one matrix are allowed
 };
 
 struct smm_hip_precond {
@@ -107,6 +108,7 @@ struct smm_hip_precond {
 	int* d_order_lo = nullptr;
 	int* d_order_up = nullptr;
 	std::vector<int> lvl_ptr_lo, lvl_ptr_up;  // host: level l covers order[lvl_ptr[l] .. lvl_ptr[l+1])
+	struct smm_precond_plan* plan = nullptr;  // launch groups of the two sweeps (smm_precond.hip)
 };
 
 namespace smm {

@@ -318,16 +318,7 @@ struct smm_precond_plan {
 
 namespace smm {
 
-static std::mutex g_planMutex;
-static std::vector<std::pair<const smm_hip_precond*, smm_precond_plan*>> g_plans;
-
-static smm_precond_plan* planOf(const smm_hip_precond* M) {
-	std::lock_guard<std::mutex> lock(g_planMutex);
-	for (auto& kv : g_plans) {
-		if (kv.first == M) return kv.second;
-	}
-	return nullptr;
-}
+static smm_precond_plan* planOf(const smm_hip_precond* M) { return M->plan; }
 
 template <typename T, int MODE>
 static int runSweep(const smm_hip_precond* M, const SweepPlan& plan, const int* d_order, const std::vector<int>& lvlPtr, const T* vals, const T* rhs,
@@ -483,8 +474,7 @@ static int createTyped(const smm_hip_csr* a, int kind, smm_hip_precond* M) {
 		return st;
 	}
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	std::lock_guard<std::mutex> lock(g_planMutex);
-	g_plans.emplace_back(M, plan);
+	M->plan = plan;
 	return SMM_HIP_OK;
 }
 
@@ -563,17 +553,7 @@ int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out
 
 int smm_hip_precond_destroy(smm_hip_precond* M) {
 	if (!M) return SMM_HIP_OK;
-	smm_precond_plan* plan = nullptr;
-	{
-		std::lock_guard<std::mutex> lock(g_planMutex);
-		for (size_t i = 0; i < g_plans.size(); ++i) {
-			if (g_plans[i].first == M) {
-				plan = g_plans[i].second;
-				g_plans.erase(g_plans.begin() + static_cast<long>(i));
-				break;
-			}
-		}
-	}
+	smm_precond_plan* plan = M->plan;
 	if (plan) {
 		devFree(plan->lo.d_lvlPtr);
 		devFree(plan->up.d_lvlPtr);

@@ -348,12 +348,17 @@ struct DonePoller {
 	bool pending[SLOTS] = {};
 	int head = 0, count = 0;
 	hipStream_t s = nullptr;
+	// one poller per host thread, reused by every solve of that thread (pinned memory and events are expensive to create)
 	int init(hipStream_t stream) {
 		s = stream;
-		SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&mailbox), SLOTS * sizeof(int), hipHostMallocDefault));
+		head = count = 0;
+		if (!mailbox) {
+			SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&mailbox), SLOTS * sizeof(int), hipHostMallocDefault));
+			for (int i = 0; i < SLOTS; ++i) SMM_HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+		}
 		for (int i = 0; i < SLOTS; ++i) {
 			mailbox[i] = 0;
-			SMM_HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+			pending[i] = false;
 		}
 		return SMM_HIP_OK;
 	}
@@ -449,7 +454,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 	cgInitScal<T><<<1, TPB, 0, s>>>(parts, sc, eps, pcg, parts2);
 	if (maxIterations == -1) maxIterations = n;  // ref:2345-2347 (no clamp otherwise)
 
-	DonePoller poller;
+	static thread_local DonePoller poller;
 	SMM_TRY(poller.init(s));
 	int seenDone = 0;
 	int nextCheck = 0;
@@ -533,7 +538,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	SMM_TRY(launchDotPartials<T>(n, r, r0, parts, nullptr, s));  // ref:2231
 	bicgInitScal<T><<<1, TPB, 0, s>>>(parts, sc);
 
-	DonePoller poller;
+	static thread_local DonePoller poller;
 	SMM_TRY(poller.init(s));
 	const int* doneFlag = &sc.p->done;
 	const int planned = std::max(1, maxIterations);  // do { } while: the body always runs once (ref:2232, 2277)
@@ -601,7 +606,7 @@ int bicgsymmetricDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, 
 	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));
 	SMM_TRY(launchDotPartials<T>(n, r, r, parts, nullptr, s));
 	bsymInitScal<T><<<1, TPB, 0, s>>>(parts, sc);
-	DonePoller poller;
+	static thread_local DonePoller poller;
 	SMM_TRY(poller.init(s));
 	const int* doneFlag = &sc.p->done;
 	const int planned = std::max(1, maxIterations);

@@ -6,19 +6,20 @@
 //          positions[]/values[] are read coalesced, partial sums meet in a wave butterfly (__shfl_xor).
 //          Rows are grid-strided.  Best for long rows and for tiny matrices.
 //
-//  STREAM  The matrix is cut once (at csr_create) into row blocks of <= CAP nonzeros and <= 256 rows.  A
-//          workgroup stages one block's positions[] and values[] into LDS with 16-byte fully coalesced loads
-//          -- the two arrays that are >95 % of the bytes of an SpMV are streamed exactly once at full width
-//          whatever the row lengths are -- then every row is summed from LDS by L lanes, each walking a
-//          contiguous piece of the row left to right.  Lanes are mapped row-fastest (thread t -> row t % R,
-//          piece t / R) so that at every step adjacent lanes read x[] at adjacent columns for banded /
-//          stencil matrices: the x gather is coalesced even though x itself is never staged.
+//  STREAM  The matrix is cut once (at the first SpMV) into row tiles of <= 256/L whole rows and <= cap-3 nonzeros
+//          (cap = 1024..4096 from the mean row length).  A persistent workgroup walks its tiles: the tile's
+//          positions[] / values[] slices -- >95 % of the bytes of an SpMV -- are fetched ONE TILE AHEAD with
+//          16-byte coalesced non-temporal loads into registers and stored to LDS (positions as byte offsets into
+//          x); then lane (row, piece) walks its piece of its row out of LDS in batches of 8 independent x[]
+//          gathers.  Rows run fastest across the lanes of a wavefront, so for banded / stencil matrices a gather
+//          instruction reads adjacent columns (coalesced) although x itself is never staged.  The L pieces of a
+//          row meet through wave shuffles, left to right.
 //          With L == 1 the sum is formed in exactly the reference's order (ref:1484-1489): bit-identical
-//          results.  With L > 1 the L pieces are added left to right.
+//          results.  With L > 1 the L piece sums are added left to right (deterministic).
 //
 // Both families can fuse one or two dot products of the freshly computed out[] into the epilogue (the p.Ap of
 // CG ref:2354, ap.r0 / as.as / as.s of BiCGStab ref:2243, 2259-2261) so those vectors are not re-read: each
-// workgroup writes its partial sums to partials[blockIdx.x] (fixed grid of NPART workgroups, fixed order).
+// workgroup writes its partial sums to partials[blockIdx.x]; consumers add NPART slots in a fixed order.
 //
 // No MFMA: 2 flops per 8-12 bytes, the path is HBM-bound.
 #include <algorithm>
@@ -536,6 +537,7 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	if (family == SMM_SPMV_STREAM) {
 		const int capNnz = streamCap<T>(m, L) - 3;
 		const int maxRows = TPB / std::min(L, WAVE);
+		std::lock_guard<std::mutex> lock(const_cast<smm_hip_csr*>(m)->tileMutex);
 		if (!m->d_rowblocks || m->stream_nnz_cap != capNnz || m->stream_max_rows != maxRows) {
 			SMM_TRY(buildRowBlocks(const_cast<smm_hip_csr*>(m), capNnz, maxRows));
 		}
