@@ -95,6 +95,7 @@ struct smm_hip_csr {
 	int n_rowblocks = 0;
 	int stream_nnz_cap = 0;  // nonzeros / rows per tile the row blocks were cut for
 	int stream_max_rows = 0;
+	int stream_chunk_tiles = 0;  // tiles dealt to an XCD group at a time (0: one contiguous eighth per group)
 	std::mutex tileMutex;  // the tile table is built lazily by the first SpMV; concurrent solves on one matrix are allowed
 };
 

@@ -186,7 +186,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smmDynLds[];
 // matrices are coalesced; (3) the L pieces of a row meet through wave shuffles, left to right.  Two workgroup barriers per
 // tile (LDS ready / LDS free); the HBM stream of tile i+1 is in flight during (2) of tile i.
 template <typename T, int L>
-__global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
+__global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int chunkTiles, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
                                                         const int* __restrict__ positions, const T* __restrict__ values, int op, const T* lhs,
                                                         const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
                                                         T* __restrict__ partials, const int* __restrict__ doneFlag) {
@@ -224,12 +224,21 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, con
 	const int nGroups = min(8, static_cast<int>(gridDim.x));
 	const int xcdGroup = blockIdx.x % nGroups;
 	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;  // workgroups in this group
-	const int perGroup = (nTiles + nGroups - 1) / nGroups;
-	const int tileEnd = min(nTiles, (xcdGroup + 1) * perGroup);
+	// Tiles are dealt to the groups in chunks of `chunkTiles` consecutive tiles, round-robin: the j-th tile of group g is
+	// tile ((j / chunkTiles) * nGroups + g) * chunkTiles + j % chunkTiles.  chunkTiles = ceil(nTiles / 8) gives each group one
+	// contiguous eighth; for a large 3-D stencil the host passes one grid plane per chunk, so the 8 XCDs sweep 8 adjacent planes
+	// at a time (buildRowBlocks explains the choice).
+	const int tileEnd = nTiles;
+	auto tileOf = [&](int j) {
+		const int c = j / chunkTiles;
+		const long long tIdx = (static_cast<long long>(c) * nGroups + xcdGroup) * chunkTiles + (j - c * chunkTiles);
+		return tIdx < nTiles ? static_cast<int>(tIdx) : nTiles;
+	};
 	// tiles that end within `cap` entries of the end of the arrays are not staged (their 16-byte pieces could run past the
 	// arrays); like over-long rows they are summed straight from HBM
 	const int stageLimit = (rowBlocks[nTiles].y & ~3) - cap;
-	int tile = xcdGroup * perGroup + blockIdx.x / nGroups;
+	int j = blockIdx.x / nGroups;
+	int tile = tileOf(j);
 
 	// software pipeline: the 16-byte loads of tile i+1 are issued (into registers) before tile i is summed out of LDS;
 	// the tile descriptors are fetched one step further ahead
@@ -239,9 +248,10 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, con
 	if (tile < tileEnd) {
 		m0 = rowBlocks[tile];
 		m1 = rowBlocks[tile + 1];
-		if (tile + groupSlots < tileEnd) {
-			nm0 = rowBlocks[tile + groupSlots];
-			nm1 = rowBlocks[tile + groupSlots + 1];
+		const int t1 = tileOf(j + groupSlots);
+		if (t1 < tileEnd) {
+			nm0 = rowBlocks[t1];
+			nm1 = rowBlocks[t1 + 1];
 		}
 		if (m1.y - m0.y <= cap - 3 && (m0.y & ~3) <= stageLimit) {
 			stageLoad<T>(regs, t, nv, m0.y & ~3, m1.y, positions, values);
@@ -261,16 +271,18 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, con
 		}
 		__syncthreads();
 		// ---- prefetch this workgroup's next tile ----
-		const int ntile = tile + groupSlots;
+		j += groupSlots;
+		const int ntile = tileOf(j);
 		const int2 m0n = nm0, m1n = nm1;
 		if (ntile < tileEnd) {
 			if (m1n.y - m0n.y <= cap - 3 && (m0n.y & ~3) <= stageLimit) {
 				stageLoad<T>(regs, t, nv, m0n.y & ~3, m1n.y, positions, values);
 				if (t < m1n.x - m0n.x) ps = start[m0n.x + t];
 			}
-			if (ntile + groupSlots < tileEnd) {
-				nm0 = rowBlocks[ntile + groupSlots];
-				nm1 = rowBlocks[ntile + groupSlots + 1];
+			const int t2 = tileOf(j + groupSlots);
+			if (t2 < tileEnd) {
+				nm0 = rowBlocks[t2];
+				nm1 = rowBlocks[t2 + 1];
 			}
 		}
 		if (direct && nrows == 1) {
@@ -437,6 +449,27 @@ int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows) {
 	m->n_rowblocks = static_cast<int>(rb.size() / 2) - 1;
 	m->stream_nnz_cap = capNnz;
 	m->stream_max_rows = maxRows;
+	// How the tiles are dealt to the 8 XCDs.  The farthest column a middle row touches tells how far apart (in rows) two uses of
+	// the same x[] line are.  When that distance is many tiles but a small fraction of the matrix (3-D stencils: one grid plane),
+	// the tiles are dealt one such span per XCD, round-robin, so the 8 XCDs sweep 8 adjacent planes together instead of 8 regions
+	// a gigabyte apart: measured -8 % on the 512^3 Laplacian (3.55 -> 3.28 ms), neutral on smaller grids; with far offsets that are
+	// a large fraction of the matrix (the banded-random benchmark matrix) contiguous eighths are best (tools/sweep_chunk.sh).
+	m->stream_chunk_tiles = 0;
+	if (rows > 0 && m->nnz > 0) {
+		const int mid = rows / 2;
+		const int len = hs[mid + 1] - hs[mid];
+		if (len > 0) {
+			std::vector<int> cols(static_cast<size_t>(len));
+			SMM_HIP_TRY(hipMemcpyAsync(cols.data(), m->d_positions + hs[mid], cols.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+			SMM_HIP_TRY(hipStreamSynchronize(s));
+			long long far = 0;
+			for (int c : cols) far = std::max<long long>(far, std::llabs(static_cast<long long>(c) - mid));
+			const double rowsPerTile = static_cast<double>(rows) / std::max(1, m->n_rowblocks);
+			const long long farTiles = static_cast<long long>(far / rowsPerTile);
+			if (farTiles >= 256 && farTiles * 32 <= m->n_rowblocks) m->stream_chunk_tiles = static_cast<int>(farTiles);
+		}
+	}
+	if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) m->stream_chunk_tiles = std::max(0, atoi(env));  // tuning override
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(&m->d_rowblocks), rb.size() * sizeof(int)));
 	SMM_HIP_TRY(hipMemcpyAsync(m->d_rowblocks, rb.data(), rb.size() * sizeof(int), hipMemcpyHostToDevice, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
@@ -504,7 +537,9 @@ static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvStreamKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
 	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
 	grid = std::max(1, std::min(std::min(m->n_rowblocks, numCUs() * perCU), NPART));
-	spmvStreamKernel<T, L><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
+	const int nGroups = std::min(8, grid);
+	const int chunkTiles = m->stream_chunk_tiles > 0 ? m->stream_chunk_tiles : (m->n_rowblocks + nGroups - 1) / nGroups;
+	spmvStreamKernel<T, L><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, chunkTiles, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
 	                                            op, lhs, x, out, dotMode, w1, partials, doneFlag);
 }
 
