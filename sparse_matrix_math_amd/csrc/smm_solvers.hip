@@ -30,8 +30,7 @@ struct Scal {
 	T beta;
 	T omega;
 	T res;      // CG: last ||r||^2 ; BiCGStab: last ||r||
-	T rrOld;    // BiCGSymmetric rSquare before the update
-	T epsv;
+	T rrPing[2];  // fused loops: rr (CG) / rr0 (BiCGStab) double-buffered by iteration parity
 	int done;
 	int iters;
 	int status;
@@ -55,6 +54,7 @@ __global__ __launch_bounds__(TPB) void cgInitScal(const T* __restrict__ partials
 	if (pcg) rz = sumParts(partials2, red);
 	if (threadIdx.x == 0) {
 		sc->rr = pcg ? rz : rr;
+		sc->rrPing[0] = sc->rr;
 		sc->res = rr;
 		sc->iters = 0;
 		sc->status = SMM_SOLVER_MAX_ITERATIONS_REACHED;
@@ -133,6 +133,134 @@ __global__ __launch_bounds__(TPB) void cgUpdateP(int n, const Scal<T>* __restric
 	}
 }
 
+// ---- fused forms: the scalar stage is folded into the vector kernel that consumes it --------------------------------------
+// Every workgroup re-adds the NPART partial sums itself (same order => same bits in every workgroup), so alpha / beta / omega
+// need no kernel of their own: two launches per CG iteration and three per BiCGStab iteration disappear.  State that must
+// survive a kernel (rr, alpha, omega, done, iterations) is written by workgroup 0 only; rr is double-buffered by iteration
+// parity because workgroup 0 writes the next value while the others still read the current one.
+template <typename T>
+__device__ __forceinline__ T sumPartsAll(const T* __restrict__ partials, T* red5) {
+	const T s = sumParts(partials, red5);
+	if (threadIdx.x == 0) red5[4] = s;
+	__syncthreads();
+	const T v = red5[4];
+	__syncthreads();
+	return v;
+}
+
+// alpha = rr / (Ap.p) ; x = alpha p + xcur ; r = -alpha Ap + r ; partial ||r||^2   (ref:2354-2375)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgFusedXR(int n, const Scal<T>* __restrict__ sc, int par, const T* __restrict__ partsA,
+                                                 const T* __restrict__ p, const T* __restrict__ Ap, const T* xcur, T* x, T* __restrict__ r,
+                                                 T* __restrict__ partsC) {
+	__shared__ T red[5];
+	if (sc->done) return;
+	const T alpha = sc->rrPing[par] / sumPartsAll(partsA, red);
+	T acc = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		x[i] = smmFma(alpha, p[i], xcur[i]);
+		const T ri = smmFma(-alpha, Ap[i], r[i]);
+		r[i] = ri;
+		acc += ri * ri;
+	}
+	const T s = blockSum256(acc, red);
+	if (threadIdx.x == 0) partsC[blockIdx.x] = s;
+}
+
+// convergence test, beta, p = beta p + r   (ref:2377-2394)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cgFusedP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, T* __restrict__ p,
+                                                const T* __restrict__ r) {
+	__shared__ T red[5];
+	if (sc->done) return;
+	const T rrNew = sumPartsAll(partsC, red);
+	const T rrOld = sc->rrPing[par];
+	const bool converged = eps * eps > rrNew;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->iters += 1;
+		sc->res = rrNew;
+		if (converged) {
+			sc->done = 1;
+			sc->status = SMM_SOLVER_SUCCESS;
+		} else {
+			sc->rrPing[par ^ 1] = rrNew;
+		}
+	}
+	if (converged) return;
+	const T beta = rrNew / rrOld;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		p[i] = smmFma(beta, p[i], r[i]);
+	}
+}
+
+// alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgFusedS(int n, Scal<T>* sc, int par, const T* __restrict__ partsA, const T* __restrict__ ap,
+                                                  const T* __restrict__ r, T* __restrict__ sv) {
+	__shared__ T red[5];
+	if (sc->done) return;
+	const T alpha = sc->rrPing[par] / sumPartsAll(partsA, red);
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		sv[i] = smmFma(-alpha, ap[i], r[i]);
+	}
+}
+
+// omega = (as.s)/(as.as) ; x, r update ; partial ||r||^2 and r.r0   (ref:2259-2269); partsB = [as.as | as.s], partsC = [r.r | r.r0]
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgFusedXR(int n, Scal<T>* sc, const T* __restrict__ partsB, const T* __restrict__ p,
+                                                   const T* __restrict__ sv, const T* __restrict__ as, const T* __restrict__ r0, T* __restrict__ x,
+                                                   T* __restrict__ r, T* __restrict__ partsC) {
+	__shared__ T red[5];
+	if (sc->done) return;
+	const T asas = sumPartsAll(partsB, red);
+	const T ass = sumPartsAll(partsB + NPART, red);
+	const T omega = ass / asas;
+	const T alpha = sc->alpha;
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->omega = omega;
+	T acc0 = T(0), acc1 = T(0);
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const T si = sv[i];
+		x[i] = smmFma(alpha, p[i], smmFma(omega, si, x[i]));
+		const T ri = smmFma(-omega, as[i], si);
+		r[i] = ri;
+		acc0 += ri * ri;
+		acc1 += ri * r0[i];
+	}
+	const T s0 = blockSum256(acc0, red);
+	const T s1 = blockSum256(acc1, red);
+	if (threadIdx.x == 0) {
+		partsC[blockIdx.x] = s0;
+		partsC[NPART + blockIdx.x] = s1;
+	}
+}
+
+// resL2Norm, loop test, beta, p = beta (-omega ap + p) + r   (ref:2268-2277)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bicgFusedP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, const T* __restrict__ ap,
+                                                  const T* __restrict__ r, T* __restrict__ p) {
+	__shared__ T red[5];
+	if (sc->done) return;
+	const T rr = sumPartsAll(partsC, red);
+	const T newRR0 = sumPartsAll(partsC + NPART, red);
+	const T res = sizeof(T) == 4 ? static_cast<T>(__fsqrt_rn(static_cast<float>(rr))) : static_cast<T>(__dsqrt_rn(static_cast<double>(rr)));
+	const T alpha = sc->alpha;
+	const T omega = sc->omega;
+	const T rr0 = sc->rrPing[par];
+	const bool leave = !(res > eps);  // while (resL2Norm > eps ...): NaN leaves the loop too
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->res = res;
+		sc->rrPing[par ^ 1] = newRR0;
+		sc->iters += 1;
+		if (leave) sc->done = 1;
+	}
+	if (leave) return;
+	const T beta = (newRR0 * alpha) / (rr0 * omega);  // ref:2271
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		p[i] = smmFma(beta, smmFma(-omega, ap[i], p[i]), r[i]);
+	}
+}
+
 // two dot products that share an operand: partials = a.a, partials2 = a.b
 template <typename T>
 __global__ __launch_bounds__(TPB) void dot2Partials(int n, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ partials,
@@ -160,6 +288,7 @@ __global__ __launch_bounds__(TPB) void bicgInitScal(const T* __restrict__ partia
 	const T rr0 = sumParts(partials, red);  // ref:2231
 	if (threadIdx.x == 0) {
 		sc->rr = rr0;
+		sc->rrPing[0] = rr0;
 		sc->res = T(0);
 		sc->iters = 0;
 		sc->done = 0;
@@ -468,18 +597,19 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 		}
 		// Ap = A p with the p.Ap partial sums fused into the epilogue (ref:2353-2354)
 		SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, Ap, 1, p, parts, doneFlag, s));
-		cgAlphaScal<T><<<1, TPB, 0, s>>>(parts, sc);
 		const T* xcur = i == 0 ? x0 : x;  // ref:2351, 2395
-		// NPART workgroups: every partial slot is (re)written each iteration, idle workgroups write 0
-		cgUpdateXR<T><<<NPART, TPB, 0, s>>>(n, sc, p, Ap, xcur, x, r, parts, pcg ? 0 : 1);
 		if (pcg) {
+			cgAlphaScal<T><<<1, TPB, 0, s>>>(parts, sc);
+			// NPART workgroups: every partial slot is (re)written each iteration, idle workgroups write 0
+			cgUpdateXR<T><<<NPART, TPB, 0, s>>>(n, sc, p, Ap, xcur, x, r, parts, 0);
 			SMM_TRY(precondApplyDev<T>(M, r, z, doneFlag, s));         // ref:2482
 			dot2Partials<T><<<NPART, TPB, 0, s>>>(n, r, z, parts, parts2, doneFlag);  // r.r and r.z, ref:2483-2484
 			cgBetaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc, eps, 1);
 			cgUpdateP<T><<<g, TPB, 0, s>>>(n, sc, p, z);
 		} else {
-			cgBetaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc, eps, 0);
-			cgUpdateP<T><<<g, TPB, 0, s>>>(n, sc, p, r);
+			// alpha and beta are formed inside the two update kernels (no scalar launches)
+			cgFusedXR<T><<<NPART, TPB, 0, s>>>(n, sc, i & 1, parts, p, Ap, xcur, x, r, parts2);
+			cgFusedP<T><<<g, TPB, 0, s>>>(n, sc, i & 1, parts2, eps, p, r);
 		}
 	}
 	SMM_HIP_TRY(hipGetLastError());
@@ -523,8 +653,8 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	SMM_TRY(sv.alloc(n));
 	SMM_TRY(as.alloc(n));
 	if (precondition) SMM_TRY(scratch.alloc(n));
-	SMM_TRY(parts.alloc(2 * NPART));
-	SMM_TRY(parts2.alloc(NPART));
+	SMM_TRY(parts.alloc(2 * NPART));   // [ap.r0] then [as.as | as.s]
+	SMM_TRY(parts2.alloc(2 * NPART));  // [r.r | r.r0]
 	SMM_TRY(sc.alloc(1));
 	const int g = NPART;  // update kernels that write partials use the full partial grid
 
@@ -557,21 +687,18 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 		} else {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, ap, 1, r0, parts, doneFlag, s));  // ref:2240 + 2243 fused
 		}
-		bicgAlphaScal<T><<<1, TPB, 0, s>>>(parts, sc);
-		bicgUpdateS<T><<<gridFor(n), TPB, 0, s>>>(n, sc, ap, r, sv);
+		// alpha, omega and beta are formed inside the three update kernels that consume them (no scalar launches)
+		bicgFusedS<T><<<gridFor(n), TPB, 0, s>>>(n, sc, i & 1, parts, ap, r, sv);
 		if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
 			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));                                           // ref:2251
-			dot2Partials<T><<<NPART, TPB, 0, s>>>(n, as, sv, parts, parts2, doneFlag);                          // ref:2259, 2261
-			bicgOmegaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc);
+			dot2Partials<T><<<NPART, TPB, 0, s>>>(n, as, sv, parts, parts.p + NPART, doneFlag);                 // ref:2259, 2261
 		} else {
 			// as = A s with as.as -> parts[0..NPART) and as.s -> parts[NPART..2 NPART) fused (ref:2256-2261)
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, as, 2, sv, parts, doneFlag, s));
-			bicgOmegaScal<T><<<1, TPB, 0, s>>>(parts, parts.p + NPART, sc);
 		}
-		bicgUpdateXR<T><<<g, TPB, 0, s>>>(n, sc, p, sv, as, r0, x, r, parts, parts2);
-		bicgBetaScal<T><<<1, TPB, 0, s>>>(parts, parts2, sc, eps);
-		bicgUpdateP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, ap, r, p);
+		bicgFusedXR<T><<<g, TPB, 0, s>>>(n, sc, parts, p, sv, as, r0, x, r, parts2);
+		bicgFusedP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, i & 1, parts2, eps, ap, r, p);
 	}
 	SMM_HIP_TRY(hipGetLastError());
 	Scal<T> h;

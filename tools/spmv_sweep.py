@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--k", type=int, default=25)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--configs", default="2:1,2:2,2:4,2:8,2:16,1:4,1:8,1:16,1:32,1:64")
-    ap.add_argument("--pos-mode", default="orig", choices=["orig", "row", "near"],
+    ap.add_argument("--pos-mode", default="orig", choices=["orig", "row", "near", "random"],
                     help="ablation: overwrite positions[] so every gather hits x[row] (row) or x[row + j - len/2] (near)")
     args = ap.parse_args()
     smm.init(0)
@@ -56,6 +56,15 @@ def main():
             j = torch.arange(nnz, device=dev, dtype=torch.int64) - torch.repeat_interleave(d_start[:-1].to(torch.int64), lens)
             rows_of = (rows_of.to(torch.int64) + j - 24).clamp_(0, n - 1).to(torch.int32)
             del j
+        if args.pos_mode == "random":
+            # worst case for the gather: stratified i.i.d. columns (entry j of a row of length L falls uniformly into the j-th of L equal
+            # slices of [0, n)), ascending by construction; SURVEY.md section 8d's "secondary" matrix, SpMV only
+            j = torch.arange(nnz, device=dev, dtype=torch.int64) - torch.repeat_interleave(d_start[:-1].to(torch.int64), lens)
+            width = (n // torch.repeat_interleave(lens, lens)).clamp_(min=1)
+            g = torch.Generator(device=dev).manual_seed(7)
+            r = (torch.rand(nnz, device=dev, generator=g, dtype=torch.float64) * width.to(torch.float64)).to(torch.int64)
+            rows_of = (j * width + torch.minimum(r, width - 1)).clamp_(0, n - 1).to(torch.int32)
+            del j, width, r
         d_pos.copy_(rows_of)
         del rows_of, lens
     A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, npd)
