@@ -110,11 +110,19 @@ class TorchComm:
         list of requests to wait on"""
         if not sends and not recvs:
             return []
-        ops = []
-        for q, lo, hi in recvs:
-            ops.append(self.dist.P2POp(self.dist.irecv, ext[lo - cmin:hi - cmin], q, self.group))
-        for q, lo, hi in sends:
-            ops.append(self.dist.P2POp(self.dist.isend, ext[lo - cmin:hi - cmin], q, self.group))
+        # the same few vectors are exchanged every iteration: build their P2POp lists (slice views + op objects) once
+        cache = getattr(self, "_p2p_cache", None)
+        if cache is None:
+            cache = self._p2p_cache = {}
+        key = (ext.data_ptr(), cmin, id(sends), id(recvs))
+        ops = cache.get(key)
+        if ops is None:
+            ops = []
+            for q, lo, hi in recvs:
+                ops.append(self.dist.P2POp(self.dist.irecv, ext[lo - cmin:hi - cmin], q, self.group))
+            for q, lo, hi in sends:
+                ops.append(self.dist.P2POp(self.dist.isend, ext[lo - cmin:hi - cmin], q, self.group))
+            cache[key] = ops
         return self.dist.batch_isend_irecv(ops)
 
 
