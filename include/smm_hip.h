@@ -72,6 +72,11 @@ extern "C" {
 #define SMM_SPMV_AUTO 0
 #define SMM_SPMV_VECTOR 1 /* L lanes of a wavefront per row, wave shuffle reduction */
 #define SMM_SPMV_STREAM 2 /* row blocks staged through LDS with 16-byte coalesced loads, row-sequential sums */
+/* OPT-IN, never chosen by AUTO: for matrices whose rows all take their columns from one set of <= 64 offsets relative to the
+ * row (stencil and banded matrices).  positions[] is then replaced by one 64-bit mask per row, verified against every
+ * entry when the family is selected, and an SpMV streams only values[].  Same result bit for bit as the other families at the
+ * same lanes_per_row.  smm_hip_csr_set_kernel returns SMM_HIP_ERR_INVALID when the matrix has no such pattern. */
+#define SMM_SPMV_PATTERN 3
 
 typedef struct smm_hip_csr smm_hip_csr;         /* device-resident CSRMatrix<T> (ref:1243-1259) */
 typedef struct smm_hip_precond smm_hip_precond; /* device-resident preconditioner */

@@ -11,6 +11,7 @@ from .host import (  # noqa: F401
     OP_ASSIGN,
     OP_SUB,
     SPMV_AUTO,
+    SPMV_PATTERN,
     SPMV_STREAM,
     SPMV_VECTOR,
     BiCGStab,

@@ -97,6 +97,15 @@ struct smm_hip_csr {
 	int stream_max_rows = 0;
 	int stream_chunk_tiles = 0;  // tiles dealt to an XCD group at a time (0: one contiguous eighth per group)
 	std::mutex tileMutex;  // the tile table is built lazily by the first SpMV; concurrent solves on one matrix are allowed
+	// PATTERN family (opt-in, smm_spmv_pattern.hip): shared column offsets + one 64-bit mask per row, its own tile table
+	int pat_state = 0;  // 0 not analysed, 1 usable, -1 the matrix has no such pattern
+	int pat_k = 0;
+	int* d_pat_off = nullptr;
+	unsigned long long* d_pat_masks = nullptr;
+	int* d_pat_rowblocks = nullptr;
+	int pat_n_rowblocks = 0;
+	int pat_nnz_cap = 0;
+	int pat_max_rows = 0;
 };
 
 struct smm_hip_precond {
@@ -131,6 +140,11 @@ int profBegin(hipStream_t s);
 void profEnd(int slot, hipStream_t s);
 
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows);
+// PATTERN family: analyse + verify the matrix (idempotent), and the launch behind launchSpmv
+int ensurePattern(smm_hip_csr* m);
+template <typename T>
+int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                      const int* doneFlag, hipStream_t s);
 void chooseSpmvConfig(smm_hip_csr* m);
 
 // partials[0..NPART) = per-block sums of a[i]*b[i]

@@ -489,6 +489,7 @@ static int streamCap(const smm_hip_csr* m, int lanes) {
 }
 
 static int lanesForAvg(double avg, int family) {
+	if (family == SMM_SPMV_PATTERN) return avg <= 24 ? 1 : avg <= 64 ? 2 : avg <= 128 ? 4 : 8;
 	if (family == SMM_SPMV_STREAM) {
 		// pieces of ~12-16 entries per lane; L == 1 keeps the reference's summation order bit for bit
 		// measured on MI355X (tools/spmv_sweep.py): ~25 entries per lane is the sweet spot
@@ -569,6 +570,12 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	if (m->rows == 0 && !dotMode) return SMM_HIP_OK;
 	int family = m->family;
 	const int L = m->lanes;
+	if (family == SMM_SPMV_PATTERN) {
+		const int profSlot = profBegin(s);
+		const int st = launchSpmvPattern<T>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s);
+		profEnd(profSlot, s);
+		return st;
+	}
 	if (family == SMM_SPMV_STREAM) {
 		const int capNnz = streamCap<T>(m, L) - 3;
 		const int maxRows = TPB / std::min(L, WAVE);
@@ -675,9 +682,18 @@ int smm_hip_csr_set_kernel(smm_hip_csr* m, int family, int lanes_per_row) {
 		setError("csr_set_kernel: null matrix");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if (family != SMM_SPMV_AUTO && family != SMM_SPMV_VECTOR && family != SMM_SPMV_STREAM) {
+	if (family != SMM_SPMV_AUTO && family != SMM_SPMV_VECTOR && family != SMM_SPMV_STREAM && family != SMM_SPMV_PATTERN) {
 		setError("csr_set_kernel: unknown family %d", family);
 		return SMM_HIP_ERR_INVALID;
+	}
+	if (family == SMM_SPMV_PATTERN) {
+		// opt-in: analyse + verify every entry now, so a matrix without a shared offset pattern is refused here and not mid-solve
+		SMM_TRY(ensureInit());
+		SMM_TRY(ensurePattern(m));
+		if (lanes_per_row > 8) {
+			setError("csr_set_kernel: the PATTERN family takes 1, 2, 4 or 8 lanes per row");
+			return SMM_HIP_ERR_INVALID;
+		}
 	}
 	if (lanes_per_row != 0 && (lanes_per_row < 1 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1)))) {
 		setError("csr_set_kernel: lanes_per_row must be 0 or a power of two in 1..64");

@@ -1,0 +1,461 @@
+// smm_spmv_pattern.hip -- SpMV for CSR matrices whose rows all draw their columns from ONE small set of offsets:
+//     positions[k] - row  in  { off[0] < off[1] < ... < off[K-1] },  K <= 64
+// i.e. every stencil / banded matrix (the Laplacians, convection-diffusion and banded-random matrices of BASELINE.json).
+//
+// For such a matrix positions[] is redundant: row i's columns are i + off[j] for the bits j set in a 64-bit row mask.  The
+// masks (8 bytes per ROW instead of 4 bytes per NONZERO) are built once and verified against every entry of positions[] on
+// the device; the kernel then streams only values[] -- for fp32 that halves the bytes of an SpMV.  The result is the same
+// number as the generic kernels bit for bit (same products, same left-to-right order with one lane per row).
+//
+// OPT-IN (smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, lanes)): the library's headline numbers and bench.py's roofline are
+// defined on the reference's layout (values + positions + start), so AUTO never selects this family.
+// smm_hip_csr_set_kernel fails with SMM_HIP_ERR_INVALID when the matrix has no such pattern.
+//
+// Kernel structure = spmvStreamKernel (smm_spmv.hip): persistent workgroups walk row tiles, values[] is fetched one tile
+// ahead with 16-byte non-temporal loads into registers, stored to LDS, and lane (row, piece) walks its piece of its row in
+// batches of 8 independent x[] gathers; the column of an entry comes from the next set bit of the row mask.
+#include <algorithm>
+
+#include "smm_device.h"
+#include "smm_internal.h"
+
+namespace smm {
+
+constexpr int TPB = 256;
+constexpr int MAXOFF = 64;
+
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef double pf64x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct PatCfg {
+	static constexpr int PIECE = 4 * TPB;                  // values staged per pass: one 16-byte load per lane (fp32)
+	static constexpr int NVMAX = sizeof(T) == 4 ? 8 : 4;   // passes held in registers one tile ahead (32 VGPRs)
+	static constexpr int PAD = 16;
+};
+
+template <typename T>
+__device__ __forceinline__ T patApplyOp(int op, const T* __restrict__ lhs, int row, T dot) {
+	if (op == SMM_OP_ASSIGN) return dot;
+	const T l = lhs[row];
+	return op == SMM_OP_ADD ? l + dot : l - dot;
+}
+
+template <typename T>
+__device__ __forceinline__ T patGather(const T* __restrict__ x, unsigned byteOffset) {
+	return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + byteOffset);
+}
+
+// index of the k-th (0-based) set bit of m; k < popcount(m)
+__device__ __forceinline__ int selectBit(unsigned long long m, int k) {
+	int pos = 0;
+	unsigned v = static_cast<unsigned>(m);
+	int c = __popc(v);
+	if (k >= c) {
+		k -= c;
+		pos = 32;
+		v = static_cast<unsigned>(m >> 32);
+	}
+	c = __popc(v & 0xFFFFu);
+	if (k >= c) { k -= c; pos += 16; v >>= 16; }
+	c = __popc(v & 0xFFu);
+	if (k >= c) { k -= c; pos += 8; v >>= 8; }
+	c = __popc(v & 0xFu);
+	if (k >= c) { k -= c; pos += 4; v >>= 4; }
+	c = __popc(v & 0x3u);
+	if (k >= c) { k -= c; pos += 2; v >>= 2; }
+	if (k >= static_cast<int>(v & 1u)) pos += 1;
+	return pos;
+}
+
+// ---- analysis: row masks + verification of every entry ----------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void patBuildMasks(int rows, int k, const int* __restrict__ offs, const int* __restrict__ start,
+                                                     const int* __restrict__ positions, unsigned long long* __restrict__ masks,
+                                                     int* __restrict__ mismatch) {
+	__shared__ int sOff[MAXOFF];
+	if (threadIdx.x < k) sOff[threadIdx.x] = offs[threadIdx.x];
+	__syncthreads();
+	for (long long row = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; row < rows; row += static_cast<long long>(gridDim.x) * TPB) {
+		unsigned long long m = 0ULL;
+		bool bad = false;
+		int prev = -1;
+		for (int e = start[row]; e < start[row + 1]; ++e) {
+			const int rel = positions[e] - static_cast<int>(row);
+			int lo = 0, hi = k;  // first index with sOff >= rel
+			while (lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if (sOff[mid] < rel) lo = mid + 1; else hi = mid;
+			}
+			// columns ascend inside a row (ref:1247-1249), so the offset indices must ascend strictly too
+			if (lo >= k || sOff[lo] != rel || lo <= prev) bad = true;
+			prev = lo;
+			if (lo < k) m |= 1ULL << lo;
+		}
+		masks[row] = m;
+		if (bad) atomicOr(mismatch, 1);
+	}
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smmPatLds[];
+
+template <typename T>
+struct PatStaged;
+template <>
+struct PatStaged<float> {
+	pf32x4 v[PatCfg<float>::NVMAX];
+};
+template <>
+struct PatStaged<double> {
+	pf64x2 v[2 * PatCfg<double>::NVMAX];
+};
+
+template <typename T>
+__device__ __forceinline__ void patStageLoad(PatStaged<T>& r, int t, int nv, int a0, int n1, const T* __restrict__ values) {
+#pragma unroll
+	for (int v = 0; v < PatCfg<T>::NVMAX; ++v) {
+		const int i = a0 + 4 * (t + v * TPB);
+		if (v < nv && i < n1) {
+			if constexpr (sizeof(T) == 4) {
+				r.v[v] = __builtin_nontemporal_load(reinterpret_cast<const pf32x4*>(values + i));
+			} else {
+				r.v[2 * v] = __builtin_nontemporal_load(reinterpret_cast<const pf64x2*>(values + i));
+				r.v[2 * v + 1] = __builtin_nontemporal_load(reinterpret_cast<const pf64x2*>(values + i + 2));
+			}
+		}
+	}
+}
+
+template <typename T>
+__device__ __forceinline__ void patStageStore(const PatStaged<T>& r, int t, int nv, int a0, int n1, T* sVal) {
+#pragma unroll
+	for (int v = 0; v < PatCfg<T>::NVMAX; ++v) {
+		const int li = 4 * (t + v * TPB);
+		if (v < nv && a0 + li < n1) {
+			if constexpr (sizeof(T) == 4) {
+				*reinterpret_cast<pf32x4*>(sVal + li) = r.v[v];
+			} else {
+				*reinterpret_cast<pf64x2*>(sVal + li) = r.v[2 * v];
+				*reinterpret_cast<pf64x2*>(sVal + li + 2) = r.v[2 * v + 1];
+			}
+		}
+	}
+}
+
+template <typename T, int L>
+__global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, int cols, int nOff, const int* __restrict__ offs,
+                                                         const int2* __restrict__ rowBlocks, const int* __restrict__ start,
+                                                         const unsigned long long* __restrict__ masks, const int* __restrict__ positions,
+                                                         const T* __restrict__ values, int op, const T* lhs, const T* __restrict__ x, T* out,
+                                                         int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
+                                                         const int* __restrict__ doneFlag) {
+	using Cfg = PatCfg<T>;
+	constexpr int GATHER = 8;
+	constexpr int LW = L > WAVE ? WAVE : L;
+	constexpr int RW = WAVE / LW;
+	constexpr int RT = RW * (TPB / WAVE);
+	// LDS: sVal[cap + PAD] | sMask[RT] (8-byte aligned) | sStart[RT + 1] | sOff[MAXOFF] | red[4]
+	T* sVal = reinterpret_cast<T*>(smmPatLds);
+	unsigned long long* sMask = reinterpret_cast<unsigned long long*>(sVal + cap + Cfg::PAD);
+	int* sStart = reinterpret_cast<int*>(sMask + RT);
+	int* sOff = sStart + RT + 4;
+	T* red = reinterpret_cast<T*>(sOff + MAXOFF);
+	if (doneFlag && *doneFlag) return;
+
+	const int t = threadIdx.x;
+	const int lane = t & (WAVE - 1);
+	const int rowInWave = lane % RW;
+	const int piece = lane / RW;
+	const int rl = (t >> 6) * RW + rowInWave;
+	const int nv = cap / Cfg::PIECE;
+	T acc0 = T(0), acc1 = T(0);
+	for (int i = t; i < cap + Cfg::PAD; i += TPB) sVal[i] = T(0);
+	if (t < MAXOFF) sOff[t] = t < nOff ? offs[t] : 0;
+
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int xcdGroup = blockIdx.x % nGroups;
+	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;
+	const int perGroup = (nTiles + nGroups - 1) / nGroups;
+	const int tileEnd = min(nTiles, (xcdGroup + 1) * perGroup);
+	const int stageLimit = (rowBlocks[nTiles].y & ~3) - cap;
+	int tile = xcdGroup * perGroup + blockIdx.x / nGroups;
+
+	PatStaged<T> regs;
+	int ps = 0;
+	unsigned long long pm = 0ULL;
+	int2 m0 = make_int2(0, 0), m1 = make_int2(0, 0), nm0 = make_int2(0, 0), nm1 = make_int2(0, 0);
+	if (tile < tileEnd) {
+		m0 = rowBlocks[tile];
+		m1 = rowBlocks[tile + 1];
+		if (tile + groupSlots < tileEnd) {
+			nm0 = rowBlocks[tile + groupSlots];
+			nm1 = rowBlocks[tile + groupSlots + 1];
+		}
+		if (m1.y - m0.y <= cap - 3 && (m0.y & ~3) <= stageLimit) {
+			patStageLoad<T>(regs, t, nv, m0.y & ~3, m1.y, values);
+			if (t < m1.x - m0.x) {
+				ps = start[m0.x + t];
+				pm = masks[m0.x + t];
+			}
+		}
+	}
+	__syncthreads();
+	while (tile < tileEnd) {
+		const int r0 = m0.x, n0 = m0.y, r1 = m1.x, n1 = m1.y;
+		const int nrows = r1 - r0;
+		const int a0 = n0 & ~3;
+		const bool direct = n1 - n0 > cap - 3 || a0 > stageLimit;
+		if (!direct) {
+			patStageStore<T>(regs, t, nv, a0, n1, sVal);
+			if (t < nrows) {
+				sStart[t] = ps - a0;
+				sMask[t] = pm;
+			}
+			if (t == 0) sStart[nrows] = n1 - a0;
+		}
+		__syncthreads();
+		const int ntile = tile + groupSlots;
+		const int2 m0n = nm0, m1n = nm1;
+		if (ntile < tileEnd) {
+			if (m1n.y - m0n.y <= cap - 3 && (m0n.y & ~3) <= stageLimit) {
+				patStageLoad<T>(regs, t, nv, m0n.y & ~3, m1n.y, values);
+				if (t < m1n.x - m0n.x) {
+					ps = start[m0n.x + t];
+					pm = masks[m0n.x + t];
+				}
+			}
+			if (ntile + groupSlots < tileEnd) {
+				nm0 = rowBlocks[ntile + groupSlots];
+				nm1 = rowBlocks[ntile + groupSlots + 1];
+			}
+		}
+		if (direct) {
+			// over-long rows and the last tiles of the matrix: one lane per row, left to right, straight from HBM (with positions[])
+			for (int rr = t; rr < nrows; rr += TPB) {
+				const int row = r0 + rr;
+				const int e = start[row + 1];
+				T dot = T(0);
+				for (int k = start[row]; k < e; ++k) {
+					dot = smmFma(values[k], x[positions[k]], dot);
+				}
+				const T o = patApplyOp(op, lhs, row, dot);
+				out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		} else {
+			T dot = T(0);
+			const int row = r0 + rl;
+			if (rl < nrows) {
+				const int b = sStart[rl];
+				const int e = sStart[rl + 1];
+				unsigned long long mm = sMask[rl];
+				int kb = b, ke = e;
+				if (LW > 1) {
+					const int piecelen = (e - b + LW - 1) / LW;
+					kb = b + piece * piecelen;
+					ke = min(e, kb + piecelen);
+					// this piece starts at the (kb - b)-th entry of the row = the (kb - b)-th set bit of the mask
+					if (piece > 0 && kb < ke) mm &= ~0ULL << selectBit(mm, kb - b);
+				}
+				for (int k = kb; k < ke; k += GATHER) {
+					const int nvalid = ke - k;
+					unsigned off[GATHER];
+					T xv[GATHER], vv[GATHER];
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						const int j = mm ? __builtin_ctzll(mm) : 0;
+						mm &= mm - 1;
+						// entries past the end of the piece get a clamped, valid column; their products are discarded
+						const int col = min(max(row + sOff[j], 0), cols - 1);
+						off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
+						vv[u] = sVal[k + u];
+					}
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						xv[u] = patGather<T>(x, off[u]);
+					}
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						const T next = smmFma(vv[u], xv[u], dot);
+						dot = u < nvalid ? next : dot;
+					}
+				}
+			}
+			if (LW > 1) {
+				T total = dot;
+#pragma unroll
+				for (int q = 1; q < LW; ++q) {
+					total += __shfl(dot, rowInWave + q * RW, WAVE);
+				}
+				dot = total;
+			}
+			if (piece == 0 && rl < nrows) {
+				const T o = patApplyOp(op, lhs, row, dot);
+				out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		}
+		__syncthreads();
+		tile = ntile;
+		m0 = m0n;
+		m1 = m1n;
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+	}
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+// Find the offset set from a sample of rows, then let the device build the row masks and verify EVERY entry against it.
+int ensurePattern(smm_hip_csr* m) {
+	std::lock_guard<std::mutex> lock(m->tileMutex);
+	if (m->pat_state != 0) return m->pat_state > 0 ? SMM_HIP_OK : SMM_HIP_ERR_INVALID;
+	m->pat_state = -1;
+	if (m->rows == 0 || m->nnz == 0) {
+		setError("pattern SpMV: empty matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipDeviceSynchronize());
+	std::vector<int> hs(static_cast<size_t>(m->rows) + 1);
+	SMM_HIP_TRY(hipMemcpyAsync(hs.data(), m->d_start, hs.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	std::vector<int> offs;
+	const int samples = std::min(m->rows, 512);
+	std::vector<int> cols;
+	for (int i = 0; i < samples; ++i) {
+		const int row = static_cast<int>(static_cast<long long>(i) * (m->rows - 1) / std::max(1, samples - 1));
+		const int len = hs[row + 1] - hs[row];
+		if (len <= 0) continue;
+		if (len > MAXOFF) {
+			setError("pattern SpMV: a row holds more than %d entries", MAXOFF);
+			return SMM_HIP_ERR_INVALID;
+		}
+		cols.resize(static_cast<size_t>(len));
+		SMM_HIP_TRY(hipMemcpyAsync(cols.data(), m->d_positions + hs[row], cols.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		for (int c : cols) offs.push_back(c - row);
+		std::sort(offs.begin(), offs.end());
+		offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+		if (offs.size() > MAXOFF) {
+			setError("pattern SpMV: rows do not share a set of <= %d column offsets", MAXOFF);
+			return SMM_HIP_ERR_INVALID;
+		}
+	}
+	if (offs.empty()) {
+		setError("pattern SpMV: no entries in the sampled rows");
+		return SMM_HIP_ERR_INVALID;
+	}
+	int* d_off = nullptr;
+	unsigned long long* d_masks = nullptr;
+	int* d_flag = nullptr;
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_off), MAXOFF * sizeof(int)));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_masks), static_cast<size_t>(m->rows) * sizeof(unsigned long long)));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_flag), sizeof(int)));
+	std::vector<int> padded(MAXOFF, 0);
+	std::copy(offs.begin(), offs.end(), padded.begin());
+	SMM_HIP_TRY(hipMemcpyAsync(d_off, padded.data(), MAXOFF * sizeof(int), hipMemcpyHostToDevice, s));
+	SMM_HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+	const int grid = static_cast<int>(std::min<long long>((m->rows + TPB - 1LL) / TPB, numCUs() * 16LL));
+	patBuildMasks<<<grid, TPB, 0, s>>>(m->rows, static_cast<int>(offs.size()), d_off, m->d_start, m->d_positions, d_masks, d_flag);
+	int mismatch = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&mismatch, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	devFree(d_flag);
+	if (mismatch) {
+		devFree(d_off);
+		devFree(d_masks);
+		setError("pattern SpMV: some entry's column offset is outside the shared offset set");
+		return SMM_HIP_ERR_INVALID;
+	}
+	m->pat_k = static_cast<int>(offs.size());
+	m->d_pat_off = d_off;
+	m->d_pat_masks = d_masks;
+	m->pat_state = 1;
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int patCap(const smm_hip_csr* m, int lanes) {
+	const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0;
+	const int rowsPerTile = TPB / std::min(lanes, WAVE);
+	const double want = avg * rowsPerTile * 1.04 + 3;
+	int nv = static_cast<int>((want + PatCfg<T>::PIECE - 1) / PatCfg<T>::PIECE);
+	nv = std::max(1, std::min(nv, PatCfg<T>::NVMAX));
+	return nv * PatCfg<T>::PIECE;
+}
+
+template <typename T, int L>
+static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+                      hipStream_t s) {
+	constexpr int LW = L > WAVE ? WAVE : L;
+	constexpr int RT = (WAVE / LW) * (TPB / WAVE);
+	const int cap = m->pat_nnz_cap + 3;
+	const size_t lds = static_cast<size_t>(cap + PatCfg<T>::PAD) * sizeof(T) + RT * 8 + (RT + 4) * 4 + MAXOFF * 4 + 4 * sizeof(T) + 32;
+	int perCU = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
+	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, numCUs() * perCU), NPART));
+	spmvPatternKernel<T, L><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, m->cols, m->pat_k, m->d_pat_off, reinterpret_cast<const int2*>(m->d_pat_rowblocks),
+	                                             m->d_start, m->d_pat_masks, m->d_positions, static_cast<const T*>(m->d_values), op, lhs, x, out, dotMode,
+	                                             w1, partials, doneFlag);
+}
+
+// tiles for this family are cut for its own LDS capacity (values only): kept beside the STREAM family's table
+static int buildPatternTiles(smm_hip_csr* m, int capNnz, int maxRows) {
+	int* keepBlocks = m->d_rowblocks;
+	const int keepN = m->n_rowblocks, keepCap = m->stream_nnz_cap, keepRows = m->stream_max_rows, keepChunk = m->stream_chunk_tiles;
+	m->d_rowblocks = nullptr;
+	const int st = buildRowBlocks(m, capNnz, maxRows);
+	if (st == SMM_HIP_OK) {
+		devFree(m->d_pat_rowblocks);
+		m->d_pat_rowblocks = m->d_rowblocks;
+		m->pat_n_rowblocks = m->n_rowblocks;
+		m->pat_nnz_cap = capNnz;
+		m->pat_max_rows = maxRows;
+	}
+	m->d_rowblocks = keepBlocks;
+	m->n_rowblocks = keepN;
+	m->stream_nnz_cap = keepCap;
+	m->stream_max_rows = keepRows;
+	m->stream_chunk_tiles = keepChunk;
+	return st;
+}
+
+template <typename T>
+int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+                      hipStream_t s) {
+	auto* mm = const_cast<smm_hip_csr*>(m);
+	SMM_TRY(ensurePattern(mm));
+	const int L = std::min(m->lanes, WAVE);
+	const int capNnz = patCap<T>(m, L) - 3;
+	const int maxRows = TPB / L;
+	{
+		std::lock_guard<std::mutex> lock(mm->tileMutex);
+		if (!m->d_pat_rowblocks || m->pat_nnz_cap != capNnz || m->pat_max_rows != maxRows) {
+			SMM_TRY(buildPatternTiles(mm, capNnz, maxRows));
+		}
+	}
+	switch (L) {
+	case 1: launchPat<T, 1>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	case 2: launchPat<T, 2>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	case 4: launchPat<T, 4>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	default: launchPat<T, 8>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template int launchSpmvPattern<float>(const smm_hip_csr*, int, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
+template int launchSpmvPattern<double>(const smm_hip_csr*, int, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
+
+}  // namespace smm

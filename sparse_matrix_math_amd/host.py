@@ -35,7 +35,7 @@ class SolverPreconditioner(enum.IntEnum):
 
 
 OP_ASSIGN, OP_ADD, OP_SUB = 0, 1, 2
-SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM = 0, 1, 2
+SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_PATTERN = 0, 1, 2, 3
 
 _SUFFIX = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 _CT = {"f32": ctypes.c_float, "f64": ctypes.c_double}

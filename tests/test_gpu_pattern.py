@@ -1,0 +1,141 @@
+"""The opt-in PATTERN SpMV family (SMM_SPMV_PATTERN, smm_spmv_pattern.hip): positions[] replaced by a shared offset list
+and one mask per row.  It must give the reference's numbers bit for bit (one lane per row = the reference's order,
+ref:1484-1499), agree bit for bit with the STREAM family at equal lanes per row, and refuse matrices without a pattern."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OP_ADD, OP_ASSIGN, OP_SUB
+from sparse_matrix_math_amd import generators as gen
+
+pytestmark = pytest.mark.gpu
+PATTERN, STREAM = 3, 2
+
+
+def matrices(dtype):
+    return {
+        "poisson2d_37x23": gen.poisson2d(37, 23, dtype=dtype),
+        "poisson2d_200": gen.poisson2d(200, dtype=dtype),
+        "convdiff3d_17": gen.convdiff3d(17, dtype=dtype),
+        "stencil3d_40x9x21": gen.stencil3d(40, 9, 21, dtype=dtype),
+        "banded_20k_k25": gen.banded_random_spd(20_000, 25, 0x5EED, 4096, dtype=dtype),
+        "banded_3k_k5": gen.banded_random_spd(3000, 5, 7, 100, dtype=dtype),
+        "tiny": gen.poisson2d(2, dtype=dtype),
+    }
+
+
+def run(A, op, lhs, x, rows, dtype):
+    out = np.zeros(rows, dtype=dtype)
+    {OP_ASSIGN: lambda: A.rMult(x, out), OP_ADD: lambda: A.rMultAdd(lhs, x, out), OP_SUB: lambda: A.rMultSub(lhs, x, out)}[op]()
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pattern_matches_oracle_and_stream(smm, oracle, dtype):
+    rng = np.random.default_rng(3)
+    for name, csr in matrices(dtype).items():
+        rows = len(csr[0]) - 1
+        A = smm.CSRMatrix(rows, rows, *csr)
+        x = rng.uniform(-1, 1, rows).astype(dtype)
+        lhs = rng.uniform(-1, 1, rows).astype(dtype)
+        for op in (OP_ASSIGN, OP_ADD, OP_SUB):
+            ref = oracle.spmv(csr, op, lhs, x)
+            for lanes in (1, 2, 4, 8):
+                A.set_kernel(STREAM, lanes)
+                want = run(A, op, lhs, x, rows, dtype)
+                A.set_kernel(PATTERN, lanes)
+                assert A.get_kernel() == (PATTERN, lanes)
+                got = run(A, op, lhs, x, rows, dtype)
+                # rows inside the last LDS-capacity's worth of nonzeros are summed by one lane each whatever `lanes` is (the
+                # "direct" tail path); the two families have different capacities, so only the rows before both tails must agree
+                # bit for bit when lanes > 1 -- the tail rows agree within the re-ordering bound
+                body = csr[0][1:] <= csr[0][-1] - 8200 if lanes > 1 else np.ones(rows, dtype=bool)
+                np.testing.assert_array_equal(got[body], want[body], err_msg=f"{name} op {op} lanes {lanes}")
+                mag = np.zeros(rows)
+                np.add.at(mag, np.repeat(np.arange(rows), np.diff(csr[0])), np.abs(csr[2].astype(np.float64) * x[csr[1]]))
+                assert np.all(np.abs(got.astype(np.float64) - want) <= 64 * np.finfo(dtype).eps * (mag + np.abs(lhs))), (name, op, lanes)
+                if lanes == 1:
+                    np.testing.assert_array_equal(got, ref, err_msg=f"{name} op {op}")
+
+
+def test_pattern_solver(smm, oracle):
+    """whole BiCGStab / CG solves through the PATTERN kernel, fused dot epilogues included.  The SpMV results are the STREAM
+    family's bit for bit, but the fused dot products are summed per workgroup and the two families deal rows to workgroups
+    differently, so the solves agree to rounding, not bitwise: same status, same iteration count, same solution to 1e-5"""
+    csr = gen.banded_random_spd(30_000, 25, 0x5EED, 8192, dtype=np.float32)
+    n = len(csr[0]) - 1
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, n).astype(np.float32)
+    res = {}
+    for family in (STREAM, PATTERN):
+        A = smm.CSRMatrix(n, n, *csr)
+        A.set_kernel(family, 1)
+        x = np.zeros(n, dtype=np.float32)
+        info = {}
+        st = smm.BiCGStab(A, b, x, 40, 1e-6, info=info)
+        x2 = np.zeros(n, dtype=np.float32)
+        info2 = {}
+        st2 = smm.ConjugateGradient(A, b, np.zeros(n, dtype=np.float32), x2, 60, 1e-6, info=info2)
+        res[family] = (int(st), info.get("iterations"), x, int(st2), info2.get("iterations"), x2)
+        # and it IS a solution: ||b - A x|| / ||b|| from the oracle's SpMV
+        r = oracle.spmv(csr, OP_SUB, b, x)
+        assert np.linalg.norm(r) <= 2e-5 * np.linalg.norm(b), family
+    assert res[STREAM][0] == res[PATTERN][0] == 0 and res[STREAM][1] == res[PATTERN][1]
+    np.testing.assert_allclose(res[STREAM][2], res[PATTERN][2], rtol=0, atol=1e-5)
+    assert res[STREAM][3] == res[PATTERN][3] == 0 and abs(res[STREAM][4] - res[PATTERN][4]) <= 1
+    np.testing.assert_allclose(res[STREAM][5], res[PATTERN][5], rtol=0, atol=1e-5)
+
+
+def test_pattern_refuses_matrices_without_one(smm):
+    # random columns: far more than 64 distinct offsets
+    csr = gen.random_rows(500, 500, 1, 9, seed=4)
+    A = smm.CSRMatrix(500, 500, *csr)
+    before = A.get_kernel()
+    with pytest.raises(smm.SmmHipError):
+        A.set_kernel(PATTERN, 0)
+    assert A.get_kernel() == before
+    # a stencil with ONE entry moved off the pattern in a row the sampling does not look at: the full verification finds it
+    start, pos, val = gen.poisson2d(300)
+    pos = pos.copy()
+    row = 44_444
+    e = start[row]  # first entry of the row (column row - 300): move it one to the left, still ascending
+    assert pos[e] == row - 300
+    pos[e] -= 1
+    B = smm.CSRMatrix(90_000, 90_000, start, pos, val)
+    with pytest.raises(smm.SmmHipError):
+        B.set_kernel(PATTERN, 1)
+    # rows longer than 64 entries
+    dense = gen.random_rows(100, 4000, 80, 90, seed=2)
+    C = smm.CSRMatrix(100, 4000, *dense)
+    with pytest.raises(smm.SmmHipError):
+        C.set_kernel(PATTERN, 1)
+    # empty matrix
+    E = smm.CSRMatrix(5, 5, np.zeros(6, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
+    with pytest.raises(smm.SmmHipError):
+        E.set_kernel(PATTERN, 1)
+
+
+def test_pattern_rectangular_and_empty_rows(smm, oracle):
+    """offsets relative to the row also describe a rectangular band; empty rows have an empty mask"""
+    rows, cols = 5000, 5600
+    rng = np.random.default_rng(9)
+    offs = np.array([0, 3, 17, 250, 599])
+    keep = rng.random((rows, len(offs))) < 0.7
+    keep[::97] = False  # empty rows
+    start = np.zeros(rows + 1, dtype=np.int32)
+    np.cumsum(keep.sum(axis=1), out=start[1:])
+    r, j = np.nonzero(keep)
+    pos = (r + offs[j]).astype(np.int32)
+    val = rng.uniform(-1, 1, len(pos))
+    csr = (start, pos, val)
+    A = smm.CSRMatrix(rows, cols, *csr)
+    x = rng.uniform(-1, 1, cols)
+    lhs = rng.uniform(-1, 1, rows)
+    ref = oracle.spmv(csr, OP_SUB, lhs, x)
+    for lanes in (1, 2):
+        A.set_kernel(PATTERN, lanes)
+        out = np.zeros(rows)
+        A.rMultSub(lhs, x, out)
+        if lanes == 1:
+            np.testing.assert_array_equal(out, ref)
+        else:
+            np.testing.assert_allclose(out, ref, rtol=0, atol=1e-14)
