@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--spmv-family", type=int, default=0)
     ap.add_argument("--spmv-lanes", type=int, default=0)
     ap.add_argument("--autotune", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) PATTERN-family measurement")
     ap.add_argument("--dist", action="store_true", help="take the row-partitioned multi-GPU code path even with one rank")
     return ap.parse_args()
 
@@ -210,12 +211,37 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(args),
-                "kernel": "spmvStreamKernel" if family == 2 else "spmvVectorKernel",
+                "kernel": {2: "spmvStreamKernel", 3: "spmvPatternKernel"}.get(family, "spmvVectorKernel"),
                 "algorithmic_bytes_per_launch": b_spmv,
                 "avg_launch_ms": spmv_avg_s * 1e3,
                 "launches": spmv_launches,
             },
         }
+        if not args.no_extras:
+            # NOT the headline: the same K iterations through the opt-in PATTERN SpMV family (positions[] replaced by a verified
+            # per-row offset mask; include/smm_hip.h SMM_SPMV_PATTERN).  It moves fewer bytes than the CSR layout section 8(d)
+            # prices, so it is reported beside the roofline object, never in it.
+            try:
+                A.set_kernel(3, 0)
+                run(min(args.warmup, args.iters_per_solve))
+                host.profile_enable(True)
+                host.profile_read(reset=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                p_iters, _ = run(args.steps)
+                torch.cuda.synchronize()
+                p_elapsed = time.perf_counter() - t0
+                p_ms, p_launches = host.profile_read(reset=True)
+                host.profile_enable(False)
+                p_bytes = nnz * s_bytes + n * 8 + (n + 1) * 4 + 2 * n * s_bytes
+                result["extras"] = {"pattern_family": {
+                    "value": p_iters / p_elapsed, "unit": "iterations/s", "ms_per_step": p_elapsed / p_iters * 1e3,
+                    "spmv_avg_launch_ms": p_ms / max(p_launches, 1), "lanes_per_row": A.get_kernel()[1],
+                    "bytes_per_launch": p_bytes, "gbps": p_bytes / (p_ms * 1e-3 / max(p_launches, 1)) / 1e9,
+                    "max_rel_err_vs_x_true": float(((x - x_true).abs() / x_true).max())}}
+            except smm.SmmHipError as e:
+                result["extras"] = {"pattern_family": {"skipped": str(e)}}
+            A.set_kernel(family, lanes)
         if args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, np_dtype, d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy(),
                                                   b.cpu().numpy(), args.cpu_seconds)

@@ -181,6 +181,14 @@ int smm_hip_bicgsymmetric_f64(const smm_hip_csr* a, double* b, double* x, int ma
 int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out);
 int smm_hip_precond_destroy(smm_hip_precond* M);
 int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower, int* levels_upper);
+/* How the two triangular sweeps of SGS / ILU0 / IC0 run (same numbers bit for bit either way):
+ * LEVELS: one launch per dependency level (runs of small levels share a launch); SYNCFREE: one launch per sweep, rows wait on
+ * per-entry ready values.  AUTO = SYNCFREE.  A sweep that fails to finish (cannot happen; bounded for safety) makes the solve
+ * or apply that used it return SMM_HIP_ERR_HIP. */
+#define SMM_SWEEP_AUTO 0
+#define SMM_SWEEP_LEVELS 1
+#define SMM_SWEEP_SYNCFREE 2
+int smm_hip_precond_set_sweep(smm_hip_precond* M, int mode);
 /* x = M^-1 rhs; rhs must not alias x (ref:1667) */
 int smm_hip_precond_apply_f32(const smm_hip_precond* M, const float* rhs, float* x);
 int smm_hip_precond_apply_f64(const smm_hip_precond* M, const double* rhs, double* x);

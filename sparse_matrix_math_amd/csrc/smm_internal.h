@@ -171,5 +171,7 @@ int bicgsymmetricDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, 
 // preconditioner apply (smm_precond.hip); doneFlag may be null
 template <typename T>
 int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* doneFlag, hipStream_t s);
+// sticky error of the synchronisation-free sweeps applied on `s`; synchronises `s`.  M may be null.
+int precondTakeError(const smm_hip_precond* M, hipStream_t s);
 
 }  // namespace smm

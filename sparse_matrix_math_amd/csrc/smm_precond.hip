@@ -13,6 +13,7 @@
 // live on the device.
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <memory>
 
 #include "smm_device.h"
@@ -120,6 +121,180 @@ __global__ __launch_bounds__(SMALL_LEVEL) void sweepChainKernel(const int* __res
 		// rows of the next level read x[] written above by other wavefronts of this workgroup
 		__threadfence_block();
 		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Synchronisation-free sweeps: ONE launch per sweep instead of one per level.
+//
+// The output vector is pre-filled with a sentinel bit pattern (a NaN no arithmetic produces).  A wavefront draws the next
+// 64 rows of the level-sorted order from a ticket counter; each lane walks its row's entries in the reference's order and,
+// for an entry whose x[col] still holds the sentinel, stops and polls again on the next pass of the wave-wide loop; when its
+// row is finished it publishes x[row] with ONE store that is value and ready flag at once.  Polls and publishes are relaxed
+// agent-scope atomics (global_load / global_store with sc1): coherent across the 8 XCDs' L2s without any cache writeback or
+// invalidate, the pattern of a decoupled look-back scan.  Every row reads only rows that come earlier in the sorted order,
+// and tickets are handed out in that order to wavefronts that are running, so the wavefront holding the earliest unfinished
+// rows can always finish them: no deadlock whatever the residency.  Lanes of one wavefront that depend on each other resolve
+// over successive passes of the loop (nobody waits inside a pass).  A pass counter bounds the loop regardless: on overrun the
+// row publishes NaN and raises the error word the host checks at the end of the solve.
+// Arithmetic per row is exactly solveRow's, so results are bit-identical to the level-scheduled and the sequential sweeps.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct SweepBits;
+template <>
+struct SweepBits<float> {
+	using U = unsigned int;
+	static constexpr U SENT = 0x7FD5EAD5u;
+	static constexpr U QNAN = 0x7FC00000u;
+};
+template <>
+struct SweepBits<double> {
+	using U = unsigned long long;
+	static constexpr U SENT = 0x7FFD5EAD5EAD5EADull;
+	static constexpr U QNAN = 0x7FF8000000000000ull;
+};
+
+template <typename T>
+__device__ __forceinline__ bool pollX(const T* x, int col, T& v) {
+	using U = typename SweepBits<T>::U;
+	const U b = __hip_atomic_load(reinterpret_cast<const U*>(x) + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__builtin_memcpy(&v, &b, sizeof(T));
+	return b != SweepBits<T>::SENT;
+}
+
+template <typename T>
+__device__ __forceinline__ void publishX(T* x, int row, T v) {
+	using U = typename SweepBits<T>::U;
+	U b;
+	__builtin_memcpy(&b, &v, sizeof(T));
+	if (b == SweepBits<T>::SENT) b = SweepBits<T>::QNAN;  // a NaN either way; never leave a finished row looking unfinished
+	__hip_atomic_store(reinterpret_cast<U*>(x) + row, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned SWEEP_PASS_LIMIT = 1u << 22;
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void sweepPrefillKernel(int n, T* __restrict__ y, T* __restrict__ x, int* __restrict__ words,
+                                                          const int* __restrict__ doneFlag) {
+	if (doneFlag && *doneFlag) return;
+	using U = typename SweepBits<T>::U;
+	if (blockIdx.x == 0 && threadIdx.x < 2) words[threadIdx.x] = 0;  // the two ticket counters; words[2] (error) is sticky
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		reinterpret_cast<U*>(y)[i] = SweepBits<T>::SENT;
+		reinterpret_cast<U*>(x)[i] = SweepBits<T>::SENT;
+	}
+}
+
+// lower sweeps: in = rhs, out = y.  upper sweeps: in = y (the lower sweep's result), out = x.
+//
+// What is on the critical path of a sweep is the time from "the last row I read has been published" to "my row is
+// published"; every dependent memory round trip in between (~1 us each) is paid once per LEVEL.  So a lane keeps a window of
+// the next SWEEP_WINDOW entries of its row (column and value) in registers, polls ALL entries of the window that are still
+// missing with independent loads in one go, and then consumes them strictly in the row's order as far as they are final:
+// one round trip (the poll) + arithmetic + the publishing store per level.
+constexpr int SWEEP_WINDOW = 8;
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restrict__ order, const int* __restrict__ start,
+                                                       const int* __restrict__ positions, const T* __restrict__ vals, const T* __restrict__ in,
+                                                       T* out, int* ticket, int* err, const int* __restrict__ doneFlag) {
+	if (doneFlag && *doneFlag) return;
+	constexpr bool LOWER = MODE == SGS_LO || MODE == ILU_LO || MODE == IC_LO;
+	constexpr int W = SWEEP_WINDOW;
+	constexpr int DIR = LOWER ? 1 : -1;
+	using U = typename SweepBits<T>::U;
+	const int lane = threadIdx.x & (WAVE - 1);
+	for (;;) {
+		int chunk = 0;
+		if (lane == 0) chunk = atomicAdd(ticket, 1);
+		chunk = __builtin_amdgcn_readfirstlane(chunk);
+		const long long base = static_cast<long long>(chunk) * WAVE;
+		if (base >= n) return;
+		bool pending = base + lane < n;
+		int row = 0, k = 0, stop = 0;
+		T acc = T(0), own = T(0);
+		if (pending) {
+			row = order[base + lane];
+			const int b = start[row];
+			const int e = start[row + 1];
+			own = in[row];
+			if (LOWER) {
+				k = b;
+				stop = e;
+				acc = own;
+			} else {
+				k = e - 1;
+				stop = b - 1;
+				acc = MODE == SGS_UP ? T(0) : own;
+			}
+		}
+		int wc[W];     // columns of the window; `row` marks the end of the row's triangular part
+		T wv[W];       // values of the window
+		int used = W;  // entries of the window already consumed (W: load the next window)
+		unsigned passes = 0;
+		while (__ballot(pending) != 0ull) {
+			if (pending) {
+				if (used == W) {
+#pragma unroll
+					for (int u = 0; u < W; ++u) {
+						const int idx = k + DIR * u;
+						const bool inside = LOWER ? idx < stop : idx > stop;
+						wc[u] = inside ? positions[idx] : row;
+						wv[u] = inside ? vals[idx] : T(1);
+					}
+					used = 0;
+				}
+				// poll every entry of the window that is still needed: independent loads, one round trip for all of them
+				U xb[W];
+				bool ended = false;
+#pragma unroll
+				for (int u = 0; u < W; ++u) {
+					ended = ended || (LOWER ? wc[u] >= row : wc[u] <= row);
+					xb[u] = SweepBits<T>::SENT;
+					if (u >= used && !ended) {
+						xb[u] = __hip_atomic_load(reinterpret_cast<const U*>(out) + wc[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+				// consume in the row's order as far as the values are final
+				bool stopped = false;
+#pragma unroll
+				for (int u = 0; u < W; ++u) {
+					if (u >= used && !stopped && pending) {
+						const int col = wc[u];
+						const T value = wv[u];
+						if (LOWER ? col >= row : col <= row) {
+							// the diagonal (or, for ILU's unit-lower part only, the end of the row)
+							T result;
+							if (MODE == SGS_LO) result = acc / value;             // ref:1695
+							else if (MODE == SGS_UP) result = own - acc / value;  // ref:1710
+							else if (MODE == ILU_LO) result = acc;
+							else result = acc / value;                            // ILU_UP, IC_LO (ref:1818), IC_UP (ref:1834)
+							publishX<T>(out, row, result);
+							pending = false;
+						} else if (xb[u] != SweepBits<T>::SENT) {
+							T xv;
+							__builtin_memcpy(&xv, &xb[u], sizeof(T));
+							if (MODE == SGS_LO) acc = smmFma(-value, xv, acc);
+							else if (MODE == SGS_UP) acc = smmFma(value, xv, acc);
+							else if (MODE == ILU_LO || MODE == ILU_UP) acc = smmFma(-value, xv, acc);
+							else {
+								const T prod = value * xv;  // ref:1812-1813, 1828-1829: multiply, then subtract
+								acc = acc - prod;
+							}
+							used = u + 1;
+						} else {
+							stopped = true;  // not final yet: poll again on the next pass
+						}
+					}
+				}
+				if (pending && used == W) k += DIR * W;
+			}
+			if (++passes > SWEEP_PASS_LIMIT && pending) {  // cannot happen; guarantees that the grid drains
+				atomicOr(err, 1);
+				publishX<T>(out, row, __builtin_nanf(""));
+				pending = false;
+			}
+		}
 	}
 }
 
@@ -314,6 +489,15 @@ static void planGroups(const std::vector<int>& lvlPtr, std::vector<SweepPlan::Gr
 // the level pointers and launch groups ride along behind the public handle
 struct smm_precond_plan {
 	smm::SweepPlan lo, up;
+	int sweep = SMM_SWEEP_AUTO;
+	// scratch of the synchronisation-free sweeps, one set per stream the preconditioner is applied on: y[n] (result of the
+	// lower sweep) and three words {ticket of the lower sweep, ticket of the upper sweep, sticky error}
+	struct Scratch {
+		void* y = nullptr;
+		int* words = nullptr;
+	};
+	std::mutex scratchMutex;
+	std::map<hipStream_t, Scratch> scratch;
 };
 
 namespace smm {
@@ -335,6 +519,83 @@ static int runSweep(const smm_hip_precond* M, const SweepPlan& plan, const int* 
 	}
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
+}
+
+static int scratchFor(const smm_hip_precond* M, size_t elemBytes, hipStream_t s, smm_precond_plan::Scratch* out) {
+	smm_precond_plan* plan = M->plan;
+	std::lock_guard<std::mutex> lock(plan->scratchMutex);
+	auto it = plan->scratch.find(s);
+	if (it == plan->scratch.end()) {
+		smm_precond_plan::Scratch sc;
+		SMM_TRY(devAlloc(&sc.y, static_cast<size_t>(std::max(1, M->a->rows)) * elemBytes));
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&sc.words), 4 * sizeof(int)));
+		SMM_HIP_TRY(hipMemsetAsync(sc.words, 0, 4 * sizeof(int), s));
+		it = plan->scratch.emplace(s, sc).first;
+	}
+	*out = it->second;
+	return SMM_HIP_OK;
+}
+
+// Wavefronts of a sweep launch.  Only the wavefronts holding rows of the level that is currently being finished (and the next
+// one or two) can make progress; every further wavefront only polls, and polling traffic slows the ones on the critical path
+// (measured: 108^3 stencil 1.8 / 2.7 / 4.7 ms per apply with 1024 / 2048 / 4096 wavefronts).  So the launch is sized to a few
+// levels' worth of rows, in one-wavefront workgroups so that they spread over the CUs.
+static int sweepWaves(int n, size_t levels) {
+	double perLevel = 4.0;
+	if (const char* env = getenv("SMM_HIP_SWEEP_WAVES_PER_LEVEL")) perLevel = std::max(0.25, atof(env));
+	const double rowsPerLevel = static_cast<double>(n) / static_cast<double>(std::max<size_t>(1, levels));
+	long long waves = static_cast<long long>(perLevel * rowsPerLevel / WAVE) + 1;
+	if (const char* env = getenv("SMM_HIP_SWEEP_WAVES")) waves = std::max(1, atoi(env));
+	const long long all = (static_cast<long long>(n) + WAVE - 1) / WAVE;
+	return static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(waves, all), static_cast<long long>(numCUs()) * 8)));
+}
+
+template <typename T, int LO, int UP>
+static int runSweepsFree(const smm_hip_precond* M, const T* vals, const T* rhs, T* x, const int* doneFlag, hipStream_t s) {
+	const smm_hip_csr* a = M->a;
+	const int n = a->rows;
+	smm_precond_plan::Scratch sc;
+	SMM_TRY(scratchFor(M, sizeof(T), s, &sc));
+	T* y = static_cast<T*>(sc.y);
+	const int fill = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
+	sweepPrefillKernel<T><<<fill, TPB, 0, s>>>(n, y, x, sc.words, doneFlag);
+	const int wLo = sweepWaves(n, M->lvl_ptr_lo.size() - 1);
+	const int wUp = sweepWaves(n, M->lvl_ptr_up.size() - 1);
+	sweepFreeKernel<T, LO><<<wLo, WAVE, 0, s>>>(n, M->d_order_lo, a->d_start, a->d_positions, vals, rhs, y, sc.words, sc.words + 2, doneFlag);
+	sweepFreeKernel<T, UP><<<wUp, WAVE, 0, s>>>(n, M->d_order_up, a->d_start, a->d_positions, vals, y, x, sc.words + 1, sc.words + 2, doneFlag);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+// the sticky error word of the synchronisation-free sweeps run on `s` (call after the stream has been synchronised)
+int precondTakeError(const smm_hip_precond* M, hipStream_t s) {
+	if (!M || !M->plan) return SMM_HIP_OK;
+	smm_precond_plan* plan = M->plan;
+	int* words = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(plan->scratchMutex);
+		auto it = plan->scratch.find(s);
+		if (it == plan->scratch.end()) return SMM_HIP_OK;
+		words = it->second.words;
+	}
+	int err = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&err, words + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (err) {
+		SMM_HIP_TRY(hipMemsetAsync(words + 2, 0, sizeof(int), s));
+		setError("preconditioner: a synchronisation-free triangular sweep ran into its pass limit");
+		return SMM_HIP_ERR_HIP;
+	}
+	return SMM_HIP_OK;
+}
+
+static bool useFreeSweeps(const smm_precond_plan* plan) {
+	int mode = plan->sweep;
+	if (mode == SMM_SWEEP_AUTO) {
+		mode = SMM_SWEEP_SYNCFREE;
+		if (const char* env = getenv("SMM_HIP_SWEEP")) mode = atoi(env);
+	}
+	return mode != SMM_SWEEP_LEVELS;
 }
 
 template <typename T>
@@ -362,6 +623,14 @@ int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* don
 	}
 	const T* aVals = static_cast<const T*>(M->a->d_values);
 	const T* fVals = static_cast<const T*>(M->d_values);
+	if (useFreeSweeps(plan)) {
+		switch (M->kind) {
+		case SMM_PRECOND_SGS: return runSweepsFree<T, SGS_LO, SGS_UP>(M, aVals, rhs, x, doneFlag, s);
+		case SMM_PRECOND_ILU0: return runSweepsFree<T, ILU_LO, ILU_UP>(M, fVals, rhs, x, doneFlag, s);
+		case SMM_PRECOND_IC0: return runSweepsFree<T, IC_LO, IC_UP>(M, fVals, rhs, x, doneFlag, s);
+		default: break;
+		}
+	}
 	switch (M->kind) {
 	case SMM_PRECOND_SGS:
 		SMM_TRY((runSweep<T, SGS_LO>(M, plan->lo, M->d_order_lo, M->lvl_ptr_lo, aVals, rhs, x, doneFlag, s)));
@@ -498,7 +767,7 @@ static int applyHost(const smm_hip_precond* M, const T* rhs, T* x) {
 	SMM_TRY(precondApplyDev<T>(M, dr, dx, nullptr, s));
 	if (n) SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	return SMM_HIP_OK;
+	return precondTakeError(M, s);
 }
 
 template <typename T>
@@ -557,6 +826,10 @@ int smm_hip_precond_destroy(smm_hip_precond* M) {
 	if (plan) {
 		devFree(plan->lo.d_lvlPtr);
 		devFree(plan->up.d_lvlPtr);
+		for (auto& kv : plan->scratch) {
+			devFree(kv.second.y);
+			devFree(kv.second.words);
+		}
 		delete plan;
 	}
 	devFree(M->d_values);
@@ -574,6 +847,15 @@ int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower,
 	if (kind) *kind = M->kind;
 	if (levels_lower) *levels_lower = M->lvl_ptr_lo.empty() ? 0 : static_cast<int>(M->lvl_ptr_lo.size()) - 1;
 	if (levels_upper) *levels_upper = M->lvl_ptr_up.empty() ? 0 : static_cast<int>(M->lvl_ptr_up.size()) - 1;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_set_sweep(smm_hip_precond* M, int mode) {
+	if (!M || mode < SMM_SWEEP_AUTO || mode > SMM_SWEEP_SYNCFREE) {
+		setError("precond_set_sweep: null handle or unknown mode");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (M->plan) M->plan->sweep = mode;  // Jacobi / NONE have no sweeps: accepted, no effect
 	return SMM_HIP_OK;
 }
 

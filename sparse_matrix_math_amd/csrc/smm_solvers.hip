@@ -618,7 +618,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 	if (status) *status = h.status;
 	if (iterations) *iterations = h.iters;
 	if (resnorm2) *resnorm2 = h.res;
-	return SMM_HIP_OK;
+	return pcg ? precondTakeError(M, s) : SMM_HIP_OK;
 }
 
 template <typename T>
@@ -706,7 +706,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	if (status) *status = h.iters > maxIterations ? SMM_SOLVER_MAX_ITERATIONS_REACHED : SMM_SOLVER_SUCCESS;  // ref:2279-2282
 	if (iterations) *iterations = h.iters;
 	if (resnorm) *resnorm = h.res;
-	return SMM_HIP_OK;
+	return precondition ? precondTakeError(M, s) : SMM_HIP_OK;
 }
 
 template <typename T>

@@ -36,6 +36,7 @@ class SolverPreconditioner(enum.IntEnum):
 
 OP_ASSIGN, OP_ADD, OP_SUB = 0, 1, 2
 SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_PATTERN = 0, 1, 2, 3
+SWEEP_AUTO, SWEEP_LEVELS, SWEEP_SYNCFREE = 0, 1, 2
 
 _SUFFIX = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 _CT = {"f32": ctypes.c_float, "f64": ctypes.c_double}
@@ -126,6 +127,10 @@ class Preconditioner:
         out = np.empty(count, dtype=self.matrix.dtype)
         check(_fn("smm_hip_precond_values", self.matrix._suf)(self._h, _host(out, self.matrix.dtype, "out"), count))
         return out
+
+    def set_sweep(self, mode):
+        """SWEEP_AUTO / SWEEP_LEVELS / SWEEP_SYNCFREE: how the triangular sweeps are launched (same numbers either way)"""
+        check(_lib.load().smm_hip_precond_set_sweep(self._h, int(mode)))
 
     def levels(self):
         kind, lo, up = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

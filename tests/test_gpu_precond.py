@@ -108,3 +108,89 @@ def test_structural_failures(smm):
     v = np.ones(2)
     with pytest.raises(smm.SmmHipError):  # rhs must not alias x (ref:1667)
         M.apply(v, v)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sweep_modes_bit_identical(smm, oracle, dtype):
+    """the level-scheduled sweeps (one launch per level) and the synchronisation-free sweeps (one launch per sweep, rows wait
+    on ready values) walk every row in the reference's order: same bits, and the oracle's sequential sweep's bits; sizes with
+    thousands of wavefronts, hundreds of levels, levels smaller and larger than a wavefront"""
+    from sparse_matrix_math_amd.host import SWEEP_LEVELS, SWEEP_SYNCFREE
+
+    P = smm.SolverPreconditioner
+    cases = {
+        "convdiff3d_48": gen.convdiff3d(48, 0.3, dtype=dtype),  # 110 592 rows, 142 levels of up to ~1700 rows
+        "poisson2d_400x130": gen.poisson2d(400, 130, dtype=dtype),  # 529 levels of <= 130 rows
+        "banded": gen.banded_random_spd(50_000, k=6, seed=11, max_offset=3000, dtype=dtype),
+        "chain": gen.banded_random_spd(3000, k=1, seed=5, max_offset=2, dtype=dtype),  # tridiagonal: every row its own level
+    }
+    rng = np.random.default_rng(12)
+    for name, csr in cases.items():
+        rows = len(csr[0]) - 1
+        A = make(smm, csr)
+        rhs = rng.uniform(-1, 1, rows).astype(dtype)
+        kinds = [P.SYMMETRIC_GAUS_SEIDEL, P.ILU0] + ([P.IC0] if name != "convdiff3d_48" else [])
+        for kind in kinds:
+            M = A.getPreconditioner(kind)
+            out = {}
+            for mode in (SWEEP_LEVELS, SWEEP_SYNCFREE):
+                M.set_sweep(mode)
+                x = np.full(rows, 7, dtype=dtype)
+                for _ in range(3):  # repeated applies reuse the ticket counters and the scratch vector
+                    M.apply(rhs, x)
+                out[mode] = x
+            np.testing.assert_array_equal(out[SWEEP_LEVELS], out[SWEEP_SYNCFREE], err_msg=f"{name} {kind}")
+            if kind == P.SYMMETRIC_GAUS_SEIDEL and rows <= 60_000:
+                np.testing.assert_array_equal(out[SWEEP_SYNCFREE], oracle.sgs_apply(csr, rhs)[1], err_msg=name)
+
+
+def test_sweep_modes_in_solver(smm):
+    """a preconditioned BiCGStab / PCG solve gives the same bits whichever way the sweeps are launched; NaN / Inf in rhs travel
+    through the synchronisation-free sweep (NaN is not the 'not ready yet' marker) instead of stalling it"""
+    from sparse_matrix_math_amd.host import SWEEP_LEVELS, SWEEP_SYNCFREE
+
+    P = smm.SolverPreconditioner
+    csr = gen.convdiff3d(30, 0.3, dtype=np.float64)
+    n = len(csr[0]) - 1
+    A = make(smm, csr)
+    b = np.random.default_rng(2).uniform(-1, 1, n)
+    res = {}
+    for mode in (SWEEP_LEVELS, SWEEP_SYNCFREE):
+        M = A.getPreconditioner(P.ILU0)
+        M.set_sweep(mode)
+        x = np.zeros(n)
+        info = {}
+        st = smm.BiCGStab(A, b, x, 200, 1e-10, M=M, info=info)
+        res[mode] = (int(st), info["iterations"], x)
+    assert res[SWEEP_LEVELS][:2] == res[SWEEP_SYNCFREE][:2]
+    assert res[SWEEP_SYNCFREE][1] < 60
+    np.testing.assert_array_equal(res[SWEEP_LEVELS][2], res[SWEEP_SYNCFREE][2])
+    spd = gen.poisson2d(90, dtype=np.float64)
+    S = make(smm, spd)
+    bs = np.random.default_rng(3).uniform(-1, 1, 8100)
+    res = {}
+    for mode in (SWEEP_LEVELS, SWEEP_SYNCFREE):
+        M = S.getPreconditioner(P.IC0)
+        M.set_sweep(mode)
+        x = np.zeros(8100)
+        info = {}
+        st = smm.ConjugateGradient(S, bs, np.zeros(8100), x, 500, 1e-10, M=M, info=info)
+        res[mode] = (int(st), info["iterations"], x)
+    assert res[SWEEP_LEVELS][:2] == res[SWEEP_SYNCFREE][:2] and res[SWEEP_SYNCFREE][0] == 0
+    np.testing.assert_array_equal(res[SWEEP_LEVELS][2], res[SWEEP_SYNCFREE][2])
+    # non-finite input
+    M = S.getPreconditioner(P.SYMMETRIC_GAUS_SEIDEL)
+    bad = bs.copy()
+    bad[17] = np.nan
+    bad[4000] = np.inf
+    outs = []
+    for mode in (SWEEP_LEVELS, SWEEP_SYNCFREE):
+        M.set_sweep(mode)
+        x = np.zeros(8100)
+        M.apply(bad, x)
+        outs.append(x)
+    np.testing.assert_array_equal(np.isnan(outs[0]), np.isnan(outs[1]))
+    ok = ~np.isnan(outs[0])
+    np.testing.assert_array_equal(outs[0][ok], outs[1][ok])
+    with pytest.raises(smm.SmmHipError):
+        M.set_sweep(9)
