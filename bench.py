@@ -124,13 +124,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # SMM_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices, halos
+    # are staged through host memory) -- a functional check of this file's N > 1 leg, never a measurement
+    backend = os.environ.get("SMM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import sparse_matrix_math_amd as smm
     from sparse_matrix_math_amd import host
@@ -278,6 +286,8 @@ def main():
             },
         }
         line.update(result)
+        if backend != "nccl":
+            line["rehearsal_backend"] = backend  # ranks share GPUs and halos go through the host: not a measurement
         if "roofline" in line:
             line["spmv_gbps"] = line["roofline"]["achieved"]
             line["spmv_pct_hbm_peak"] = 100.0 * line["roofline"]["frac"]

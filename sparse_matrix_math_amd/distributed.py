@@ -92,24 +92,49 @@ class TorchComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        # gloo has no point-to-point or all-gather on device tensors: a multi-process REHEARSAL of the GPU path on a box without
+        # RCCL peers (several ranks sharing one GPU, bench.py with SMM_BENCH_BACKEND=gloo) stages those through host memory
+        self.staged = dist.get_backend(group) == "gloo"
 
     def all_reduce_sum(self, t):
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def all_gather_pairs(self, a, b, torch, device):
-        mine = torch.tensor([a, b], dtype=torch.int64, device=device)
+        mine = torch.tensor([a, b], dtype=torch.int64, device="cpu" if self.staged else device)
         if self.world == 1:
             return [(a, b)]
         out = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(out, mine, group=self.group)
         return [(int(t[0]), int(t[1])) for t in out]
 
+    def _exchange_staged(self, ext, cmin, sends, recvs):
+        class _Landing:
+            def __init__(self, req, dst, buf):
+                self.req, self.dst, self.buf = req, dst, buf
+
+            def wait(self):
+                self.req.wait()
+                if self.dst is not None:
+                    self.dst.copy_(self.buf)
+
+        out = []
+        for q, lo, hi in recvs:
+            dst = ext[lo - cmin:hi - cmin]
+            buf = dst.new_empty(dst.shape, device="cpu")
+            out.append(_Landing(self.dist.irecv(buf, q, group=self.group), dst, buf))
+        for q, lo, hi in sends:
+            buf = ext[lo - cmin:hi - cmin].cpu()
+            out.append(_Landing(self.dist.isend(buf, q, group=self.group), None, buf))
+        return out
+
     def exchange(self, ext, cmin, sends, recvs):
         """start the halo exchange of `ext` (the halo-extended vector whose element 0 is global column cmin); returns a
         list of requests to wait on"""
         if not sends and not recvs:
             return []
+        if self.staged and ext.is_cuda:
+            return self._exchange_staged(ext, cmin, sends, recvs)
         # the same few vectors are exchanged every iteration: build their P2POp lists (slice views + op objects) once
         cache = getattr(self, "_p2p_cache", None)
         if cache is None:
