@@ -354,6 +354,12 @@ public:
 		}
 		return dev;
 	}
+	// Tuning only (results unchanged): SpMV kernel family and lanes per row for this matrix, e.g. SMM_SPMV_PATTERN for stencil /
+	// banded matrices.  Returns the ABI status: non-zero when the matrix does not qualify (the previous choice stays).
+	int setSpmvKernel(const int family, const int lanesPerRow = 0) const noexcept {
+		(void)device();
+		return dev ? smm_hip_csr_set_kernel(dev, family, lanesPerRow) : SMM_HIP_ERR_NO_DEVICE;
+	}
 	// call after editing values/positions in place through the raw accessors below
 	void invalidateDevice() noexcept {
 		smm_hip_csr_destroy(dev);

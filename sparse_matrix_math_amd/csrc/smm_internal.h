@@ -69,6 +69,12 @@ struct DevBuf {
 		p = nullptr;
 		n = 0;
 	}
+	T* detach() {  // the caller takes over the allocation
+		T* q = p;
+		p = nullptr;
+		n = 0;
+		return q;
+	}
 	operator T*() const { return p; }
 };
 

@@ -356,12 +356,11 @@ int ensurePattern(smm_hip_csr* m) {
 		setError("pattern SpMV: no entries in the sampled rows");
 		return SMM_HIP_ERR_INVALID;
 	}
-	int* d_off = nullptr;
-	unsigned long long* d_masks = nullptr;
-	int* d_flag = nullptr;
-	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_off), MAXOFF * sizeof(int)));
-	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_masks), static_cast<size_t>(m->rows) * sizeof(unsigned long long)));
-	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_flag), sizeof(int)));
+	DevBuf<int> d_off, d_flag;  // released on every early return
+	DevBuf<unsigned long long> d_masks;
+	SMM_TRY(d_off.alloc(MAXOFF));
+	SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
+	SMM_TRY(d_flag.alloc(1));
 	std::vector<int> padded(MAXOFF, 0);
 	std::copy(offs.begin(), offs.end(), padded.begin());
 	SMM_HIP_TRY(hipMemcpyAsync(d_off, padded.data(), MAXOFF * sizeof(int), hipMemcpyHostToDevice, s));
@@ -371,16 +370,13 @@ int ensurePattern(smm_hip_csr* m) {
 	int mismatch = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(&mismatch, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	devFree(d_flag);
 	if (mismatch) {
-		devFree(d_off);
-		devFree(d_masks);
 		setError("pattern SpMV: some entry's column offset is outside the shared offset set");
 		return SMM_HIP_ERR_INVALID;
 	}
 	m->pat_k = static_cast<int>(offs.size());
-	m->d_pat_off = d_off;
-	m->d_pat_masks = d_masks;
+	m->d_pat_off = d_off.detach();
+	m->d_pat_masks = d_masks.detach();
 	m->pat_state = 1;
 	return SMM_HIP_OK;
 }

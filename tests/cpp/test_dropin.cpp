@@ -175,6 +175,15 @@ static void testSolvers() {
 			CHECK(SMM::BiCGSymmetric<T>(m, rhs, x, -1, l2Eps<T>()) == SMM::SolverStatus::SUCCESS);
 			for (const T ri : x) CHECK(approx(T(1), ri, infEps<T>()));
 		}
+		{  // tuning knob, results unchanged: the opt-in PATTERN SpMV family on a stencil matrix gives the default family's bits
+			SMM::Vector<T> v(m.getDenseRowCount()), y0(m.getDenseRowCount(), 0), y1(m.getDenseRowCount(), 0);
+			for (int i = 0; i < v.getSize(); ++i) v[i] = T(1) / T(1 + i % 7);
+			m.rMult(v, y0);
+			CHECK(m.setSpmvKernel(SMM_SPMV_PATTERN, 1) == SMM_HIP_OK);
+			m.rMult(v, y1);
+			for (int i = 0; i < v.getSize(); ++i) CHECK(y0[i] == y1[i]);
+			CHECK(m.setSpmvKernel(SMM_SPMV_AUTO) == SMM_HIP_OK);
+		}
 		{  // status quirks (ref:2342-2347, 2277-2282)
 			SMM::Vector<T> x(m.getDenseRowCount(), 0);
 			const SMM::SolverStatus s1 = SMM::ConjugateGradient<T>(m, rhs, x, x, 0, l2Eps<T>());
