@@ -52,4 +52,95 @@ __device__ __forceinline__ T blockSum256(T v, T* lds4) {
 	return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Streaming element-wise map over vectors: out[k][i] = f(in[0][i], in[1][i], ...), optionally with per-lane accumulators
+// captured by f.  Measured on MI355X (tools/membw.hip, the CG x/r update on 2^27 doubles): one element per lane per trip
+// 4.3-4.7 TB/s, 16-byte accesses with 4 trips' loads issued before the first store 5.7 TB/s -- the loads of a lane must be in
+// flight together, and an in-place update (x and xcur may be the same vector) stops the compiler from hoisting them itself.
+//   * every lane loads all its inputs for U packs of 16 bytes, then computes, then stores: element-wise aliasing between
+//     inputs and outputs is therefore allowed;
+//   * f(const T (&in)[NIN], T (&out)[NOUT]) is called once per element, in ascending index order within a lane;
+//   * NT selects the non-temporal policy for vectors that do not fit the caches anyway;
+//   * pointers that are not 16-byte aligned (a slice of a larger vector) and the last n % (16 / sizeof(T)) elements take the
+//     one-element-per-lane path.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct Pack16;
+template <>
+struct Pack16<float> {
+	typedef float V __attribute__((ext_vector_type(4)));
+	static constexpr int N = 4;
+};
+template <>
+struct Pack16<double> {
+	typedef double V __attribute__((ext_vector_type(2)));
+	static constexpr int N = 2;
+};
+
+constexpr int STREAM_TPB = 256;
+constexpr int STREAM_U = 4;
+
+template <typename T, bool NT, int NIN, int NOUT, typename F>
+__device__ __forceinline__ void streamMap(long long n, const T* const* in, T* const* out, F&& f) {  // out may be null when NOUT == 0
+	using V = typename Pack16<T>::V;
+	constexpr int N = Pack16<T>::N;
+	unsigned long long bits = 0;
+#pragma unroll
+	for (int k = 0; k < NIN; ++k) bits |= reinterpret_cast<unsigned long long>(in[k]);
+#pragma unroll
+	for (int k = 0; k < NOUT; ++k) bits |= reinterpret_cast<unsigned long long>(out[k]);
+	long long done = 0;
+	if ((bits & 15ull) == 0) {
+		const long long nvec = n / N;
+		const long long chunk = static_cast<long long>(STREAM_U) * STREAM_TPB;
+		for (long long base = static_cast<long long>(blockIdx.x) * chunk; base < nvec; base += static_cast<long long>(gridDim.x) * chunk) {
+			V a[NIN][STREAM_U];
+#pragma unroll
+			for (int u = 0; u < STREAM_U; ++u) {
+				const long long i = base + u * STREAM_TPB + threadIdx.x;
+				if (i < nvec) {
+#pragma unroll
+					for (int k = 0; k < NIN; ++k) {
+						const V* p = reinterpret_cast<const V*>(in[k]) + i;
+						a[k][u] = NT ? __builtin_nontemporal_load(p) : *p;
+					}
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < STREAM_U; ++u) {
+				const long long i = base + u * STREAM_TPB + threadIdx.x;
+				if (i < nvec) {
+					V o[NOUT > 0 ? NOUT : 1];
+#pragma unroll
+					for (int e = 0; e < N; ++e) {
+						T iv[NIN];
+						T ov[NOUT > 0 ? NOUT : 1];
+#pragma unroll
+						for (int k = 0; k < NIN; ++k) iv[k] = a[k][u][e];
+						f(iv, ov);
+#pragma unroll
+						for (int k = 0; k < NOUT; ++k) o[k][e] = ov[k];
+					}
+#pragma unroll
+					for (int k = 0; k < NOUT; ++k) {
+						V* p = reinterpret_cast<V*>(out[k]) + i;
+						if (NT) __builtin_nontemporal_store(o[k], p);
+						else *p = o[k];
+					}
+				}
+			}
+		}
+		done = nvec * N;
+	}
+	for (long long i = done + static_cast<long long>(blockIdx.x) * STREAM_TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * STREAM_TPB) {
+		T iv[NIN];
+		T ov[NOUT > 0 ? NOUT : 1];
+#pragma unroll
+		for (int k = 0; k < NIN; ++k) iv[k] = in[k][i];
+		f(iv, ov);
+#pragma unroll
+		for (int k = 0; k < NOUT; ++k) out[k][i] = ov[k];
+	}
+}
+
 }  // namespace smm

@@ -149,28 +149,29 @@ __device__ __forceinline__ T sumPartsAll(const T* __restrict__ partials, T* red5
 }
 
 // alpha = rr / (Ap.p) ; x = alpha p + xcur ; r = -alpha Ap + r ; partial ||r||^2   (ref:2354-2375)
-template <typename T>
-__global__ __launch_bounds__(TPB) void cgFusedXR(int n, const Scal<T>* __restrict__ sc, int par, const T* __restrict__ partsA,
-                                                 const T* __restrict__ p, const T* __restrict__ Ap, const T* xcur, T* x, T* __restrict__ r,
-                                                 T* __restrict__ partsC) {
+// (the vector loops of the fused kernels go through streamMap, smm_device.h: 16-byte accesses, 4 packs per lane in flight)
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void cgFusedXR(int n, const Scal<T>* __restrict__ sc, int par, const T* __restrict__ partsA, const T* p,
+                                                 const T* Ap, const T* xcur, T* x, T* r, T* __restrict__ partsC) {
 	__shared__ T red[5];
 	if (sc->done) return;
 	const T alpha = sc->rrPing[par] / sumPartsAll(partsA, red);
 	T acc = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		x[i] = smmFma(alpha, p[i], xcur[i]);
-		const T ri = smmFma(-alpha, Ap[i], r[i]);
-		r[i] = ri;
+	const T* const in[4] = {p, xcur, Ap, r};
+	T* const out[2] = {x, r};
+	streamMap<T, NT, 4, 2>(n, in, out, [&](const T(&v)[4], T(&o)[2]) {
+		o[0] = smmFma(alpha, v[0], v[1]);
+		const T ri = smmFma(-alpha, v[2], v[3]);
+		o[1] = ri;
 		acc += ri * ri;
-	}
+	});
 	const T s = blockSum256(acc, red);
 	if (threadIdx.x == 0) partsC[blockIdx.x] = s;
 }
 
 // convergence test, beta, p = beta p + r   (ref:2377-2394)
-template <typename T>
-__global__ __launch_bounds__(TPB) void cgFusedP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, T* __restrict__ p,
-                                                const T* __restrict__ r) {
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void cgFusedP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, T* p, const T* r) {
 	__shared__ T red[5];
 	if (sc->done) return;
 	const T rrNew = sumPartsAll(partsC, red);
@@ -188,29 +189,27 @@ __global__ __launch_bounds__(TPB) void cgFusedP(int n, Scal<T>* sc, int par, con
 	}
 	if (converged) return;
 	const T beta = rrNew / rrOld;
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		p[i] = smmFma(beta, p[i], r[i]);
-	}
+	const T* const in[2] = {p, r};
+	T* const out[1] = {p};
+	streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
 }
 
 // alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247)
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgFusedS(int n, Scal<T>* sc, int par, const T* __restrict__ partsA, const T* __restrict__ ap,
-                                                  const T* __restrict__ r, T* __restrict__ sv) {
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void bicgFusedS(int n, Scal<T>* sc, int par, const T* __restrict__ partsA, const T* ap, const T* r, T* sv) {
 	__shared__ T red[5];
 	if (sc->done) return;
 	const T alpha = sc->rrPing[par] / sumPartsAll(partsA, red);
 	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		sv[i] = smmFma(-alpha, ap[i], r[i]);
-	}
+	const T* const in[2] = {ap, r};
+	T* const out[1] = {sv};
+	streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(-alpha, v[0], v[1]); });
 }
 
 // omega = (as.s)/(as.as) ; x, r update ; partial ||r||^2 and r.r0   (ref:2259-2269); partsB = [as.as | as.s], partsC = [r.r | r.r0]
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgFusedXR(int n, Scal<T>* sc, const T* __restrict__ partsB, const T* __restrict__ p,
-                                                   const T* __restrict__ sv, const T* __restrict__ as, const T* __restrict__ r0, T* __restrict__ x,
-                                                   T* __restrict__ r, T* __restrict__ partsC) {
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void bicgFusedXR(int n, Scal<T>* sc, const T* __restrict__ partsB, const T* p, const T* sv, const T* as,
+                                                   const T* r0, T* x, T* r, T* __restrict__ partsC) {
 	__shared__ T red[5];
 	if (sc->done) return;
 	const T asas = sumPartsAll(partsB, red);
@@ -219,14 +218,16 @@ __global__ __launch_bounds__(TPB) void bicgFusedXR(int n, Scal<T>* sc, const T* 
 	const T alpha = sc->alpha;
 	if (blockIdx.x == 0 && threadIdx.x == 0) sc->omega = omega;
 	T acc0 = T(0), acc1 = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		const T si = sv[i];
-		x[i] = smmFma(alpha, p[i], smmFma(omega, si, x[i]));
-		const T ri = smmFma(-omega, as[i], si);
-		r[i] = ri;
+	const T* const in[5] = {sv, x, p, as, r0};
+	T* const out[2] = {x, r};
+	streamMap<T, NT, 5, 2>(n, in, out, [&](const T(&v)[5], T(&o)[2]) {
+		const T si = v[0];
+		o[0] = smmFma(alpha, v[2], smmFma(omega, si, v[1]));
+		const T ri = smmFma(-omega, v[3], si);
+		o[1] = ri;
 		acc0 += ri * ri;
-		acc1 += ri * r0[i];
-	}
+		acc1 += ri * v[4];
+	});
 	const T s0 = blockSum256(acc0, red);
 	const T s1 = blockSum256(acc1, red);
 	if (threadIdx.x == 0) {
@@ -236,9 +237,8 @@ __global__ __launch_bounds__(TPB) void bicgFusedXR(int n, Scal<T>* sc, const T* 
 }
 
 // resL2Norm, loop test, beta, p = beta (-omega ap + p) + r   (ref:2268-2277)
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgFusedP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, const T* __restrict__ ap,
-                                                  const T* __restrict__ r, T* __restrict__ p) {
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void bicgFusedP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, const T* ap, const T* r, T* p) {
 	__shared__ T red[5];
 	if (sc->done) return;
 	const T rr = sumPartsAll(partsC, red);
@@ -256,9 +256,9 @@ __global__ __launch_bounds__(TPB) void bicgFusedP(int n, Scal<T>* sc, int par, c
 	}
 	if (leave) return;
 	const T beta = (newRR0 * alpha) / (rr0 * omega);  // ref:2271
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		p[i] = smmFma(beta, smmFma(-omega, ap[i], p[i]), r[i]);
-	}
+	const T* const in[3] = {ap, p, r};
+	T* const out[1] = {p};
+	streamMap<T, NT, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) { o[0] = smmFma(beta, smmFma(-omega, v[0], v[1]), v[2]); });
 }
 
 // two dot products that share an operand: partials = a.a, partials2 = a.b
@@ -268,11 +268,11 @@ __global__ __launch_bounds__(TPB) void dot2Partials(int n, const T* __restrict__
 	__shared__ T red[4];
 	if (doneFlag && *doneFlag) return;
 	T acc0 = T(0), acc1 = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		const T ai = a[i];
-		acc0 += ai * ai;
-		acc1 += ai * b[i];
-	}
+	const T* const in[2] = {a, b};
+	streamMap<T, false, 2, 0>(n, in, nullptr, [&](const T(&v)[2], T(&)[1]) {
+		acc0 += v[0] * v[0];
+		acc1 += v[0] * v[1];
+	});
 	const T s0 = blockSum256(acc0, red);
 	const T s1 = blockSum256(acc1, red);
 	if (threadIdx.x == 0) {
@@ -467,6 +467,23 @@ __global__ __launch_bounds__(TPB) void bsymUpdateP(int n, const Scal<T>* __restr
 // ---------------------------------------------------------------------------------------------------------
 static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, NPART))); }
 
+// Non-temporal loads / stores for an update kernel whose vectors cannot stay in the 256 MB Infinity Cache until the next kernel
+// reads them anyway; cache-resident problems keep the default policy.  SMM_HIP_UPDATE_NT=0/1 overrides (measurements).
+static bool updateNT(long long n, size_t elemBytes, int vectors) {
+	static const int forced = [] {
+		const char* env = getenv("SMM_HIP_UPDATE_NT");
+		return env ? atoi(env) : -1;
+	}();
+	if (forced >= 0) return forced != 0;
+	return static_cast<double>(n) * static_cast<double>(elemBytes) * vectors > 192.0 * 1024 * 1024;
+}
+
+#define SMM_LAUNCH_UPDATE(KERNEL, NTFLAG, GRID, STREAM, ...)                    \
+	do {                                                                       \
+		if (NTFLAG) KERNEL<T, true><<<(GRID), TPB, 0, (STREAM)>>>(__VA_ARGS__); \
+		else KERNEL<T, false><<<(GRID), TPB, 0, (STREAM)>>>(__VA_ARGS__);       \
+	} while (0)
+
 // Polls the device `done` flag without stalling the queue: every `interval` iterations the flag is copied into a
 // pinned mailbox behind an event; the host reads mailboxes whose event has completed and waits only when more
 // than two are outstanding.
@@ -608,8 +625,8 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			cgUpdateP<T><<<g, TPB, 0, s>>>(n, sc, p, z);
 		} else {
 			// alpha and beta are formed inside the two update kernels (no scalar launches)
-			cgFusedXR<T><<<NPART, TPB, 0, s>>>(n, sc, i & 1, parts, p, Ap, xcur, x, r, parts2);
-			cgFusedP<T><<<g, TPB, 0, s>>>(n, sc, i & 1, parts2, eps, p, r);
+			SMM_LAUNCH_UPDATE(cgFusedXR, updateNT(n, sizeof(T), 6), NPART, s, n, sc, i & 1, parts, p, Ap, xcur, x, r, parts2);
+			SMM_LAUNCH_UPDATE(cgFusedP, updateNT(n, sizeof(T), 3), g, s, n, sc, i & 1, parts2, eps, p, r);
 		}
 	}
 	SMM_HIP_TRY(hipGetLastError());
@@ -688,7 +705,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, ap, 1, r0, parts, doneFlag, s));  // ref:2240 + 2243 fused
 		}
 		// alpha, omega and beta are formed inside the three update kernels that consume them (no scalar launches)
-		bicgFusedS<T><<<gridFor(n), TPB, 0, s>>>(n, sc, i & 1, parts, ap, r, sv);
+		SMM_LAUNCH_UPDATE(bicgFusedS, updateNT(n, sizeof(T), 3), gridFor(n), s, n, sc, i & 1, parts, ap, r, sv);
 		if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
 			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));                                           // ref:2251
@@ -697,8 +714,8 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 			// as = A s with as.as -> parts[0..NPART) and as.s -> parts[NPART..2 NPART) fused (ref:2256-2261)
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, as, 2, sv, parts, doneFlag, s));
 		}
-		bicgFusedXR<T><<<g, TPB, 0, s>>>(n, sc, parts, p, sv, as, r0, x, r, parts2);
-		bicgFusedP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, i & 1, parts2, eps, ap, r, p);
+		SMM_LAUNCH_UPDATE(bicgFusedXR, updateNT(n, sizeof(T), 7), g, s, n, sc, parts, p, sv, as, r0, x, r, parts2);
+		SMM_LAUNCH_UPDATE(bicgFusedP, updateNT(n, sizeof(T), 4), gridFor(n), s, n, sc, i & 1, parts2, eps, ap, r, p);
 	}
 	SMM_HIP_TRY(hipGetLastError());
 	Scal<T> h;

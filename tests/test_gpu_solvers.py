@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 from test_oracle import gen_matrices
 
-from oracle.oracle import PRECOND_ILU0
+from oracle.oracle import PRECOND_ILU0, PRECOND_JACOBI, PRECOND_NONE, PRECOND_SGS
 from sparse_matrix_math_amd import generators as gen
 
 pytestmark = pytest.mark.gpu
@@ -25,8 +25,24 @@ def make(smm, csr):
     return smm.CSRMatrix(rows, rows, *csr)
 
 
+def bicgstab_sensitivity(oracle, csr, b, it, precond, precond_values):
+    """How far the REFERENCE ALGORITHM's own x moves when b changes by one unit in the last place (three random sign
+    patterns), in the oracle.  A different summation order of the dot products is a perturbation of that kind, and BiCGStab
+    in fp32 can amplify it by 10^3 within ten iterations on the non-symmetric test matrix (measured: 1e-4 .. 2e-3 for
+    max|x| = 2.7); a fixed tolerance that ignores this passes or fails by luck."""
+    rows = len(b)
+    base = oracle.bicgstab(csr, b, np.zeros(rows, dtype=b.dtype), it, 1e-30, precond, precond_values)[1].astype(np.float64)
+    worst = 0.0
+    for seed in range(3):
+        sign = np.random.default_rng(seed).choice([-1.0, 1.0], size=rows).astype(b.dtype)
+        pert = np.nextafter(b, b + sign).astype(b.dtype)
+        x = oracle.bicgstab(csr, pert, np.zeros(rows, dtype=b.dtype), it, 1e-30, precond, precond_values)[1]
+        worst = max(worst, float(np.max(np.abs(x.astype(np.float64) - base))))
+    return worst
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_fixed_iterations_match_reference(smm, golden, dtype):
+def test_fixed_iterations_match_reference(smm, golden, oracle, dtype):
     P = smm.SolverPreconditioner
     dn = np.dtype(dtype).name
     for mname, csr in gen_matrices(dtype).items():
@@ -39,6 +55,7 @@ def test_fixed_iterations_match_reference(smm, golden, dtype):
         b = gen.row_sums(start, val)
         tag = f"gen/{mname}/{dn}"
         preconds = {"none": None, "sgs": A.getPreconditioner(P.SYMMETRIC_GAUS_SEIDEL), "jacobi": A.getPreconditioner(P.JACOBI)}
+        ocodes = {"none": (PRECOND_NONE, None), "sgs": (PRECOND_SGS, None), "jacobi": (PRECOND_JACOBI, oracle.jacobi_setup(csr)[1])}
         for it in (1, 3, 10):
             if symmetric:
                 x0 = np.zeros(rows, dtype=dtype)
@@ -52,7 +69,9 @@ def test_fixed_iterations_match_reference(smm, golden, dtype):
                 info = {}
                 st = smm.BiCGStab(A, b.copy(), x, it, 1e-30, M, info=info)
                 assert int(st) == int(golden[f"{tag}/bicgstab_{pname}/it{it}/status"]) == 0 and info["iterations"] == it
-                assert close(x, golden[f"{tag}/bicgstab_{pname}/it{it}/x"], dtype), (mname, pname, it)
+                ref = golden[f"{tag}/bicgstab_{pname}/it{it}/x"]
+                allowed = max(RTOL[dtype] * max(1.0, float(np.max(np.abs(ref)))), 4 * bicgstab_sensitivity(oracle, csr, b, it, *ocodes[pname]))
+                assert float(np.max(np.abs(x.astype(np.float64) - ref))) <= allowed, (mname, pname, it)
         if symmetric:
             x = np.zeros(rows, dtype=dtype)
             st = smm.ConjugateGradient(A, b, x, x, -1, 1e-6)  # x aliases x0, as the reference's tests call it

@@ -1,0 +1,194 @@
+// tools/membw.hip -- read-bandwidth calibration of one MI355X: what a pure streaming read of 4 GB reaches, as a function of
+// load flavour, loads in flight per lane, workgroups per CU and number of arrays.  The SpMV / dot kernels are judged
+// against the best line of this table, not only against the 8 TB/s spec number.
+//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/membw tools/membw.hip && gpurun_out/membw
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x)                                                                        \
+	do {                                                                                \
+		hipError_t e = (x);                                                             \
+		if (e != hipSuccess) {                                                          \
+			std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+			std::exit(1);                                                               \
+		}                                                                               \
+	} while (0)
+
+// each workgroup owns contiguous chunks of U * 256 * 16 bytes, grid-strided; NT selects non-temporal loads
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void readKernel(const f32x4* __restrict__ a, long long n16, float* __restrict__ sink) {
+	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+	const long long chunk = static_cast<long long>(U) * 256;
+	for (long long base = static_cast<long long>(blockIdx.x) * chunk; base < n16; base += static_cast<long long>(gridDim.x) * chunk) {
+		f32x4 v[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const long long i = base + u * 256 + threadIdx.x;
+			if (i < n16) {
+				v[u] = NT ? __builtin_nontemporal_load(a + i) : a[i];
+			} else {
+				v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) acc += v[u];
+	}
+	const float s = acc.x + acc.y + acc.z + acc.w;
+	if (s == 123.456f) sink[0] = s;  // never true for the data used; keeps the loads alive
+}
+
+// two arrays read in lock step (the SpMV's values[] and positions[])
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void read2Kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, long long n16, float* __restrict__ sink) {
+	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+	const long long chunk = static_cast<long long>(U) * 256;
+	for (long long base = static_cast<long long>(blockIdx.x) * chunk; base < n16; base += static_cast<long long>(gridDim.x) * chunk) {
+		f32x4 v[U], w[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const long long i = base + u * 256 + threadIdx.x;
+			const bool ok = i < n16;
+			v[u] = ok ? (NT ? __builtin_nontemporal_load(a + i) : a[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+			w[u] = ok ? (NT ? __builtin_nontemporal_load(b + i) : b[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) acc += v[u] * w[u];
+	}
+	const float s = acc.x + acc.y + acc.z + acc.w;
+	if (s == 123.456f) sink[0] = s;
+}
+
+// the CG x/r update (4 reads, 2 writes, one partial sum) written the way csrc/smm_solvers.hip writes its update kernels
+// (one element per lane per trip) and as 16-byte accesses with U trips in flight
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void xrScalar(long long n, double alpha, const double* __restrict__ p, const double* __restrict__ Ap, const double* xcur,
+                                               double* x, double* __restrict__ r, double* __restrict__ parts) {
+	double acc = 0;
+	for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * 256) {
+		x[i] = alpha * p[i] + xcur[i];
+		const double ri = -alpha * Ap[i] + r[i];
+		r[i] = ri;
+		acc += ri * ri;
+	}
+	if (acc == 123.456) parts[0] = acc;
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void xrVec(long long n, double alpha, const double* __restrict__ p, const double* __restrict__ Ap, const double* xcur,
+                                            double* x, double* __restrict__ r, double* __restrict__ parts) {
+	double acc = 0;
+	const long long nv = n / 2;
+	const f64x2* pv = reinterpret_cast<const f64x2*>(p);
+	const f64x2* av = reinterpret_cast<const f64x2*>(Ap);
+	const f64x2* cv = reinterpret_cast<const f64x2*>(xcur);
+	f64x2* xv = reinterpret_cast<f64x2*>(x);
+	f64x2* rv = reinterpret_cast<f64x2*>(r);
+	const long long chunk = static_cast<long long>(U) * 256;
+	for (long long base = static_cast<long long>(blockIdx.x) * chunk; base < nv; base += static_cast<long long>(gridDim.x) * chunk) {
+		f64x2 a[U], b[U], c[U], d[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const long long i = base + u * 256 + threadIdx.x;
+			if (i < nv) {
+				a[u] = NT ? __builtin_nontemporal_load(pv + i) : pv[i];
+				b[u] = NT ? __builtin_nontemporal_load(av + i) : av[i];
+				c[u] = NT ? __builtin_nontemporal_load(cv + i) : cv[i];
+				d[u] = NT ? __builtin_nontemporal_load(rv + i) : rv[i];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const long long i = base + u * 256 + threadIdx.x;
+			if (i < nv) {
+				const f64x2 xn = alpha * a[u] + c[u];
+				const f64x2 rn = -alpha * b[u] + d[u];
+				if (NT) {
+					__builtin_nontemporal_store(xn, xv + i);
+					__builtin_nontemporal_store(rn, rv + i);
+				} else {
+					xv[i] = xn;
+					rv[i] = rn;
+				}
+				acc += rn.x * rn.x;
+				acc += rn.y * rn.y;
+			}
+		}
+	}
+	if (acc == 123.456) parts[0] = acc;
+}
+
+template <typename F>
+static double timeIt(F launch, int reps) {
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0));
+	CHECK(hipEventCreate(&e1));
+	for (int i = 0; i < 3; ++i) launch();
+	CHECK(hipDeviceSynchronize());
+	CHECK(hipEventRecord(e0));
+	for (int i = 0; i < reps; ++i) launch();
+	CHECK(hipEventRecord(e1));
+	CHECK(hipEventSynchronize(e1));
+	float ms = 0.f;
+	CHECK(hipEventElapsedTime(&ms, e0, e1));
+	CHECK(hipEventDestroy(e0));
+	CHECK(hipEventDestroy(e1));
+	return ms / reps;
+}
+
+template <int U, bool NT>
+static void runOne(const f32x4* a, const f32x4* b, long long n16, float* sink, int cus) {
+	for (int perCU : {2, 4, 8, 16}) {
+		const int grid = cus * perCU;
+		const double ms1 = timeIt([&] { readKernel<U, NT><<<grid, 256>>>(a, 2 * n16, sink); }, 10);
+		const double ms2 = timeIt([&] { read2Kernel<U, NT><<<grid, 256>>>(a, b, n16, sink); }, 10);
+		const double bytes = 2.0 * n16 * 16;
+		std::printf("U=%d %s wgs/CU=%2d : one array %7.3f ms %7.1f GB/s | two arrays %7.3f ms %7.1f GB/s\n", U, NT ? "nt   " : "plain", perCU, ms1,
+		            bytes / ms1 / 1e6, ms2, bytes / ms2 / 1e6);
+	}
+}
+
+int main() {
+	hipDeviceProp_t prop;
+	CHECK(hipGetDeviceProperties(&prop, 0));
+	const int cus = prop.multiProcessorCount;
+	const long long n16 = (2LL << 30) / 16;  // 2 GB per array, two arrays (contiguous: the one-array runs read both as one)
+	f32x4* a = nullptr;
+	float* sink = nullptr;
+	CHECK(hipMalloc(&a, 2 * n16 * 16));
+	CHECK(hipMalloc(&sink, 64));
+	CHECK(hipMemset(a, 0, 2 * n16 * 16));
+	const f32x4* b = a + n16;
+	std::printf("%s, %d CUs; reading 4 GB per launch\n", prop.name, cus);
+	runOne<1, false>(a, b, n16, sink, cus);
+	runOne<2, false>(a, b, n16, sink, cus);
+	runOne<4, false>(a, b, n16, sink, cus);
+	runOne<8, false>(a, b, n16, sink, cus);
+	runOne<2, true>(a, b, n16, sink, cus);
+	runOne<4, true>(a, b, n16, sink, cus);
+	runOne<8, true>(a, b, n16, sink, cus);
+	{
+		// 4 vectors of 1 GiB (134 M doubles, the 512^3 grid): 4 reads + 2 writes = 6.44 GB per launch
+		const long long n = 134217728LL;
+		double* v = reinterpret_cast<double*>(a);
+		double *p = v, *Ap = v + n, *x = v + 2 * n, *r = v + 3 * n;
+		double* parts = reinterpret_cast<double*>(sink);
+		const double bytes = 6.0 * n * 8;
+		for (int perCU : {4, 8, 16}) {
+			const int grid = cus * perCU;
+			const double t0 = timeIt([&] { xrScalar<<<grid, 256>>>(n, 1e-9, p, Ap, x, x, r, parts); }, 5);
+			const double t1 = timeIt([&] { xrVec<1, false><<<grid, 256>>>(n, 1e-9, p, Ap, x, x, r, parts); }, 5);
+			const double t2 = timeIt([&] { xrVec<2, false><<<grid, 256>>>(n, 1e-9, p, Ap, x, x, r, parts); }, 5);
+			const double t3 = timeIt([&] { xrVec<2, true><<<grid, 256>>>(n, 1e-9, p, Ap, x, x, r, parts); }, 5);
+			const double t4 = timeIt([&] { xrVec<4, true><<<grid, 256>>>(n, 1e-9, p, Ap, x, x, r, parts); }, 5);
+			std::printf("x/r update fp64 n=2^27 wgs/CU=%2d: scalar %.3f ms %.0f GB/s | 16B U1 %.3f ms %.0f | U2 %.3f ms %.0f | U2 nt %.3f ms %.0f | U4 nt %.3f ms %.0f\n", perCU, t0,
+			            bytes / t0 / 1e6, t1, bytes / t1 / 1e6, t2, bytes / t2 / 1e6, t3, bytes / t3 / 1e6, t4, bytes / t4 / 1e6);
+		}
+	}
+	CHECK(hipFree(a));
+	CHECK(hipFree(sink));
+	return 0;
+}
