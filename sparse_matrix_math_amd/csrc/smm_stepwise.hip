@@ -82,13 +82,12 @@ __global__ void stepCoefAlpha(const T* __restrict__ sums, StepState<T>* st) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void stepUpdateS(int n, const StepState<T>* __restrict__ st, const T* __restrict__ ap, const T* __restrict__ r,
-                                                   T* __restrict__ sv) {
+__global__ __launch_bounds__(TPB) void stepUpdateS(int n, const StepState<T>* __restrict__ st, const T* ap, const T* r, T* sv) {
 	if (st->f[0]) return;
 	const T alpha = st->c[1];
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		sv[i] = smmFma(-alpha, ap[i], r[i]);  // ref:2245-2247
-	}
+	const T* const in[2] = {ap, r};
+	T* const out[1] = {sv};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(-alpha, v[0], v[1]); });  // ref:2245-2247
 }
 
 template <typename T>
@@ -98,22 +97,23 @@ __global__ void stepCoefOmega(const T* __restrict__ sums, StepState<T>* st) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void stepUpdateXR(int n, const StepState<T>* __restrict__ st, const T* __restrict__ p, const T* __restrict__ sv,
-                                                    const T* __restrict__ as, const T* __restrict__ r0, T* __restrict__ x, T* __restrict__ r,
-                                                    T* __restrict__ partials) {
+__global__ __launch_bounds__(TPB) void stepUpdateXR(int n, const StepState<T>* __restrict__ st, const T* p, const T* sv, const T* as, const T* r0,
+                                                    T* x, T* r, T* __restrict__ partials) {
 	__shared__ T red[4];
 	if (st->f[0]) return;
 	const T alpha = st->c[1];
 	const T omega = st->c[2];
 	T acc0 = T(0), acc1 = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		const T si = sv[i];
-		x[i] = smmFma(alpha, p[i], smmFma(omega, si, x[i]));  // ref:2264
-		const T ri = smmFma(-omega, as[i], si);               // ref:2265
-		r[i] = ri;
+	const T* const in[5] = {sv, x, p, as, r0};
+	T* const out[2] = {x, r};
+	streamMap<T, false, 5, 2>(n, in, out, [&](const T(&v)[5], T(&o)[2]) {
+		const T si = v[0];
+		o[0] = smmFma(alpha, v[2], smmFma(omega, si, v[1]));  // ref:2264
+		const T ri = smmFma(-omega, v[3], si);                // ref:2265
+		o[1] = ri;
 		acc0 += ri * ri;
-		acc1 += ri * r0[i];
-	}
+		acc1 += ri * v[4];
+	});
 	const T s0 = blockSum256(acc0, red);
 	const T s1 = blockSum256(acc1, red);
 	if (threadIdx.x == 0) {
@@ -136,16 +136,15 @@ __global__ void stepCoefBeta(const T* __restrict__ sums, StepState<T>* st, T eps
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void stepUpdateP(int n, const StepState<T>* __restrict__ st, const T* __restrict__ ap, const T* __restrict__ r,
-                                                   T* __restrict__ p) {
+__global__ __launch_bounds__(TPB) void stepUpdateP(int n, const StepState<T>* __restrict__ st, const T* ap, const T* r, T* p) {
 	// the reference also updates p on the converging iteration (ref:2272-2274 precede the loop test); p is not an output,
 	// so that last update is skipped together with every later no-op iteration
 	if (st->f[0]) return;
 	const T beta = st->c[3];
 	const T omega = st->c[2];
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		p[i] = smmFma(beta, smmFma(-omega, ap[i], p[i]), r[i]);
-	}
+	const T* const in[3] = {ap, p, r};
+	T* const out[1] = {p};
+	streamMap<T, false, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) { o[0] = smmFma(beta, smmFma(-omega, v[0], v[1]), v[2]); });
 }
 
 static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, NPART))); }
@@ -267,18 +266,20 @@ __global__ void cgStepCoefAlpha(const T* __restrict__ sums, StepState<T>* st) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void cgStepUpdateXR(int n, const StepState<T>* __restrict__ st, const T* __restrict__ p, const T* __restrict__ Ap,
-                                                      const T* xcur, T* x, T* __restrict__ r, T* __restrict__ partials) {
+__global__ __launch_bounds__(TPB) void cgStepUpdateXR(int n, const StepState<T>* __restrict__ st, const T* p, const T* Ap, const T* xcur, T* x, T* r,
+                                                      T* __restrict__ partials) {
 	__shared__ T red[4];
 	if (st->f[0]) return;
 	const T alpha = st->c[1];
 	T acc = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		x[i] = smmFma(alpha, p[i], xcur[i]);  // ref:2372
-		const T ri = smmFma(-alpha, Ap[i], r[i]);
-		r[i] = ri;
+	const T* const in[4] = {p, xcur, Ap, r};
+	T* const out[2] = {x, r};
+	streamMap<T, false, 4, 2>(n, in, out, [&](const T(&v)[4], T(&o)[2]) {
+		o[0] = smmFma(alpha, v[0], v[1]);  // ref:2372
+		const T ri = smmFma(-alpha, v[2], v[3]);
+		o[1] = ri;
 		acc += ri * ri;
-	}
+	});
 	const T s = blockSum256(acc, red);
 	if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
@@ -299,12 +300,12 @@ __global__ void cgStepCoefBeta(const T* __restrict__ sums, StepState<T>* st, T e
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void cgStepUpdateP(int n, const StepState<T>* __restrict__ st, const T* __restrict__ r, T* __restrict__ p) {
+__global__ __launch_bounds__(TPB) void cgStepUpdateP(int n, const StepState<T>* __restrict__ st, const T* r, T* p) {
 	if (st->f[0]) return;
 	const T beta = st->c[3];
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		p[i] = smmFma(beta, p[i], r[i]);  // ref:2391-2393
-	}
+	const T* const in[2] = {p, r};
+	T* const out[1] = {p};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });  // ref:2391-2393
 }
 
 template <typename T>
