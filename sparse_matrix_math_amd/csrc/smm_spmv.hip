@@ -173,7 +173,11 @@ __device__ __forceinline__ double readLane(double v, int j) {
 
 template <typename T>
 __device__ __forceinline__ T gatherX(const T* __restrict__ x, unsigned byteOffset) {
+#ifdef SMM_EXP_NOGATHER  // ablation builds only: what the kernel costs without its x[] loads
+	return T(1) + T(byteOffset & 1u);
+#else
 	return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + byteOffset);
+#endif
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smmDynLds[];

@@ -121,6 +121,75 @@ __global__ __launch_bounds__(256) void xrVec(long long n, double alpha, const do
 	if (acc == 123.456) parts[0] = acc;
 }
 
+// The SpMV STREAM kernel's skeleton without its gathers: a persistent workgroup walks tiles of NV * 1024 elements of two
+// arrays; the tile is fetched one tile ahead into registers (NV 16-byte non-temporal loads per lane and array), stored to
+// LDS, and after a barrier every lane sums a strided slice of it out of LDS (like lane = row walking its row).  MODE 0: no
+// LDS (sum straight from the registers); MODE 1: through LDS with the two barriers; XCD: deal contiguous eighths to
+// blockIdx % 8 like the SpMV does, otherwise tiles are interleaved over all workgroups.
+template <int NV, int MODE, bool XCD>
+__global__ __launch_bounds__(256) void tileKernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, int nTiles, float* __restrict__ sink) {
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	float* sa = lds;
+	float* sb = lds + NV * 1024 + 16;
+	const int t = threadIdx.x;
+	int tile, step, end;
+	if (XCD) {
+		const int g = blockIdx.x % 8;
+		const int slots = (gridDim.x - g + 7) / 8;
+		const int per = (nTiles + 7) / 8;
+		tile = g * per + blockIdx.x / 8;
+		step = slots;
+		end = min(nTiles, (g + 1) * per);
+	} else {
+		tile = blockIdx.x;
+		step = gridDim.x;
+		end = nTiles;
+	}
+	f32x4 ra[NV], rb[NV];
+	auto load = [&](int tl) {
+		const long long base = static_cast<long long>(tl) * NV * 256;
+#pragma unroll
+		for (int v = 0; v < NV; ++v) {
+			ra[v] = __builtin_nontemporal_load(a + base + v * 256 + t);
+			rb[v] = __builtin_nontemporal_load(b + base + v * 256 + t);
+		}
+	};
+	float acc = 0.f;
+	if (tile < end) load(tile);
+	while (tile < end) {
+		const int next = tile + step;
+		if (MODE == 0) {
+			f32x4 ca[NV], cb[NV];
+#pragma unroll
+			for (int v = 0; v < NV; ++v) {
+				ca[v] = ra[v];
+				cb[v] = rb[v];
+			}
+			if (next < end) load(next);
+#pragma unroll
+			for (int v = 0; v < NV; ++v) {
+				const f32x4 p = ca[v] * cb[v];
+				acc += p.x + p.y + p.z + p.w;
+			}
+		} else {
+#pragma unroll
+			for (int v = 0; v < NV; ++v) {
+				*reinterpret_cast<f32x4*>(sa + 4 * (v * 256 + t)) = ra[v];
+				*reinterpret_cast<f32x4*>(sb + 4 * (v * 256 + t)) = rb[v];
+			}
+			__syncthreads();
+			if (next < end) load(next);
+			// lane = "row" of NV * 4 consecutive entries (odd stride would need padding; 4 * NV words: conflicts like a real row length)
+			const int k0 = t * (NV * 4);
+#pragma unroll
+			for (int u = 0; u < NV * 4; ++u) acc += sa[k0 + u] * sb[k0 + u];
+			__syncthreads();
+		}
+		tile = next;
+	}
+	if (acc == 123.456f) sink[0] = acc;
+}
+
 template <typename F>
 static double timeIt(F launch, int reps) {
 	hipEvent_t e0, e1;
@@ -170,6 +239,33 @@ int main() {
 	runOne<2, true>(a, b, n16, sink, cus);
 	runOne<4, true>(a, b, n16, sink, cus);
 	runOne<8, true>(a, b, n16, sink, cus);
+	// working sets that fit the 256 MB Infinity Cache (and, at 16 MB, the eight 4 MB L2s): what the path from beyond L2 delivers
+	// when HBM is not involved
+	for (long long mb : {16LL, 64LL, 128LL, 192LL, 512LL}) {
+		const long long m16 = mb * 1024 * 1024 / 16;
+		const double ms = timeIt([&] { readKernel<8, true><<<cus * 4, 256>>>(a, m16, sink); }, 50);
+		const double ms2 = timeIt([&] { readKernel<8, false><<<cus * 4, 256>>>(a, m16, sink); }, 50);
+		std::printf("re-reading %4lld MB: nt %7.4f ms %8.1f GB/s | plain %7.4f ms %8.1f GB/s\n", mb, ms, m16 * 16.0 / ms / 1e6, ms2, m16 * 16.0 / ms2 / 1e6);
+	}
+	{
+		const double bytes = 2.0 * n16 * 16;
+		auto tiles = [&](auto kern, int nv, int perCU, const char* name) {
+			const int nTiles = static_cast<int>(n16 / (nv * 256));
+			const size_t ldsBytes = (2 * (nv * 1024 + 16)) * sizeof(float);
+			const double ms = timeIt([&] { kern<<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink); }, 10);
+			std::printf("tile skeleton %-28s NV=%d wgs/CU=%d: %7.3f ms %7.1f GB/s\n", name, nv, perCU, ms, bytes / ms / 1e6);
+		};
+		for (int perCU : {2, 4}) {
+			tiles(tileKernel<4, 0, false>, 4, perCU, "registers only, interleaved");
+			tiles(tileKernel<4, 0, true>, 4, perCU, "registers only, XCD eighths");
+			tiles(tileKernel<4, 1, false>, 4, perCU, "through LDS, interleaved");
+			tiles(tileKernel<4, 1, true>, 4, perCU, "through LDS, XCD eighths");
+		}
+		for (int perCU : {4, 8}) {
+			tiles(tileKernel<2, 1, true>, 2, perCU, "through LDS, XCD eighths");
+			tiles(tileKernel<2, 1, false>, 2, perCU, "through LDS, interleaved");
+		}
+	}
 	{
 		// 4 vectors of 1 GiB (134 M doubles, the 512^3 grid): 4 reads + 2 writes = 6.44 GB per launch
 		const long long n = 134217728LL;
