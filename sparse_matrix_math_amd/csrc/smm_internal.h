@@ -145,6 +145,14 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 int profBegin(hipStream_t s);
 void profEnd(int slot, hipStream_t s);
 
+// flag ORed into the `op` argument of the STREAM / PATTERN kernels: write out[] with non-temporal stores.  Set for outputs too
+// large to still be in cache when the next kernel reads them (measured on the 512^3 fp64 Laplacian: 3.15 -> 2.97 ms; written
+// bytes cost 2-4x read bytes on this memory system, tools/membw.hip)
+constexpr int SPMV_NT_OUT = 0x100;
+inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
+	return static_cast<double>(m->rows) * static_cast<double>(elemBytes) > 64.0 * 1024 * 1024 ? SPMV_NT_OUT : 0;
+}
+
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows);
 // PATTERN family: analyse + verify the matrix (idempotent), and the launch behind launchSpmv
 int ensurePattern(smm_hip_csr* m);

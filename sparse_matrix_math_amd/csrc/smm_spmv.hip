@@ -191,11 +191,13 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smmDynLds[];
 // tile (LDS ready / LDS free); the HBM stream of tile i+1 is in flight during (2) of tile i.
 template <typename T, int L>
 __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int chunkTiles, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
-                                                        const int* __restrict__ positions, const T* __restrict__ values, int op, const T* lhs,
+                                                        const int* __restrict__ positions, const T* __restrict__ values, int opFlags, const T* lhs,
                                                         const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
                                                         T* __restrict__ partials, const int* __restrict__ doneFlag) {
 	using Cfg = StreamCfg<T>;
 	constexpr int GATHER = 8;
+	const int op = opFlags & 0xFF;
+	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;  // out[] of a large matrix is streamed, not cached (host decides)
 	constexpr int LW = L > WAVE ? WAVE : L;  // lanes per row
 	constexpr int RW = WAVE / LW;            // rows per wavefront
 	constexpr int RT = RW * (TPB / WAVE);    // rows per tile
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 			if (t < nrows) sStart[t] = ps - a0;
 			if (t == 0) sStart[nrows] = n1 - a0;
 		}
-		__syncthreads();
+		ldsBarrier();  // the tile is in LDS (LDS-only barrier: global loads and stores stay in flight across it)
 		// ---- prefetch this workgroup's next tile ----
 		j += groupSlots;
 		const int ntile = tileOf(j);
@@ -398,12 +400,17 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 			if (piece == 0 && rl < nrows) {
 				const int row = r0 + rl;
 				const T o = applyOp(op, lhs, row, dot);
-				out[row] = o;
+#ifdef SMM_EXP_NOOUT  // ablation builds only: the kernel without its out[] stream
+				if (o == T(123.456)) out[row] = o;
+#else
+				if (ntOut) __builtin_nontemporal_store(o, out + row);
+				else out[row] = o;
+#endif
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
 			}
 		}
-		__syncthreads();  // every lane is done with the LDS copy of this tile
+		ldsBarrier();  // every lane is done with the LDS copy of this tile
 		tile = ntile;
 		m0 = m0n;
 		m1 = m1n;
@@ -545,7 +552,7 @@ static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 	const int nGroups = std::min(8, grid);
 	const int chunkTiles = m->stream_chunk_tiles > 0 ? m->stream_chunk_tiles : (m->n_rowblocks + nGroups - 1) / nGroups;
 	spmvStreamKernel<T, L><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, chunkTiles, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
-	                                            op, lhs, x, out, dotMode, w1, partials, doneFlag);
+	                                            op | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1, partials, doneFlag);
 }
 
 template <typename T>

@@ -145,11 +145,13 @@ template <typename T, int L>
 __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, int cols, int nOff, const int* __restrict__ offs,
                                                          const int2* __restrict__ rowBlocks, const int* __restrict__ start,
                                                          const unsigned long long* __restrict__ masks, const int* __restrict__ positions,
-                                                         const T* __restrict__ values, int op, const T* lhs, const T* __restrict__ x, T* out,
+                                                         const T* __restrict__ values, int opFlags, const T* lhs, const T* __restrict__ x, T* out,
                                                          int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
                                                          const int* __restrict__ doneFlag) {
 	using Cfg = PatCfg<T>;
 	constexpr int GATHER = 8;
+	const int op = opFlags & 0xFF;
+	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;
 	constexpr int LW = L > WAVE ? WAVE : L;
 	constexpr int RW = WAVE / LW;
 	constexpr int RT = RW * (TPB / WAVE);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 			}
 			if (t == 0) sStart[nrows] = n1 - a0;
 		}
-		__syncthreads();
+		ldsBarrier();
 		const int ntile = tile + groupSlots;
 		const int2 m0n = nm0, m1n = nm1;
 		if (ntile < tileEnd) {
@@ -291,12 +293,13 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 			}
 			if (piece == 0 && rl < nrows) {
 				const T o = patApplyOp(op, lhs, row, dot);
-				out[row] = o;
+				if (ntOut) __builtin_nontemporal_store(o, out + row);
+				else out[row] = o;
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
 			}
 		}
-		__syncthreads();
+		ldsBarrier();
 		tile = ntile;
 		m0 = m0n;
 		m1 = m1n;
@@ -402,7 +405,7 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* x, T*
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
 	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, numCUs() * perCU), NPART));
 	spmvPatternKernel<T, L><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, m->cols, m->pat_k, m->d_pat_off, reinterpret_cast<const int2*>(m->d_pat_rowblocks),
-	                                             m->d_start, m->d_pat_masks, m->d_positions, static_cast<const T*>(m->d_values), op, lhs, x, out, dotMode,
+	                                             m->d_start, m->d_pat_masks, m->d_positions, static_cast<const T*>(m->d_values), op | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode,
 	                                             w1, partials, doneFlag);
 }
 

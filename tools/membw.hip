@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void xrVec(long long n, double alpha, const do
 // LDS (sum straight from the registers); MODE 1: through LDS with the two barriers; XCD: deal contiguous eighths to
 // blockIdx % 8 like the SpMV does, otherwise tiles are interleaved over all workgroups.
 template <int NV, int MODE, bool XCD>
-__global__ __launch_bounds__(256) void tileKernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, int nTiles, float* __restrict__ sink) {
+__global__ __launch_bounds__(256) void tileKernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, int nTiles, float* __restrict__ sink,
+                                                  double* __restrict__ y = nullptr) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	float* sa = lds;
 	float* sb = lds + NV * 1024 + 16;
@@ -183,6 +184,21 @@ __global__ __launch_bounds__(256) void tileKernel(const f32x4* __restrict__ a, c
 			const int k0 = t * (NV * 4);
 #pragma unroll
 			for (int u = 0; u < NV * 4; ++u) acc += sa[k0 + u] * sb[k0 + u];
+			// MODE 2 / 3: one 8-byte result per lane and tile, like the SpMV's out[] (plain / non-temporal store)
+			if (MODE == 2) y[static_cast<long long>(tile) * 256 + t] = acc;
+			if (MODE == 3) __builtin_nontemporal_store(static_cast<double>(acc), y + static_cast<long long>(tile) * 256 + t);
+			if (MODE == 4 || MODE == 5) {
+				// results meet in LDS (after everybody is done with the tile), then 128 lanes write the 2 KB with 16-byte stores
+				__syncthreads();
+				reinterpret_cast<double*>(sa)[t] = acc;
+				__syncthreads();
+				if (t < 128) {
+					const f64x2 v = reinterpret_cast<const f64x2*>(sa)[t];
+					f64x2* dst = reinterpret_cast<f64x2*>(y + static_cast<long long>(tile) * 256) + t;
+					if (MODE == 5) __builtin_nontemporal_store(v, dst);
+					else *dst = v;
+				}
+			}
 			__syncthreads();
 		}
 		tile = next;
@@ -252,7 +268,7 @@ int main() {
 		auto tiles = [&](auto kern, int nv, int perCU, const char* name) {
 			const int nTiles = static_cast<int>(n16 / (nv * 256));
 			const size_t ldsBytes = (2 * (nv * 1024 + 16)) * sizeof(float);
-			const double ms = timeIt([&] { kern<<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink); }, 10);
+			const double ms = timeIt([&] { kern<<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, nullptr); }, 10);
 			std::printf("tile skeleton %-28s NV=%d wgs/CU=%d: %7.3f ms %7.1f GB/s\n", name, nv, perCU, ms, bytes / ms / 1e6);
 		};
 		for (int perCU : {2, 4}) {
@@ -260,6 +276,23 @@ int main() {
 			tiles(tileKernel<4, 0, true>, 4, perCU, "registers only, XCD eighths");
 			tiles(tileKernel<4, 1, false>, 4, perCU, "through LDS, interleaved");
 			tiles(tileKernel<4, 1, true>, 4, perCU, "through LDS, XCD eighths");
+		}
+		{
+			// the same skeleton writing 8 bytes per lane and tile (NV = 2: 16 KB read per 2 KB written, the 7-point fp64 stencil's ratio)
+			double* y = nullptr;
+			CHECK(hipMalloc(&y, (n16 / 512 + 1) * 256 * sizeof(double)));
+			for (int perCU : {4, 6}) {
+				const int nTiles = static_cast<int>(n16 / 512);
+				const size_t ldsBytes = (2 * (2 * 1024 + 16)) * sizeof(float);
+				const double wbytes = nTiles * 256.0 * 8;
+				const double m1 = timeIt([&] { tileKernel<2, 1, true><<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
+				const double m2 = timeIt([&] { tileKernel<2, 2, true><<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
+				const double m3 = timeIt([&] { tileKernel<2, 3, true><<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
+				const double m4 = timeIt([&] { tileKernel<2, 4, true><<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
+				const double m5 = timeIt([&] { tileKernel<2, 5, true><<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
+				std::printf("tile skeleton NV=2 wgs/CU=%d: read only %.3f ms | + %.2f GB written, plain stores %.3f ms | non-temporal stores %.3f ms | 16-byte stores via LDS %.3f ms | same nt %.3f ms\n", perCU, m1, wbytes / 1e9, m2, m3, m4, m5);
+			}
+			CHECK(hipFree(y));
 		}
 		for (int perCU : {4, 8}) {
 			tiles(tileKernel<2, 1, true>, 2, perCU, "through LDS, XCD eighths");
