@@ -104,12 +104,19 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
     t0 = time.perf_counter()
     st, _, it, _ = oracle.bicgstab(csr, b, x0, iters, 0.0, omp=True)
     dt = time.perf_counter() - t0
+    # the same loop on one core (what the reference's default, non-TBB build does): two iterations are enough to time it
+    oracle.set_threads(1)
+    t0 = time.perf_counter()
+    _, _, it1, _ = oracle.bicgstab(csr, b, x0, 2, 0.0, omp=True)
+    dt1 = time.perf_counter() - t0
+    oracle.set_threads(cores)
     return {
         "value": it / dt,
         "unit": "iterations/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{it} BiCGStab iterations of the same {len(b)}-row matrix (OpenMP port of the reference loop, {dt:.1f} s)",
+        "value_1_core": it1 / dt1,
     }
 
 
