@@ -1,7 +1,7 @@
 // smm_blas1.hip -- streaming reductions and AXPY-style updates (gfx950).
 //
 // dot: Vector<T>::operator* (ref:305-328) / secondNormSquared (ref:296-303).  The reference sums serially (or as
-// a grain-8192 TBB tree); here every lane keeps a private sum over a grid-strided slice (16-byte loads), lanes
+// a grain-8192 TBB tree); here every lane keeps a private sum over its packs of 16 bytes (streamMap, smm_device.h), lanes
 // meet in a wave butterfly (__shfl_xor), waves meet through LDS, and each of the NPART workgroups writes one
 // partial; a one-workgroup kernel adds the partials in a fixed order.  No atomics: results are bitwise
 // reproducible from run to run.  Accumulation is in T, like the reference.
@@ -13,19 +13,6 @@
 namespace smm {
 
 constexpr int TPB = 256;
-
-template <typename T>
-struct Vec16;
-template <>
-struct Vec16<float> {
-	using type = float4;
-	static constexpr int N = 4;
-};
-template <>
-struct Vec16<double> {
-	using type = double2;
-	static constexpr int N = 2;
-};
 
 template <typename T, bool NT>
 __global__ __launch_bounds__(TPB) void dotPartialsKernel(int n, const T* a, const T* b, T* __restrict__ partials, const int* __restrict__ doneFlag) {
@@ -54,17 +41,20 @@ __global__ __launch_bounds__(TPB) void sumPartialsKernel(const T* __restrict__ p
 
 template <typename T>
 __global__ __launch_bounds__(TPB) void axpyKernel(int n, T alpha, const T* x, const T* y, T* out) {
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		out[i] = smmFma(alpha, x[i], y[i]);
-	}
+	const T* const in[2] = {x, y};
+	T* const o[1] = {out};
+	streamMap<T, false, 2, 1>(n, in, o, [&](const T(&v)[2], T(&r)[1]) { r[0] = smmFma(alpha, v[0], v[1]); });
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void copy2Kernel(int n, const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2) {
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		const T v = src[i];
-		d1[i] = v;
-		if (d2) d2[i] = v;
+__global__ __launch_bounds__(TPB) void copy2Kernel(int n, const T* src, T* d1, T* d2) {
+	const T* const in[1] = {src};
+	if (d2) {
+		T* const o[2] = {d1, d2};
+		streamMap<T, false, 1, 2>(n, in, o, [](const T(&v)[1], T(&r)[2]) { r[0] = r[1] = v[0]; });
+	} else {
+		T* const o[1] = {d1};
+		streamMap<T, false, 1, 1>(n, in, o, [](const T(&v)[1], T(&r)[1]) { r[0] = v[0]; });
 	}
 }
 

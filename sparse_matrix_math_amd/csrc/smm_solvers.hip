@@ -105,18 +105,20 @@ __global__ __launch_bounds__(TPB) void cgBetaScal(const T* __restrict__ partials
 // ---- vector stages -------------------------------------------------------------------------------------
 // x = alpha p + xcur ; r = -alpha Ap + r ; partial ||r||^2   (ref:2371-2375)
 template <typename T>
-__global__ __launch_bounds__(TPB) void cgUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ p, const T* __restrict__ Ap,
-                                                  const T* xcur, T* x, T* __restrict__ r, T* __restrict__ partials, int wantNorm) {
+__global__ __launch_bounds__(TPB) void cgUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* p, const T* Ap, const T* xcur, T* x, T* r,
+                                                  T* __restrict__ partials, int wantNorm) {
 	__shared__ T red[4];
 	if (sc->done) return;
 	const T alpha = sc->alpha;
 	T acc = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		x[i] = smmFma(alpha, p[i], xcur[i]);
-		const T ri = smmFma(-alpha, Ap[i], r[i]);
-		r[i] = ri;
+	const T* const in[4] = {p, xcur, Ap, r};
+	T* const out[2] = {x, r};
+	streamMap<T, false, 4, 2>(n, in, out, [&](const T(&v)[4], T(&o)[2]) {
+		o[0] = smmFma(alpha, v[0], v[1]);
+		const T ri = smmFma(-alpha, v[2], v[3]);
+		o[1] = ri;
 		acc += ri * ri;
-	}
+	});
 	if (wantNorm) {
 		const T s = blockSum256(acc, red);
 		if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(TPB) void cgUpdateXR(int n, const Scal<T>* __restri
 
 // p = beta p + z   (ref:2391-2393 with z = r; ref:2497-2499 with z = M^-1 r)
 template <typename T>
-__global__ __launch_bounds__(TPB) void cgUpdateP(int n, const Scal<T>* __restrict__ sc, T* __restrict__ p, const T* __restrict__ z) {
+__global__ __launch_bounds__(TPB) void cgUpdateP(int n, const Scal<T>* __restrict__ sc, T* p, const T* z) {
 	if (sc->done) return;
 	const T beta = sc->beta;
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		p[i] = smmFma(beta, p[i], z[i]);
-	}
+	const T* const in[2] = {p, z};
+	T* const out[1] = {p};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
 }
 
 // ---- fused forms: the scalar stage is folded into the vector kernel that consumes it --------------------------------------
@@ -296,95 +298,6 @@ __global__ __launch_bounds__(TPB) void bicgInitScal(const T* __restrict__ partia
 	}
 }
 
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgAlphaScal(const T* __restrict__ partials, Scal<T>* sc) {
-	__shared__ T red[4];
-	if (sc->done) return;
-	const T denom = sumParts(partials, red);  // ap.r0, ref:2243
-	if (threadIdx.x == 0) {
-		sc->denom = denom;
-		sc->alpha = sc->rr / denom;  // ref:2244
-	}
-}
-
-// s = -alpha ap + r   (ref:2245-2247)
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgUpdateS(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ ap, const T* __restrict__ r,
-                                                   T* __restrict__ sv) {
-	if (sc->done) return;
-	const T alpha = sc->alpha;
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		sv[i] = smmFma(-alpha, ap[i], r[i]);
-	}
-}
-
-// omega = (as.s) / (as.as)   (ref:2259-2261); partials = as.as, partials2 = as.s
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgOmegaScal(const T* __restrict__ partials, const T* __restrict__ partials2, Scal<T>* sc) {
-	__shared__ T red[4];
-	if (sc->done) return;
-	const T asas = sumParts(partials, red);
-	const T ass = sumParts(partials2, red);
-	if (threadIdx.x == 0) {
-		sc->omega = ass / asas;
-	}
-}
-
-// x = alpha p + (omega s + x) ; r = -omega as + s ; partial ||r||^2 and r.r0   (ref:2263-2269)
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ p, const T* __restrict__ sv,
-                                                    const T* __restrict__ as, const T* __restrict__ r0, T* __restrict__ x, T* __restrict__ r,
-                                                    T* __restrict__ partials, T* __restrict__ partials2) {
-	__shared__ T red[4];
-	if (sc->done) return;
-	const T alpha = sc->alpha;
-	const T omega = sc->omega;
-	T acc0 = T(0), acc1 = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		const T si = sv[i];
-		x[i] = smmFma(alpha, p[i], smmFma(omega, si, x[i]));
-		const T ri = smmFma(-omega, as[i], si);
-		r[i] = ri;
-		acc0 += ri * ri;
-		acc1 += ri * r0[i];
-	}
-	const T s0 = blockSum256(acc0, red);
-	const T s1 = blockSum256(acc1, red);
-	if (threadIdx.x == 0) {
-		partials[blockIdx.x] = s0;
-		partials2[blockIdx.x] = s1;
-	}
-}
-
-// resL2Norm, beta, loop condition (ref:2268-2277)
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgBetaScal(const T* __restrict__ partials, const T* __restrict__ partials2, Scal<T>* sc, T eps) {
-	__shared__ T red[4];
-	if (sc->done) return;
-	const T rr = sumParts(partials, red);
-	const T newRR0 = sumParts(partials2, red);
-	if (threadIdx.x == 0) {
-		const T res = sizeof(T) == 4 ? static_cast<T>(__fsqrt_rn(static_cast<float>(rr))) : static_cast<T>(__dsqrt_rn(static_cast<double>(rr)));
-		sc->res = res;
-		sc->beta = (newRR0 * sc->alpha) / (sc->rr * sc->omega);  // ref:2271
-		sc->rr = newRR0;
-		sc->iters += 1;
-		if (!(res > eps)) sc->done = 1;  // while (resL2Norm > eps ...), NaN leaves the loop (ref:2277)
-	}
-}
-
-// p = beta (-omega ap + p) + r   (ref:2272-2274)
-template <typename T>
-__global__ __launch_bounds__(TPB) void bicgUpdateP(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ ap, const T* __restrict__ r,
-                                                   T* __restrict__ p) {
-	if (sc->done) return;
-	const T beta = sc->beta;
-	const T omega = sc->omega;
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		p[i] = smmFma(beta, smmFma(-omega, ap[i], p[i]), r[i]);
-	}
-}
-
 // ---- BiCGSymmetric stages (ref:2021-2102) ----------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(TPB) void bsymInitScal(const T* __restrict__ partials, Scal<T>* sc) {
@@ -415,20 +328,22 @@ __global__ __launch_bounds__(TPB) void bsymAlphaScal(const T* __restrict__ parti
 
 // x += alpha p ; r -= alpha ap  (ref:2068-2071: plain += / -= forms, not _smm_fma)
 template <typename T>
-__global__ __launch_bounds__(TPB) void bsymUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ p, const T* __restrict__ ap,
-                                                    T* __restrict__ x, T* __restrict__ r, T* __restrict__ partials) {
+__global__ __launch_bounds__(TPB) void bsymUpdateXR(int n, const Scal<T>* __restrict__ sc, const T* p, const T* ap, T* x, T* r,
+                                                    T* __restrict__ partials) {
 	__shared__ T red[4];
 	if (sc->done) return;
 	const T alpha = sc->alpha;
 	T acc = T(0);
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		const T pa = alpha * p[i];
-		x[i] = x[i] + pa;
-		const T qa = alpha * ap[i];
-		const T ri = r[i] - qa;
-		r[i] = ri;
+	const T* const in[4] = {p, x, ap, r};
+	T* const out[2] = {x, r};
+	streamMap<T, false, 4, 2>(n, in, out, [&](const T(&v)[4], T(&o)[2]) {
+		const T pa = alpha * v[0];
+		o[0] = v[1] + pa;
+		const T qa = alpha * v[2];
+		const T ri = v[3] - qa;
+		o[1] = ri;
 		acc += ri * ri;
-	}
+	});
 	const T s = blockSum256(acc, red);
 	if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
@@ -453,13 +368,15 @@ __global__ __launch_bounds__(TPB) void bsymBetaScal(const T* __restrict__ partia
 
 // p = r + beta p  (ref:2090-2092)
 template <typename T>
-__global__ __launch_bounds__(TPB) void bsymUpdateP(int n, const Scal<T>* __restrict__ sc, const T* __restrict__ r, T* __restrict__ p) {
+__global__ __launch_bounds__(TPB) void bsymUpdateP(int n, const Scal<T>* __restrict__ sc, const T* r, T* p) {
 	if (sc->done) return;
 	const T beta = sc->beta;
-	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
-		const T bp = beta * p[i];
-		p[i] = r[i] + bp;
-	}
+	const T* const in[2] = {p, r};
+	T* const out[1] = {p};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) {
+		const T bp = beta * v[0];
+		o[0] = v[1] + bp;
+	});
 }
 
 // ---------------------------------------------------------------------------------------------------------
