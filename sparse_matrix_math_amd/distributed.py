@@ -191,9 +191,17 @@ class DistBiCGStab:
         # views used every iteration, made once (the loop below is host-side latency critical at 8 GPUs)
         sums1, sums2 = ops.sums[:1], ops.sums[:2]
         x_view, p_own, s_own = ops.own(ops.x_ext), ops.own(ops.p_ext), ops.own(ops.s_ext)
+        # Preconditioned form (ref:2209-2224, 2234-2235, 2250-2251): every A v is followed by M^-1.  M is BLOCK-JACOBI BY RANK:
+        # each rank applies its preconditioner (Jacobi / ILU0 / SGS) of its own diagonal block A_loc, no communication; with
+        # one rank it is the single-GPU preconditioner, with more ranks a weaker one (iteration counts differ).
+        pre = bool(getattr(ops, "has_precond", False))
         # r = b - A x (ref:2215)
         ops.copy_into_ext(ops.x_ext, x_own)
-        self._matvec(ops.x_ext, x_view, ops.r, OP_SUB, b, 0, None)
+        if pre:
+            self._matvec(ops.x_ext, x_view, ops.scratch, OP_SUB, b, 0, None)
+            ops.precond_apply(ops.scratch, ops.r)  # ref:2217-2224
+        else:
+            self._matvec(ops.x_ext, x_view, ops.r, OP_SUB, b, 0, None)
         ops.stage(STAGE_INIT_LOCAL, x_own, eps)  # r0 = p = r, local r.r0
         comm.all_reduce_sum(sums1)
         ops.stage(STAGE_INIT_APPLY, x_own, eps)
@@ -204,12 +212,23 @@ class DistBiCGStab:
                 done, _, _ = ops.result()
                 if done:
                     break
-            self._matvec(ops.p_ext, p_own, ops.ap, OP_ASSIGN, None, 1, ops.r0)  # ap = A p, local ap.r0
-            ops.stage(STAGE_ALPHA_LOCAL, x_own, eps)
+            if pre:
+                self._matvec(ops.p_ext, p_own, ops.scratch, OP_ASSIGN, None, 0, None)  # ref:2234
+                ops.precond_apply(ops.scratch, ops.ap)  # ap = M^-1 A p, ref:2235
+                ops.dot_into(ops.ap, ops.r0, 0)  # local ap.r0, ref:2243
+            else:
+                self._matvec(ops.p_ext, p_own, ops.ap, OP_ASSIGN, None, 1, ops.r0)  # ap = A p, local ap.r0
+                ops.stage(STAGE_ALPHA_LOCAL, x_own, eps)
             comm.all_reduce_sum(sums1)
             ops.stage(STAGE_ALPHA_APPLY, x_own, eps)  # alpha, s
-            self._matvec(ops.s_ext, s_own, ops.as_, OP_ASSIGN, None, 2, s_own)  # as = A s, as.as, as.s
-            ops.stage(STAGE_OMEGA_LOCAL, x_own, eps)
+            if pre:
+                self._matvec(ops.s_ext, s_own, ops.scratch, OP_ASSIGN, None, 0, None)  # ref:2250
+                ops.precond_apply(ops.scratch, ops.as_)  # as = M^-1 A s, ref:2251
+                ops.dot_into(ops.as_, ops.as_, 0)  # local as.as and as.s, ref:2259-2261
+                ops.dot_into(ops.as_, s_own, 1)
+            else:
+                self._matvec(ops.s_ext, s_own, ops.as_, OP_ASSIGN, None, 2, s_own)  # as = A s, as.as, as.s
+                ops.stage(STAGE_OMEGA_LOCAL, x_own, eps)
             comm.all_reduce_sum(sums2)
             ops.stage(STAGE_OMEGA_APPLY, x_own, eps)  # omega, x, r, local ||r||^2 and r.r0
             comm.all_reduce_sum(sums2)
@@ -262,7 +281,7 @@ class HipOps:
     """Local kernels on one MI355X through the C ABI (csrc/smm_stepwise.hip, smm_spmv.hip).  Vectors are torch tensors
     (device memory management only); all launches go to torch's current stream so RCCL and the kernels are ordered."""
 
-    def __init__(self, torch, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, np_dtype, device):
+    def __init__(self, torch, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, np_dtype, device, precond=None):
         from . import _lib, host
 
         self.torch, self.host, self.lib = torch, host, _lib.load()
@@ -291,12 +310,29 @@ class HipOps:
         self._stage = getattr(self.lib, f"smm_hip_bicgstab_ws_stage_{self.suf}")
         self._result = getattr(self.lib, f"smm_hip_bicgstab_ws_result_{self.suf}")
         self._cg_stage = getattr(self.lib, f"smm_hip_cg_ws_stage_{self.suf}")
+        # block-Jacobi preconditioning: this rank's preconditioner of its diagonal block A_loc (square, local column numbers)
+        self.has_precond = precond is not None and int(precond) != 0
+        if self.has_precond:
+            self.M = host.Preconditioner(self.A_loc, precond)
+            self.scratch = torch.zeros(max(1, self.n_local), dtype=tdt, device=device)
+            self._apply = getattr(self.lib, f"smm_hip_precond_apply_dev_{self.suf}")
+            self._dot = getattr(self.lib, f"smm_hip_dot_dev_{self.suf}")
+            self._elem = self.np_dtype.itemsize
 
     def own(self, ext):
         return ext[self.own_offset:self.own_offset + self.n_local]
 
     def copy_into_ext(self, ext, own_values):
         self.own(ext).copy_(own_values)
+
+    def precond_apply(self, src, dst):
+        d = self.host._dptr
+        self.check(self._apply(self.M._h, d(src), d(dst), self._stream()))
+
+    def dot_into(self, a, b, k):
+        """sums[k] = a . b over this rank's rows (fixed-order partial sums, no atomics)"""
+        d = self.host._dptr
+        self.check(self._dot(self.n_local, d(a), d(b), ctypes.c_void_p(self.sums.data_ptr() + k * self._elem), self._stream()))
 
     def begin_solve(self):
         self._cached_stream = ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
@@ -333,9 +369,10 @@ class HipOps:
             self.ws = ctypes.c_void_p()
 
 
-def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np_dtype, device, group=None, solver="bicgstab"):
+def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np_dtype, device, group=None, solver="bicgstab", precond=None):
     """start/positions/values: this rank's rows (local start[], GLOBAL columns) as device tensors.  Collective.
-    solver: "bicgstab" (DistBiCGStab) or "cg" (DistCG)."""
+    solver: "bicgstab" (DistBiCGStab) or "cg" (DistCG).  precond (BiCGStab only): a SolverPreconditioner kind (JACOBI / ILU0 /
+    SYMMETRIC_GAUS_SEIDEL) applied block-Jacobi by rank."""
     comm = TorchComm(dist, group)
     rank = comm.rank
     own_lo, own_hi = bounds[rank], bounds[rank + 1]
@@ -347,7 +384,9 @@ def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np
     needs = comm.all_gather_pairs(cmin, cmax_excl, torch, device)
     sends, recvs = plan_halo(bounds, needs, rank)
     loc, rem = split_local_remote(torch, start, positions, values, own_lo, own_hi, cmin)
-    ops = HipOps(torch, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, np_dtype, device)
+    if precond is not None and solver == "cg":
+        raise ValueError("the distributed CG has no preconditioned form (the reference's PCG takes IC0 only, ref:2414)")
+    ops = HipOps(torch, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, np_dtype, device, precond=precond)
     solver = (DistCG if solver == "cg" else DistBiCGStab)(ops, comm, cmin, sends, recvs)
     solver.halo_elements = sum(hi - lo for _, lo, hi in recvs)
     return solver

@@ -12,8 +12,10 @@ class NumpyOps:
     """Same contract as distributed.HipOps, computed on the CPU with the oracle's SpMV: checks the driver's partition / halo /
     staging logic without a GPU.  Vectors are torch CPU tensors (so gloo can move them); arithmetic is numpy on their memory."""
 
-    def __init__(self, torch, oracle, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, dtype):
+    def __init__(self, torch, oracle, loc, rem, n_global, own_lo, own_hi, cmin, cmax_excl, dtype, precond=None):
         self.torch, self.oracle = torch, oracle
+        self.precond = precond  # None | "jacobi" | "sgs" | "ilu0": applied to this rank's diagonal block (block-Jacobi by rank)
+        self.has_precond = precond is not None
         self.dtype = np.dtype(dtype)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         self.n_global, self.n_local = n_global, own_hi - own_lo
@@ -26,6 +28,29 @@ class NumpyOps:
         self.partial = np.zeros(2, dtype=self.dtype)
         self.c = {"rr0": 0.0, "alpha": 0.0, "omega": 0.0, "beta": 0.0, "res": 0.0}
         self.done, self.iters = 0, 0
+        if self.has_precond:
+            self.scratch = torch.zeros(self.n_local, dtype=tdt)
+            if precond == "jacobi":
+                err, self.diag = oracle.jacobi_setup(self.csr["loc"])
+                assert err == 0
+            elif precond == "ilu0":
+                err, self.lu = oracle.ilu0_factorize(self.csr["loc"])
+                assert err == 0
+
+    def precond_apply(self, src, dst):
+        rhs = src.numpy().copy()
+        if self.precond == "jacobi":
+            out = self.oracle.jacobi_apply(self.diag, rhs)
+        elif self.precond == "sgs":
+            err, out = self.oracle.sgs_apply(self.csr["loc"], rhs)
+            assert err == 0
+        else:
+            err, out = self.oracle.ilu0_apply(self.csr["loc"], self.lu, rhs)
+            assert err == 0
+        dst.numpy()[:] = out
+
+    def dot_into(self, a, b, k):
+        self.sums.numpy()[k] = np.dot(a.numpy(), b.numpy())
 
     def own(self, ext):
         return ext[self.own_offset:self.own_offset + self.n_local]

@@ -37,7 +37,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, dtype_name, max_it, eps, out_dir):
+def _worker(rank, world, port, case, dtype_name, max_it, eps, out_dir, precond=None):
     import torch
     import torch.distributed as dist
 
@@ -65,7 +65,7 @@ def _worker(rank, world, port, case, dtype_name, max_it, eps, out_dir):
         needs = comm.all_gather_pairs(cmin, cmax, torch, "cpu")
         sends, recvs = plan_halo(bounds, needs, rank)
         loc, rem = split_local_remote(torch, lstart, lpos, lval, lo, hi, cmin)
-        ops = NumpyOps(torch, Oracle(), loc, rem, n, lo, hi, cmin, cmax, dtype)
+        ops = NumpyOps(torch, Oracle(), loc, rem, n, lo, hi, cmin, cmax, dtype, precond=precond)
         solver = DistBiCGStab(ops, comm, cmin, sends, recvs)
         x = torch.zeros(hi - lo, dtype=torch.float32 if dtype == np.float32 else torch.float64)
         status, iters, res = solver.solve(torch.from_numpy(b_full[lo:hi].copy()), x, max_it, eps, check_every=3)
@@ -123,3 +123,40 @@ def test_gloo_bicgstab_matches_single_process(tmp_path, oracle, world, case, dty
         assert iters == it_ref
     tol = 2e-4 if dtype == np.float32 else 1e-9
     assert float(np.max(np.abs(x - x_ref))) <= tol * max(1.0, float(np.max(np.abs(x_ref))))
+
+
+@pytest.mark.parametrize("world,case,precond,dtype", [
+    (2, "convdiff", "jacobi", np.float64),
+    (1, "convdiff", "sgs", np.float64),
+    (2, "convdiff", "sgs", np.float64),
+    (3, "poisson", "ilu0", np.float64),
+])
+def test_gloo_preconditioned_bicgstab(tmp_path, oracle, world, case, precond, dtype):
+    """BiCGStab with M = the ranks' own preconditioners of their diagonal blocks (block-Jacobi by rank).  Jacobi is
+    diagonal, so any number of ranks reproduces the single-process Jacobi run; with one rank SGS is the reference's SGS run;
+    with more ranks SGS / ILU0 are a different (weaker) preconditioner: the solve must still converge to the same solution,
+    identically on every rank, in no more iterations than the unpreconditioned run."""
+    import torch.multiprocessing as mp
+
+    from oracle.oracle import PRECOND_JACOBI, PRECOND_NONE, PRECOND_SGS
+
+    eps = 1e-10
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, np.dtype(dtype).name, -1, eps, str(tmp_path), precond), nprocs=world, join=True)
+    csr = _case(case, dtype)
+    n = len(csr[0]) - 1
+    b = gen.row_sums(csr[0], csr[2])
+    x = np.zeros(n, dtype=dtype)
+    metas = [np.load(tmp_path / f"meta_{r}.npy") for r in range(world)]
+    for r, m in enumerate(metas):
+        x[int(m[3]):int(m[4])] = np.load(tmp_path / f"x_{r}.npy")
+        assert int(m[0]) == 0 and (m[:3] == metas[0][:3]).all()
+    iters = int(metas[0][1])
+    np.testing.assert_allclose(x, 1.0, rtol=1e-7)
+    _, _, it_none, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), -1, eps, PRECOND_NONE)
+    assert 0 < iters <= it_none
+    if precond == "jacobi" or world == 1:
+        code, vals = (PRECOND_JACOBI, oracle.jacobi_setup(csr)[1]) if precond == "jacobi" else (PRECOND_SGS, None)
+        _, x_ref, it_ref, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), -1, eps, code, vals)
+        assert abs(iters - it_ref) <= 1
+        assert float(np.max(np.abs(x - x_ref))) <= 1e-8

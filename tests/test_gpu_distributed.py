@@ -12,7 +12,7 @@ from sparse_matrix_math_amd import generators as gen
 pytestmark = pytest.mark.gpu
 
 
-def _solve_threads(smm, csr, b_full, world, dtype, max_it, eps):
+def _solve_threads(smm, csr, b_full, world, dtype, max_it, eps, precond=None):
     import torch
 
     from sparse_matrix_math_amd.distributed import DistBiCGStab, HipOps, partition_rows_by_nnz, plan_halo, split_local_remote
@@ -38,7 +38,7 @@ def _solve_threads(smm, csr, b_full, world, dtype, max_it, eps):
             needs = comm.all_gather_pairs(cmin, cmax, torch, dev)
             sends, recvs = plan_halo(bounds, needs, rank)
             loc, rem = split_local_remote(torch, lstart, lpos, lval, lo, hi, cmin)
-            ops = HipOps(torch, loc, rem, n, lo, hi, cmin, cmax, dtype, dev)
+            ops = HipOps(torch, loc, rem, n, lo, hi, cmin, cmax, dtype, dev, precond=precond)
             solver = DistBiCGStab(ops, comm, cmin, sends, recvs)
             x = torch.zeros(hi - lo, dtype=torch.float32 if dtype == np.float32 else torch.float64, device=dev)
             b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
@@ -88,6 +88,40 @@ def test_virtual_ranks_match_oracle(smm, oracle, world, dtype):
         (status, iters, res), x = _solve_threads(smm, csr, b, world, dtype, -1, eps)
         assert status == 0 and res <= eps
         np.testing.assert_allclose(x, x_true, rtol=1e-3 if dtype == np.float32 else 1e-7)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_virtual_ranks_preconditioned(smm, oracle, world):
+    """BiCGStab preconditioned block-Jacobi by rank (each rank's Jacobi / ILU0 / SGS of its diagonal block) through the
+    product kernels.  One rank = the single-GPU preconditioned solver bit for bit; Jacobi is the same preconditioner for any
+    number of ranks; SGS / ILU0 on several ranks are weaker preconditioners that must still converge to the solution."""
+    P = smm.SolverPreconditioner
+    dtype = np.float64
+    csr = gen.convdiff3d(16, 0.3, dtype=dtype)
+    n = len(csr[0]) - 1
+    x_true = np.random.default_rng(7).uniform(0.5, 1.5, n)
+    b = oracle.spmv(csr, 0, None, x_true)
+    A = smm.CSRMatrix(n, n, *csr)
+    eps = 1e-9
+    (st0, it_none, _), _ = _solve_threads(smm, csr, b, world, dtype, -1, eps)
+    for kind in (P.JACOBI, P.ILU0, P.SYMMETRIC_GAUS_SEIDEL):
+        (status, iters, res), x = _solve_threads(smm, csr, b, world, dtype, -1, eps, precond=kind)
+        assert status == 0 and res <= eps, (kind, world)
+        np.testing.assert_allclose(x, x_true, rtol=1e-6, err_msg=f"{kind} world {world}")
+        # BiCGStab's count is erratic (Jacobi on a constant diagonal is only a scaling, yet 66 vs 88 iterations were seen):
+        # only a gross failure of the preconditioned recurrence is caught here; ILU0 / SGS must actually help
+        assert iters <= 2 * it_none, (kind, world, iters, it_none)
+        if kind != P.JACOBI:
+            assert iters < it_none, (kind, world, iters, it_none)
+        xs = np.zeros(n)
+        info = {}
+        st = smm.BiCGStab(A, b.copy(), xs, -1, eps, A.getPreconditioner(kind), info=info)
+        if world == 1:
+            # the same kernels in the same order: only the dot products differ (stage-wise partial sums vs fused epilogues)
+            assert int(st) == 0 and abs(info["iterations"] - iters) <= 1
+            np.testing.assert_allclose(x, xs, rtol=1e-7)
+        elif kind != P.JACOBI:
+            assert iters >= info["iterations"] - 3  # block-Jacobi by rank does not beat the global preconditioner by more than noise
 
 
 def test_single_rank_rccl_group_and_row_range_generator(smm, oracle):
