@@ -455,12 +455,14 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     s_bytes = np.dtype(np_dtype).itemsize
     # one matvec = the A_loc launch + the A_rem launch; algorithmic bytes of this rank's slice (SURVEY.md section 8d formula)
     b_local = nnz_local * (s_bytes + 4) + (hi - lo + 1) * 4 + ops.x_ext.numel() * s_bytes + (hi - lo) * s_bytes
-    matvec_s = spmv_ms * 1e-3 / max(spmv_launches // 2, 1)
+    # a matvec is two launches (A_loc, then A_rem) unless nothing of this rank's rows lives on another rank
+    per_matvec = 1 if (getattr(ops, "rem_empty", False) and not solver.sends and not solver.recvs) else 2
+    matvec_s = spmv_ms * 1e-3 / max(spmv_launches // per_matvec, 1)
     achieved = b_local / matvec_s / 1e9
     return {
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "kernel": "spmvStreamKernel (A_loc + A_rem launches of rank 0)", "algorithmic_bytes_per_launch": b_local,
-                     "avg_launch_ms": matvec_s * 1e3, "launches": spmv_launches // 2},
+                     "kernel": "spmvStreamKernel (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")"),
+                     "algorithmic_bytes_per_launch": b_local, "avg_launch_ms": matvec_s * 1e3, "launches": spmv_launches // per_matvec},
         "elapsed": elapsed,
         "iters": iters,
         "nnz": nnz_total,
