@@ -175,6 +175,8 @@ template <typename T>
 __device__ __forceinline__ T gatherX(const T* __restrict__ x, unsigned byteOffset) {
 #ifdef SMM_EXP_NOGATHER  // ablation builds only: what the kernel costs without its x[] loads
 	return T(1) + T(byteOffset & 1u);
+#elif defined(SMM_EXP_NTGATHER)  // ablation builds only: x[] gathers with the non-temporal policy
+	return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + byteOffset));
 #else
 	return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + byteOffset);
 #endif
