@@ -110,7 +110,7 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
     _, _, it1, _ = oracle.bicgstab(csr, b, x0, 2, 0.0, omp=True)
     dt1 = time.perf_counter() - t0
     oracle.set_threads(cores)
-    return {
+    out = {
         "value": it / dt,
         "unit": "iterations/s",
         "cores": cores,
@@ -118,6 +118,21 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
         "sample": f"{it} BiCGStab iterations of the same {len(b)}-row matrix (OpenMP port of the reference loop, {dt:.1f} s)",
         "value_1_core": it1 / dt1,
     }
+    # the real reference (oracle/_ref/libsmm_ref.so, built from /root/reference where that exists and carried to the GPU box as a
+    # binary): its own SMM::BiCGStab on the same matrix, single-threaded as its default build is -- two iterations
+    try:
+        from oracle.oracle import Reference
+
+        if Reference.available():
+            ref = Reference()
+            with ref.csr(csr) as m:
+                t0 = time.perf_counter()
+                ref.bicgstab(m, b, x0, 2, 0.0)
+                dtr = time.perf_counter() - t0
+            out["reference_1_core"] = 2 / dtr
+    except Exception as e:  # noqa: BLE001 -- the reference leg is optional; the port above is the baseline
+        out["reference_error"] = str(e)[:200]
+    return out
 
 
 def main():
