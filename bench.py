@@ -87,6 +87,16 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
     import numpy as np
 
@@ -117,6 +127,7 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
         "kind": "port",
         "sample": f"{it} BiCGStab iterations of the same {len(b)}-row matrix (OpenMP port of the reference loop, {dt:.1f} s)",
         "value_1_core": it1 / dt1,
+        "cpu_model": cpu_model(),
     }
     # the real reference (oracle/_ref/libsmm_ref.so, built from /root/reference where that exists and carried to the GPU box as a
     # binary): its own SMM::BiCGStab on the same matrix, single-threaded as its default build is -- two iterations
