@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--autotune", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) PATTERN-family measurement")
     ap.add_argument("--dist", action="store_true", help="take the row-partitioned multi-GPU code path even with one rank")
+    ap.add_argument("--dist-driver", choices=["native", "python"], default="native",
+                    help="N > 1: the loop behind the C ABI (csrc/smm_dist.hip, RCCL) or the Python driver over torch.distributed")
     return ap.parse_args()
 
 
@@ -146,8 +148,28 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as FRESH child processes -- before
+    this process has imported torch or made any GPU call -- relay their output (rank 0 prints the JSON line) and return
+    their exit status.  Nothing is ever exec'ed from a process that has touched the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")  # torch.distributed.run would set (and warn about) it anyway
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist

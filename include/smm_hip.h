@@ -44,6 +44,7 @@ extern "C" {
 #define SMM_HIP_ERR_PRECOND (-4)   /* structural failure in a preconditioner (missing / tiny diagonal, empty row): the
                                       reference's non-zero return of apply()/init() (ref:1668-1693) */
 #define SMM_HIP_ERR_NOMEM (-5)
+#define SMM_HIP_ERR_COMM (-6)      /* multi-GPU communicator failure (RCCL error, missing librccl, failed host callback) */
 
 /* SolverStatus, ref:2010-2014 */
 #define SMM_SOLVER_SUCCESS 0
@@ -67,6 +68,7 @@ extern "C" {
 
 #define SMM_DTYPE_F32 0
 #define SMM_DTYPE_F64 1
+#define SMM_DTYPE_I64 2 /* only as the element type handed to smm_hip_host_allreduce_fn */
 
 /* SpMV kernel families (smm_hip_csr_set_kernel).  AUTO picks from nnz/row. */
 #define SMM_SPMV_AUTO 0
@@ -254,6 +256,71 @@ int smm_hip_cg_ws_stage_f32(smm_hip_bicgstab_ws* ws, int stage, const float* d_x
 int smm_hip_cg_ws_stage_f64(smm_hip_bicgstab_ws* ws, int stage, const double* d_xcur, double* d_x, double eps, smm_hip_stream stream);
 /* synchronises `stream`; SolverStatus of the stage-wise CG (iterations / ||r||^2 / done come from smm_hip_bicgstab_ws_result_*) */
 int smm_hip_cg_ws_status(const smm_hip_bicgstab_ws* ws, smm_hip_stream stream, int* solver_status);
+
+/* ---- multi-GPU: rows range-partitioned over the GPUs of one node, ONE PROCESS PER GPU ------------------------------------------
+ * The reference is a single-process CPU library (no counterpart).  Rank g owns rows
+ * [bounds[g], bounds[g+1]) of the n_global x n_global matrix -- its slice of values / positions / start (ref:1243-1259) with
+ * GLOBAL column numbers and a local start[] (start[0] == 0) -- and the matching slices of b and x.  Each SpMV first fetches the
+ * x-vector halo from the owning ranks (point to point), each dot product is completed by an all-reduce of 1-2 scalars; both run
+ * on a side stream of the communicator while the caller's stream computes what does not depend on them.
+ *
+ * Communicators:
+ *   smm_hip_comm_create_rccl   RCCL over xGMI.  Rank 0 calls smm_hip_comm_unique_id and hands the 128 bytes to every rank (any
+ *                              out-of-band channel: torch.distributed, MPI, a file); then every rank calls create_rccl.  librccl is
+ *                              resolved with dlopen at this point, so single-GPU users of the library never need it.
+ *   smm_hip_comm_create_host   the caller moves the bytes: two callbacks (sum all-reduce of a small host array; a batch of sends and
+ *                              receives of host buffers).  For tests / rehearsals with several ranks on one GPU, where RCCL cannot run.
+ *   smm_hip_comm_create_self   a single rank (no communication).
+ * The library's device (smm_hip_init) is the one the communicator uses.  Calls on a communicator and on the distributed matrices
+ * built on it are collective: every rank makes the same calls in the same order. */
+typedef struct smm_hip_comm smm_hip_comm;
+typedef struct smm_hip_dist_csr smm_hip_dist_csr;
+#define SMM_HIP_COMM_ID_BYTES 128
+#define SMM_COMM_SELF 0
+#define SMM_COMM_RCCL 1
+#define SMM_COMM_HOST 2
+/* in-place sum over all ranks of buf[0..count); dtype is SMM_DTYPE_F32 / F64 / I64.  Return 0 on success. */
+typedef int (*smm_hip_host_allreduce_fn)(void* user, void* buf, int count, int dtype);
+/* post n_recv receives and n_send sends of host buffers (peer rank, pointer, byte count each) and wait for all of them */
+typedef int (*smm_hip_host_sendrecv_fn)(void* user, int n_send, const int* send_peer, void* const* send_buf, const size_t* send_bytes,
+                                        int n_recv, const int* recv_peer, void* const* recv_buf, const size_t* recv_bytes);
+int smm_hip_comm_unique_id(void* id /* SMM_HIP_COMM_ID_BYTES */);
+int smm_hip_comm_create_rccl(int rank, int world, const void* id, smm_hip_comm** out);
+int smm_hip_comm_create_host(int rank, int world, smm_hip_host_allreduce_fn allreduce, smm_hip_host_sendrecv_fn sendrecv, void* user,
+                             smm_hip_comm** out);
+int smm_hip_comm_create_self(smm_hip_comm** out);
+int smm_hip_comm_destroy(smm_hip_comm* comm);
+int smm_hip_comm_info(const smm_hip_comm* comm, int* rank, int* world, int* kind);
+/* runs every collective the solvers use once and checks the results (collective) */
+int smm_hip_comm_selftest(smm_hip_comm* comm);
+/* bounds[0..world]: contiguous row ranges with ~equal nonzeros, from a host start[rows+1] */
+int smm_hip_partition_rows_by_nnz(const int* start, int rows, int world, int* bounds);
+/* This rank's rows as DEVICE arrays (d_start local, d_positions global columns).  Collective: exchanges the column ranges,
+ * plans the halo, splits the rows on the device into A_loc (owned columns) and A_rem (halo columns).  The arrays are copied. */
+int smm_hip_dist_csr_create_dev_f32(smm_hip_comm* comm, int n_global, const int* bounds, const int* d_start, const int* d_positions,
+                                    const float* d_values, smm_hip_dist_csr** out);
+int smm_hip_dist_csr_create_dev_f64(smm_hip_comm* comm, int n_global, const int* bounds, const int* d_start, const int* d_positions,
+                                    const double* d_values, smm_hip_dist_csr** out);
+int smm_hip_dist_csr_destroy(smm_hip_dist_csr* A);
+int smm_hip_dist_csr_info(const smm_hip_dist_csr* A, int* n_local, int* ext_len, int* own_offset, int* halo_elements, long long* nnz_loc,
+                          long long* nnz_rem);
+/* the two local blocks (owned by A): a_loc is the square diagonal block a block-Jacobi preconditioner is built on
+ * (smm_hip_precond_create(a_loc, kind, &M)); both accept smm_hip_csr_set_kernel */
+int smm_hip_dist_csr_local_block(const smm_hip_dist_csr* A, smm_hip_csr** a_loc, smm_hip_csr** a_rem);
+/* out = op(lhs, A x) on the owned rows; d_x, d_lhs, d_out are this rank's slices (n_local).  rMult / rMultAdd / rMultSub, ref:1458-1515 */
+int smm_hip_dist_spmv_dev_f32(smm_hip_dist_csr* A, int op, const float* d_lhs, const float* d_x, float* d_out, smm_hip_stream stream);
+int smm_hip_dist_spmv_dev_f64(smm_hip_dist_csr* A, int op, const double* d_lhs, const double* d_x, double* d_out, smm_hip_stream stream);
+/* BiCGStab (ref:2191-2303) / ConjugateGradient (ref:2316-2398) with the semantics of smm_hip_bicgstab_dev_* / smm_hip_cg_dev_*; every
+ * rank gets the same status / iterations / resnorm.  M_loc (may be NULL): JACOBI / ILU0 / SGS of this rank's diagonal block, applied
+ * block-Jacobi by rank -- the same preconditioner as on one GPU only for JACOBI or world == 1. */
+int smm_hip_dist_bicgstab_dev_f32(smm_hip_dist_csr* A, const float* d_b, float* d_x, int maxIterations, float eps, const smm_hip_precond* M_loc,
+                                  smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm);
+int smm_hip_dist_bicgstab_dev_f64(smm_hip_dist_csr* A, const double* d_b, double* d_x, int maxIterations, double eps, const smm_hip_precond* M_loc,
+                                  smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm);
+int smm_hip_dist_cg_dev_f32(smm_hip_dist_csr* A, const float* d_b, const float* d_x0, float* d_x, int maxIterations, float eps,
+                            smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm2);
+int smm_hip_dist_cg_dev_f64(smm_hip_dist_csr* A, const double* d_b, const double* d_x0, double* d_x, int maxIterations, double eps,
+                            smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm2);
 
 /* ---- synthetic workload generators (BASELINE.json configs; device-side so 5e8-entry matrices need no host
  *      std::map as in ref:606-618).  d_start[rows+1], d_positions[nnz], d_values[nnz] are DEVICE arrays sized by

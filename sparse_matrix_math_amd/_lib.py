@@ -15,6 +15,7 @@ SMM_HIP_ERR_HIP = -2
 SMM_HIP_ERR_NO_DEVICE = -3
 SMM_HIP_ERR_PRECOND = -4
 SMM_HIP_ERR_NOMEM = -5
+SMM_HIP_ERR_COMM = -6
 
 
 class SmmHipError(RuntimeError):
@@ -29,6 +30,11 @@ def library_path(fma=False):
 
 
 _P = c_void_p  # opaque handles and device pointers travel as void*
+
+# callbacks of the host-staged communicator (smm_hip_comm_create_host)
+HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int, c_int)
+HOST_SENDRECV_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_void_p), POINTER(c_size_t), c_int, POINTER(c_int),
+                                    POINTER(c_void_p), POINTER(c_size_t))
 
 # name -> (restype, argtypes); {T} expands to float/double for the _f32/_f64 twins
 _TYPED = {
@@ -56,7 +62,13 @@ _TYPED = {
     "smm_hip_bicgstab_ws_stage": (c_int, [_P, c_int, _P, "T", _P]),
     "smm_hip_cg_ws_stage": (c_int, [_P, c_int, _P, _P, "T", _P]),
     "smm_hip_bicgstab_ws_result": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
+    "smm_hip_dist_csr_create_dev": (c_int, [_P, c_int, POINTER(c_int), _P, _P, _P, POINTER(_P)]),
+    "smm_hip_dist_spmv_dev": (c_int, [_P, c_int, _P, _P, _P, _P]),
+    "smm_hip_dist_bicgstab_dev": (c_int, [_P, _P, _P, c_int, "T", _P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
+    "smm_hip_dist_cg_dev": (c_int, [_P, _P, _P, _P, c_int, "T", _P, POINTER(c_int), POINTER(c_int), "PT"]),
 }
+
+
 
 _PLAIN = {
     "smm_hip_init": (c_int, [c_int]),
@@ -85,6 +97,17 @@ _PLAIN = {
     "smm_hip_cg_ws_status": (c_int, [_P, _P, POINTER(c_int)]),
     "smm_hip_bicgstab_ws_bind": (c_int, [_P, _P, _P, _P]),
     "smm_hip_bicgstab_ws_pointers": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "smm_hip_comm_unique_id": (c_int, [_P]),
+    "smm_hip_comm_create_rccl": (c_int, [c_int, c_int, _P, POINTER(_P)]),
+    "smm_hip_comm_create_host": (c_int, [c_int, c_int, HOST_ALLREDUCE_FN, HOST_SENDRECV_FN, _P, POINTER(_P)]),
+    "smm_hip_comm_create_self": (c_int, [POINTER(_P)]),
+    "smm_hip_comm_destroy": (c_int, [_P]),
+    "smm_hip_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "smm_hip_comm_selftest": (c_int, [_P]),
+    "smm_hip_partition_rows_by_nnz": (c_int, [_P, c_int, c_int, _P]),
+    "smm_hip_dist_csr_destroy": (c_int, [_P]),
+    "smm_hip_dist_csr_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_longlong), POINTER(c_longlong)]),
+    "smm_hip_dist_csr_local_block": (c_int, [_P, POINTER(_P), POINTER(_P)]),
 }
 
 

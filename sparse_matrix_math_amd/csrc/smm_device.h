@@ -52,6 +52,49 @@ __device__ __forceinline__ T blockSum256(T v, T* lds4) {
 	return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "Last workgroup done" completion of a fused reduction.  Every workgroup of a launch has stored its partial sum(s) to
+// partials[k * npart + blockIdx.x] (k < nsets).  Instead of a separate one-workgroup kernel that adds them, the workgroup that
+// finishes LAST adds the npart partials of each quantity -- in the same fixed order (i = t, t + 256, ...; then blockSum256), so the
+// bits are those of the separate kernel -- and stores the totals to totals[0 .. nsets).  One launch (and one dependent kernel
+// boundary, ~1.5-2 us) fewer per reduction: the row-partitioned solvers (smm_dist.hip) all-reduce `totals` right after.
+//
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): every storing wave drains its stores (s_waitcnt vmcnt(0)), the
+// workgroup meets at a barrier, lane 0 releases at agent scope and takes a ticket with a relaxed agent-scope atomic add; the
+// workgroup whose ticket is gridDim.x - 1 acquires at agent scope and reads the partials with agent-scope (L1-bypassing) loads.
+// The last workgroup resets the ticket counter, so the buffer is ready for the next launch on the stream.
+// All 256 threads of every workgroup of the launch must call this (it contains barriers).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void lastBlockSums(const T* partials, int npart, int nsets, T* totals, unsigned* ticket) {
+	__shared__ int sIsLast;
+	__shared__ T sRed[4];
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const unsigned mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int last = mine == gridDim.x - 1 ? 1 : 0;
+		if (last) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		sIsLast = last;
+	}
+	__syncthreads();
+	if (!sIsLast) return;
+	for (int k = 0; k < nsets; ++k) {
+		T acc = T(0);
+		for (int i = threadIdx.x; i < npart; i += 256) {
+			acc += __hip_atomic_load(partials + k * npart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		const T s = blockSum256(acc, sRed);
+		if (threadIdx.x == 0) totals[k] = s;
+	}
+	if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Workgroup barrier for kernels whose waves meet ONLY in LDS.  __syncthreads() is a workgroup-scope fence + s_barrier, and the
 // fence (which cannot know the address space) waits for every outstanding global access of the wave as well: vmcnt(0).  In a
 // software-pipelined tile loop that drains the prefetch of the next tile and the acknowledgement of the out[] store at every

@@ -1,0 +1,1137 @@
+// smm_dist.hip -- the SpMV + Krylov loop row-partitioned over the GPUs of one node, behind the C ABI.
+//
+// One process per GPU.  Rank g owns a contiguous range of rows of A (values / positions / start exactly as in the reference's
+// CSRMatrix, ref:1243-1259, with GLOBAL column numbers) and the matching slices of every vector.  The reference has no
+// counterpart (single process, shared memory: SURVEY.md section 2.1); what is kept is the arithmetic of ref:2191-2283 (BiCGStab)
+// and ref:2316-2398 (ConjugateGradient): the same update expressions in the same order, with the dot products completed across
+// ranks.
+//
+//   * halo: a rank needs x only on the column range its rows touch.  The parts owned by other ranks are received point to point
+//     (RCCL ncclSend / ncclRecv over xGMI) straight into a halo-extended vector [left halo | owned | right halo].
+//   * the local rows are split ON THE DEVICE into A_loc (owned columns) and A_rem (halo columns): A_loc x runs on the caller's
+//     stream while the exchange is in flight on the communicator's side stream; A_rem x is added in place when it has landed,
+//     with the dot products of the freshly computed vector fused into that launch and completed by its last workgroup
+//     (lastBlockSums, smm_device.h) -- no separate reduction kernels.
+//   * the 1-2 scalars of each reduction point are all-reduced in place (ncclAllReduce) on the side stream; every workgroup of
+//     the next update kernel reads the all-reduced totals and forms alpha / omega / beta itself, so there are no scalar launches:
+//     8 kernels per BiCGStab iteration (4 SpMV launches, s, r, x, p updates), 6 per CG iteration.  The x update does not depend
+//     on the last all-reduce of an iteration (||r||^2, r.r0) and runs beside it.
+//   * nothing in the loop synchronises with the host; the `done` flag is polled through a pinned mailbox (DonePoller).
+//
+// Communicators: RCCL (librccl resolved with dlopen at run time, so single-GPU users need no RCCL), or host callbacks (the
+// caller moves the bytes: used by the tests to run several ranks on one GPU, where RCCL cannot, and by the gloo rehearsal of
+// bench.py), or none (world size 1).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rccl/rccl.h>  // types and prototypes only: every call goes through dlsym'd pointers
+#include <rocprim/device/device_scan.hpp>
+
+#include "smm_device.h"
+#include "smm_internal.h"
+
+namespace smm {
+
+constexpr int TPB = 256;
+
+// ---------------------------------------------------------------------------------------------------------
+// RCCL through dlopen
+// ---------------------------------------------------------------------------------------------------------
+struct RcclApi {
+	void* handle = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static RcclApi* rccl() {
+	static RcclApi api;
+	static std::mutex mu;
+	std::lock_guard<std::mutex> lock(mu);
+	if (api.handle) return &api;
+	// the copy PyTorch already mapped (same SONAME) wins, so one RCCL serves both; otherwise the system ROCm one
+	const char* candidates[] = {getenv("SMM_HIP_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+	for (const char* c : candidates) {
+		if (h) break;
+		if (c && *c) h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+	}
+	if (!h) {
+		setError("RCCL not found (dlopen librccl.so.1: %s); set SMM_HIP_RCCL_PATH", dlerror());
+		return nullptr;
+	}
+#define SMM_RCCL_SYM(NAME)                                                        \
+	api.NAME = reinterpret_cast<decltype(api.NAME)>(dlsym(h, "nccl" #NAME));      \
+	if (!api.NAME) {                                                              \
+		setError("RCCL symbol nccl" #NAME " missing");                           \
+		return nullptr;                                                           \
+	}
+	SMM_RCCL_SYM(GetUniqueId)
+	SMM_RCCL_SYM(CommInitRank)
+	SMM_RCCL_SYM(CommDestroy)
+	SMM_RCCL_SYM(AllReduce)
+	SMM_RCCL_SYM(Send)
+	SMM_RCCL_SYM(Recv)
+	SMM_RCCL_SYM(GroupStart)
+	SMM_RCCL_SYM(GroupEnd)
+	SMM_RCCL_SYM(GetErrorString)
+#undef SMM_RCCL_SYM
+	api.handle = h;
+	return &api;
+}
+
+static int rcclFail(ncclResult_t r, const char* what) {
+	RcclApi* api = rccl();
+	setError("RCCL error %d (%s) in %s", static_cast<int>(r), api && api->GetErrorString ? api->GetErrorString(r) : "?", what);
+	return SMM_HIP_ERR_COMM;
+}
+#define SMM_RCCL_TRY(expr)                                  \
+	do {                                                    \
+		ncclResult_t _r = (expr);                           \
+		if (_r != ncclSuccess) return rcclFail(_r, #expr);  \
+	} while (0)
+
+struct Seg {  // a contiguous piece of a halo-extended vector exchanged with one peer
+	int peer, offset, count;
+};
+
+}  // namespace smm
+
+struct smm_hip_comm {
+	int rank = 0, world = 1, kind = SMM_COMM_SELF;
+	ncclComm_t nccl = nullptr;
+	smm_hip_host_allreduce_fn hostAllreduce = nullptr;
+	smm_hip_host_sendrecv_fn hostSendrecv = nullptr;
+	void* user = nullptr;
+	hipStream_t stream = nullptr;  // side stream of the collectives (high priority: a pending exchange must get its few workgroups
+	                               // before the persistent SpMV grid of the caller's stream fills every CU)
+	std::vector<hipEvent_t> events;
+	size_t nextEvent = 0;
+	char* pinned = nullptr;  // host staging of the callback kind
+	size_t pinnedBytes = 0;
+	long long* d_i64 = nullptr;  // set-up reductions
+	size_t i64Count = 0;
+};
+
+namespace smm {
+
+static hipEvent_t takeEvent(smm_hip_comm* c) {
+	if (c->events.empty()) {
+		c->events.resize(64);
+		for (auto& e : c->events) {
+			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+		}
+	}
+	hipEvent_t e = c->events[c->nextEvent];
+	c->nextEvent = (c->nextEvent + 1) % c->events.size();
+	return e;
+}
+
+// everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+static int orderAfter(smm_hip_comm* c, hipStream_t from, hipStream_t to) {
+	if (from == to) return SMM_HIP_OK;
+	hipEvent_t e = takeEvent(c);
+	if (!e) {
+		setError("comm: event pool exhausted");
+		return SMM_HIP_ERR_HIP;
+	}
+	SMM_HIP_TRY(hipEventRecord(e, from));
+	SMM_HIP_TRY(hipStreamWaitEvent(to, e, 0));
+	return SMM_HIP_OK;
+}
+
+static int ensurePinned(smm_hip_comm* c, size_t bytes) {
+	if (c->pinnedBytes >= bytes) return SMM_HIP_OK;
+	if (c->pinned) hipHostFree(c->pinned);
+	c->pinned = nullptr;
+	c->pinnedBytes = 0;
+	SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->pinned), bytes, hipHostMallocDefault));
+	c->pinnedBytes = bytes;
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static ncclDataType_t ncclTypeOf() { return sizeof(T) == 4 ? ncclFloat32 : ncclFloat64; }
+
+// in-place sum of d_buf[0..count) over the ranks, enqueued on `s` (the callback kind blocks until `s` has drained)
+template <typename T>
+static int commAllreduce(smm_hip_comm* c, T* d_buf, int count, hipStream_t s) {
+	if (c->kind == SMM_COMM_SELF) return SMM_HIP_OK;
+	if (c->kind == SMM_COMM_RCCL) {
+		SMM_RCCL_TRY(rccl()->AllReduce(d_buf, d_buf, static_cast<size_t>(count), ncclTypeOf<T>(), ncclSum, c->nccl, s));
+		return SMM_HIP_OK;
+	}
+	SMM_TRY(ensurePinned(c, count * sizeof(T)));
+	SMM_HIP_TRY(hipMemcpyAsync(c->pinned, d_buf, count * sizeof(T), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (c->hostAllreduce(c->user, c->pinned, count, dtypeOf<T>()) != 0) {
+		setError("comm: host all-reduce callback failed");
+		return SMM_HIP_ERR_COMM;
+	}
+	SMM_HIP_TRY(hipMemcpyAsync(d_buf, c->pinned, count * sizeof(T), hipMemcpyHostToDevice, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // the staging buffer is reused by the next call
+	return SMM_HIP_OK;
+}
+
+// blocking sum of host 64-bit integers (set-up only)
+static int commAllreduceI64(smm_hip_comm* c, long long* h, int count) {
+	if (c->kind == SMM_COMM_SELF) return SMM_HIP_OK;
+	if (c->kind == SMM_COMM_HOST) {
+		if (c->hostAllreduce(c->user, h, count, SMM_DTYPE_I64) != 0) {
+			setError("comm: host all-reduce callback failed");
+			return SMM_HIP_ERR_COMM;
+		}
+		return SMM_HIP_OK;
+	}
+	if (c->i64Count < static_cast<size_t>(count)) {
+		if (c->d_i64) hipFree(c->d_i64);
+		c->d_i64 = nullptr;
+		SMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_i64), count * sizeof(long long)));
+		c->i64Count = count;
+	}
+	SMM_HIP_TRY(hipMemcpyAsync(c->d_i64, h, count * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+	SMM_RCCL_TRY(rccl()->AllReduce(c->d_i64, c->d_i64, static_cast<size_t>(count), ncclInt64, ncclSum, c->nccl, c->stream));
+	SMM_HIP_TRY(hipMemcpyAsync(h, c->d_i64, count * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+	SMM_HIP_TRY(hipStreamSynchronize(c->stream));
+	return SMM_HIP_OK;
+}
+
+// halo exchange of the halo-extended vector `ext`, enqueued on `s`
+template <typename T>
+static int commExchange(smm_hip_comm* c, T* ext, const std::vector<Seg>& sends, const std::vector<Seg>& recvs, hipStream_t s) {
+	if (sends.empty() && recvs.empty()) return SMM_HIP_OK;
+	if (c->kind == SMM_COMM_SELF) {
+		setError("comm: a single-rank communicator cannot exchange halos");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (c->kind == SMM_COMM_RCCL) {
+		RcclApi* api = rccl();
+		SMM_RCCL_TRY(api->GroupStart());
+		for (const Seg& g : recvs) SMM_RCCL_TRY(api->Recv(ext + g.offset, static_cast<size_t>(g.count), ncclTypeOf<T>(), g.peer, c->nccl, s));
+		for (const Seg& g : sends) SMM_RCCL_TRY(api->Send(ext + g.offset, static_cast<size_t>(g.count), ncclTypeOf<T>(), g.peer, c->nccl, s));
+		SMM_RCCL_TRY(api->GroupEnd());
+		return SMM_HIP_OK;
+	}
+	size_t total = 0;
+	for (const Seg& g : sends) total += g.count * sizeof(T);
+	for (const Seg& g : recvs) total += g.count * sizeof(T);
+	SMM_TRY(ensurePinned(c, total));
+	std::vector<int> sp, rp;
+	std::vector<void*> sb, rb;
+	std::vector<size_t> sn, rn;
+	char* at = c->pinned;
+	for (const Seg& g : sends) {
+		SMM_HIP_TRY(hipMemcpyAsync(at, ext + g.offset, g.count * sizeof(T), hipMemcpyDeviceToHost, s));
+		sp.push_back(g.peer);
+		sb.push_back(at);
+		sn.push_back(g.count * sizeof(T));
+		at += g.count * sizeof(T);
+	}
+	char* recvBase = at;
+	for (const Seg& g : recvs) {
+		rp.push_back(g.peer);
+		rb.push_back(at);
+		rn.push_back(g.count * sizeof(T));
+		at += g.count * sizeof(T);
+	}
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (c->hostSendrecv(c->user, static_cast<int>(sp.size()), sp.data(), sb.data(), sn.data(), static_cast<int>(rp.size()), rp.data(), rb.data(), rn.data()) != 0) {
+		setError("comm: host send/recv callback failed");
+		return SMM_HIP_ERR_COMM;
+	}
+	at = recvBase;
+	for (const Seg& g : recvs) {
+		SMM_HIP_TRY(hipMemcpyAsync(ext + g.offset, at, g.count * sizeof(T), hipMemcpyHostToDevice, s));
+		at += g.count * sizeof(T);
+	}
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// splitting the local rows into A_loc / A_rem on the device
+// ---------------------------------------------------------------------------------------------------------
+__global__ void colRangeKernel(long long nnz, const int* __restrict__ positions, int* __restrict__ minmax) {
+	int lo = 0x7fffffff, hi = -1;
+	for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < nnz; i += static_cast<long long>(gridDim.x) * blockDim.x) {
+		const int c = positions[i];
+		lo = min(lo, c);
+		hi = max(hi, c);
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		lo = min(lo, __shfl_xor(lo, o, WAVE));
+		hi = max(hi, __shfl_xor(hi, o, WAVE));
+	}
+	if ((threadIdx.x & 63) == 0 && hi >= 0) {
+		atomicMin(minmax, lo);
+		atomicMax(minmax + 1, hi);
+	}
+}
+
+// counts[row] = entries of the row with an owned column; counts[nLocal + 1 + row] = the others.  Both arrays have nLocal + 1
+// slots so that an exclusive scan over nLocal + 1 elements ends with the total.
+__global__ void splitCountKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, int ownLo, int ownHi,
+                                 int* __restrict__ cntLoc, int* __restrict__ cntRem) {
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row <= nLocal; row += gridDim.x * blockDim.x) {
+		int nl = 0, nr = 0;
+		if (row < nLocal) {
+			const int e = start[row + 1];
+			for (int k = start[row]; k < e; ++k) {
+				const int c = positions[k];
+				if (c >= ownLo && c < ownHi) ++nl;
+				else ++nr;
+			}
+		}
+		cntLoc[row] = nl;
+		cntRem[row] = nr;
+	}
+}
+
+template <typename T>
+__global__ void splitScatterKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ values, int ownLo,
+                                   int ownHi, int cmin, const int* __restrict__ startLoc, const int* __restrict__ startRem, int* __restrict__ posLoc,
+                                   T* __restrict__ valLoc, int* __restrict__ posRem, T* __restrict__ valRem) {
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nLocal; row += gridDim.x * blockDim.x) {
+		int il = startLoc[row], ir = startRem[row];
+		const int e = start[row + 1];
+		for (int k = start[row]; k < e; ++k) {  // order inside a row is preserved (columns stay ascending, ref:1247-1249)
+			const int c = positions[k];
+			const T v = values[k];
+			if (c >= ownLo && c < ownHi) {
+				posLoc[il] = c - ownLo;
+				valLoc[il] = v;
+				++il;
+			} else {
+				posRem[ir] = c - cmin;
+				valRem[ir] = v;
+				++ir;
+			}
+		}
+	}
+}
+
+static int exclusiveScan(int* d_inout, int count, hipStream_t s) {
+	size_t tempBytes = 0;
+	SMM_HIP_TRY(rocprim::exclusive_scan(nullptr, tempBytes, d_inout, d_inout, 0, static_cast<size_t>(count), rocprim::plus<int>(), s));
+	void* temp = nullptr;
+	SMM_TRY(devAlloc(&temp, tempBytes ? tempBytes : 1));
+	const hipError_t e = rocprim::exclusive_scan(temp, tempBytes, d_inout, d_inout, 0, static_cast<size_t>(count), rocprim::plus<int>(), s);
+	if (e == hipSuccess) (void)hipStreamSynchronize(s);
+	devFree(temp);
+	SMM_HIP_TRY(e);
+	return SMM_HIP_OK;
+}
+
+// recurrence state of the distributed loops
+template <typename T>
+struct DistScal {
+	T rrPing[2];  // BiCGStab: rr0 / CG: ||r||^2, double-buffered by iteration parity (workgroup 0 writes the next while others read)
+	T alpha, omega, res;
+	int done, iters, status, pad;
+};
+
+}  // namespace smm
+
+struct smm_hip_dist_csr {
+	smm_hip_comm* comm = nullptr;
+	int dtype = 0;
+	int nGlobal = 0, rowBegin = 0, rowEnd = 0, nLocal = 0;
+	int cmin = 0, cmaxExcl = 0, extLen = 1, ownOffset = 0;
+	long long nnzLoc = 0, nnzRem = 0;
+	int haloElements = 0;
+	smm_hip_csr* aLoc = nullptr;
+	smm_hip_csr* aRem = nullptr;
+	void* arrays[6] = {};  // startLoc, posLoc, valLoc, startRem, posRem, valRem (owned)
+	std::vector<smm::Seg> sends, recvs;
+	bool remEmpty = true;
+	// workspace of the solvers, kept across solves
+	void *r = nullptr, *r0 = nullptr, *ap = nullptr, *as = nullptr, *scratch = nullptr;
+	void *pExt = nullptr, *sExt = nullptr, *xExt = nullptr;
+	void *partsA = nullptr, *partsB = nullptr, *partsC = nullptr;  // finishing buffers (PARTS_LEN): totals are all-reduced in place
+	void* sc = nullptr;
+};
+
+namespace smm {
+
+template <typename T>
+static int distWorkspace(smm_hip_dist_csr* D) {
+	if (D->r) return SMM_HIP_OK;
+	const size_t vb = static_cast<size_t>(std::max(1, D->nLocal)) * sizeof(T);
+	const size_t eb = static_cast<size_t>(std::max(1, D->extLen)) * sizeof(T);
+	SMM_TRY(devAlloc(&D->r, vb));
+	SMM_TRY(devAlloc(&D->r0, vb));
+	SMM_TRY(devAlloc(&D->ap, vb));
+	SMM_TRY(devAlloc(&D->as, vb));
+	SMM_TRY(devAlloc(&D->pExt, eb));
+	SMM_TRY(devAlloc(&D->sExt, eb));
+	SMM_TRY(devAlloc(&D->xExt, eb));
+	SMM_TRY(devAlloc(&D->partsA, PARTS_LEN * sizeof(T)));
+	SMM_TRY(devAlloc(&D->partsB, PARTS_LEN * sizeof(T)));
+	SMM_TRY(devAlloc(&D->partsC, PARTS_LEN * sizeof(T)));
+	SMM_TRY(devAlloc(&D->sc, sizeof(DistScal<T>)));
+	hipStream_t s = libStream();
+	// halo slots outside every recv segment are never read by A_rem; zero keeps them finite.  Tickets start at 0.
+	SMM_HIP_TRY(hipMemsetAsync(D->pExt, 0, eb, s));
+	SMM_HIP_TRY(hipMemsetAsync(D->sExt, 0, eb, s));
+	SMM_HIP_TRY(hipMemsetAsync(D->xExt, 0, eb, s));
+	SMM_HIP_TRY(hipMemsetAsync(D->partsA, 0, PARTS_LEN * sizeof(T), s));
+	SMM_HIP_TRY(hipMemsetAsync(D->partsB, 0, PARTS_LEN * sizeof(T), s));
+	SMM_HIP_TRY(hipMemsetAsync(D->partsC, 0, PARTS_LEN * sizeof(T), s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const int* d_start, const int* d_positions, const T* d_values,
+                      smm_hip_dist_csr** out) {
+	if (!out) {
+		setError("dist_csr_create: out is null");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*out = nullptr;
+	if (!comm || !bounds || !d_start || nGlobal < 0) {
+		setError("dist_csr_create: null argument");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	const int world = comm->world, rank = comm->rank;
+	if (bounds[0] != 0 || bounds[world] != nGlobal) {
+		setError("dist_csr_create: bounds must run from 0 to n_global");
+		return SMM_HIP_ERR_INVALID;
+	}
+	for (int q = 0; q < world; ++q) {
+		if (bounds[q] > bounds[q + 1]) {
+			setError("dist_csr_create: bounds must be non-decreasing");
+			return SMM_HIP_ERR_INVALID;
+		}
+	}
+	struct Guard {
+		smm_hip_dist_csr* d;
+		~Guard() {
+			if (d) smm_hip_dist_csr_destroy(d);
+		}
+	} guard{new smm_hip_dist_csr()};
+	smm_hip_dist_csr* D = guard.d;
+	D->comm = comm;
+	D->dtype = dtypeOf<T>();
+	D->nGlobal = nGlobal;
+	D->rowBegin = bounds[rank];
+	D->rowEnd = bounds[rank + 1];
+	const int nLocal = D->nLocal = D->rowEnd - D->rowBegin;
+	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipDeviceSynchronize());  // the caller's arrays may still be being written on one of its streams (set-up path)
+	int nnz = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&nnz, d_start + nLocal, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (nnz < 0 || (nnz > 0 && (!d_positions || !d_values))) {
+		setError("dist_csr_create: bad start[] or null positions / values");
+		return SMM_HIP_ERR_INVALID;
+	}
+	// column range this rank's rows touch
+	int hmm[2] = {0x7fffffff, -1};
+	if (nnz > 0) {
+		DevBuf<int> mm;
+		SMM_TRY(mm.alloc(2));
+		SMM_HIP_TRY(hipMemcpyAsync(mm, hmm, sizeof(hmm), hipMemcpyHostToDevice, s));
+		colRangeKernel<<<std::min(2048, (nnz + 255) / 256), 256, 0, s>>>(nnz, d_positions, mm);
+		SMM_HIP_TRY(hipMemcpyAsync(hmm, mm, sizeof(hmm), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		if (hmm[0] < 0 || hmm[1] >= nGlobal) {
+			setError("dist_csr_create: column %d outside [0, %d)", hmm[0] < 0 ? hmm[0] : hmm[1], nGlobal);
+			return SMM_HIP_ERR_INVALID;
+		}
+	}
+	D->cmin = nnz > 0 ? std::min(hmm[0], D->rowBegin) : D->rowBegin;
+	D->cmaxExcl = nnz > 0 ? std::max(hmm[1] + 1, D->rowEnd) : D->rowEnd;
+	D->extLen = std::max(1, D->cmaxExcl - D->cmin);
+	D->ownOffset = D->rowBegin - D->cmin;
+	// every rank learns every rank's range (an all-gather written as a sum of disjoint contributions)
+	std::vector<long long> needs(2 * static_cast<size_t>(world), 0);
+	needs[2 * rank] = D->cmin;
+	needs[2 * rank + 1] = D->cmaxExcl;
+	SMM_TRY(commAllreduceI64(comm, needs.data(), 2 * world));
+	for (int q = 0; q < world; ++q) {
+		if (q == rank) continue;
+		long long lo = std::max<long long>(needs[2 * rank], bounds[q]), hi = std::min<long long>(needs[2 * rank + 1], bounds[q + 1]);
+		if (lo < hi) {
+			D->recvs.push_back({q, static_cast<int>(lo - D->cmin), static_cast<int>(hi - lo)});
+			D->haloElements += static_cast<int>(hi - lo);
+		}
+		lo = std::max<long long>(needs[2 * q], D->rowBegin);
+		hi = std::min<long long>(needs[2 * q + 1], D->rowEnd);
+		if (lo < hi) D->sends.push_back({q, static_cast<int>(lo - D->cmin), static_cast<int>(hi - lo)});
+	}
+	// split
+	int* cnt = nullptr;
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&cnt), 2 * (static_cast<size_t>(nLocal) + 1) * sizeof(int)));
+	D->arrays[0] = cnt;  // becomes startLoc | startRem
+	int* startLoc = cnt;
+	int* startRem = cnt + nLocal + 1;
+	const int grid = std::max(1, std::min(8192, (nLocal + 256) / 256));
+	splitCountKernel<<<grid, 256, 0, s>>>(nLocal, d_start, d_positions, D->rowBegin, D->rowEnd, startLoc, startRem);
+	SMM_HIP_TRY(hipGetLastError());
+	SMM_TRY(exclusiveScan(startLoc, nLocal + 1, s));
+	SMM_TRY(exclusiveScan(startRem, nLocal + 1, s));
+	int totals[2] = {0, 0};
+	SMM_HIP_TRY(hipMemcpyAsync(&totals[0], startLoc + nLocal, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipMemcpyAsync(&totals[1], startRem + nLocal, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	D->nnzLoc = totals[0];
+	D->nnzRem = totals[1];
+	D->remEmpty = totals[1] == 0;
+	SMM_TRY(devAlloc(&D->arrays[1], std::max<size_t>(1, totals[0]) * sizeof(int)));
+	SMM_TRY(devAlloc(&D->arrays[2], std::max<size_t>(1, totals[0]) * sizeof(T)));
+	SMM_TRY(devAlloc(&D->arrays[4], std::max<size_t>(1, totals[1]) * sizeof(int)));
+	SMM_TRY(devAlloc(&D->arrays[5], std::max<size_t>(1, totals[1]) * sizeof(T)));
+	if (nLocal > 0) {
+		splitScatterKernel<T><<<grid, 256, 0, s>>>(nLocal, d_start, d_positions, d_values, D->rowBegin, D->rowEnd, D->cmin, startLoc, startRem,
+		                                          static_cast<int*>(D->arrays[1]), static_cast<T*>(D->arrays[2]), static_cast<int*>(D->arrays[4]),
+		                                          static_cast<T*>(D->arrays[5]));
+		SMM_HIP_TRY(hipGetLastError());
+	}
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (dtypeOf<T>() == SMM_DTYPE_F32) {
+		SMM_TRY(smm_hip_csr_create_dev_f32(nLocal, nLocal, startLoc, static_cast<int*>(D->arrays[1]), static_cast<float*>(D->arrays[2]), &D->aLoc));
+		SMM_TRY(smm_hip_csr_create_dev_f32(nLocal, D->extLen, startRem, static_cast<int*>(D->arrays[4]), static_cast<float*>(D->arrays[5]), &D->aRem));
+	} else {
+		SMM_TRY(smm_hip_csr_create_dev_f64(nLocal, nLocal, startLoc, static_cast<int*>(D->arrays[1]), static_cast<double*>(D->arrays[2]), &D->aLoc));
+		SMM_TRY(smm_hip_csr_create_dev_f64(nLocal, D->extLen, startRem, static_cast<int*>(D->arrays[4]), static_cast<double*>(D->arrays[5]), &D->aRem));
+	}
+	SMM_TRY(distWorkspace<T>(D));
+	guard.d = nullptr;
+	*out = D;
+	return SMM_HIP_OK;
+}
+
+// out = op(lhs, A ext) on the owned rows.  `ext` is a halo-extended vector whose owned slice is current; the halo is fetched here.
+// dotMode / w1 / parts as in launchSpmv; with dotMode != 0 parts is a finishing buffer and its totals are complete (locally) when
+// the last launch ends.
+template <typename T>
+static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s) {
+	smm_hip_comm* c = D->comm;
+	const T* own = ext + D->ownOffset;
+	const bool exchange = !D->sends.empty() || !D->recvs.empty();
+	const int finish = dotMode ? SPMV_FINISH : 0;
+	if (D->remEmpty && !exchange) return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
+	hipEvent_t landed = nullptr;
+	if (exchange) {
+		hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;  // the callback kind blocks anyway
+		SMM_TRY(orderAfter(c, s, cs));
+		SMM_TRY(commExchange<T>(c, ext, D->sends, D->recvs, cs));
+		if (cs != s) {
+			landed = takeEvent(c);
+			SMM_HIP_TRY(hipEventRecord(landed, cs));
+		}
+	}
+	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s));
+	if (landed) SMM_HIP_TRY(hipStreamWaitEvent(s, landed, 0));
+	return launchSpmv<T>(D->aRem, op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
+}
+
+// all-reduce of the totals of a finishing buffer on the side stream; *joined = event the caller's stream must wait for (null when
+// nothing is pending)
+template <typename T>
+static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t s, hipEvent_t* joined) {
+	smm_hip_comm* c = D->comm;
+	*joined = nullptr;
+	if (c->kind == SMM_COMM_SELF) return SMM_HIP_OK;
+	T* totals = parts + PARTS_TOTALS;
+	if (c->kind == SMM_COMM_HOST) return commAllreduce<T>(c, totals, count, s);
+	SMM_TRY(orderAfter(c, s, c->stream));
+	SMM_TRY(commAllreduce<T>(c, totals, count, c->stream));
+	*joined = takeEvent(c);
+	SMM_HIP_TRY(hipEventRecord(*joined, c->stream));
+	return SMM_HIP_OK;
+}
+
+static int join(hipStream_t s, hipEvent_t e) {
+	if (e) SMM_HIP_TRY(hipStreamWaitEvent(s, e, 0));
+	return SMM_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels of the loops: each reads the all-reduced totals itself (no scalar launches)
+// ---------------------------------------------------------------------------------------------------------
+// totals[0] = a.b, totals[1] = a.c (nsets 2); NPART workgroups, finished by the last one
+template <typename T>
+__global__ __launch_bounds__(TPB) void distDots(int n, const T* a, const T* b, const T* cvec, int nsets, T* parts, const int* __restrict__ doneFlag) {
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	T acc0 = T(0), acc1 = T(0);
+	if (nsets == 2) {
+		const T* const in[3] = {a, b, cvec};
+		streamMap<T, false, 3, 0>(n, in, nullptr, [&](const T(&v)[3], T(&)[1]) {
+			acc0 += v[0] * v[1];
+			acc1 += v[0] * v[2];
+		});
+	} else {
+		const T* const in[2] = {a, b};
+		streamMap<T, false, 2, 0>(n, in, nullptr, [&](const T(&v)[2], T(&)[1]) { acc0 += v[0] * v[1]; });
+	}
+	const T s0 = blockSum256(acc0, red);
+	if (threadIdx.x == 0) parts[blockIdx.x] = s0;
+	if (nsets == 2) {
+		const T s1 = blockSum256(acc1, red);
+		if (threadIdx.x == 0) parts[NPART + blockIdx.x] = s1;
+	}
+	lastBlockSums<T>(parts, NPART, nsets, parts + PARTS_TOTALS, partsTicket(parts));
+}
+
+template <typename T>
+__global__ void distBicgInit(const T* __restrict__ totals, DistScal<T>* sc) {
+	sc->rrPing[0] = totals[0];  // rr0 = r.r0, ref:2231
+	sc->res = T(0);
+	sc->iters = 0;
+	sc->done = 0;
+	sc->status = SMM_SOLVER_SUCCESS;
+}
+
+// alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247)
+template <typename T>
+__global__ __launch_bounds__(TPB) void distBicgS(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsA, const T* ap, const T* r, T* sv) {
+	if (sc->done) return;
+	const T alpha = sc->rrPing[par] / totalsA[0];
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
+	const T* const in[2] = {ap, r};
+	T* const out[1] = {sv};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(-alpha, v[0], v[1]); });
+}
+
+// omega = (as.s) / (as.as) ; r = -omega as + s ; local ||r||^2 and r.r0   (ref:2259-2261, 2265)
+template <typename T>
+__global__ __launch_bounds__(TPB) void distBicgR(int n, DistScal<T>* sc, const T* __restrict__ totalsB, const T* sv, const T* as, const T* r0, T* r,
+                                                 T* partsC) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T omega = totalsB[1] / totalsB[0];
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->omega = omega;
+	T acc0 = T(0), acc1 = T(0);
+	const T* const in[3] = {sv, as, r0};
+	T* const out[1] = {r};
+	streamMap<T, false, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) {
+		const T ri = smmFma(-omega, v[1], v[0]);
+		o[0] = ri;
+		acc0 += ri * ri;
+		acc1 += ri * v[2];
+	});
+	const T s0 = blockSum256(acc0, red);
+	const T s1 = blockSum256(acc1, red);
+	if (threadIdx.x == 0) {
+		partsC[blockIdx.x] = s0;
+		partsC[NPART + blockIdx.x] = s1;
+	}
+	lastBlockSums<T>(partsC, NPART, 2, partsC + PARTS_TOTALS, partsTicket(partsC));
+}
+
+// x = alpha p + (omega s + x)   (ref:2264) -- independent of the all-reduce of ||r||^2, r.r0 and runs beside it
+template <typename T>
+__global__ __launch_bounds__(TPB) void distBicgX(int n, const DistScal<T>* __restrict__ sc, const T* p, const T* sv, T* x) {
+	if (sc->done) return;
+	const T alpha = sc->alpha, omega = sc->omega;
+	const T* const in[3] = {sv, x, p};
+	T* const out[1] = {x};
+	streamMap<T, false, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) { o[0] = smmFma(alpha, v[2], smmFma(omega, v[0], v[1])); });
+}
+
+// resL2Norm, loop test, beta, p = beta (-omega ap + p) + r   (ref:2268-2277)
+template <typename T>
+__global__ __launch_bounds__(TPB) void distBicgP(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, const T* ap, const T* r, T* p) {
+	if (sc->done) return;
+	const T rr = totalsC[0];
+	const T newRR0 = totalsC[1];
+	const T res = sizeof(T) == 4 ? static_cast<T>(__fsqrt_rn(static_cast<float>(rr))) : static_cast<T>(__dsqrt_rn(static_cast<double>(rr)));
+	const T alpha = sc->alpha, omega = sc->omega, rr0 = sc->rrPing[par];
+	const bool leave = !(res > eps);
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->res = res;
+		sc->rrPing[par ^ 1] = newRR0;
+		sc->iters += 1;
+		if (leave) sc->done = 1;
+	}
+	if (leave) return;
+	const T beta = (newRR0 * alpha) / (rr0 * omega);  // ref:2271
+	const T* const in[3] = {ap, p, r};
+	T* const out[1] = {p};
+	streamMap<T, false, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) { o[0] = smmFma(beta, smmFma(-omega, v[0], v[1]), v[2]); });
+}
+
+template <typename T>
+__global__ void distCgInit(const T* __restrict__ totals, DistScal<T>* sc, T eps) {
+	const T rr = totals[0];  // ref:2341
+	sc->rrPing[0] = rr;
+	sc->res = rr;
+	sc->iters = 0;
+	sc->done = 0;
+	sc->status = SMM_SOLVER_MAX_ITERATIONS_REACHED;
+	if (eps * eps > rr) {  // ref:2342-2344: x stays untouched
+		sc->done = 1;
+		sc->status = SMM_SOLVER_SUCCESS;
+	}
+}
+
+// alpha = rr / (Ap.p) ; r = -alpha Ap + r ; local ||r||^2   (ref:2354-2375)
+template <typename T>
+__global__ __launch_bounds__(TPB) void distCgR(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsA, const T* Ap, T* r, T* partsC) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T alpha = sc->rrPing[par] / totalsA[0];
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
+	T acc = T(0);
+	const T* const in[2] = {Ap, r};
+	T* const out[1] = {r};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) {
+		const T ri = smmFma(-alpha, v[0], v[1]);
+		o[0] = ri;
+		acc += ri * ri;
+	});
+	const T s0 = blockSum256(acc, red);
+	if (threadIdx.x == 0) partsC[blockIdx.x] = s0;
+	lastBlockSums<T>(partsC, NPART, 1, partsC + PARTS_TOTALS, partsTicket(partsC));
+}
+
+// x = alpha p + xcur   (ref:2372)
+template <typename T>
+__global__ __launch_bounds__(TPB) void distCgX(int n, const DistScal<T>* __restrict__ sc, const T* p, const T* xcur, T* x) {
+	if (sc->done) return;
+	const T alpha = sc->alpha;
+	const T* const in[2] = {p, xcur};
+	T* const out[1] = {x};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(alpha, v[0], v[1]); });
+}
+
+// convergence test, beta, p = beta p + r   (ref:2377-2394)
+template <typename T>
+__global__ __launch_bounds__(TPB) void distCgP(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, T* p, const T* r) {
+	if (sc->done) return;
+	const T rrNew = totalsC[0];
+	const T rrOld = sc->rrPing[par];
+	const bool converged = eps * eps > rrNew;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->iters += 1;
+		sc->res = rrNew;
+		if (converged) {
+			sc->done = 1;
+			sc->status = SMM_SOLVER_SUCCESS;
+		} else {
+			sc->rrPing[par ^ 1] = rrNew;
+		}
+	}
+	if (converged) return;
+	const T beta = rrNew / rrOld;
+	const T* const in[2] = {p, r};
+	T* const out[1] = {p};
+	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
+}
+
+static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, NPART))); }
+static int pollInterval(int it) { return std::max(4, std::min(64, it / 4)); }
+
+template <typename T>
+static int checkDist(const smm_hip_dist_csr* D, const char* who) {
+	if (!D || D->dtype != dtypeOf<T>()) {
+		setError("%s: null distributed matrix or dtype mismatch", who);
+		return SMM_HIP_ERR_INVALID;
+	}
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int distSpmv(smm_hip_dist_csr* D, int op, const T* lhs, const T* xOwn, T* out, hipStream_t s) {
+	SMM_TRY(checkDist<T>(D, "dist_spmv"));
+	SMM_TRY(ensureInit());
+	if (op < SMM_OP_ASSIGN || op > SMM_OP_SUB || (D->nLocal > 0 && (!xOwn || !out || (op != SMM_OP_ASSIGN && !lhs)))) {
+		setError("dist_spmv: bad op or null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	T* xExt = static_cast<T*>(D->xExt);
+	if (D->nLocal > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, xOwn, sizeof(T) * D->nLocal, hipMemcpyDeviceToDevice, s));
+	return distMatvec<T>(D, xExt, op, lhs, out, 0, nullptr, nullptr, nullptr, s);
+}
+
+template <typename T>
+static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations, T eps, const smm_hip_precond* M, hipStream_t s, int* status,
+                        int* iterations, T* resnorm) {
+	SMM_TRY(checkDist<T>(D, "dist_bicgstab"));
+	SMM_TRY(ensureInit());
+	const int n = D->nLocal;
+	if (n > 0 && (!b || !x)) {
+		setError("dist_bicgstab: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	// block-Jacobi by rank: M is this rank's preconditioner of its diagonal block A_loc, applied without
+	// communication; with one rank it is the single-GPU preconditioner, with more a weaker one (iteration counts differ)
+	const bool pre = M != nullptr && M->kind != SMM_PRECOND_NONE;
+	if (pre && (M->a != D->aLoc || M->kind == SMM_PRECOND_IC0)) {
+		setError("dist_bicgstab: preconditioner must be JACOBI / ILU0 / SGS of the local diagonal block (smm_hip_dist_csr_local_block)");
+		return SMM_HIP_ERR_INVALID;
+	}
+	maxIterations = std::min(maxIterations, D->nGlobal);  // ref:2200
+	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2201-2203
+	T *r = static_cast<T*>(D->r), *r0 = static_cast<T*>(D->r0), *ap = static_cast<T*>(D->ap), *as = static_cast<T*>(D->as);
+	T *pExt = static_cast<T*>(D->pExt), *sExt = static_cast<T*>(D->sExt), *xExt = static_cast<T*>(D->xExt);
+	T *p = pExt + D->ownOffset, *sv = sExt + D->ownOffset;
+	T *partsA = static_cast<T*>(D->partsA), *partsB = static_cast<T*>(D->partsB), *partsC = static_cast<T*>(D->partsC);
+	auto* sc = static_cast<DistScal<T>*>(D->sc);
+	if (pre && !D->scratch) SMM_TRY(devAlloc(&D->scratch, static_cast<size_t>(std::max(1, n)) * sizeof(T)));
+	T* scratch = static_cast<T*>(D->scratch);
+	hipEvent_t ev = nullptr;
+
+	// r = b - A x (ref:2215) [; r = M^-1 r, ref:2217-2224]
+	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
+	if (pre) {
+		SMM_TRY(distMatvec<T>(D, xExt, SMM_OP_SUB, b, scratch, 0, nullptr, nullptr, nullptr, s));
+		SMM_TRY(precondApplyDev<T>(M, scratch, r, nullptr, s));
+	} else {
+		SMM_TRY(distMatvec<T>(D, xExt, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));
+	}
+	SMM_TRY(launchCopy2<T>(n, r, r0, p, s));                              // r0 = p = r, ref:2225-2226
+	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);  // r.r0 with r0 == r, ref:2231
+	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev));
+	SMM_TRY(join(s, ev));
+	distBicgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc);
+
+	static thread_local DonePoller poller;
+	SMM_TRY(poller.init(s));
+	const int* doneFlag = &sc->done;
+	const int planned = std::max(1, maxIterations);  // do { } while: the body always runs once (ref:2232, 2277)
+	int nextCheck = 1;
+	for (int i = 0; i < planned; ++i) {
+		if (i == nextCheck) {
+			const int seen = poller.post(doneFlag);
+			if (seen < 0) return seen;
+			if (seen) break;
+			nextCheck = i + pollInterval(i);
+		}
+		const int par = i & 1;
+		// ap = [M^-1] A p ; ap.r0 (ref:2233-2243)
+		if (pre) {
+			SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
+			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));
+			distDots<T><<<NPART, TPB, 0, s>>>(n, ap, r0, nullptr, 1, partsA, doneFlag);
+		} else {
+			SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s));
+		}
+		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev));
+		SMM_TRY(join(s, ev));
+		distBicgS<T><<<gridFor(n), TPB, 0, s>>>(n, sc, par, partsA + PARTS_TOTALS, ap, r, sv);
+		// as = [M^-1] A s ; as.as, as.s (ref:2249-2261)
+		if (pre) {
+			SMM_TRY(distMatvec<T>(D, sExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
+			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));
+			distDots<T><<<NPART, TPB, 0, s>>>(n, as, as, sv, 2, partsB, doneFlag);
+		} else {
+			SMM_TRY(distMatvec<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s));
+		}
+		SMM_TRY(allreduceTotals<T>(D, partsB, 2, s, &ev));
+		SMM_TRY(join(s, ev));
+		distBicgR<T><<<NPART, TPB, 0, s>>>(n, sc, partsB + PARTS_TOTALS, sv, as, r0, r, partsC);
+		SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev));  // on the side stream ...
+		distBicgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, sv, x);  // ... while x is updated
+		SMM_TRY(join(s, ev));
+		distBicgP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, par, partsC + PARTS_TOTALS, eps, ap, r, p);
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	DistScal<T> h;
+	SMM_HIP_TRY(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (status) *status = h.iters > maxIterations ? SMM_SOLVER_MAX_ITERATIONS_REACHED : SMM_SOLVER_SUCCESS;  // ref:2279-2282
+	if (iterations) *iterations = h.iters;
+	if (resnorm) *resnorm = h.res;
+	return pre ? precondTakeError(M, s) : SMM_HIP_OK;
+}
+
+template <typename T>
+static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIterations, T eps, hipStream_t s, int* status, int* iterations,
+                  T* resnorm2) {
+	SMM_TRY(checkDist<T>(D, "dist_cg"));
+	SMM_TRY(ensureInit());
+	const int n = D->nLocal;
+	if (n > 0 && (!b || !x0 || !x)) {
+		setError("dist_cg: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2345-2347 (no clamp otherwise)
+	T *r = static_cast<T*>(D->r), *ap = static_cast<T*>(D->ap);
+	T *pExt = static_cast<T*>(D->pExt), *xExt = static_cast<T*>(D->xExt);
+	T* p = pExt + D->ownOffset;
+	T *partsA = static_cast<T*>(D->partsA), *partsC = static_cast<T*>(D->partsC);
+	auto* sc = static_cast<DistScal<T>*>(D->sc);
+	hipEvent_t ev = nullptr;
+	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x0, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
+	SMM_TRY(distMatvec<T>(D, xExt, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
+	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));                                        // p = r, ref:2340
+	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);
+	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev));
+	SMM_TRY(join(s, ev));
+	distCgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc, eps);
+	static thread_local DonePoller poller;
+	SMM_TRY(poller.init(s));
+	const int* doneFlag = &sc->done;
+	int nextCheck = 0;
+	for (int i = 0; i < maxIterations; ++i) {
+		if (i == nextCheck) {
+			const int seen = poller.post(doneFlag);
+			if (seen < 0) return seen;
+			if (seen) break;
+			nextCheck = i + pollInterval(i);
+		}
+		const int par = i & 1;
+		SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, p, partsA, doneFlag, s));  // Ap = A p ; p.Ap, ref:2353-2354
+		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev));
+		SMM_TRY(join(s, ev));
+		distCgR<T><<<NPART, TPB, 0, s>>>(n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC);
+		SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev));                        // on the side stream ...
+		distCgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, i == 0 ? x0 : x, x);      // ... while x is updated (ref:2351, 2395)
+		SMM_TRY(join(s, ev));
+		distCgP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, par, partsC + PARTS_TOTALS, eps, p, r);
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	DistScal<T> h;
+	SMM_HIP_TRY(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (status) *status = h.status;
+	if (iterations) *iterations = h.iters;
+	if (resnorm2) *resnorm2 = h.res;
+	return SMM_HIP_OK;
+}
+
+}  // namespace smm
+
+using namespace smm;
+
+extern "C" {
+
+int smm_hip_comm_unique_id(void* id) {
+	if (!id) {
+		setError("comm_unique_id: null buffer");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	RcclApi* api = rccl();
+	if (!api) return SMM_HIP_ERR_COMM;
+	static_assert(sizeof(ncclUniqueId) == SMM_HIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+	ncclUniqueId u;
+	SMM_RCCL_TRY(api->GetUniqueId(&u));
+	memcpy(id, &u, sizeof(u));
+	return SMM_HIP_OK;
+}
+
+static int commFinish(smm_hip_comm* c, smm_hip_comm** out) {
+	int least = 0, greatest = 0;
+	hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
+	if (e != hipSuccess) {
+		smm_hip_comm_destroy(c);
+		return hipFail(e, "comm stream", __FILE__, __LINE__);
+	}
+	*out = c;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_comm_create_self(smm_hip_comm** out) {
+	if (!out) {
+		setError("comm_create: out is null");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*out = nullptr;
+	SMM_TRY(ensureInit());
+	auto* c = new smm_hip_comm();
+	return commFinish(c, out);
+}
+
+int smm_hip_comm_create_rccl(int rank, int world, const void* id, smm_hip_comm** out) {
+	if (!out || !id || world < 1 || rank < 0 || rank >= world) {
+		setError("comm_create_rccl: bad arguments");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*out = nullptr;
+	SMM_TRY(ensureInit());
+	RcclApi* api = rccl();
+	if (!api) return SMM_HIP_ERR_COMM;
+	auto* c = new smm_hip_comm();
+	c->rank = rank;
+	c->world = world;
+	c->kind = SMM_COMM_RCCL;
+	ncclUniqueId u;
+	memcpy(&u, id, sizeof(u));
+	const ncclResult_t r = api->CommInitRank(&c->nccl, world, u, rank);
+	if (r != ncclSuccess) {
+		delete c;
+		return rcclFail(r, "ncclCommInitRank");
+	}
+	return commFinish(c, out);
+}
+
+int smm_hip_comm_create_host(int rank, int world, smm_hip_host_allreduce_fn allreduce, smm_hip_host_sendrecv_fn sendrecv, void* user,
+                             smm_hip_comm** out) {
+	if (!out || !allreduce || !sendrecv || world < 1 || rank < 0 || rank >= world) {
+		setError("comm_create_host: bad arguments");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*out = nullptr;
+	SMM_TRY(ensureInit());
+	auto* c = new smm_hip_comm();
+	c->rank = rank;
+	c->world = world;
+	c->kind = SMM_COMM_HOST;
+	c->hostAllreduce = allreduce;
+	c->hostSendrecv = sendrecv;
+	c->user = user;
+	return commFinish(c, out);
+}
+
+int smm_hip_comm_destroy(smm_hip_comm* c) {
+	if (!c) return SMM_HIP_OK;
+	if (c->stream) {
+		hipStreamSynchronize(c->stream);
+		hipStreamDestroy(c->stream);
+	}
+	for (hipEvent_t e : c->events) {
+		if (e) hipEventDestroy(e);
+	}
+	if (c->nccl && rccl()) rccl()->CommDestroy(c->nccl);
+	if (c->pinned) hipHostFree(c->pinned);
+	if (c->d_i64) hipFree(c->d_i64);
+	delete c;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_comm_info(const smm_hip_comm* c, int* rank, int* world, int* kind) {
+	if (!c) {
+		setError("comm_info: null communicator");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (rank) *rank = c->rank;
+	if (world) *world = c->world;
+	if (kind) *kind = c->kind;
+	return SMM_HIP_OK;
+}
+
+// exercises every collective the loops use on this communicator: an all-reduce of (rank + 1) and a ring exchange (with one rank:
+// a send to / receive from itself).  Returns SMM_HIP_ERR_COMM when a result is wrong.
+int smm_hip_comm_selftest(smm_hip_comm* c) {
+	if (!c) {
+		setError("comm_selftest: null communicator");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	hipStream_t s = c->stream;
+	DevBuf<double> buf;
+	SMM_TRY(buf.alloc(4));
+	double h[4] = {static_cast<double>(c->rank + 1), 2.0 * (c->rank + 1), static_cast<double>(c->rank), -1.0};
+	SMM_HIP_TRY(hipMemcpyAsync(buf, h, sizeof(h), hipMemcpyHostToDevice, s));
+	if (c->kind != SMM_COMM_SELF) SMM_TRY(commAllreduce<double>(c, buf, 2, s));
+	if (c->kind != SMM_COMM_SELF) {
+		const int next = (c->rank + 1) % c->world, prev = (c->rank + c->world - 1) % c->world;
+		std::vector<Seg> sends{{next, 2, 1}}, recvs{{prev, 3, 1}};
+		SMM_TRY(commExchange<double>(c, buf.p, sends, recvs, s));
+	}
+	double g[4];
+	SMM_HIP_TRY(hipMemcpyAsync(g, buf, sizeof(g), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (c->kind != SMM_COMM_SELF) {
+		const double want = 0.5 * c->world * (c->world + 1);
+		const int prev = (c->rank + c->world - 1) % c->world;
+		if (g[0] != want || g[1] != 2 * want || g[3] != static_cast<double>(prev)) {
+			setError("comm_selftest: got %g %g %g, expected %g %g %d", g[0], g[1], g[3], want, 2 * want, prev);
+			return SMM_HIP_ERR_COMM;
+		}
+	}
+	return SMM_HIP_OK;
+}
+
+int smm_hip_partition_rows_by_nnz(const int* start, int rows, int world, int* bounds) {
+	if (!start || !bounds || rows < 0 || world < 1) {
+		setError("partition_rows_by_nnz: bad arguments");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const long long total = start[rows];
+	bounds[0] = 0;
+	for (int g = 1; g < world; ++g) {
+		const long long target = total * g / world;
+		const int* it = std::lower_bound(start + bounds[g - 1], start + rows, target, [](int v, long long t) { return static_cast<long long>(v) < t; });
+		bounds[g] = static_cast<int>(it - start);
+	}
+	bounds[world] = rows;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_create_dev_f32(smm_hip_comm* comm, int n_global, const int* bounds, const int* d_start, const int* d_positions,
+                                    const float* d_values, smm_hip_dist_csr** out) {
+	return distCreate<float>(comm, n_global, bounds, d_start, d_positions, d_values, out);
+}
+int smm_hip_dist_csr_create_dev_f64(smm_hip_comm* comm, int n_global, const int* bounds, const int* d_start, const int* d_positions,
+                                    const double* d_values, smm_hip_dist_csr** out) {
+	return distCreate<double>(comm, n_global, bounds, d_start, d_positions, d_values, out);
+}
+
+int smm_hip_dist_csr_destroy(smm_hip_dist_csr* D) {
+	if (!D) return SMM_HIP_OK;
+	smm_hip_csr_destroy(D->aLoc);
+	smm_hip_csr_destroy(D->aRem);
+	for (void* p : D->arrays) devFree(p);
+	for (void* p : {D->r, D->r0, D->ap, D->as, D->scratch, D->pExt, D->sExt, D->xExt, D->partsA, D->partsB, D->partsC, D->sc}) devFree(p);
+	delete D;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_info(const smm_hip_dist_csr* D, int* n_local, int* ext_len, int* own_offset, int* halo_elements, long long* nnz_loc,
+                          long long* nnz_rem) {
+	if (!D) {
+		setError("dist_csr_info: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (n_local) *n_local = D->nLocal;
+	if (ext_len) *ext_len = D->extLen;
+	if (own_offset) *own_offset = D->ownOffset;
+	if (halo_elements) *halo_elements = D->haloElements;
+	if (nnz_loc) *nnz_loc = D->nnzLoc;
+	if (nnz_rem) *nnz_rem = D->nnzRem;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_local_block(const smm_hip_dist_csr* D, smm_hip_csr** a_loc, smm_hip_csr** a_rem) {
+	if (!D) {
+		setError("dist_csr_local_block: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a_loc) *a_loc = D->aLoc;
+	if (a_rem) *a_rem = D->aRem;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_spmv_dev_f32(smm_hip_dist_csr* D, int op, const float* d_lhs, const float* d_x, float* d_out, smm_hip_stream stream) {
+	return distSpmv<float>(D, op, d_lhs, d_x, d_out, pickStream(stream));
+}
+int smm_hip_dist_spmv_dev_f64(smm_hip_dist_csr* D, int op, const double* d_lhs, const double* d_x, double* d_out, smm_hip_stream stream) {
+	return distSpmv<double>(D, op, d_lhs, d_x, d_out, pickStream(stream));
+}
+
+int smm_hip_dist_bicgstab_dev_f32(smm_hip_dist_csr* D, const float* d_b, float* d_x, int maxIterations, float eps, const smm_hip_precond* M_loc,
+                                  smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm) {
+	return distBicgstab<float>(D, d_b, d_x, maxIterations, eps, M_loc, pickStream(stream), solver_status, iterations, resnorm);
+}
+int smm_hip_dist_bicgstab_dev_f64(smm_hip_dist_csr* D, const double* d_b, double* d_x, int maxIterations, double eps, const smm_hip_precond* M_loc,
+                                  smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm) {
+	return distBicgstab<double>(D, d_b, d_x, maxIterations, eps, M_loc, pickStream(stream), solver_status, iterations, resnorm);
+}
+
+int smm_hip_dist_cg_dev_f32(smm_hip_dist_csr* D, const float* d_b, const float* d_x0, float* d_x, int maxIterations, float eps,
+                            smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm2) {
+	return distCg<float>(D, d_b, d_x0, d_x, maxIterations, eps, pickStream(stream), solver_status, iterations, resnorm2);
+}
+int smm_hip_dist_cg_dev_f64(smm_hip_dist_csr* D, const double* d_b, const double* d_x0, double* d_x, int maxIterations, double eps,
+                            smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm2) {
+	return distCg<double>(D, d_b, d_x0, d_x, maxIterations, eps, pickStream(stream), solver_status, iterations, resnorm2);
+}
+
+}  // extern "C"

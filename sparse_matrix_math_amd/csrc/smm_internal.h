@@ -137,9 +137,11 @@ constexpr int NPART = 2048;  // 256 CUs x 8 resident workgroups of 256 lanes
 
 // dotMode of the SpMV epilogue: which per-row products are block-reduced into `partials`
 //   0 none; 1: out[i]*w1[i] -> partials[0..NPART); 2: out[i]*out[i] -> partials[0..), out[i]*w1[i] -> partials[NPART..)
+// extraFlags: SPMV_FINISH -- the partial-sum buffer is a "finishing" buffer of PARTS_LEN elements: the workgroup that ends last adds
+// the partials (lastBlockSums, smm_device.h) and leaves the totals at partials[PARTS_TOTALS + k]; the ticket counter sits behind them.
 template <typename T>
 int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
-               const int* doneFlag, hipStream_t s);
+               const int* doneFlag, hipStream_t s, int extraFlags = 0);
 
 // live event timing of SpMV launches (smm_hip_profile_*): begin returns a slot or -1 when profiling is off
 int profBegin(hipStream_t s);
@@ -149,6 +151,12 @@ void profEnd(int slot, hipStream_t s);
 // large to still be in cache when the next kernel reads them (measured on the 512^3 fp64 Laplacian: 3.15 -> 2.97 ms; written
 // bytes cost 2-4x read bytes on this memory system, tools/membw.hip)
 constexpr int SPMV_NT_OUT = 0x100;
+// flag ORed into `op`: finish the fused reduction in the launch itself (see launchSpmv)
+constexpr int SPMV_FINISH = 0x200;
+constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer
+constexpr int PARTS_LEN = 2 * NPART + 4;   // elements of a finishing buffer: 2 x NPART partials, 2 totals, 8 bytes for the ticket
+template <typename T>
+__host__ __device__ inline unsigned* partsTicket(T* partials) { return reinterpret_cast<unsigned*>(partials + PARTS_TOTALS + 2); }
 inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
 	return static_cast<double>(m->rows) * static_cast<double>(elemBytes) > 64.0 * 1024 * 1024 ? SPMV_NT_OUT : 0;
 }
@@ -171,6 +179,67 @@ template <typename T>
 int launchAxpy(int n, T a, const T* x, const T* y, T* out, hipStream_t s);
 template <typename T>
 int launchCopy2(int n, const T* src, T* dst1, T* dst2, hipStream_t s);
+
+// Polls the device `done` flag without stalling the queue: every `interval` iterations the flag is copied into a
+// pinned mailbox behind an event; the host reads mailboxes whose event has completed and waits only when more
+// than two are outstanding.
+struct DonePoller {
+	static constexpr int SLOTS = 4;
+	int* mailbox = nullptr;
+	hipEvent_t ev[SLOTS] = {};
+	bool pending[SLOTS] = {};
+	int head = 0, count = 0;
+	hipStream_t s = nullptr;
+	// one poller per host thread, reused by every solve of that thread (pinned memory and events are expensive to create)
+	int init(hipStream_t stream) {
+		s = stream;
+		head = count = 0;
+		if (!mailbox) {
+			SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&mailbox), SLOTS * sizeof(int), hipHostMallocDefault));
+			for (int i = 0; i < SLOTS; ++i) SMM_HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+		}
+		for (int i = 0; i < SLOTS; ++i) {
+			mailbox[i] = 0;
+			pending[i] = false;
+		}
+		return SMM_HIP_OK;
+	}
+	~DonePoller() {
+		for (int i = 0; i < SLOTS; ++i) {
+			if (ev[i]) hipEventDestroy(ev[i]);
+		}
+		if (mailbox) hipHostFree(mailbox);
+	}
+	// returns 1 when a completed check saw done, 0 otherwise, <0 on error
+	int post(const int* d_done) {
+		int seen = 0;
+		if (count == SLOTS - 1) seen = drain(true);
+		if (seen) return seen;
+		const int slot = (head + count) % SLOTS;
+		SMM_HIP_TRY(hipMemcpyAsync(&mailbox[slot], d_done, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipEventRecord(ev[slot], s));
+		pending[slot] = true;
+		++count;
+		return drain(false);
+	}
+	int drain(bool block) {
+		while (count > 0) {
+			if (block && count >= 2) {
+				SMM_HIP_TRY(hipEventSynchronize(ev[head]));
+			} else {
+				const hipError_t q = hipEventQuery(ev[head]);
+				if (q == hipErrorNotReady) return 0;
+				if (q != hipSuccess) return hipFail(q, "hipEventQuery", __FILE__, __LINE__);
+			}
+			const int v = mailbox[head];
+			pending[head] = false;
+			head = (head + 1) % SLOTS;
+			--count;
+			if (v) return 1;
+		}
+		return 0;
+	}
+};
 
 // solver drivers (smm_solvers.hip)
 template <typename T>

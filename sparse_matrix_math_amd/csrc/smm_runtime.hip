@@ -72,15 +72,38 @@ hipStream_t libStream() { return g_stream; }
 int numCUs() { return g_cus > 0 ? g_cus : 256; }
 
 // ---- caching allocator: free blocks keyed by size, reused exactly --------------------------------------
+// Every `_dev` entry point is asynchronous on the caller's stream, and handles are destroyed (Python __del__, error returns)
+// while kernels that read their buffers may still be queued.  A freed block therefore first goes to a QUARANTINE list; it
+// becomes reusable only after a hipDeviceSynchronize() issued after the free -- paid once, by the first allocation that wants
+// a quarantined block, and releasing the whole quarantine.  (hipFree would have synchronised implicitly; so does this, but
+// once per batch of frees instead of once per block.)  In the steady state of solve-after-solve the device is idle at that
+// point (a solve ends with a stream synchronise), so the synchronise costs microseconds.
 static std::mutex g_allocMutex;
-static std::multimap<size_t, void*> g_free;
+static std::multimap<size_t, void*> g_free;        // safe to hand out
+static std::multimap<size_t, void*> g_quarantine;  // freed, but work that uses them may still be queued on some stream
 static std::map<void*, size_t> g_live;
+
+static bool releaseQuarantineLocked(std::unique_lock<std::mutex>& lock) {
+	if (g_quarantine.empty()) return false;
+	std::multimap<size_t, void*> batch;
+	batch.swap(g_quarantine);  // blocks freed from here on wait for the next synchronise
+	lock.unlock();
+	const hipError_t e = hipDeviceSynchronize();
+	lock.lock();
+	if (e != hipSuccess) {
+		g_quarantine.insert(batch.begin(), batch.end());
+		return false;
+	}
+	g_free.insert(batch.begin(), batch.end());
+	return true;
+}
 
 int devAlloc(void** p, size_t bytes) {
 	bytes = (bytes + 255) & ~static_cast<size_t>(255);
 	{
-		std::lock_guard<std::mutex> lock(g_allocMutex);
+		std::unique_lock<std::mutex> lock(g_allocMutex);
 		auto it = g_free.find(bytes);
+		if (it == g_free.end() && g_quarantine.count(bytes) && releaseQuarantineLocked(lock)) it = g_free.find(bytes);
 		if (it != g_free.end()) {
 			*p = it->second;
 			g_free.erase(it);
@@ -107,15 +130,16 @@ void devFree(void* p) {
 	std::lock_guard<std::mutex> lock(g_allocMutex);
 	auto it = g_live.find(p);
 	if (it == g_live.end()) {
-		hipFree(p);
+		hipFree(p);  // synchronises implicitly
 		return;
 	}
-	g_free.emplace(it->second, p);
+	g_quarantine.emplace(it->second, p);
 	g_live.erase(it);
 }
 
 void devTrim() {
-	std::lock_guard<std::mutex> lock(g_allocMutex);
+	std::unique_lock<std::mutex> lock(g_allocMutex);
+	releaseQuarantineLocked(lock);
 	for (auto& kv : g_free) hipFree(kv.second);
 	g_free.clear();
 }

@@ -401,67 +401,6 @@ static bool updateNT(long long n, size_t elemBytes, int vectors) {
 		else KERNEL<T, false><<<(GRID), TPB, 0, (STREAM)>>>(__VA_ARGS__);       \
 	} while (0)
 
-// Polls the device `done` flag without stalling the queue: every `interval` iterations the flag is copied into a
-// pinned mailbox behind an event; the host reads mailboxes whose event has completed and waits only when more
-// than two are outstanding.
-struct DonePoller {
-	static constexpr int SLOTS = 4;
-	int* mailbox = nullptr;
-	hipEvent_t ev[SLOTS] = {};
-	bool pending[SLOTS] = {};
-	int head = 0, count = 0;
-	hipStream_t s = nullptr;
-	// one poller per host thread, reused by every solve of that thread (pinned memory and events are expensive to create)
-	int init(hipStream_t stream) {
-		s = stream;
-		head = count = 0;
-		if (!mailbox) {
-			SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&mailbox), SLOTS * sizeof(int), hipHostMallocDefault));
-			for (int i = 0; i < SLOTS; ++i) SMM_HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-		}
-		for (int i = 0; i < SLOTS; ++i) {
-			mailbox[i] = 0;
-			pending[i] = false;
-		}
-		return SMM_HIP_OK;
-	}
-	~DonePoller() {
-		for (int i = 0; i < SLOTS; ++i) {
-			if (ev[i]) hipEventDestroy(ev[i]);
-		}
-		if (mailbox) hipHostFree(mailbox);
-	}
-	// returns 1 when a completed check saw done, 0 otherwise, <0 on error
-	int post(const int* d_done) {
-		int seen = 0;
-		if (count == SLOTS - 1) seen = drain(true);
-		if (seen) return seen;
-		const int slot = (head + count) % SLOTS;
-		SMM_HIP_TRY(hipMemcpyAsync(&mailbox[slot], d_done, sizeof(int), hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipEventRecord(ev[slot], s));
-		pending[slot] = true;
-		++count;
-		return drain(false);
-	}
-	int drain(bool block) {
-		while (count > 0) {
-			if (block && count >= 2) {
-				SMM_HIP_TRY(hipEventSynchronize(ev[head]));
-			} else {
-				const hipError_t q = hipEventQuery(ev[head]);
-				if (q == hipErrorNotReady) return 0;
-				if (q != hipSuccess) return hipFail(q, "hipEventQuery", __FILE__, __LINE__);
-			}
-			const int v = mailbox[head];
-			pending[head] = false;
-			head = (head + 1) % SLOTS;
-			--count;
-			if (v) return 1;
-		}
-		return 0;
-	}
-};
-
 static int checkInterval(int it) { return std::max(4, std::min(64, it / 4)); }
 
 template <typename T>

@@ -59,6 +59,8 @@ __global__ __launch_bounds__(TPB) void spmvVectorKernel(int rows, const int* __r
                                                         const int* __restrict__ doneFlag) {
 	__shared__ T red[4];
 	if (doneFlag && *doneFlag) return;
+	const int opFlags = op;
+	op &= 0xFF;
 	const int lane = threadIdx.x % L;
 	const int rowsPerBlock = TPB / L;
 	const int rowInBlock = threadIdx.x / L;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(TPB) void spmvVectorKernel(int rows, const int* __r
 		}
 		const T s1 = blockSum256(acc1, red);
 		if (threadIdx.x == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
 	}
 }
 
@@ -429,6 +432,7 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 			partials[i] = T(0);
 			if (dotMode == 2) partials[NPART + i] = T(0);
 		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
 	}
 }
 
@@ -559,7 +563,7 @@ static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 
 template <typename T>
 int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
-               hipStream_t s) {
+               hipStream_t s, int extraFlags) {
 	if (m->dtype != dtypeOf<T>()) {
 		setError("spmv: matrix dtype does not match the _f32/_f64 entry point");
 		return SMM_HIP_ERR_INVALID;
@@ -580,12 +584,17 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		setError("spmv: fused dot needs w1 and partials");
 		return SMM_HIP_ERR_INVALID;
 	}
+	if ((extraFlags & ~SPMV_FINISH) || ((extraFlags & SPMV_FINISH) && !dotMode)) {
+		setError("spmv: bad extra flags");
+		return SMM_HIP_ERR_INVALID;
+	}
 	if (m->rows == 0 && !dotMode) return SMM_HIP_OK;
+	op |= extraFlags;  // the kernels split `op` into the operation (low byte) and flags
 	int family = m->family;
 	const int L = m->lanes;
 	if (family == SMM_SPMV_PATTERN) {
 		const int profSlot = profBegin(s);
-		const int st = launchSpmvPattern<T>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s);
+		const int st = launchSpmvPattern<T>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s);  // `op` carries the flags
 		profEnd(profSlot, s);
 		return st;
 	}
@@ -628,8 +637,8 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	return SMM_HIP_OK;
 }
 
-template int launchSpmv<float>(const smm_hip_csr*, int, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
-template int launchSpmv<double>(const smm_hip_csr*, int, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
+template int launchSpmv<float>(const smm_hip_csr*, int, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t, int);
+template int launchSpmv<double>(const smm_hip_csr*, int, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t, int);
 
 // host-pointer entry: copy in, run, copy out (the reference's calling convention, ref:1110-1126)
 template <typename T>

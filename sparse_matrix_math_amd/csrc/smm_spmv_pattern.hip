@@ -315,6 +315,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 			partials[i] = T(0);
 			if (dotMode == 2) partials[NPART + i] = T(0);
 		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
 	}
 }
 

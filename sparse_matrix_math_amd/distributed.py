@@ -393,9 +393,200 @@ def build_hip_solver(torch, dist, start, positions, values, bounds, n_global, np
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# native driver: the whole loop behind the C ABI (csrc/smm_dist.hip) -- Python only sets it up
+# ---------------------------------------------------------------------------------------------------------------------
+class NativeComm:
+    """smm_hip_comm: RCCL over xGMI (`rccl`), host callbacks carried by torch.distributed gloo (`gloo`: several ranks may share a
+    GPU; a rehearsal, never a measurement), arbitrary Python callbacks (`host`), or a single rank (`single`)."""
+
+    def __init__(self, handle, keep=()):
+        self._h = handle
+        self._keep = keep  # callback objects must outlive the communicator
+
+    @classmethod
+    def single(cls):
+        from . import _lib
+
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().smm_hip_comm_create_self(ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def rccl(cls, dist, group=None):
+        """rank 0 draws the RCCL unique id, torch.distributed carries it to the other ranks (any backend)"""
+        from . import _lib
+
+        lib = _lib.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.smm_hip_comm_unique_id(ident))
+        box = [ident.raw]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = ctypes.c_void_p()
+        _lib.check(lib.smm_hip_comm_create_rccl(rank, world, ctypes.create_string_buffer(box[0], 128), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def host(cls, rank, world, allreduce, sendrecv):
+        """allreduce(np_array) sums in place over the ranks; sendrecv(sends, recvs) with lists of (peer, np.uint8 array)"""
+        from . import _lib
+
+        np_of = {0: np.float32, 1: np.float64, 2: np.int64}
+
+        def _ar(_user, buf, count, dtype):
+            try:
+                ct = np.ctypeslib.as_ctypes_type(np_of[dtype])
+                allreduce(np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ct)), (count,)))
+                return 0
+            except Exception:  # noqa: BLE001 -- a Python exception must not unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def _sr(_user, ns, speer, sbuf, sbytes, nr, rpeer, rbuf, rbytes):
+            try:
+                def view(ptr, n):
+                    return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_ubyte)), (n,)) if n else np.empty(0, np.uint8)
+
+                sends = [(speer[i], view(sbuf[i], sbytes[i])) for i in range(ns)]
+                recvs = [(rpeer[i], view(rbuf[i], rbytes[i])) for i in range(nr)]
+                sendrecv(sends, recvs)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        cb1, cb2 = _lib.HOST_ALLREDUCE_FN(_ar), _lib.HOST_SENDRECV_FN(_sr)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().smm_hip_comm_create_host(int(rank), int(world), cb1, cb2, None, ctypes.byref(h)))
+        return cls(h, keep=(cb1, cb2))
+
+    @classmethod
+    def gloo(cls, dist, group=None):
+        import torch
+
+        def allreduce(a):
+            dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM, group=group)
+
+        def sendrecv(sends, recvs):
+            reqs = [dist.irecv(torch.from_numpy(buf), src=peer, group=group) for peer, buf in recvs]
+            reqs += [dist.isend(torch.from_numpy(buf), dst=peer, group=group) for peer, buf in sends]
+            for r in reqs:
+                r.wait()
+
+        return cls.host(dist.get_rank(group), dist.get_world_size(group), allreduce, sendrecv)
+
+    def info(self):
+        from . import _lib
+
+        r, w, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().smm_hip_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)))
+        return {"rank": r.value, "world": w.value, "kind": {0: "self", 1: "rccl", 2: "host"}[k.value]}
+
+    def selftest(self):
+        from . import _lib
+
+        _lib.check(_lib.load().smm_hip_comm_selftest(self._h))
+
+    def close(self):
+        if self._h:
+            from . import _lib
+
+            _lib.load().smm_hip_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class _BlockView:
+    """non-owning view of one of a distributed matrix's local blocks (enough of host.CSRMatrix for host.Preconditioner / set_kernel)"""
+
+    def __init__(self, handle, owner, np_dtype):
+        from . import host
+
+        self._h, self._owner = handle, owner
+        self.dtype = np.dtype(np_dtype)
+        self._suf = host._suffix(np_dtype)
+        host.CSRMatrix._read_info(self)
+
+    def set_kernel(self, family=0, lanes_per_row=0):
+        from . import _lib
+
+        _lib.check(_lib.load().smm_hip_csr_set_kernel(self._h, int(family), int(lanes_per_row)))
+
+
+class NativeDistMatrix:
+    """smm_hip_dist_csr: this rank's rows of a row-partitioned matrix + the native solvers on it.  Collective."""
+
+    def __init__(self, comm, n_global, bounds, d_start, d_positions, d_values, np_dtype):
+        from . import _lib, host
+
+        self.comm, self.lib, self.check, self.host = comm, _lib.load(), _lib.check, host
+        self.np_dtype = np.dtype(np_dtype)
+        self.suf = host._suffix(np_dtype)
+        self.n_global = int(n_global)
+        self._h = ctypes.c_void_p()
+        b = (ctypes.c_int * len(bounds))(*[int(v) for v in bounds])
+        self.check(getattr(self.lib, f"smm_hip_dist_csr_create_dev_{self.suf}")(comm._h, self.n_global, b, host._dptr(d_start), host._dptr(d_positions),
+                                                                               host._dptr(d_values), ctypes.byref(self._h)))
+        n, e, o, h = (ctypes.c_int() for _ in range(4))
+        nl, nr = ctypes.c_longlong(), ctypes.c_longlong()
+        self.check(self.lib.smm_hip_dist_csr_info(self._h, ctypes.byref(n), ctypes.byref(e), ctypes.byref(o), ctypes.byref(h), ctypes.byref(nl), ctypes.byref(nr)))
+        self.n_local, self.ext_len, self.own_offset, self.halo_elements, self.nnz_loc, self.nnz_rem = n.value, e.value, o.value, h.value, nl.value, nr.value
+        self._M = None
+
+    def local_blocks(self):
+        a, r = ctypes.c_void_p(), ctypes.c_void_p()
+        self.check(self.lib.smm_hip_dist_csr_local_block(self._h, ctypes.byref(a), ctypes.byref(r)))
+        return _BlockView(a, self, self.np_dtype), _BlockView(r, self, self.np_dtype)
+
+    def set_precond(self, kind):
+        """block-Jacobi by rank: JACOBI / ILU0 / SGS of this rank's diagonal block (None: no preconditioner)"""
+        if self._M is not None:
+            self._M.close()
+        self._M = None
+        if kind is not None and int(kind) != 0:
+            self._M = self.host.Preconditioner(self.local_blocks()[0], kind)
+
+    def spmv(self, op, d_lhs, d_x, d_out, stream=None):
+        d = self.host._dptr
+        self.check(getattr(self.lib, f"smm_hip_dist_spmv_dev_{self.suf}")(self._h, int(op), d(d_lhs), d(d_x), d(d_out), d(stream)))
+
+    def bicgstab(self, d_b, d_x, max_iterations, eps, stream=None):
+        d = self.host._dptr
+        st, it = ctypes.c_int(), ctypes.c_int()
+        res = (ctypes.c_float if self.suf == "f32" else ctypes.c_double)()
+        self.check(getattr(self.lib, f"smm_hip_dist_bicgstab_dev_{self.suf}")(self._h, d(d_b), d(d_x), int(max_iterations), self.np_dtype.type(eps),
+                                                                             self.host._mh(self._M), d(stream), ctypes.byref(st), ctypes.byref(it), ctypes.byref(res)))
+        return st.value, it.value, res.value
+
+    def cg(self, d_b, d_x0, d_x, max_iterations, eps, stream=None):
+        d = self.host._dptr
+        st, it = ctypes.c_int(), ctypes.c_int()
+        res = (ctypes.c_float if self.suf == "f32" else ctypes.c_double)()
+        self.check(getattr(self.lib, f"smm_hip_dist_cg_dev_{self.suf}")(self._h, d(d_b), d(d_x0), d(d_x), int(max_iterations), self.np_dtype.type(eps), d(stream),
+                                                                       ctypes.byref(st), ctypes.byref(it), ctypes.byref(res)))
+        return st.value, it.value, res.value
+
+    def close(self):
+        if self._M is not None:
+            self._M.close()
+            self._M = None
+        if self._h:
+            self.lib.smm_hip_dist_csr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # bench.py leg for N > 1: the same 10M-row banded matrix, rows split over the ranks (strong scaling)
 # ---------------------------------------------------------------------------------------------------------------------
 def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
+    """One rank of `bench.py --gpus N`: the 10M-row banded matrix range-partitioned by nonzeros (strong scaling).  Driver:
+    "native" (default) -- the loop of csrc/smm_dist.hip behind the C ABI, RCCL communicator created from a unique id carried by
+    torch.distributed; "python" -- DistBiCGStab above over torch.distributed collectives (the stage-wise kernels)."""
     import time
 
     import torch
@@ -404,6 +595,8 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     from . import host
 
     n = args.rows
+    driver = getattr(args, "dist_driver", "native")
+    staged = dist.get_backend() == "gloo"
     stream = torch.cuda.current_stream().cuda_stream
     row_start = lambda i: host_gen_row_start(args, i)  # noqa: E731
     bounds = partition_rows_by_nnz(row_start, n, world)
@@ -414,22 +607,41 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     d_val = torch.empty(nnz_local, dtype=t_dtype, device=dev)
     host.gen_banded_rows_dev(n, args.band_k, args.seed, args.max_offset, args.diag_shift, lo, hi, d_start, d_pos, d_val, np_dtype, stream)
     torch.cuda.synchronize()
-    solver = build_hip_solver(torch, dist, d_start, d_pos, d_val, bounds, n, np_dtype, dev)
-    del d_pos, d_val
-    ops = solver.ops
     # b = A x_true, x_true uniform in [0.5, 1.5) generated per rank from (seed, rank)
     x_true = torch.rand(hi - lo, dtype=t_dtype, device=dev, generator=torch.Generator(device=dev).manual_seed(args.seed + rank)) + 0.5
     b = torch.empty(hi - lo, dtype=t_dtype, device=dev)
-    ops.copy_into_ext(ops.x_ext, x_true)
-    solver._matvec(ops.x_ext, ops.own(ops.x_ext), b, OP_ASSIGN, None, 0, None)
     x = torch.zeros(hi - lo, dtype=t_dtype, device=dev)
+    if driver == "native":
+        comm = NativeComm.gloo(dist) if staged else NativeComm.rccl(dist)
+        comm.selftest()
+        A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, np_dtype)
+        del d_pos, d_val
+        A.spmv(OP_ASSIGN, None, x_true, b, stream)
+        halo, ext_len = A.halo_elements, A.ext_len
+        one_launch = A.nnz_rem == 0 and A.halo_elements == 0
+        comm_info = comm.info()
+
+        def solve(it):
+            return A.bicgstab(b, x, it, 0.0, stream)
+    else:
+        solver = build_hip_solver(torch, dist, d_start, d_pos, d_val, bounds, n, np_dtype, dev)
+        del d_pos, d_val
+        ops = solver.ops
+        ops.copy_into_ext(ops.x_ext, x_true)
+        solver._matvec(ops.x_ext, ops.own(ops.x_ext), b, OP_ASSIGN, None, 0, None)
+        halo, ext_len = solver.halo_elements, ops.x_ext.numel()
+        one_launch = getattr(ops, "rem_empty", False) and not solver.sends and not solver.recvs
+        comm_info = {"rank": rank, "world": world, "kind": "torch.distributed/" + dist.get_backend()}
+
+        def solve(it):
+            return solver.solve(b, x, it, 0.0, check_every=1 << 30)
 
     def run(total):
         done, last = 0, None
         while done < total:
             it = min(args.iters_per_solve, total - done)
             x.zero_()
-            status, iters, resnorm = solver.solve(b, x, it, 0.0, check_every=1 << 30)
+            status, iters, resnorm = solve(it)
             if iters != it or not np.isfinite(resnorm) or resnorm <= 0:
                 raise SystemExit(f"rank {rank}: BiCGStab ran {iters} of {it} iterations (resnorm {resnorm}): the timed region is invalid")
             done += iters
@@ -450,13 +662,14 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     spmv_ms, spmv_launches = host.profile_read(reset=True)
     host.profile_enable(False)
     err = ((x - x_true).abs() / x_true).max().reshape(1)
+    if staged:
+        err = err.cpu()
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
     nnz_total = row_start(n)
     s_bytes = np.dtype(np_dtype).itemsize
     # one matvec = the A_loc launch + the A_rem launch; algorithmic bytes of this rank's slice (SURVEY.md section 8d formula)
-    b_local = nnz_local * (s_bytes + 4) + (hi - lo + 1) * 4 + ops.x_ext.numel() * s_bytes + (hi - lo) * s_bytes
-    # a matvec is two launches (A_loc, then A_rem) unless nothing of this rank's rows lives on another rank
-    per_matvec = 1 if (getattr(ops, "rem_empty", False) and not solver.sends and not solver.recvs) else 2
+    b_local = nnz_local * (s_bytes + 4) + (hi - lo + 1) * 4 + ext_len * s_bytes + (hi - lo) * s_bytes
+    per_matvec = 1 if one_launch else 2
     matvec_s = spmv_ms * 1e-3 / max(spmv_launches // per_matvec, 1)
     achieved = b_local / matvec_s / 1e9
     return {
@@ -468,7 +681,9 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         "nnz": nnz_total,
         "resnorm": float(resnorm),
         "max_rel_err_vs_x_true": float(err.item()),
-        "per_rank": {"rows": hi - lo, "nnz": nnz_local, "halo_elements": solver.halo_elements,
+        "distributed": {"driver": driver, "comm": comm_info["kind"], "comm_ranks": comm_info["world"],
+                        "kernels_per_iteration": 8 if driver == "native" else 13, "allreduces_per_iteration": 3, "halo_exchanges_per_iteration": 2},
+        "per_rank": {"rows": hi - lo, "nnz": nnz_local, "halo_elements": halo,
                      "spmv_launch_ms_rank0": spmv_ms / max(spmv_launches, 1), "spmv_launches_rank0": spmv_launches},
     }
 

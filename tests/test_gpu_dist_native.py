@@ -1,0 +1,282 @@
+"""The native row-partitioned solvers (csrc/smm_dist.hip, behind smm_hip_dist_*) on ONE GPU.
+
+RCCL cannot put two ranks on one device, so several ranks are run as threads of this process joined by a host-callback
+communicator (smm_hip_comm_create_host): every byte of the halo exchanges and all-reduces really travels between the ranks, only
+through host memory.  The RCCL code path itself is exercised with a real one-rank RCCL communicator (dlopen, ncclCommInitRank,
+ncclAllReduce, grouped ncclSend / ncclRecv to itself) and, end to end, by bench.py's two-process gloo rehearsal.
+Reference of every result: the single-process CPU oracle."""
+import json
+import os
+import queue
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from sparse_matrix_math_amd import generators as gen
+
+pytestmark = pytest.mark.gpu
+
+
+class _Shared:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.mail = {}
+        self.lock = threading.Lock()
+
+
+def _host_comm(shared, rank):
+    """smm_hip_comm over host callbacks: the ranks are threads of this process"""
+    from sparse_matrix_math_amd.distributed import NativeComm
+
+    def allreduce(a):
+        shared.slots[rank] = a.copy()
+        shared.barrier.wait()
+        total = shared.slots[0].copy()
+        for q in range(1, shared.world):
+            total += shared.slots[q]
+        shared.barrier.wait()
+        a[:] = total
+
+    def box(src, dst):
+        with shared.lock:
+            return shared.mail.setdefault((src, dst), queue.Queue())
+
+    def sendrecv(sends, recvs):  # pairwise hand-off: a rank without neighbours never gets here, so no global barrier
+        for peer, buf in sends:
+            box(rank, peer).put(buf.copy())
+        for peer, buf in recvs:
+            buf[:] = box(peer, rank).get(timeout=120)
+
+    return NativeComm.host(rank, shared.world, allreduce, sendrecv)
+
+
+def _run_ranks(world, fn):
+    """fn(rank, shared) -> result, run on `world` threads; an exception in one rank aborts the others' barriers"""
+    shared = _Shared(world)
+    out, errors = [None] * world, []
+
+    def main(rank):
+        try:
+            import torch
+
+            torch.cuda.set_device(0)
+            out[rank] = fn(rank, shared)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", precond=None, x0_full=None):
+    import torch
+
+    from sparse_matrix_math_amd.distributed import NativeDistMatrix, partition_rows_by_nnz
+
+    dev = torch.device("cuda:0")
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    start, pos, val = csr
+    n = len(start) - 1
+    bounds = partition_rows_by_nnz(lambda i: int(start[i]), n, world)
+
+    def rank_main(rank, shared):
+        lo, hi = bounds[rank], bounds[rank + 1]
+        comm = _host_comm(shared, rank)
+        comm.selftest()
+        d_start = torch.from_numpy((start[lo:hi + 1] - start[lo]).astype(np.int32)).to(dev)
+        d_pos = torch.from_numpy(pos[start[lo]:start[hi]].copy()).to(dev)
+        d_val = torch.from_numpy(val[start[lo]:start[hi]].copy()).to(dev)
+        A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, dtype)
+        assert A.n_local == hi - lo and A.nnz_loc + A.nnz_rem == int(start[hi] - start[lo])
+        A.set_precond(precond)
+        b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
+        x = torch.zeros(hi - lo, dtype=tdt, device=dev) if x0_full is None else torch.from_numpy(x0_full[lo:hi].copy()).to(dev)
+        # y = A x through the distributed SpMV as well
+        y = torch.empty(hi - lo, dtype=tdt, device=dev)
+        A.spmv(0, None, b, y)
+        if solver == "cg":
+            res = A.cg(b, x, x, max_it, eps)
+        else:
+            res = A.bicgstab(b, x, max_it, eps)
+        torch.cuda.synchronize()
+        r = (res, lo, hi, x.cpu().numpy(), y.cpu().numpy(), A.halo_elements)
+        A.close()
+        comm.close()
+        return r
+
+    out = _run_ranks(world, rank_main)
+    x, y = np.zeros(n, dtype=dtype), np.zeros(n, dtype=dtype)
+    for res, lo, hi, xs, ys, _ in out:
+        x[lo:hi], y[lo:hi] = xs, ys
+        assert res == out[0][0]  # every rank reports the same status / iterations / residual
+    return out[0][0], x, y, sum(o[5] for o in out)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_native_bicgstab_matches_oracle(smm, oracle, world, dtype):
+    cases = {
+        "banded": gen.banded_random_spd(60000, k=12, seed=4, max_offset=9000, dtype=dtype),
+        "convdiff": gen.convdiff3d(20, 0.3, dtype=dtype),
+    }
+    tol = 3e-4 if dtype == np.float32 else 1e-10
+    for name, csr in cases.items():
+        n = len(csr[0]) - 1
+        x_true = np.random.default_rng(3).uniform(0.5, 1.5, n).astype(dtype)
+        b = oracle.spmv(csr, 0, None, x_true)
+        for max_it in (1, 6):
+            (status, iters, res), x, y, halo = _solve(smm, csr, b, world, dtype, max_it, 1e-30)
+            st_ref, x_ref, it_ref, res_ref = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), max_it, 1e-30)
+            assert status == st_ref == 0 and iters == it_ref == max_it, (name, world)
+            assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref))), (name, world, max_it)
+            assert abs(res - res_ref) <= 50 * tol * max(res_ref, 1e-30) + 1e-30
+            assert (halo > 0) == (world > 1)
+            y_ref = oracle.spmv(csr, 0, None, b)
+            assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
+        if name == "convdiff":
+            eps = 1e-3 if dtype == np.float32 else 1e-8
+            (status, iters, res), x, _, _ = _solve(smm, csr, b, world, dtype, -1, eps)
+            assert status == 0 and res <= eps
+            np.testing.assert_allclose(x, x_true, rtol=1e-3 if dtype == np.float32 else 1e-7)
+    # maxIterations == 0: the body runs once and the status is MAX_ITERATIONS_REACHED (ref:2277-2282)
+    csr = cases["convdiff"]
+    n = len(csr[0]) - 1
+    b = oracle.spmv(csr, 0, None, np.ones(n, dtype=dtype))
+    (status, iters, _), _, _, _ = _solve(smm, csr, b, world, dtype, 0, 1e-30)
+    assert (status, iters) == (2, 1)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_native_cg_matches_oracle(smm, oracle, world):
+    dtype = np.float64
+    csr = gen.poisson2d(48, dtype=dtype)
+    n = len(csr[0]) - 1
+    b = gen.row_sums(csr[0], csr[2]).astype(dtype)
+    for max_it in (1, 3, 10):
+        (status, iters, res), x, _, _ = _solve(smm, csr, b, world, dtype, max_it, 0.0, solver="cg")
+        st_ref, x_ref, it_ref, res_ref = oracle.cg(csr, b, np.zeros(n), max_it, 0.0)
+        assert (status, iters) == (st_ref, it_ref) == (2, max_it)
+        np.testing.assert_allclose(x, x_ref, rtol=1e-10, atol=1e-12)
+        assert abs(res - res_ref) <= 1e-8 * res_ref
+    (status, iters, res), x, _, _ = _solve(smm, csr, b, world, dtype, -1, 1e-8, solver="cg")
+    st_ref, x_ref, it_ref, _ = oracle.cg(csr, b, np.zeros(n), -1, 1e-8)
+    assert status == st_ref == 0 and abs(iters - it_ref) <= 2
+    np.testing.assert_allclose(x, np.ones(n), rtol=1e-6)
+    # early exit leaves x untouched (ref:2342-2344)
+    x0 = np.ones(n)
+    (status, iters, _), x, _, _ = _solve(smm, csr, b, world, dtype, -1, 1e-6, solver="cg", x0_full=x0)
+    assert (status, iters) == (0, 0)
+    np.testing.assert_array_equal(x, x0)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_native_preconditioned(smm, oracle, world):
+    """block-Jacobi by rank: one rank = the single-GPU preconditioned solver; Jacobi is the same preconditioner for any number of
+    ranks; SGS / ILU0 on several ranks are weaker preconditioners that must still converge and still help"""
+    P = smm.SolverPreconditioner
+    dtype = np.float64
+    csr = gen.convdiff3d(16, 0.3, dtype=dtype)
+    n = len(csr[0]) - 1
+    x_true = np.random.default_rng(7).uniform(0.5, 1.5, n)
+    b = oracle.spmv(csr, 0, None, x_true)
+    A = smm.CSRMatrix(n, n, *csr)
+    eps = 1e-9
+    (_, it_none, _), _, _, _ = _solve(smm, csr, b, world, dtype, -1, eps)
+    for kind in (P.JACOBI, P.ILU0, P.SYMMETRIC_GAUS_SEIDEL):
+        (status, iters, res), x, _, _ = _solve(smm, csr, b, world, dtype, -1, eps, precond=kind)
+        assert status == 0 and res <= eps, (kind, world)
+        np.testing.assert_allclose(x, x_true, rtol=1e-6, err_msg=f"{kind} world {world}")
+        assert iters <= 2 * it_none, (kind, world, iters, it_none)
+        if kind != P.JACOBI:
+            assert iters < it_none, (kind, world, iters, it_none)
+        if world == 1:
+            xs = np.zeros(n)
+            info = {}
+            st = smm.BiCGStab(A, b.copy(), xs, -1, eps, A.getPreconditioner(kind), info=info)
+            assert int(st) == 0 and abs(info["iterations"] - iters) <= 1
+            np.testing.assert_allclose(x, xs, rtol=1e-7)
+
+
+def test_native_rccl_single_rank(smm, oracle):
+    """a real RCCL communicator (one rank): librccl found by dlopen, ncclCommInitRank from a unique id, the all-reduce and the grouped
+    send / recv (to itself) of the self-test, and the loop with its all-reduces on the side stream"""
+    import torch
+
+    from sparse_matrix_math_amd import _lib
+    from sparse_matrix_math_amd.distributed import NativeComm, NativeDistMatrix
+    import ctypes
+
+    lib = _lib.load()
+    ident = ctypes.create_string_buffer(128)
+    _lib.check(lib.smm_hip_comm_unique_id(ident))
+    h = ctypes.c_void_p()
+    _lib.check(lib.smm_hip_comm_create_rccl(0, 1, ident, ctypes.byref(h)))
+    comm = NativeComm(h)
+    assert comm.info() == {"rank": 0, "world": 1, "kind": "rccl"}
+    comm.selftest()
+    dev = torch.device("cuda:0")
+    dtype = np.float32
+    csr = gen.banded_random_spd(50000, 10, 77, 6000, dtype, 1.0)
+    n = len(csr[0]) - 1
+    x_true = np.random.default_rng(3).uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, 0, None, x_true)
+    tens = [torch.from_numpy(a).to(dev) for a in csr]
+    A = NativeDistMatrix(comm, n, [0, n], tens[0], tens[1], tens[2], dtype)
+    x = torch.zeros(n, dtype=torch.float32, device=dev)
+    status, iters, res = A.bicgstab(torch.from_numpy(b).to(dev), x, 5, 0.0)
+    st_ref, x_ref, it_ref, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 5, 0.0)
+    assert status == st_ref and iters == it_ref == 5
+    assert float(np.max(np.abs(x.cpu().numpy() - x_ref))) <= 3e-4 * float(np.max(np.abs(x_ref)))
+    A.close()
+    comm.close()
+
+
+def test_partition_rows_by_nnz_native_matches_python(smm):
+    import ctypes
+
+    from sparse_matrix_math_amd import _lib
+    from sparse_matrix_math_amd.distributed import partition_rows_by_nnz
+
+    start = gen.banded_random_spd(30000, 6, 1, 4000, np.float32)[0]
+    for world in (1, 2, 3, 8):
+        out = (ctypes.c_int * (world + 1))()
+        _lib.check(_lib.load().smm_hip_partition_rows_by_nnz(start.ctypes.data_as(ctypes.c_void_p), len(start) - 1, world, out))
+        assert list(out) == partition_rows_by_nnz(lambda i: int(start[i]), len(start) - 1, world)
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_self_launch_rehearsal(ranks):
+    """`python bench.py --gpus N` exactly as the driver types it (no torch.distributed.run in front): bench.py starts its own N rank
+    processes.  Here the ranks share the one GPU and SMM_BENCH_BACKEND=gloo carries the communicator's bytes through the host, so
+    this checks function, not speed: per-rank generation, the device-side A_loc / A_rem split, the native loop with real
+    inter-process exchanges and all-reduces, the max-over-ranks timing and the single JSON line of rank 0."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rows", "600000", "--max-offset", "65536", "--steps", "20",
+           "--warmup", "10", "--iters-per-solve", "10"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == ranks and line["steps"] == 20 and line["scaling"] == "strong"
+    assert line["unit"] == "iterations/s" and line["value"] > 0
+    assert line["rehearsal_backend"] == "gloo"
+    assert line["distributed"] == {"driver": "native", "comm": "host", "comm_ranks": ranks, "kernels_per_iteration": 8,
+                                   "allreduces_per_iteration": 3, "halo_exchanges_per_iteration": 2}
+    assert line["per_rank"]["halo_elements"] > 0
+    assert line["max_rel_err_vs_x_true"] < 1e-3
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
