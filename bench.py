@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--spmv-lanes", type=int, default=0)
     ap.add_argument("--autotune", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) PATTERN-family measurement")
+    ap.add_argument("--mtx", default=None, help="extras leg (BASELINE config 5): a Matrix Market file read by the drop-in header's direct-to-CSR loader and "
+                    "solved with BiCGStab + none / Jacobi / ILU0 (tests/cpp/mtx_bicgstab); default: ./atmosmodd.mtx when it exists")
     ap.add_argument("--dist", action="store_true", help="take the row-partitioned multi-GPU code path even with one rank")
     ap.add_argument("--dist-driver", choices=["native", "python"], default="native",
                     help="N > 1: the loop behind the C ABI (csrc/smm_dist.hip, RCCL) or the Python driver over torch.distributed")
@@ -145,6 +147,25 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
             out["reference_1_core"] = 2 / dtr
     except Exception as e:  # noqa: BLE001 -- the reference leg is optional; the port above is the baseline
         out["reference_error"] = str(e)[:200]
+    return out
+
+
+def mtx_leg(path):
+    """BASELINE config 5 on a real file through the C++ drop-in header (tests/cpp/mtx_bicgstab.cpp): not the headline"""
+    import subprocess
+
+    tool = os.path.join(ROOT, "tests", "cpp", "mtx_bicgstab")
+    if not os.path.exists(tool):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "mtx_bicgstab"], check=True)
+    out = {"file": os.path.basename(path)}
+    for kind in ("none", "jacobi", "ilu0"):
+        r = subprocess.run([tool, path, kind, "2000", "1e-8"], capture_output=True, text=True, timeout=1800)
+        if r.returncode != 0:
+            out[kind] = {"error": (r.stderr or r.stdout)[-300:]}
+            continue
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        out.update(rows=j["rows"], nnz=j["nnz"], load_s=j["load_s"])
+        out[kind] = {k: j[k] for k in ("status", "iterations", "resnorm", "solve_s", "precond_setup_s", "max_abs_err_vs_ones")}
     return out
 
 
@@ -305,6 +326,9 @@ def main():
             except smm.SmmHipError as e:
                 result["extras"] = {"pattern_family": {"skipped": str(e)}}
             A.set_kernel(family, lanes)
+        mtx = args.mtx or (os.path.join(ROOT, "atmosmodd.mtx") if os.path.exists(os.path.join(ROOT, "atmosmodd.mtx")) else None)
+        if mtx:
+            result.setdefault("extras", {})["mtx_bicgstab"] = mtx_leg(mtx)
         if args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, np_dtype, d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy(),
                                                   b.cpu().numpy(), args.cpu_seconds)

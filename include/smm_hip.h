@@ -172,6 +172,18 @@ int smm_hip_bicgstab_dev_f32(const smm_hip_csr* a, const float* d_b, float* d_x,
 int smm_hip_bicgstab_dev_f64(const smm_hip_csr* a, const double* d_b, double* d_x, int maxIterations, double eps,
                              const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm);
 
+/* The generic form of the reference's template `BiCGStab<Preconditioner, T>` (ref:2191-2199): ANY preconditioner, given as a host
+ * function with the reference's contract `int apply(const T* rhs, T* x)` on HOST vectors of length rows (non-zero = failure; rhs
+ * and x never alias).  SpMV, reductions and updates run on the device as in smm_hip_bicgstab_*; every apply costs two PCIe copies of
+ * one vector and two stream drains, so this is the slow path for preconditioners the library does not have.  A failing apply ends
+ * the solve with SMM_HIP_ERR_PRECOND. */
+typedef int (*smm_hip_apply_fn_f32)(void* user, const float* rhs, float* x);
+typedef int (*smm_hip_apply_fn_f64)(void* user, const double* rhs, double* x);
+int smm_hip_bicgstab_functor_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, smm_hip_apply_fn_f32 apply, void* user,
+                                 int* solver_status, int* iterations, float* resnorm);
+int smm_hip_bicgstab_functor_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps, smm_hip_apply_fn_f64 apply, void* user,
+                                 int* solver_status, int* iterations, double* resnorm);
+
 /* BiCGSymmetric (ref:2021-2102): same kernels as CG plus the DIVERGED heuristics (ref:2056-2058, 2079-2081) */
 int smm_hip_bicgsymmetric_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, int* solver_status, int* iterations);
 int smm_hip_bicgsymmetric_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps, int* solver_status, int* iterations);

@@ -9,8 +9,13 @@
 // compiles against this header unchanged and runs those calls on an MI355X: same names, same argument order and meaning,
 // same return values (SolverStatus; int != 0 on failure for init / apply).  Matrix assembly (TripletMatrix, CSR arrays)
 // stays on the host exactly as in the reference; the CSR arrays are mirrored to the GPU the first time a hot-path call
-// needs them.  Nothing here computes on the CPU: every rMult* / solver / apply call goes through libsmm_hip.so and fails
-// (returns non-zero / SolverStatus::DIVERGED with smm_hip_last_error() set) when no GPU is present.
+// needs them.  Nothing here computes on the CPU: every rMult* / solver / apply call goes through libsmm_hip.so.
+//
+// FAILURES OF THE GPU PATH ARE OBSERVABLE (the reference's signatures have no room for them, so they are reported beside them):
+//   * SMM::lastHipStatus() -- the SMM_HIP_* status of the last hot-path call of this thread (0 = ok), text in smm_hip_last_error();
+//   * rMult / rMultAdd / rMultSub fill `out` with NaN, Vector::operator* returns NaN, solvers return SolverStatus::DIVERGED
+//     (and lastHipStatus() != 0 tells that apart from a numerical divergence), apply() / init() return non-zero;
+//   * compile with -DSMM_HIP_ABORT_ON_ERROR to print the message and abort() instead.
 //
 // Written from the documented behaviour of the reference; no reference source is reproduced here.
 // Additions the reference lacks: CSRMatrix::init(rows, cols, start, positions, values) (raw CSR arrays, ref can only be
@@ -23,7 +28,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -72,7 +79,29 @@ struct Abi<double> {
 	static int bicgsym(const smm_hip_csr* a, double* b, double* x, int it, double eps, int* st) { return smm_hip_bicgsymmetric_f64(a, b, x, it, eps, st, nullptr); }
 	static int apply(const smm_hip_precond* M, const double* r, double* x) { return smm_hip_precond_apply_f64(M, r, x); }
 };
+inline int& statusSlot() noexcept {
+	static thread_local int st = SMM_HIP_OK;
+	return st;
+}
+// every hot-path call funnels its ABI status through here
+inline int note(int abi) noexcept {
+	statusSlot() = abi;
+#ifdef SMM_HIP_ABORT_ON_ERROR
+	if (abi != SMM_HIP_OK) {
+		std::fprintf(stderr, "smm_hip: error %d: %s\n", abi, smm_hip_last_error());
+		std::abort();
+	}
+#endif
+	return abi;
+}
+template <typename T>
+inline void fillNaN(T* p, int n) noexcept {
+	for (int i = 0; p && i < n; ++i) p[i] = std::numeric_limits<T>::quiet_NaN();
+}
 }  // namespace detail
+
+// SMM_HIP_* status of the calling thread's last hot-path call (rMult*, dot / norms, solvers, preconditioner init / apply); 0 = ok
+inline int lastHipStatus() noexcept { return detail::statusSlot(); }
 
 // ---- Vector<T> (ref:42-381): host buffer that decays to T*, dot product and norms on the GPU ---------------------------
 template <typename T>
@@ -107,7 +136,7 @@ public:
 	// dot product (ref:305-328) and norms (ref:287-303) -- reductions of the hot path, computed on the GPU
 	const T operator*(const Vector& o) const {
 		T r = T(0);
-		detail::Abi<T>::dot(getSize(), buf.data(), o.buf.data(), &r);
+		if (detail::note(detail::Abi<T>::dot(getSize(), buf.data(), o.buf.data(), &r)) != SMM_HIP_OK) r = std::numeric_limits<T>::quiet_NaN();
 		return r;
 	}
 	T secondNormSquared() const { return (*this) * (*this); }
@@ -222,11 +251,11 @@ public:
 			if (h) return 0;
 			const smm_hip_csr* dev = m->device();
 			if (!dev) return 1;
-			return smm_hip_precond_create(dev, kind, &h) == SMM_HIP_OK ? 0 : 1;
+			return detail::note(smm_hip_precond_create(dev, kind, &h)) == SMM_HIP_OK ? 0 : 1;
 		}
 		int apply(const T* rhs, T* x) const noexcept {
 			if (init()) return 1;
-			return detail::Abi<T>::apply(h, rhs, x) == SMM_HIP_OK ? 0 : 1;
+			return detail::note(detail::Abi<T>::apply(h, rhs, x)) == SMM_HIP_OK ? 0 : 1;
 		}
 		const smm_hip_precond* handle() const noexcept { return init() ? nullptr : h; }
 
@@ -350,7 +379,7 @@ public:
 	// device mirror of the three arrays, created on first use; nullptr when there is no GPU
 	const smm_hip_csr* device() const noexcept {
 		if (!dev && start) {
-			if (detail::Abi<T>::create(denseRowCount, denseColCount, start.get(), positions.get(), values.get(), &dev) != SMM_HIP_OK) dev = nullptr;
+			if (detail::note(detail::Abi<T>::create(denseRowCount, denseColCount, start.get(), positions.get(), values.get(), &dev)) != SMM_HIP_OK) dev = nullptr;
 		}
 		return dev;
 	}
@@ -371,8 +400,8 @@ public:
 
 private:
 	void spmv(int op, const T* lhs, const T* mult, T* out) const noexcept {
-		const smm_hip_csr* d = device();
-		if (d) detail::Abi<T>::spmv(d, op, lhs, mult, out);
+		const smm_hip_csr* d = device();  // a failed mirror has already noted its status
+		if (!d || detail::note(detail::Abi<T>::spmv(d, op, lhs, mult, out)) != SMM_HIP_OK) detail::fillNaN(out, denseRowCount);
 	}
 	void computeFirstActive() noexcept {  // ref:1619-1628
 		firstActiveStart = denseRowCount;
@@ -400,9 +429,24 @@ private:
 // ---- solvers ---------------------------------------------------------------------------------------------------------------
 namespace detail {
 inline SolverStatus toStatus(int abi, int solver) {
-	if (abi != SMM_HIP_OK) return SolverStatus::DIVERGED;  // no GPU / HIP failure: text in smm_hip_last_error()
+	// no GPU / HIP failure: DIVERGED, with lastHipStatus() != 0 (a numerical DIVERGED leaves it 0) and the text in smm_hip_last_error()
+	if (note(abi) != SMM_HIP_OK) return SolverStatus::DIVERGED;
 	return static_cast<SolverStatus>(solver);
 }
+template <typename T>
+struct Functor;
+template <>
+struct Functor<float> {
+	static int run(const smm_hip_csr* a, float* b, float* x, int it, float eps, smm_hip_apply_fn_f32 fn, void* user, int* st) {
+		return smm_hip_bicgstab_functor_f32(a, b, x, it, eps, fn, user, st, nullptr, nullptr);
+	}
+};
+template <>
+struct Functor<double> {
+	static int run(const smm_hip_csr* a, double* b, double* x, int it, double eps, smm_hip_apply_fn_f64 fn, void* user, int* st) {
+		return smm_hip_bicgstab_functor_f64(a, b, x, it, eps, fn, user, st, nullptr, nullptr);
+	}
+};
 }  // namespace detail
 
 // ref:2316-2398
@@ -425,20 +469,25 @@ inline SolverStatus ConjugateGradient(const CSRMatrix<T>& a, const T* const b, c
 	return detail::toStatus(rc, st);
 }
 
-// ref:2191-2283.  Preconditioner must be one of CSRMatrix<T>'s preconditioner classes (they live on the GPU); an arbitrary
-// host type with an apply() member cannot run inside the device-resident loop.
+// ref:2191-2283.  CSRMatrix<T>'s own preconditioner classes live on the GPU and run inside the device-resident loop.  ANY other type
+// with the reference's `int apply(const T* rhs, T* x) const` (ref:2199, 2218, 2235, 2251) is accepted as well: the loop then runs
+// its SpMVs, reductions and updates on the device and calls the functor on the host around two PCIe copies per apply (the slow
+// path: smm_hip_bicgstab_functor_*).
 template <typename Preconditioner, typename T>
 inline SolverStatus BiCGStab(const CSRMatrix<T>& a, T* b, T* x, int maxIterations, T eps, const Preconditioner& preconditioner) {
-	static_assert(std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value ||
-	                  std::is_base_of<typename CSRMatrix<T>::PreconditionerBase, Preconditioner>::value,
-	              "BiCGStab on the GPU needs one of CSRMatrix<T>'s preconditioner classes");
 	int st = 0;
 	const smm_hip_csr* d = a.device();
-	const smm_hip_precond* h = preconditioner.handle();
-	constexpr bool precondition = !std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value;
-	if (!d || (precondition && !h)) return SolverStatus::DIVERGED;
-	const int rc = detail::Abi<T>::bicgstab(d, b, x, maxIterations, eps, h, &st);
-	return detail::toStatus(rc, st);
+	if (!d) return SolverStatus::DIVERGED;
+	if constexpr (std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value ||
+	              std::is_base_of<typename CSRMatrix<T>::PreconditionerBase, Preconditioner>::value) {
+		const smm_hip_precond* h = preconditioner.handle();
+		constexpr bool precondition = !std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value;
+		if (precondition && !h) return SolverStatus::DIVERGED;
+		return detail::toStatus(detail::Abi<T>::bicgstab(d, b, x, maxIterations, eps, h, &st), st);
+	} else {
+		auto trampoline = +[](void* user, const T* rhs, T* out) -> int { return static_cast<const Preconditioner*>(user)->apply(rhs, out); };
+		return detail::toStatus(detail::Functor<T>::run(d, b, x, maxIterations, eps, trampoline, const_cast<Preconditioner*>(&preconditioner), &st), st);
+	}
 }
 
 // ref:2294-2303
@@ -456,52 +505,172 @@ inline SolverStatus BiCGSymmetric(const CSRMatrix<T>& a, T* b, T* x, int maxIter
 	return detail::toStatus(rc, st);
 }
 
-// ---- Matrix Market loader (ref:2507-2669 reads `coordinate real|integer symmetric` only; `general` and `pattern` are additions) ----
-enum class MatrixLoadStatus { SUCCESS = 0, FAILED_TO_OPEN_FILE, FAILED_TO_OPEN_FILE_UNKNOWN_FORMAT, PARSE_ERROR_INVALID_FILE, PARSE_ERROR_UNSUPPORTED_FORMAT };
+// ---- file loaders (ref:2507-2669) ---------------------------------------------------------------------------------------------
+// Same enumerators in the same order as ref:2507-2522; additions follow them.
+enum class MatrixLoadStatus {
+	SUCCESS = 0,
+	FAILED_TO_OPEN_FILE,
+	FAILED_TO_OPEN_FILE_UNKNOWN_FORMAT,
+	FAILED_TO_PARSE_FILE,
+	PARSE_ERROR_MMX_FILE_MISSING_BANNER,
+	PARSE_ERROR_MMX_FILE_UNSUPPORTED_TYPE,
+	PARSE_ERROR_MMX_FILE_UNSUPPORTED_FORMAT,
+	PARSE_ERROR_MMX_FILE_UNSUPPORTED_EL_TYPE,
+	PARSE_ERROR_MMX_FILE_UNSUPPORTED_STRUCTURE,
+	// additions
+	PARSE_ERROR_INDEX_OUT_OF_RANGE,  // an entry outside rows x cols (undefined behaviour in the reference)
+	MATRIX_TOO_LARGE                 // more than 2^31 - 1 stored entries after mirroring: start[] is int (ref:1251-1257)
+};
 
-template <typename T>
-inline MatrixLoadStatus loadMatrix(const char* path, TripletMatrix<T>& out) {
-	std::ifstream in(path);
-	if (!in) return MatrixLoadStatus::FAILED_TO_OPEN_FILE;
-	std::string line;
-	if (!std::getline(in, line)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
-	std::transform(line.begin(), line.end(), line.begin(), [](unsigned char c) { return static_cast<char>(std::tolower(c)); });
-	std::istringstream hdr(line);
-	std::string banner, object, format, field, symmetry;
-	hdr >> banner >> object >> format >> field >> symmetry;
-	if (banner != "%%matrixmarket") return MatrixLoadStatus::FAILED_TO_OPEN_FILE_UNKNOWN_FORMAT;
-	if (object != "matrix" || format != "coordinate") return MatrixLoadStatus::PARSE_ERROR_UNSUPPORTED_FORMAT;
-	const bool pattern = field == "pattern";
-	if (!pattern && field != "real" && field != "integer" && field != "double") return MatrixLoadStatus::PARSE_ERROR_UNSUPPORTED_FORMAT;
-	const bool symmetric = symmetry == "symmetric";
-	if (!symmetric && symmetry != "general") return MatrixLoadStatus::PARSE_ERROR_UNSUPPORTED_FORMAT;
-	while (std::getline(in, line) && (line.empty() || line[0] == '%')) {
-	}
+namespace detail {
+struct MmEntry {
+	int row, col;
+	double value;
+};
+struct MmHeader {
 	int rows = 0, cols = 0;
-	long long entries = 0;
-	{
-		std::istringstream sz(line);
-		if (!(sz >> rows >> cols >> entries)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
-	}
-	out.init(rows, cols);
-	for (long long e = 0; e < entries; ++e) {
-		int r = 0, c = 0;
-		double v = 1.0;
-		if (!(in >> r >> c)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
-		if (!pattern && !(in >> v)) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
-		if (r < 1 || c < 1 || r > rows || c > cols) return MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
-		out.addEntry(r - 1, c - 1, static_cast<T>(v));
-		if (symmetric && r != c) out.addEntry(c - 1, r - 1, static_cast<T>(v));  // mirror the off-diagonals, ref:2598-2601
+	long long declared = 0;
+	bool pattern = false, symmetric = false;
+};
+inline void lower(std::string& s) {
+	for (char& c : s) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+}
+// Banner, comments and size line exactly as ref:2537-2581 reads them: `%%MatrixMarket` case-sensitive, the four qualifiers
+// case-insensitive; `coordinate` only; `real` / `integer` (ref) and `pattern` (addition: every entry is 1); `symmetric` (ref) and
+// `general` (addition).
+inline MatrixLoadStatus readMmHeader(std::istream& file, MmHeader& h) {
+	std::string banner, matrix, format, type, structure;
+	file >> banner;
+	if (banner != "%%MatrixMarket") return MatrixLoadStatus::PARSE_ERROR_MMX_FILE_MISSING_BANNER;
+	file >> matrix;
+	lower(matrix);
+	if (matrix != "matrix") return MatrixLoadStatus::PARSE_ERROR_MMX_FILE_UNSUPPORTED_TYPE;
+	file >> format;
+	lower(format);
+	if (format != "coordinate") return MatrixLoadStatus::PARSE_ERROR_MMX_FILE_UNSUPPORTED_FORMAT;
+	file >> type;
+	lower(type);
+	h.pattern = type == "pattern";
+	if (!h.pattern && type != "real" && type != "integer") return MatrixLoadStatus::PARSE_ERROR_MMX_FILE_UNSUPPORTED_EL_TYPE;
+	file >> structure;
+	lower(structure);
+	h.symmetric = structure == "symmetric";
+	if (!h.symmetric && structure != "general") return MatrixLoadStatus::PARSE_ERROR_MMX_FILE_UNSUPPORTED_STRUCTURE;
+	while (file.peek() == '%' || std::isspace(file.peek())) file.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
+	file >> h.rows >> h.cols >> h.declared;
+	if (file.fail() || h.rows < 0 || h.cols < 0) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+	return MatrixLoadStatus::SUCCESS;
+}
+// Entries until end of file, like the reference's loop (ref:2584-2608: the declared count only sizes the container); every
+// entry goes to sink(row, col, value) with 0-based indices, off-diagonal entries of a symmetric file also mirrored (ref:2598-2601).
+template <typename Sink>
+inline MatrixLoadStatus readMmEntries(std::istream& file, const MmHeader& h, Sink&& sink) {
+	while (std::isspace(file.peek())) file.get();
+	while (!file.eof() && file.peek() != std::char_traits<char>::eof()) {
+		int row = 0, col = 0;
+		double value = 1.0;
+		file >> row >> col;
+		if (!h.pattern) file >> value;
+		if (file.fail()) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+		if (row < 1 || col < 1 || row > h.rows || col > h.cols) return MatrixLoadStatus::PARSE_ERROR_INDEX_OUT_OF_RANGE;
+		sink(row - 1, col - 1, value);
+		if (h.symmetric && row != col) sink(col - 1, row - 1, value);
+		while (std::isspace(file.peek())) file.get();
 	}
 	return MatrixLoadStatus::SUCCESS;
 }
+}  // namespace detail
 
+// ref:2531-2609, same signature: Matrix Market coordinate file into a TripletMatrix (duplicates add up, ref:612-617)
 template <typename T>
-inline MatrixLoadStatus loadMatrix(const char* path, CSRMatrix<T>& out) {
-	TripletMatrix<T> triplet;
-	const MatrixLoadStatus st = loadMatrix(path, triplet);
+inline MatrixLoadStatus loadMatrixMarketMatrix(const char* filepath, TripletMatrix<T>& out) {
+	std::ifstream file(filepath);
+	if (!file.is_open()) return MatrixLoadStatus::FAILED_TO_OPEN_FILE;
+	detail::MmHeader h;
+	const MatrixLoadStatus st = detail::readMmHeader(file, h);
 	if (st != MatrixLoadStatus::SUCCESS) return st;
-	return out.init(triplet) == 0 ? MatrixLoadStatus::SUCCESS : MatrixLoadStatus::PARSE_ERROR_INVALID_FILE;
+	out.init(h.rows, h.cols, static_cast<int>(std::min<long long>(h.declared, std::numeric_limits<int>::max())));
+	return detail::readMmEntries(file, h, [&](int r, int c, double v) { out.addEntry(r, c, static_cast<T>(v)); });
+}
+
+// Addition: the same file DIRECT TO CSR, without the std::map of the triplet form (ref:606-618 costs ~50 bytes and a tree insertion
+// per entry: 5e8 entries do not fit).  Entries are collected, stably sorted by (row, column) and duplicates added in file order --
+// the same sums in the same order as TripletMatrix::addEntry forms them -- and the three CSR arrays are written in one pass.
+template <typename T>
+inline MatrixLoadStatus loadMatrixMarketMatrix(const char* filepath, CSRMatrix<T>& out) {
+	std::ifstream file(filepath);
+	if (!file.is_open()) return MatrixLoadStatus::FAILED_TO_OPEN_FILE;
+	detail::MmHeader h;
+	MatrixLoadStatus st = detail::readMmHeader(file, h);
+	if (st != MatrixLoadStatus::SUCCESS) return st;
+	std::vector<detail::MmEntry> entries;
+	if (h.declared > 0) entries.reserve(static_cast<size_t>(h.symmetric ? 2 * h.declared : h.declared));
+	st = detail::readMmEntries(file, h, [&](int r, int c, double v) { entries.push_back({r, c, v}); });
+	if (st != MatrixLoadStatus::SUCCESS) return st;
+	std::stable_sort(entries.begin(), entries.end(), [](const detail::MmEntry& a, const detail::MmEntry& b) { return a.row != b.row ? a.row < b.row : a.col < b.col; });
+	std::vector<int> start(static_cast<size_t>(h.rows) + 1, 0), positions;
+	std::vector<T> values;
+	positions.reserve(entries.size());
+	values.reserve(entries.size());
+	for (size_t i = 0; i < entries.size();) {
+		size_t j = i;
+		T sum = T(0);  // TripletMatrix::addEntry: data[key] += value starting from T() (ref:612-617)
+		for (; j < entries.size() && entries[j].row == entries[i].row && entries[j].col == entries[i].col; ++j) sum += static_cast<T>(entries[j].value);
+		if (positions.size() == static_cast<size_t>(std::numeric_limits<int>::max())) return MatrixLoadStatus::MATRIX_TOO_LARGE;
+		positions.push_back(entries[i].col);
+		values.push_back(sum);
+		start[static_cast<size_t>(entries[i].row) + 1]++;
+		i = j;
+	}
+	for (int r = 0; r < h.rows; ++r) start[static_cast<size_t>(r) + 1] += start[static_cast<size_t>(r)];
+	return out.init(h.rows, h.cols, start.data(), positions.data(), values.data()) == 0 ? MatrixLoadStatus::SUCCESS : MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+}
+
+// ref:2611-2643: dense text `rows cols { {a, b, ...}, {...} }`; zeros are not stored
+template <typename T>
+inline MatrixLoadStatus loadSMMDTMatrix(const char* filepath, TripletMatrix<T>& out) {
+	std::ifstream file(filepath);
+	if (!file.is_open()) return MatrixLoadStatus::FAILED_TO_OPEN_FILE;
+	int rows = 0, cols = 0;
+	file >> rows >> cols;
+	if (file.fail() || rows < 0 || cols < 0) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+	out.init(rows, cols, 0);
+	file.ignore(std::numeric_limits<std::streamsize>::max(), '{');
+	for (int i = 0; i < rows; ++i) {
+		file.ignore(std::numeric_limits<std::streamsize>::max(), '{');
+		for (int j = 0; j < cols; ++j) {
+			T val;
+			file >> val;
+			if (file.fail()) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+			if (val != 0) out.addEntry(i, j, val);
+			file.ignore(1, ',');
+		}
+		file.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
+	}
+	file.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
+	if (file.fail()) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+	return MatrixLoadStatus::SUCCESS;
+}
+
+// ref:2645-2656: by file extension
+template <typename T>
+inline MatrixLoadStatus loadMatrix(const char* filepath, TripletMatrix<T>& out) {
+	const char* dot = std::strrchr(filepath, '.');
+	if (dot && std::strcmp(dot + 1, "mtx") == 0) return loadMatrixMarketMatrix(filepath, out);
+	if (dot && std::strcmp(dot + 1, "smmdt") == 0) return loadSMMDTMatrix(filepath, out);
+	return MatrixLoadStatus::FAILED_TO_OPEN_FILE_UNKNOWN_FORMAT;
+}
+
+// ref:2658-2669.  `.mtx` goes direct to CSR (above); the dense text format is small by nature and keeps the triplet route.
+template <typename T>
+inline MatrixLoadStatus loadMatrix(const char* filepath, CSRMatrix<T>& out) {
+	const char* dot = std::strrchr(filepath, '.');
+	if (dot && std::strcmp(dot + 1, "mtx") == 0) return loadMatrixMarketMatrix(filepath, out);
+	TripletMatrix<T> triplet;
+	const MatrixLoadStatus status = loadMatrix(filepath, triplet);
+	if (status != MatrixLoadStatus::SUCCESS) return status;
+	out.init(triplet);
+	return MatrixLoadStatus::SUCCESS;
 }
 
 }  // namespace SMM

@@ -49,6 +49,7 @@ _TYPED = {
     "smm_hip_cg_dev": (c_int, [_P, _P, _P, _P, c_int, "T", _P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
     "smm_hip_bicgstab": (c_int, [_P, _P, _P, c_int, "T", _P, POINTER(c_int), POINTER(c_int), "PT"]),
     "smm_hip_bicgstab_dev": (c_int, [_P, _P, _P, c_int, "T", _P, _P, POINTER(c_int), POINTER(c_int), "PT"]),
+    "smm_hip_bicgstab_functor": (c_int, [_P, _P, _P, c_int, "T", "APPLY", _P, POINTER(c_int), POINTER(c_int), "PT"]),
     "smm_hip_bicgsymmetric": (c_int, [_P, _P, _P, c_int, "T", POINTER(c_int), POINTER(c_int)]),
     "smm_hip_precond_apply": (c_int, [_P, _P, _P]),
     "smm_hip_precond_apply_dev": (c_int, [_P, _P, _P, _P]),
@@ -160,7 +161,10 @@ def load(fma=False):
         for suf, ct in (("f32", c_float), ("f64", c_double)):
             fn = getattr(lib, f"{base}_{suf}")
             fn.restype = res
-            fn.argtypes = [ct if a == "T" else POINTER(ct) if a == "PT" else a for a in args]
+            apply_t = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(ct), POINTER(ct))
+            fn.argtypes = [ct if a == "T" else POINTER(ct) if a == "PT" else apply_t if a == "APPLY" else a for a in args]
+            if "APPLY" in args:
+                fn.apply_type = apply_t
     _lib = lib
     return lib
 

@@ -494,27 +494,43 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 	return pcg ? precondTakeError(M, s) : SMM_HIP_OK;
 }
 
+// M^-1 of the preconditioned loop: the library's device-resident preconditioners, or a HOST functor of the caller (the reference's
+// BiCGStab template takes any type with `int apply(const T* rhs, T* x) const`, ref:2191-2199, 2218, 2235, 2251)
 template <typename T>
-int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const smm_hip_precond* M, hipStream_t s, int* status,
-                int* iterations, T* resnorm) {
-	if (!a || a->dtype != dtypeOf<T>()) {
-		setError("bicgstab: null matrix or dtype mismatch");
-		return SMM_HIP_ERR_INVALID;
+struct DevApplier {
+	const smm_hip_precond* M;
+	static constexpr bool hostSide = false;
+	int operator()(const T* in, T* out, const int* doneFlag, hipStream_t s) const { return precondApplyDev<T>(M, in, out, doneFlag, s); }
+};
+
+// The vector goes to the host, the caller's functor runs there, the result comes back: two PCIe copies and two stream drains per
+// apply.  Everything else of the iteration stays on the device.  A non-zero return of the functor ends the solve with
+// SMM_HIP_ERR_PRECOND (the reference ignores apply()'s return value inside the loop; a failing apply leaves x undefined there).
+template <typename T>
+struct HostApplier {
+	int (*fn)(void* user, const T* rhs, T* x);
+	void* user;
+	int n;
+	T* hostIn;   // pinned
+	T* hostOut;  // pinned
+	static constexpr bool hostSide = true;
+	int operator()(const T* in, T* out, const int* /*doneFlag*/, hipStream_t s) const {
+		if (n == 0) return SMM_HIP_OK;
+		SMM_HIP_TRY(hipMemcpyAsync(hostIn, in, sizeof(T) * n, hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		if (fn(user, hostIn, hostOut) != 0) {
+			setError("bicgstab: the caller's preconditioner apply() returned non-zero");
+			return SMM_HIP_ERR_PRECOND;
+		}
+		SMM_HIP_TRY(hipMemcpyAsync(out, hostOut, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		return SMM_HIP_OK;
 	}
-	if (a->rows != a->cols) {
-		setError("bicgstab: matrix must be square");
-		return SMM_HIP_ERR_INVALID;
-	}
-	const bool precondition = M != nullptr && M->kind != SMM_PRECOND_NONE;  // ref:2209
-	if (precondition && (M->a != a || M->kind == SMM_PRECOND_IC0)) {
-		setError("bicgstab: preconditioner must be JACOBI / ILU0 / SGS created for this matrix");
-		return SMM_HIP_ERR_INVALID;
-	}
+};
+
+template <typename T, typename Applier>
+static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const bool precondition, const Applier& apply, hipStream_t s,
+                        int* status, int* iterations, T* resnorm) {
 	const int n = a->rows;
-	if (n > 0 && (!b || !x)) {
-		setError("bicgstab: null vector");
-		return SMM_HIP_ERR_INVALID;
-	}
 	maxIterations = std::min(maxIterations, n);  // ref:2200
 	if (maxIterations == -1) maxIterations = n;  // ref:2201-2203
 	DevBuf<T> r, r0, p, ap, sv, as, scratch, parts, parts2;
@@ -533,7 +549,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 
 	if (precondition) {
 		SMM_TRY(launchSpmv<T>(a, SMM_OP_SUB, b, x, scratch, 0, nullptr, nullptr, nullptr, s));  // ref:2215
-		SMM_TRY(precondApplyDev<T>(M, scratch, r, nullptr, s));                                  // ref:2217-2224
+		SMM_TRY(apply(scratch, r, nullptr, s));                                                  // ref:2217-2224
 	} else {
 		SMM_TRY(launchSpmv<T>(a, SMM_OP_SUB, b, x, r, 0, nullptr, nullptr, nullptr, s));
 	}
@@ -547,7 +563,14 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	const int planned = std::max(1, maxIterations);  // do { } while: the body always runs once (ref:2232, 2277)
 	int nextCheck = 1;
 	for (int i = 0; i < planned; ++i) {
-		if (i == nextCheck) {
+		if (Applier::hostSide && i > 0) {
+			// a host functor drains the stream at every apply anyway: test the flag directly so that it is never called for an
+			// iteration the loop has already left
+			int done = 0;
+			SMM_HIP_TRY(hipMemcpyAsync(&done, doneFlag, sizeof(int), hipMemcpyDeviceToHost, s));
+			SMM_HIP_TRY(hipStreamSynchronize(s));
+			if (done) break;
+		} else if (i == nextCheck) {
 			const int seen = poller.post(doneFlag);
 			if (seen < 0) return seen;
 			if (seen) break;
@@ -555,7 +578,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 		}
 		if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
-			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));                                          // ref:2235
+			SMM_TRY(apply(scratch, ap, doneFlag, s));                                                          // ref:2235
 			SMM_TRY(launchDotPartials<T>(n, ap, r0, parts, doneFlag, s));                                      // ref:2243
 		} else {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, ap, 1, r0, parts, doneFlag, s));  // ref:2240 + 2243 fused
@@ -564,7 +587,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 		SMM_LAUNCH_UPDATE(bicgFusedS, updateNT(n, sizeof(T), 3), gridFor(n), s, n, sc, i & 1, parts, ap, r, sv);
 		if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
-			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));                                           // ref:2251
+			SMM_TRY(apply(scratch, as, doneFlag, s));                                                           // ref:2251
 			dot2Partials<T><<<NPART, TPB, 0, s>>>(n, as, sv, parts, parts.p + NPART, doneFlag);                 // ref:2259, 2261
 		} else {
 			// as = A s with as.as -> parts[0..NPART) and as.s -> parts[NPART..2 NPART) fused (ref:2256-2261)
@@ -579,7 +602,76 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	if (status) *status = h.iters > maxIterations ? SMM_SOLVER_MAX_ITERATIONS_REACHED : SMM_SOLVER_SUCCESS;  // ref:2279-2282
 	if (iterations) *iterations = h.iters;
 	if (resnorm) *resnorm = h.res;
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int bicgstabCheck(const smm_hip_csr* a, const T* b, T* x) {
+	if (!a || a->dtype != dtypeOf<T>()) {
+		setError("bicgstab: null matrix or dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a->rows != a->cols) {
+		setError("bicgstab: matrix must be square");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a->rows > 0 && (!b || !x)) {
+		setError("bicgstab: null vector");
+		return SMM_HIP_ERR_INVALID;
+	}
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const smm_hip_precond* M, hipStream_t s, int* status,
+                int* iterations, T* resnorm) {
+	SMM_TRY(bicgstabCheck<T>(a, b, x));
+	const bool precondition = M != nullptr && M->kind != SMM_PRECOND_NONE;  // ref:2209
+	if (precondition && (M->a != a || M->kind == SMM_PRECOND_IC0)) {
+		setError("bicgstab: preconditioner must be JACOBI / ILU0 / SGS created for this matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const DevApplier<T> apply{M};
+	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm)));
 	return precondition ? precondTakeError(M, s) : SMM_HIP_OK;
+}
+
+// host vectors, host functor: the generic form of the reference's template (ref:2191-2199)
+template <typename T>
+static int bicgstabFunctorHost(const smm_hip_csr* a, T* b, T* x, int maxIterations, T eps, int (*fn)(void*, const T*, T*), void* user, int* status,
+                               int* iterations, T* resnorm) {
+	if (!fn) {
+		setError("bicgstab_functor: null apply function");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	SMM_TRY(bicgstabCheck<T>(a, b, x));
+	const int n = a->rows;
+	hipStream_t s = libStream();
+	DevBuf<T> db, dx;
+	SMM_TRY(db.alloc(n));
+	SMM_TRY(dx.alloc(n));
+	T* pinned = nullptr;
+	SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(T) * 2 * static_cast<size_t>(std::max(1, n)), hipHostMallocDefault));
+	struct Unpin {
+		T* p;
+		~Unpin() { hipHostFree(p); }
+	} unpin{pinned};
+	if (n) {
+		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	}
+	const HostApplier<T> apply{fn, user, n, pinned, pinned + std::max(1, n)};
+	const int rc = bicgstabLoop<T, HostApplier<T>>(a, db, dx, maxIterations, eps, true, apply, s, status, iterations, resnorm);
+	if (rc != SMM_HIP_OK) {
+		hipStreamSynchronize(s);  // kernels of the abandoned loop may still be queued on buffers that are about to be released
+		return rc;
+	}
+	if (n) {
+		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
+	return SMM_HIP_OK;
 }
 
 template <typename T>
@@ -768,6 +860,15 @@ int smm_hip_bicgstab_dev_f64(const smm_hip_csr* a, const double* d_b, double* d_
                              smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm) {
 	SMM_TRY(ensureInit());
 	return bicgstabDev<double>(a, d_b, d_x, maxIterations, eps, M, pickStream(stream), solver_status, iterations, resnorm);
+}
+
+int smm_hip_bicgstab_functor_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, smm_hip_apply_fn_f32 apply, void* user,
+                                 int* solver_status, int* iterations, float* resnorm) {
+	return bicgstabFunctorHost<float>(a, b, x, maxIterations, eps, apply, user, solver_status, iterations, resnorm);
+}
+int smm_hip_bicgstab_functor_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps, smm_hip_apply_fn_f64 apply, void* user,
+                                 int* solver_status, int* iterations, double* resnorm) {
+	return bicgstabFunctorHost<double>(a, b, x, maxIterations, eps, apply, user, solver_status, iterations, resnorm);
 }
 
 int smm_hip_bicgsymmetric_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, int* solver_status, int* iterations) {

@@ -6,31 +6,14 @@
 // Needs a GPU at run time (the library has no CPU path); exits non-zero on the first failed check.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <string>
 #include <vector>
 
 #include "smm_hip/sparse_matrix_math.h"
 
-static int g_failed = 0, g_checks = 0;
-#define CHECK(cond)                                                                   \
-	do {                                                                              \
-		++g_checks;                                                                   \
-		if (!(cond)) {                                                                \
-			++g_failed;                                                               \
-			std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);             \
-		}                                                                             \
-	} while (0)
-
-template <typename T>
-static bool approx(T ref, T got, double eps) {
-	return std::fabs(static_cast<double>(ref) - static_cast<double>(got)) <= eps * std::max(1.0, std::fabs(static_cast<double>(ref)));
-}
-
-template <typename T>
-constexpr T l2Eps() { return std::is_same<T, float>::value ? T(1e-4) : T(1e-8); }
-template <typename T>
-constexpr double infEps() { return std::is_same<T, float>::value ? 1e-4 : 1e-8; }
+#include "dropin_checks.h"
 
 template <typename T>
 static SMM::Vector<T> sumColumsPerRow(const SMM::CSRMatrix<T>& m) {  // test/include/test_common.h:13-21
@@ -223,26 +206,68 @@ static void testIC0KnownAnswer() {  // test/cpp/cg.cpp:28-60
 	for (int i = 0; i < size; ++i) CHECK(approx(resRef[i], res[i], 1e-4));
 }
 
-static void testLoader() {  // test/cpp/csr.cpp:787-866 shape: a symmetric coordinate file mirrors its off-diagonals
-	const std::string path = "/tmp/smm_hip_dropin_test.mtx";
-	{
-		std::ofstream f(path);
-		f << "%%MatrixMarket matrix coordinate real symmetric\n% comment\n3 3 4\n1 1 2.0\n2 1 -1.0\n2 2 2.0\n3 3 2.0\n";
+// a preconditioner the library does not have, written by the user against the reference's concept `int apply(const T*, T*) const`
+// (ref:2199): BiCGStab<Preconditioner, T> must accept it (host-functor path) and agree with the built-in Jacobi
+template <typename T>
+struct UserJacobi {
+	std::vector<T> inv;
+	mutable int calls = 0;
+	int apply(const T* rhs, T* x) const noexcept {
+		++calls;
+		for (size_t i = 0; i < inv.size(); ++i) x[i] = rhs[i] * inv[i];
+		return 0;
 	}
-	SMM::CSRMatrix<double> m;
-	CHECK(SMM::loadMatrix(path.c_str(), m) == SMM::MatrixLoadStatus::SUCCESS);
-	CHECK(m.getNonZeroCount() == 5 && m.getValue(0, 1) == -1.0 && m.getValue(1, 0) == -1.0 && m.getValue(2, 2) == 2.0);
-	{
-		std::ofstream f(path);
-		f << "%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 4.0\n1 2 1.0\n2 2 3.0\n";
+};
+template <typename T>
+struct FailingPreconditioner {
+	int apply(const T*, T*) const noexcept { return 1; }
+};
+
+template <typename T>
+static void testUserPreconditionerAndErrors() {
+	const int n = 40;
+	SMM::TripletMatrix<T> t(n, n);
+	for (int i = 0; i < n; ++i) {  // non-symmetric, diagonally dominant
+		t.addEntry(i, i, T(4 + (i % 3)));
+		if (i > 0) t.addEntry(i, i - 1, T(-1.25));
+		if (i + 1 < n) t.addEntry(i, i + 1, T(-0.75));
+		if (i + 7 < n) t.addEntry(i, i + 7, T(0.5));
 	}
-	SMM::CSRMatrix<double> g;
-	CHECK(SMM::loadMatrix(path.c_str(), g) == SMM::MatrixLoadStatus::SUCCESS);
-	CHECK(g.getNonZeroCount() == 3 && g.getValue(0, 1) == 1.0 && g.getValue(1, 0) == 0.0);
-	double b[2] = {5, 3}, x[2] = {0, 0};
-	CHECK(SMM::BiCGStab<double>(g, b, x, -1, 1e-12) == SMM::SolverStatus::SUCCESS);
-	CHECK(approx(1.0, x[0], 1e-9) && approx(1.0, x[1], 1e-9));
-	CHECK(SMM::loadMatrix("/nonexistent/file.mtx", g) == SMM::MatrixLoadStatus::FAILED_TO_OPEN_FILE);
+	SMM::CSRMatrix<T> m(t);
+	SMM::Vector<T> rhs = sumColumsPerRow(m);
+	UserJacobi<T> user;
+	user.inv.resize(n);
+	for (int i = 0; i < n; ++i) user.inv[i] = T(1) / m.getValue(i, i);
+	SMM::Vector<T> x(n, 0);
+	CHECK((SMM::BiCGStab<UserJacobi<T>, T>(m, rhs, x, -1, l2Eps<T>(), user)) == SMM::SolverStatus::SUCCESS);
+	CHECK(SMM::lastHipStatus() == SMM_HIP_OK && user.calls >= 3);
+	for (int i = 0; i < n; ++i) CHECK(approx(T(1), x[i], 10 * infEps<T>()));
+	// same iteration through the library's own Jacobi (division instead of multiplication by the reciprocal: close, not identical)
+	SMM::Vector<T> xj(n, 0);
+	auto jac = m.template getPreconditioner<SMM::SolverPreconditioner::JACOBI>();
+	CHECK((SMM::BiCGStab<decltype(jac), T>(m, rhs, xj, -1, l2Eps<T>(), jac)) == SMM::SolverStatus::SUCCESS);
+	for (int i = 0; i < n; ++i) CHECK(approx(xj[i], x[i], 100 * infEps<T>()));
+	// a failing apply() is reported: DIVERGED + the ABI status says why
+	SMM::Vector<T> xf(n, 0);
+	CHECK((SMM::BiCGStab<FailingPreconditioner<T>, T>(m, rhs, xf, 5, l2Eps<T>(), FailingPreconditioner<T>())) == SMM::SolverStatus::DIVERGED);
+	CHECK(SMM::lastHipStatus() == SMM_HIP_ERR_PRECOND);
+	// errors of the GPU path are observable: x aliasing out is rejected by the ABI (assert(mult != res), ref:1503) -> NaN + status
+	SMM::Vector<T> v(n, 1);
+	m.rMult(v, v);
+	CHECK(SMM::lastHipStatus() == SMM_HIP_ERR_INVALID && std::isnan(v[0]) && std::isnan(v[n - 1]));
+	SMM::Vector<T> ok(n, 1), out(n, 0);
+	m.rMult(ok, out);
+	CHECK(SMM::lastHipStatus() == SMM_HIP_OK && !std::isnan(out[0]));
+	// a preconditioner that cannot be built (no diagonal) refuses: non-zero init / apply, DIVERGED from the solver, status set
+	SMM::TripletMatrix<T> nd(2, 2);
+	nd.addEntry(0, 1, 1);
+	nd.addEntry(1, 0, 1);
+	SMM::CSRMatrix<T> noDiag(nd);
+	auto sgs = noDiag.template getPreconditioner<SMM::SolverPreconditioner::SYMMETRIC_GAUS_SEIDEL>();
+	T r2[2] = {1, 1}, x2[2] = {0, 0};
+	CHECK(sgs.apply(r2, x2) != 0);
+	CHECK(SMM::lastHipStatus() == SMM_HIP_ERR_PRECOND);
+	CHECK((SMM::BiCGStab<decltype(sgs), T>(noDiag, r2, x2, 3, l2Eps<T>(), sgs)) == SMM::SolverStatus::DIVERGED);
 }
 
 int main() {
@@ -256,7 +281,10 @@ int main() {
 	testSolvers<double>();
 	testIC0KnownAnswer<float>();
 	testIC0KnownAnswer<double>();
-	testLoader();
+	testLoader<float>(true);
+	testLoader<double>(true);
+	testUserPreconditionerAndErrors<float>();
+	testUserPreconditionerAndErrors<double>();
 	std::printf("%d checks, %d failed\n", g_checks, g_failed);
 	return g_failed ? 1 : 0;
 }

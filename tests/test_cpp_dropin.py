@@ -22,6 +22,23 @@ def test_compiles_against_the_reference_api():
         assert r.returncode == 77 and "no CPU fallback" in r.stdout
 
 
+def test_loaders_and_error_reporting_host_only():
+    """Matrix Market (general / symmetric / pattern, duplicates, the reference's status codes by name) and dense-text loaders,
+    direct-to-CSR == triplet route, and -- without a GPU -- NaN / DIVERGED / lastHipStatus() instead of silently doing nothing"""
+    _build()
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_loader")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 failed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_host_side_under_address_and_ub_sanitizers():
+    """the same translation unit built with -fsanitize=address,undefined (CPU sanitizer build)"""
+    _build()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_loader_asan")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "0 failed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
 @pytest.mark.gpu
 def test_reference_tests_pass_on_gpu():
     if not os.path.exists(BINARY):
