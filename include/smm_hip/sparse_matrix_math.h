@@ -483,10 +483,12 @@ inline SolverStatus BiCGStab(const CSRMatrix<T>& a, T* b, T* x, int maxIteration
 		const smm_hip_precond* h = preconditioner.handle();
 		constexpr bool precondition = !std::is_same<Preconditioner, typename CSRMatrix<T>::IDPreconditioner>::value;
 		if (precondition && !h) return SolverStatus::DIVERGED;
-		return detail::toStatus(detail::Abi<T>::bicgstab(d, b, x, maxIterations, eps, h, &st), st);
+		const int rc = detail::Abi<T>::bicgstab(d, b, x, maxIterations, eps, h, &st);
+		return detail::toStatus(rc, st);
 	} else {
 		auto trampoline = +[](void* user, const T* rhs, T* out) -> int { return static_cast<const Preconditioner*>(user)->apply(rhs, out); };
-		return detail::toStatus(detail::Functor<T>::run(d, b, x, maxIterations, eps, trampoline, const_cast<Preconditioner*>(&preconditioner), &st), st);
+		const int rc = detail::Functor<T>::run(d, b, x, maxIterations, eps, trampoline, const_cast<Preconditioner*>(&preconditioner), &st);
+		return detail::toStatus(rc, st);
 	}
 }
 

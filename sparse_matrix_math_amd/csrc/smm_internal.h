@@ -89,6 +89,12 @@ constexpr int dtypeOf() { return std::is_same<T, float>::value ? SMM_DTYPE_F32 :
 struct smm_hip_csr {
 	int rows = 0, cols = 0, nnz = 0, dtype = 0;
 	int firstActiveStart = 0;
+	// nnz / firstActiveStart / the SpMV configuration of a matrix wrapped around caller-owned DEVICE arrays are read from the device
+	// the first time they are needed, on the stream of that first use (ensureCsrReady): creating the handle enqueues nothing and
+	// waits for nothing, so it is naturally ordered behind whatever the caller still has in flight on that stream
+	bool ready = false;
+	bool kernelForced = false;  // smm_hip_csr_set_kernel chose the family / lanes: the heuristic must not overwrite them
+	std::mutex readyMutex;
 	int* d_start = nullptr;
 	int* d_positions = nullptr;
 	void* d_values = nullptr;
@@ -161,7 +167,10 @@ inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
 	return static_cast<double>(m->rows) * static_cast<double>(elemBytes) > 64.0 * 1024 * 1024 ? SPMV_NT_OUT : 0;
 }
 
-int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows);
+int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s);
+// streamKnown: `s` is the stream the caller orders its work on (the `_dev` entry points); otherwise (host-side queries and set-up
+// calls that have no stream) the whole device is drained first and the library's own stream is used
+int ensureCsrReady(const smm_hip_csr* m, hipStream_t s, bool streamKnown);
 // PATTERN family: analyse + verify the matrix (idempotent), and the launch behind launchSpmv
 int ensurePattern(smm_hip_csr* m);
 template <typename T>

@@ -805,6 +805,7 @@ int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out
 		return SMM_HIP_ERR_INVALID;
 	}
 	SMM_TRY(ensureInit());
+	SMM_TRY(ensureCsrReady(a, nullptr, false));  // a set-up call without a stream: drains the device once
 	auto* M = new smm_hip_precond();
 	M->kind = kind;
 	M->dtype = a->dtype;

@@ -179,11 +179,16 @@ __global__ void countLeadingEmpty(int rows, const int* __restrict__ start, int* 
 	if (local) atomicAdd(out, local);
 }
 
-static int finishCsr(smm_hip_csr* m) {
-	hipStream_t s = libStream();
-	// device arrays handed in by the caller may still be being written on one of the caller's streams; the library's own
-	// (non-blocking) stream is not ordered behind those, so set-up paths that read them wait for the whole device first
-	SMM_HIP_TRY(hipDeviceSynchronize());
+int ensureCsrReady(const smm_hip_csr* cm, hipStream_t s, bool streamKnown) {
+	auto* m = const_cast<smm_hip_csr*>(cm);
+	std::lock_guard<std::mutex> lock(m->readyMutex);
+	if (m->ready) return SMM_HIP_OK;
+	if (!streamKnown) {
+		// a host-side query (csr_info, set_kernel, precond_create ...) has no stream to be ordered behind: the arrays may still be
+		// being written on any of the caller's streams
+		SMM_HIP_TRY(hipDeviceSynchronize());
+		s = libStream();
+	}
 	int* d_cnt = nullptr;
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_cnt), sizeof(int)));
 	SMM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), s));
@@ -195,11 +200,12 @@ static int finishCsr(smm_hip_csr* m) {
 	}
 	int first = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(&first, d_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream only (8 bytes come back)
 	devFree(d_cnt);
 	m->nnz = nnz;
 	m->firstActiveStart = first;
-	chooseSpmvConfig(m);
+	if (!m->kernelForced) chooseSpmvConfig(m);
+	m->ready = true;
 	return SMM_HIP_OK;
 }
 
@@ -249,10 +255,18 @@ static int csrCreate(int rows, int cols, const int* start, const int* positions,
 			return hipFail(e, "csr upload", __FILE__, __LINE__);
 		}
 	}
-	const int st = finishCsr(m);
-	if (st != SMM_HIP_OK) {
-		smm_hip_csr_destroy(m);
-		return st;
+	if (!onDevice) {
+		// host arrays: everything is known here
+		m->nnz = start[rows];
+		m->firstActiveStart = rows;
+		for (int i = 0; i < rows; ++i) {  // ref:1619-1628
+			if (start[i + 1] != 0) {
+				m->firstActiveStart = i;
+				break;
+			}
+		}
+		chooseSpmvConfig(m);
+		m->ready = true;
 	}
 	*out = m;
 	return SMM_HIP_OK;
@@ -364,6 +378,7 @@ int smm_hip_csr_info(const smm_hip_csr* m, int* rows, int* cols, int* nnz, int* 
 		setError("csr_info: null handle");
 		return SMM_HIP_ERR_INVALID;
 	}
+	if (nnz || first_active_start) SMM_TRY(ensureCsrReady(m, nullptr, false));
 	if (rows) *rows = m->rows;
 	if (cols) *cols = m->cols;
 	if (nnz) *nnz = m->nnz;

@@ -23,6 +23,9 @@
 //
 // No MFMA: 2 flops per 8-12 bytes, the path is HBM-bound.
 #include <algorithm>
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
 
 #include "smm_device.h"
 #include "smm_internal.h"
@@ -439,57 +442,106 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-// Cut rows into tiles of <= capNnz nonzeros and <= maxRows rows; a row longer than capNnz gets a tile of its own.
-int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows) {
-	std::vector<int> hs(static_cast<size_t>(m->rows) + 1);
-	hipStream_t s = libStream();
-	SMM_HIP_TRY(hipDeviceSynchronize());  // start[] may have been produced on a caller's stream (see finishCsr)
-	SMM_HIP_TRY(hipMemcpyAsync(hs.data(), m->d_start, hs.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
-	std::vector<int> rb;  // pairs {first row, start[first row]}
-	rb.reserve(2 * static_cast<size_t>(m->nnz / capNnz + m->rows / maxRows + 2));
-	int r = 0;
-	const int rows = m->rows;
-	while (r < rows) {
-		rb.push_back(r);
-		rb.push_back(hs[r]);
-		const int base = hs[r];
-		int e = r + 1;  // always take at least one row (alone it may exceed capNnz: over-long row)
-		const int limitRow = std::min(rows, r + maxRows);
-		while (e < limitRow && hs[e + 1] - base <= capNnz) ++e;
-		r = e;
+// ---- tile table, built ON THE DEVICE -----------------------------------------------------------------------------------------
+// Rows are cut into tiles of <= capNnz nonzeros and <= maxRows whole rows (a row longer than capNnz is a tile of its own).  A
+// greedy cut from row 0 is a sequential chain over the whole matrix, so the row range is first divided at fixed seams -- the rows
+// whose start[] falls into [c G, (c+1) G), G = 64 tiles' worth of nonzeros, found by binary search -- and each of these
+// super-chunks is cut greedily by one thread (every step is a binary search over at most maxRows + 1 entries of start[], not a
+// walk over rows).  A seam costs at most one under-filled tile per 64.  Two passes (count, exclusive scan, write) give a dense
+// table.  start[] never travels to the host (537 MB and a 134 M-iteration host loop for the 512^3 Laplacian before); everything is
+// enqueued on the CALLER's stream and only the tile count (8 bytes) comes back.
+constexpr int TILES_PER_CHUNK = 64;
+
+__device__ __forceinline__ int firstRowAtOrAfter(const int* __restrict__ start, int rows, long long target) {
+	int lo = 0, hi = rows;  // smallest r in [0, rows] with start[r] >= target (start[rows] = nnz is the sentinel)
+	while (lo < hi) {
+		const int mid = lo + (hi - lo) / 2;
+		if (start[mid] >= target) hi = mid;
+		else lo = mid + 1;
 	}
-	rb.push_back(rows);
-	rb.push_back(hs[rows]);
+	return lo;
+}
+
+// offsets == nullptr: counts[c] = tiles of super-chunk c.  Otherwise: tiles of chunk c are written from tiles[offsets[c]].
+__global__ void tileCutKernel(int rows, const int* __restrict__ start, int capNnz, int maxRows, long long chunkNnz, int nChunks, int* __restrict__ counts,
+                              const int* __restrict__ offsets, int2* __restrict__ tiles) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= nChunks) return;
+	int r = firstRowAtOrAfter(start, rows, static_cast<long long>(c) * chunkNnz);
+	const int rEnd = c == nChunks - 1 ? rows : firstRowAtOrAfter(start, rows, static_cast<long long>(c + 1) * chunkNnz);
+	int n = 0;
+	int at = offsets ? offsets[c] : 0;
+	while (r < rEnd) {
+		const int base = start[r];
+		if (offsets) tiles[at + n] = make_int2(r, base);
+		++n;
+		// largest e in (r, min(rEnd, r + maxRows)] with start[e] - base <= capNnz; at least r + 1 (an over-long row stands alone)
+		int lo = r + 1, hi = min(rEnd, r + maxRows);
+		while (lo < hi) {
+			const int mid = lo + (hi - lo + 1) / 2;
+			if (start[mid] - base <= capNnz) lo = mid;
+			else hi = mid - 1;
+		}
+		r = lo;
+	}
+	if (!offsets) counts[c] = n;
+	if (offsets && c == nChunks - 1) tiles[offsets[nChunks]] = make_int2(rows, start[rows]);  // closing sentinel {rows, nnz}
+}
+
+// info[1] = the farthest column a middle row touches, as a distance from the row
+__global__ void farColumnKernel(int rows, const int* __restrict__ start, const int* __restrict__ positions, int* __restrict__ info) {
+	const int mid = rows / 2;
+	int far = 0;
+	for (int k = start[mid] + threadIdx.x; k < start[mid + 1]; k += blockDim.x) far = max(far, abs(positions[k] - mid));
+	if (far) atomicMax(info + 1, far);
+}
+
+int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
+	const int rows = m->rows;
 	devFree(m->d_rowblocks);
 	m->d_rowblocks = nullptr;
-	m->n_rowblocks = static_cast<int>(rb.size() / 2) - 1;
+	m->n_rowblocks = 0;
 	m->stream_nnz_cap = capNnz;
 	m->stream_max_rows = maxRows;
-	// How the tiles are dealt to the 8 XCDs.  The farthest column a middle row touches tells how far apart (in rows) two uses of
-	// the same x[] line are.  When that distance is many tiles but a small fraction of the matrix (3-D stencils: one grid plane),
-	// the tiles are dealt one such span per XCD, round-robin, so the 8 XCDs sweep 8 adjacent planes together instead of 8 regions
-	// a gigabyte apart: measured -8 % on the 512^3 Laplacian (3.55 -> 3.28 ms), neutral on smaller grids; with far offsets that are
-	// a large fraction of the matrix (the banded-random benchmark matrix) contiguous eighths are best (tools/sweep_chunk.sh).
 	m->stream_chunk_tiles = 0;
-	if (rows > 0 && m->nnz > 0) {
-		const int mid = rows / 2;
-		const int len = hs[mid + 1] - hs[mid];
-		if (len > 0) {
-			std::vector<int> cols(static_cast<size_t>(len));
-			SMM_HIP_TRY(hipMemcpyAsync(cols.data(), m->d_positions + hs[mid], cols.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-			SMM_HIP_TRY(hipStreamSynchronize(s));
-			long long far = 0;
-			for (int c : cols) far = std::max<long long>(far, std::llabs(static_cast<long long>(c) - mid));
-			const double rowsPerTile = static_cast<double>(rows) / std::max(1, m->n_rowblocks);
-			const long long farTiles = static_cast<long long>(far / rowsPerTile);
-			if (farTiles >= 256 && farTiles * 32 <= m->n_rowblocks) m->stream_chunk_tiles = static_cast<int>(farTiles);
+	const long long chunkNnz = static_cast<long long>(TILES_PER_CHUNK) * capNnz;
+	const int nChunks = static_cast<int>(m->nnz / chunkNnz) + 1;
+	DevBuf<int> counts, info;
+	SMM_TRY(counts.alloc(static_cast<size_t>(nChunks) + 1));
+	SMM_TRY(info.alloc(2));
+	SMM_HIP_TRY(hipMemsetAsync(counts, 0, (static_cast<size_t>(nChunks) + 1) * sizeof(int), s));
+	SMM_HIP_TRY(hipMemsetAsync(info, 0, 2 * sizeof(int), s));
+	const int grid = (nChunks + 63) / 64;
+	tileCutKernel<<<grid, 64, 0, s>>>(rows, m->d_start, capNnz, maxRows, chunkNnz, nChunks, counts, nullptr, nullptr);
+	{
+		size_t tempBytes = 0;
+		SMM_HIP_TRY(rocprim::exclusive_scan(nullptr, tempBytes, counts.p, counts.p, 0, static_cast<size_t>(nChunks) + 1, rocprim::plus<int>(), s));
+		DevBuf<char> temp;
+		SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
+		SMM_HIP_TRY(rocprim::exclusive_scan(temp.p, tempBytes, counts.p, counts.p, 0, static_cast<size_t>(nChunks) + 1, rocprim::plus<int>(), s));
+		if (rows > 0) farColumnKernel<<<1, 64, 0, s>>>(rows, m->d_start, m->d_positions, info);
+		int host[2] = {0, 0};
+		SMM_HIP_TRY(hipMemcpyAsync(&host[0], counts.p + nChunks, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipMemcpyAsync(&host[1], info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream: the table's size decides the allocation and the grid
+		const int nTiles = host[0];
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&m->d_rowblocks), (static_cast<size_t>(nTiles) + 1) * sizeof(int2)));
+		tileCutKernel<<<grid, 64, 0, s>>>(rows, m->d_start, capNnz, maxRows, chunkNnz, nChunks, nullptr, counts, reinterpret_cast<int2*>(m->d_rowblocks));
+		SMM_HIP_TRY(hipGetLastError());
+		m->n_rowblocks = nTiles;
+		// How the tiles are dealt to the 8 XCDs.  The farthest column a middle row touches tells how far apart (in rows) two uses of
+		// the same x[] line are.  When that distance is many tiles but a small fraction of the matrix (3-D stencils: one grid plane),
+		// the tiles are dealt one such span per XCD, round-robin, so the 8 XCDs sweep 8 adjacent planes together instead of 8 regions
+		// a gigabyte apart: measured -8 % on the 512^3 Laplacian (3.55 -> 3.28 ms), neutral on smaller grids; with far offsets that are
+		// a large fraction of the matrix (the banded-random benchmark matrix) contiguous eighths are best (tools/sweep_chunk.sh).
+		if (rows > 0 && nTiles > 0) {
+			const double rowsPerTile = static_cast<double>(rows) / nTiles;
+			const long long farTiles = static_cast<long long>(host[1] / rowsPerTile);
+			if (farTiles >= 256 && farTiles * 32 <= nTiles) m->stream_chunk_tiles = static_cast<int>(farTiles);
 		}
+		SMM_HIP_TRY(hipStreamSynchronize(s));  // the scratch buffers above go back to the allocator when this scope ends
 	}
 	if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) m->stream_chunk_tiles = std::max(0, atoi(env));  // tuning override
-	SMM_TRY(devAlloc(reinterpret_cast<void**>(&m->d_rowblocks), rb.size() * sizeof(int)));
-	SMM_HIP_TRY(hipMemcpyAsync(m->d_rowblocks, rb.data(), rb.size() * sizeof(int), hipMemcpyHostToDevice, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
 	return SMM_HIP_OK;
 }
 
@@ -568,6 +620,7 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		setError("spmv: matrix dtype does not match the _f32/_f64 entry point");
 		return SMM_HIP_ERR_INVALID;
 	}
+	SMM_TRY(ensureCsrReady(m, s, true));
 	if (op < SMM_OP_ASSIGN || op > SMM_OP_SUB) {
 		setError("spmv: bad op %d", op);
 		return SMM_HIP_ERR_INVALID;
@@ -603,7 +656,7 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		const int maxRows = TPB / std::min(L, WAVE);
 		std::lock_guard<std::mutex> lock(const_cast<smm_hip_csr*>(m)->tileMutex);
 		if (!m->d_rowblocks || m->stream_nnz_cap != capNnz || m->stream_max_rows != maxRows) {
-			SMM_TRY(buildRowBlocks(const_cast<smm_hip_csr*>(m), capNnz, maxRows));
+			SMM_TRY(buildRowBlocks(const_cast<smm_hip_csr*>(m), capNnz, maxRows, s));
 		}
 	}
 	int grid;
@@ -708,9 +761,10 @@ int smm_hip_csr_set_kernel(smm_hip_csr* m, int family, int lanes_per_row) {
 		setError("csr_set_kernel: unknown family %d", family);
 		return SMM_HIP_ERR_INVALID;
 	}
+	SMM_TRY(ensureInit());
+	SMM_TRY(ensureCsrReady(m, nullptr, false));
 	if (family == SMM_SPMV_PATTERN) {
 		// opt-in: analyse + verify every entry now, so a matrix without a shared offset pattern is refused here and not mid-solve
-		SMM_TRY(ensureInit());
 		SMM_TRY(ensurePattern(m));
 		if (lanes_per_row > 8) {
 			setError("csr_set_kernel: the PATTERN family takes 1, 2, 4 or 8 lanes per row");
@@ -729,6 +783,7 @@ int smm_hip_csr_set_kernel(smm_hip_csr* m, int family, int lanes_per_row) {
 		m->lanes = lanesForAvg(avg, family);
 	}
 	if (lanes_per_row) m->lanes = lanes_per_row;
+	m->kernelForced = family != SMM_SPMV_AUTO || lanes_per_row != 0;
 	return SMM_HIP_OK;
 }
 
@@ -737,6 +792,8 @@ int smm_hip_csr_get_kernel(const smm_hip_csr* m, int* family, int* lanes_per_row
 		setError("csr_get_kernel: null matrix");
 		return SMM_HIP_ERR_INVALID;
 	}
+	SMM_TRY(ensureInit());
+	SMM_TRY(ensureCsrReady(m, nullptr, false));
 	if (family) *family = m->family;
 	if (lanes_per_row) *lanes_per_row = m->lanes;
 	return SMM_HIP_OK;
@@ -748,9 +805,10 @@ int smm_hip_csr_autotune(smm_hip_csr* m) {
 		return SMM_HIP_ERR_INVALID;
 	}
 	SMM_TRY(ensureInit());
+	SMM_TRY(ensureCsrReady(m, nullptr, false));
 	if (m->rows == 0 || m->nnz == 0) return SMM_HIP_OK;
 	hipStream_t s = libStream();
-	SMM_HIP_TRY(hipDeviceSynchronize());  // the matrix may still be being written on a caller's stream
+	SMM_HIP_TRY(hipDeviceSynchronize());  // the matrix may still be being written on a caller's stream (set-up call, no stream)
 	const size_t esz = m->dtype == SMM_DTYPE_F32 ? 4 : 8;
 	void *dx = nullptr, *dy = nullptr;
 	SMM_TRY(devAlloc(&dx, esz * static_cast<size_t>(m->cols ? m->cols : 1)));
@@ -789,6 +847,7 @@ int smm_hip_csr_autotune(smm_hip_csr* m) {
 	}
 	m->family = bestFamily;
 	m->lanes = bestLanes;
+	m->kernelForced = true;
 	hipEventDestroy(e0);
 	hipEventDestroy(e1);
 	devFree(dx);

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 // ---- host side ----------------------------------------------------------------------------------------------------------
 // Find the offset set from a sample of rows, then let the device build the row masks and verify EVERY entry against it.
 int ensurePattern(smm_hip_csr* m) {
+	SMM_TRY(ensureCsrReady(m, nullptr, false));
 	std::lock_guard<std::mutex> lock(m->tileMutex);
 	if (m->pat_state != 0) return m->pat_state > 0 ? SMM_HIP_OK : SMM_HIP_ERR_INVALID;
 	m->pat_state = -1;
@@ -411,11 +412,11 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* x, T*
 }
 
 // tiles for this family are cut for its own LDS capacity (values only): kept beside the STREAM family's table
-static int buildPatternTiles(smm_hip_csr* m, int capNnz, int maxRows) {
+static int buildPatternTiles(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 	int* keepBlocks = m->d_rowblocks;
 	const int keepN = m->n_rowblocks, keepCap = m->stream_nnz_cap, keepRows = m->stream_max_rows, keepChunk = m->stream_chunk_tiles;
 	m->d_rowblocks = nullptr;
-	const int st = buildRowBlocks(m, capNnz, maxRows);
+	const int st = buildRowBlocks(m, capNnz, maxRows, s);
 	if (st == SMM_HIP_OK) {
 		devFree(m->d_pat_rowblocks);
 		m->d_pat_rowblocks = m->d_rowblocks;
@@ -442,7 +443,7 @@ int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* x, T*
 	{
 		std::lock_guard<std::mutex> lock(mm->tileMutex);
 		if (!m->d_pat_rowblocks || m->pat_nnz_cap != capNnz || m->pat_max_rows != maxRows) {
-			SMM_TRY(buildPatternTiles(mm, capNnz, maxRows));
+			SMM_TRY(buildPatternTiles(mm, capNnz, maxRows, s));
 		}
 	}
 	switch (L) {

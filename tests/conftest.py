@@ -36,6 +36,22 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_v2():
+    """BiCGSymmetric DIVERGED cases as the real reference decides them (oracle/gen_golden_v2.py)"""
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_outputs_v2.npz"))
+
+
+def bicgsymmetric_cases(golden_v2, dtype):
+    dn = np.dtype(dtype).name
+    names = sorted({k.split("/")[1] for k in golden_v2.files if k.startswith("bicgsymmetric/") and k.split("/")[2] == dn})
+    for name in names:
+        tag = f"bicgsymmetric/{name}/{dn}"
+        g = golden_v2
+        yield name, (g[f"{tag}/start"], g[f"{tag}/positions"], g[f"{tag}/values"]), g[f"{tag}/b"], int(g[f"{tag}/maxit"]), float(g[f"{tag}/eps"]), \
+            int(g[f"{tag}/status"]), g[f"{tag}/x"]
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle.oracle import Oracle
 

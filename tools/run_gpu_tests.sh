@@ -6,7 +6,7 @@ shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout -k 10 1100 python -m pytest ${@:-tests} -m gpu -x -q -p no:cacheprovider > $OUT/$TAG.log 2>&1
+timeout -k 10 1100 python -m pytest ${@:-tests} -m gpu -q -p no:cacheprovider > $OUT/$TAG.log 2>&1
 RC=$?
 tail -n 40 $OUT/$TAG.log
 echo "pytest exit $RC"
