@@ -60,13 +60,27 @@ def spmv_bytes(rows, cols, nnz, s):
     return nnz * (s + 4) + (rows + 1) * 4 + cols * s + rows * s
 
 
+def spmv_kernel_source_sha():
+    """sha256 over the sources the SpMV kernel is compiled from: a traffic measurement is only quoted for the kernel it was taken on"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("smm_spmv.hip", "smm_device.h", "smm_internal.h"):
+        with open(os.path.join(ROOT, "sparse_matrix_math_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(args):
-    """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json), if they match"""
+    """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/spmv_traffic.json; tools/pmc_traffic.sh +
+    tools/traffic_json.py write it, one rocprofv3 pass per counter group) -- quoted ONLY when it was measured on this workload AND on
+    the kernel source this tree builds (sha stamped at measurement time); otherwise null rather than a stale number."""
     path = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("rows") == args.rows and t.get("dtype") == args.dtype and t.get("band_k") == args.band_k:
+        if (t.get("rows") == args.rows and t.get("dtype") == args.dtype and t.get("band_k") == args.band_k
+                and t.get("kernel_source_sha16") == spmv_kernel_source_sha()):
             return t.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
@@ -74,21 +88,30 @@ def load_traffic(args):
 
 
 def host_cores():
-    """threads for the CPU baseline: the affinity mask, clipped by the cgroup CPU quota and by the GPU box's CPU share
-    (16 host cores per GPU); SMM_BENCH_CPU_THREADS overrides"""
-    if os.environ.get("SMM_BENCH_CPU_THREADS"):
-        return max(1, int(os.environ["SMM_BENCH_CPU_THREADS"]))
+    """(all, share): every PHYSICAL core this process may run on (affinity mask clipped by the cgroup CPU quota, SMT siblings counted
+    once -- SURVEY.md section 8d: "all physical cores of the GPU host"), and the GPU box's CPU share of 16 cores per GPU.
+    SMM_BENCH_CPU_THREADS overrides the first."""
     try:
-        n = len(os.sched_getaffinity(0))
+        cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
+        cpus = list(range(os.cpu_count() or 1))
+    physical = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                physical.add(f.read().strip())
+        except OSError:
+            physical.add(str(c))
+    n = len(physical)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             n = min(n, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, 16))
+    if os.environ.get("SMM_BENCH_CPU_THREADS"):
+        n = max(1, int(os.environ["SMM_BENCH_CPU_THREADS"]))
+    return max(1, n), max(1, min(n, 16))
 
 
 def cpu_model():
@@ -107,34 +130,41 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
     from oracle.oracle import Oracle
 
     oracle = Oracle()
-    cores = host_cores()
-    oracle.set_threads(cores)
+    cores, share = host_cores()
     csr = (start, positions, values)
     x0 = np.zeros(len(b), dtype=np_dtype)
-    t0 = time.perf_counter()
-    oracle.bicgstab(csr, b, x0, 1, 0.0, omp=True)  # also warms the page cache / first touch
-    one = time.perf_counter() - t0
-    iters = int(max(2, min(200, budget_s / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    st, _, it, _ = oracle.bicgstab(csr, b, x0, iters, 0.0, omp=True)
-    dt = time.perf_counter() - t0
+
+    def timed(threads, budget):
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        oracle.bicgstab(csr, b, x0, 1, 0.0, omp=True)  # also warms the page cache / first touch
+        one = time.perf_counter() - t0
+        iters = int(max(2, min(200, budget / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        _, _, it, _ = oracle.bicgstab(csr, b, x0, iters, 0.0, omp=True)
+        return it, time.perf_counter() - t0
+
+    it, dt = timed(cores, budget_s * 0.6)
+    out = {
+        "value": it / dt,
+        "unit": "iterations/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{it} BiCGStab iterations of the same {len(b)}-row matrix (OpenMP port of the reference loop, {dt:.1f} s, all {cores} physical cores)",
+        "cpu_model": cpu_model(),
+    }
+    if share != cores:  # the 16-core share of one GPU of the box
+        it16, dt16 = timed(share, budget_s * 0.3)
+        out["value_16_cores"] = it16 / dt16
     # the same loop on one core (what the reference's default, non-TBB build does): two iterations are enough to time it
     oracle.set_threads(1)
     t0 = time.perf_counter()
     _, _, it1, _ = oracle.bicgstab(csr, b, x0, 2, 0.0, omp=True)
     dt1 = time.perf_counter() - t0
     oracle.set_threads(cores)
-    out = {
-        "value": it / dt,
-        "unit": "iterations/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{it} BiCGStab iterations of the same {len(b)}-row matrix (OpenMP port of the reference loop, {dt:.1f} s)",
-        "value_1_core": it1 / dt1,
-        "cpu_model": cpu_model(),
-    }
-    # the real reference (oracle/_ref/libsmm_ref.so, built from /root/reference where that exists and carried to the GPU box as a
-    # binary): its own SMM::BiCGStab on the same matrix, single-threaded as its default build is -- two iterations
+    out["value_1_core"] = it1 / dt1
+    # the real reference (oracle/_ref/libsmm_ref.so: built from /root/reference in the build container and DELIBERATELY carried to the
+    # GPU box as a binary): its own SMM::BiCGStab on the same matrix, single-threaded as its default build is
     try:
         from oracle.oracle import Reference
 
@@ -147,6 +177,77 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
             out["reference_1_core"] = 2 / dtr
     except Exception as e:  # noqa: BLE001 -- the reference leg is optional; the port above is the baseline
         out["reference_error"] = str(e)[:200]
+    return out
+
+
+def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
+    """NOT the headline: two more SpMV-only measurements the roofline discussion refers to:
+    (a) SURVEY.md section 8d's secondary matrix -- the benchmark matrix's shape with i.i.d. uniform columns, the worst case for the x gather;
+    (b) BASELINE config 4's matrix on one GPU -- the 3-D 7-point Laplacian 512^3 in fp64 (13.9 GB per SpMV)."""
+    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def time_spmv(A, n, td, reps):
+        x = torch.rand(n, dtype=td, device=dev)
+        y = torch.empty(n, dtype=td, device=dev)
+        for _ in range(2):
+            A.spmv_dev(0, None, x, y, stream)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            A.spmv_dev(0, None, x, y, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    try:
+        n = args.rows
+        np_dtype = np.float32 if args.dtype == "f32" else np.float64
+        td = torch.float32 if args.dtype == "f32" else torch.float64
+        s = np.dtype(np_dtype).itemsize
+        nnz = host.gen_banded_nnz(n, args.band_k, args.seed, args.max_offset)
+        d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+        d_val = torch.empty(nnz, dtype=td, device=dev)
+        host.gen_banded_dev(n, args.band_k, args.seed, args.max_offset, d_start, d_pos, d_val, np_dtype, stream, diag_shift=args.diag_shift)
+        torch.cuda.synchronize()
+        # stratified i.i.d. columns: entry j of a row of length L falls uniformly into the j-th of L equal slices of [0, n): ascending
+        lens = (d_start[1:] - d_start[:-1]).to(torch.int64)
+        j = torch.arange(nnz, device=dev, dtype=torch.int64) - torch.repeat_interleave(d_start[:-1].to(torch.int64), lens)
+        width = (n // torch.repeat_interleave(lens, lens)).clamp_(min=1)
+        g = torch.Generator(device=dev).manual_seed(7)
+        r = (torch.rand(nnz, device=dev, generator=g, dtype=torch.float64) * width.to(torch.float64)).to(torch.int64)
+        d_pos.copy_((j * width + torch.minimum(r, width - 1)).clamp_(0, n - 1).to(torch.int32))
+        del lens, j, width, r
+        A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np_dtype)
+        ms = time_spmv(A, n, td, 5)
+        bts = spmv_bytes(n, n, nnz, s)
+        out["spmv_iid_columns"] = {"rows": n, "nnz": nnz, "dtype": args.dtype, "avg_launch_ms": ms, "gbps": bts / ms / 1e6, "frac": bts / ms / 1e6 / HBM_PEAK_GBPS,
+                                   "note": "same shape and values as the bench matrix, columns i.i.d. uniform: every gather pulls its own 128-byte line"}
+        A.close()
+        del A, d_start, d_pos, d_val
+    except Exception as e:  # noqa: BLE001 -- extras never fail the bench line
+        out["spmv_iid_columns"] = {"skipped": str(e)[:200]}
+    try:
+        N = 512
+        n, nnz = N ** 3, host.gen_stencil3d_nnz(N, N, N)
+        d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+        d_val = torch.empty(nnz, dtype=torch.float64, device=dev)
+        host.gen_stencil3d_dev(N, N, N, 6.0, -1.0, -1.0, d_start, d_pos, d_val, np.float64, stream)
+        A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np.float64)
+        t0 = time.perf_counter()
+        ms_first = time_spmv(A, n, torch.float64, 1)  # includes nothing of the set-up: time_spmv warms up first
+        torch.cuda.synchronize()
+        ms = time_spmv(A, n, torch.float64, 5)
+        bts = spmv_bytes(n, n, nnz, 8)
+        out["spmv_laplacian512_f64"] = {"rows": n, "nnz": nnz, "dtype": "f64", "avg_launch_ms": ms, "gbps": bts / ms / 1e6, "frac": bts / ms / 1e6 / HBM_PEAK_GBPS,
+                                        "setup_plus_first_launches_s": time.perf_counter() - t0 - ms * 5e-3}
+        A.close()
+        del A, d_start, d_pos, d_val, ms_first
+    except Exception as e:  # noqa: BLE001
+        out["spmv_laplacian512_f64"] = {"skipped": str(e)[:200]}
+    torch.cuda.empty_cache()
     return out
 
 
@@ -326,6 +427,8 @@ def main():
             except smm.SmmHipError as e:
                 result["extras"] = {"pattern_family": {"skipped": str(e)}}
             A.set_kernel(family, lanes)
+        if not args.no_extras:
+            result.setdefault("extras", {}).update(extra_spmv_legs(args, smm, host, torch, np, dev, stream))
         mtx = args.mtx or (os.path.join(ROOT, "atmosmodd.mtx") if os.path.exists(os.path.join(ROOT, "atmosmodd.mtx")) else None)
         if mtx:
             result.setdefault("extras", {})["mtx_bicgstab"] = mtx_leg(mtx)

@@ -202,12 +202,17 @@ int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower,
 #define SMM_SWEEP_AUTO 0
 #define SMM_SWEEP_LEVELS 1
 #define SMM_SWEEP_SYNCFREE 2
+#define SMM_SWEEP_SYNCFREE_XCD 3 /* SYNCFREE with every wavefront of a sweep on ONE XCD: rows meet in that XCD's L2 */
 int smm_hip_precond_set_sweep(smm_hip_precond* M, int mode);
 /* x = M^-1 rhs; rhs must not alias x (ref:1667) */
 int smm_hip_precond_apply_f32(const smm_hip_precond* M, const float* rhs, float* x);
 int smm_hip_precond_apply_f64(const smm_hip_precond* M, const double* rhs, double* x);
 int smm_hip_precond_apply_dev_f32(const smm_hip_precond* M, const float* d_rhs, float* d_x, smm_hip_stream stream);
 int smm_hip_precond_apply_dev_f64(const smm_hip_precond* M, const double* d_rhs, double* d_x, smm_hip_stream stream);
+/* The asynchronous apply cannot report a triangular sweep that failed to finish (the escape bound of the synchronisation-free sweeps:
+ * it then publishes NaN and raises a sticky flag).  This call synchronises `stream`, returns SMM_HIP_ERR_HIP when a sweep applied on it
+ * since the last call tripped the bound, and clears the flag.  The solver entry points call it themselves before they return. */
+int smm_hip_precond_take_error(const smm_hip_precond* M, smm_hip_stream stream);
 /* copies the factor values (ILU0 / IC0: nnz values on A's pattern; JACOBI: rows diagonal entries) to the host */
 int smm_hip_precond_values_f32(const smm_hip_precond* M, float* out, size_t count);
 int smm_hip_precond_values_f64(const smm_hip_precond* M, double* out, size_t count);

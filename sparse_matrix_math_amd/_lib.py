@@ -88,6 +88,7 @@ _PLAIN = {
     "smm_hip_precond_create": (c_int, [_P, c_int, POINTER(_P)]),
     "smm_hip_precond_destroy": (c_int, [_P]),
     "smm_hip_precond_set_sweep": (c_int, [_P, c_int]),
+    "smm_hip_precond_take_error": (c_int, [_P, _P]),
     "smm_hip_precond_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "smm_hip_gen_poisson2d_nnz": (c_longlong, [c_int, c_int]),
     "smm_hip_gen_stencil3d_nnz": (c_longlong, [c_int, c_int, c_int]),

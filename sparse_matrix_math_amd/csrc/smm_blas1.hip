@@ -6,6 +6,7 @@
 // partial; a one-workgroup kernel adds the partials in a fixed order.  No atomics: results are bitwise
 // reproducible from run to run.  Accumulation is in T, like the reference.
 #include <algorithm>
+#include <map>
 
 #include "smm_device.h"
 #include "smm_internal.h"
@@ -110,14 +111,20 @@ static int dotDev(int n, const T* a, const T* b, T* d_result, hipStream_t s) {
 		setError("dot: bad arguments");
 		return SMM_HIP_ERR_INVALID;
 	}
-	// one persistent partial-sum buffer per scalar type: this entry point only enqueues, so a buffer handed back to the
-	// allocator here could be given to another stream while these two kernels are still pending.  (Callers drive the
-	// `_dev` entry points from one stream at a time, see include/smm_hip.h.)
-	static T* partials = nullptr;
+	// This entry point only enqueues, so its partial-sum buffer cannot go back to the allocator here.  One persistent buffer PER
+	// STREAM (and scalar type): calls on one stream are ordered by the stream, calls on different streams never share a buffer.
+	static std::map<hipStream_t, T*> buffers;
 	static std::mutex mu;
+	T* partials = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(mu);
-		if (!partials) SMM_TRY(devAlloc(reinterpret_cast<void**>(&partials), NPART * sizeof(T)));
+		auto it = buffers.find(s);
+		if (it == buffers.end()) {
+			T* p = nullptr;
+			SMM_TRY(devAlloc(reinterpret_cast<void**>(&p), NPART * sizeof(T)));
+			it = buffers.emplace(s, p).first;
+		}
+		partials = it->second;
 	}
 	SMM_TRY(launchDotPartials<T>(n, a, b, partials, nullptr, s));
 	SMM_TRY(launchSumPartials<T>(partials, d_result, s));

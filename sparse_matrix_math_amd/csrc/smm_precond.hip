@@ -163,16 +163,22 @@ __device__ __forceinline__ typename SweepBits<T>::U pollBits(const T* x, int col
 	return __hip_atomic_load(reinterpret_cast<const U*>(x) + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T>
+// ONE_XCD: every wavefront of the sweep runs on the same XCD, whose L2 is then the meeting point: the publishing store is a plain
+// (workgroup-scope) store that KEEPS the line in that L2 instead of the sc1 store that pushes it out to the memory side, and the
+// agent-scope poll (sc1: bypasses the CU's own L1 only) finds it there -- a hop costs an L2 round trip instead of two fabric trips.
+template <typename T, bool ONE_XCD = false>
 __device__ __forceinline__ void publishX(T* x, int row, T v) {
 	using U = typename SweepBits<T>::U;
 	U b;
 	__builtin_memcpy(&b, &v, sizeof(T));
 	if (b == SweepBits<T>::SENT) b = SweepBits<T>::QNAN;  // a NaN either way; never leave a finished row looking unfinished
-	__hip_atomic_store(reinterpret_cast<U*>(x) + row, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (ONE_XCD) __hip_atomic_store(reinterpret_cast<U*>(x) + row, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	else __hip_atomic_store(reinterpret_cast<U*>(x) + row, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr unsigned SWEEP_PASS_LIMIT = 1u << 21;
+// HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wavefront runs on
+__device__ __forceinline__ int xccId() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xF; }
+
 
 template <typename T>
 __global__ __launch_bounds__(TPB) void sweepPrefillKernel(int n, T* __restrict__ y, T* __restrict__ x, int* __restrict__ words,
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(TPB) void sweepPrefillKernel(int n, T* __restrict__
 	if (doneFlag && *doneFlag) return;
 	using U = typename SweepBits<T>::U;
 	if (blockIdx.x == 0 && threadIdx.x < 2) words[threadIdx.x] = 0;  // the two ticket counters; words[2] (error) is sticky
+	if (blockIdx.x == 0 && threadIdx.x >= 3 && threadIdx.x < 5) words[threadIdx.x] = -1;  // XCD elected by each sweep (ONE_XCD)
 	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
 		reinterpret_cast<U*>(y)[i] = SweepBits<T>::SENT;
 		reinterpret_cast<U*>(x)[i] = SweepBits<T>::SENT;
@@ -195,11 +202,23 @@ __global__ __launch_bounds__(TPB) void sweepPrefillKernel(int n, T* __restrict__
 // one round trip (the poll) + arithmetic + the publishing store per level.
 constexpr int SWEEP_WINDOW = 8;
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool ONE_XCD>
 __global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restrict__ order, const int* __restrict__ start,
                                                        const int* __restrict__ positions, const T* __restrict__ vals, const T* __restrict__ in,
-                                                       T* out, int* ticket, int* err, const int* __restrict__ doneFlag) {
+                                                       T* out, int* ticket, int* err, const int* __restrict__ doneFlag, unsigned passLimit,
+                                                       int* elected) {
 	if (doneFlag && *doneFlag) return;
+	if (ONE_XCD) {
+		// the first wavefront to arrive elects its XCD; wavefronts elsewhere leave at once.  Any number (>= 1) of participants
+		// finishes the sweep: rows are drawn from the ticket counter in dependency order by whoever is running.
+		int mine = xccId(), chosen = 0;
+		if ((threadIdx.x & (WAVE - 1)) == 0) {
+			const int prev = atomicCAS(elected, -1, mine);
+			chosen = prev == -1 ? mine : prev;
+		}
+		chosen = __builtin_amdgcn_readfirstlane(chosen);
+		if (chosen != mine) return;
+	}
 	constexpr bool LOWER = MODE == SGS_LO || MODE == ILU_LO || MODE == IC_LO;
 	constexpr int W = SWEEP_WINDOW;
 	constexpr int DIR = LOWER ? 1 : -1;
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restr
 							else if (MODE == SGS_UP) result = own - acc / value;  // ref:1710
 							else if (MODE == ILU_LO) result = acc;
 							else result = acc / value;                            // ILU_UP, IC_LO (ref:1818), IC_UP (ref:1834)
-							publishX<T>(out, row, result);
+							publishX<T, ONE_XCD>(out, row, result);
 							pending = false;
 						} else if (xb[u] != SweepBits<T>::SENT) {
 							T xv;
@@ -290,9 +309,9 @@ __global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restr
 				}
 				if (pending && used == W) k += DIR * W;
 			}
-			if (++passes > SWEEP_PASS_LIMIT && pending) {  // cannot happen; guarantees that the grid drains
+			if (++passes > passLimit && pending) {  // cannot happen; guarantees that the grid drains
 				atomicOr(err, 1);
-				publishX<T>(out, row, __builtin_nanf(""));
+				publishX<T, ONE_XCD>(out, row, __builtin_nanf(""));
 				pending = false;
 			}
 		}
@@ -491,6 +510,10 @@ static void planGroups(const std::vector<int>& lvlPtr, std::vector<SweepPlan::Gr
 struct smm_precond_plan {
 	smm::SweepPlan lo, up;
 	int sweep = SMM_SWEEP_AUTO;
+	// Escape bound of the synchronisation-free sweeps, in polling passes of a waiting wavefront.  A waiter polls about as fast as a
+	// worker consumes one window of SWEEP_WINDOW entries, so a row that must wait for a row of L entries needs ~L / SWEEP_WINDOW
+	// passes per dependency: the bound grows with the longest row of the matrix and can only trip on a genuine hang.
+	unsigned passLimit = 1u << 21;
 	// scratch of the synchronisation-free sweeps, one set per stream the preconditioner is applied on: y[n] (result of the
 	// lower sweep) and three words {ticket of the lower sweep, ticket of the upper sweep, sticky error}
 	struct Scratch {
@@ -499,6 +522,9 @@ struct smm_precond_plan {
 	};
 	std::mutex scratchMutex;
 	std::map<hipStream_t, Scratch> scratch;
+	// one apply = prefill + lower sweep + upper sweep on the same scratch: the three launches of an apply are enqueued under this
+	// lock, so applies issued by several host threads on one stream stay whole (the stream then runs them one after the other)
+	std::mutex enqueueMutex;
 };
 
 namespace smm {
@@ -527,6 +553,15 @@ static int scratchFor(const smm_hip_precond* M, size_t elemBytes, hipStream_t s,
 	std::lock_guard<std::mutex> lock(plan->scratchMutex);
 	auto it = plan->scratch.find(s);
 	if (it == plan->scratch.end()) {
+		if (plan->scratch.size() >= 8) {
+			// a caller that keeps creating streams would otherwise pin one n-sized buffer per stream for ever
+			SMM_HIP_TRY(hipDeviceSynchronize());
+			for (auto& kv : plan->scratch) {
+				devFree(kv.second.y);
+				devFree(kv.second.words);
+			}
+			plan->scratch.clear();
+		}
 		smm_precond_plan::Scratch sc;
 		SMM_TRY(devAlloc(&sc.y, static_cast<size_t>(std::max(1, M->a->rows)) * elemBytes));
 		SMM_TRY(devAlloc(reinterpret_cast<void**>(&sc.words), 8 * sizeof(int)));
@@ -541,17 +576,18 @@ static int scratchFor(const smm_hip_precond* M, size_t elemBytes, hipStream_t s,
 // one or two) can make progress; every further wavefront only polls, and polling traffic slows the ones on the critical path
 // (measured: 108^3 stencil 1.8 / 2.7 / 4.7 ms per apply with 1024 / 2048 / 4096 wavefronts).  So the launch is sized to a few
 // levels' worth of rows, in one-wavefront workgroups so that they spread over the CUs.
-static int sweepWaves(int n, size_t levels) {
-	double perLevel = 4.0;
+static int sweepWaves(int n, size_t levels, bool oneXcd = false) {
+	double perLevel = oneXcd ? 3.0 : 4.0;
 	if (const char* env = getenv("SMM_HIP_SWEEP_WAVES_PER_LEVEL")) perLevel = std::max(0.25, atof(env));
 	const double rowsPerLevel = static_cast<double>(n) / static_cast<double>(std::max<size_t>(1, levels));
 	long long waves = static_cast<long long>(perLevel * rowsPerLevel / WAVE) + 1;
 	if (const char* env = getenv("SMM_HIP_SWEEP_WAVES")) waves = std::max(1, atoi(env));
 	const long long all = (static_cast<long long>(n) + WAVE - 1) / WAVE;
-	return static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(waves, all), static_cast<long long>(numCUs()) * 8)));
+	const long long cap = oneXcd ? static_cast<long long>(numCUs() / 8) * 16 : static_cast<long long>(numCUs()) * 8;  // resident wavefronts
+	return static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(waves, all), cap)));
 }
 
-template <typename T, int LO, int UP>
+template <typename T, int LO, int UP, bool ONE_XCD>
 static int runSweepsFree(const smm_hip_precond* M, const T* vals, const T* rhs, T* x, const int* doneFlag, hipStream_t s) {
 	const smm_hip_csr* a = M->a;
 	const int n = a->rows;
@@ -559,11 +595,15 @@ static int runSweepsFree(const smm_hip_precond* M, const T* vals, const T* rhs, 
 	SMM_TRY(scratchFor(M, sizeof(T), s, &sc));
 	T* y = static_cast<T*>(sc.y);
 	const int fill = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
+	// ONE_XCD: workgroups are dealt round-robin over the 8 XCDs, so 8 x as many are launched and the elected eighth stays
+	const int spread = ONE_XCD ? 8 : 1;
+	const int wLo = spread * sweepWaves(n, M->lvl_ptr_lo.size() - 1, ONE_XCD);
+	const int wUp = spread * sweepWaves(n, M->lvl_ptr_up.size() - 1, ONE_XCD);
+	const unsigned limit = M->plan->passLimit;
+	std::lock_guard<std::mutex> whole(M->plan->enqueueMutex);
 	sweepPrefillKernel<T><<<fill, TPB, 0, s>>>(n, y, x, sc.words, doneFlag);
-	const int wLo = sweepWaves(n, M->lvl_ptr_lo.size() - 1);
-	const int wUp = sweepWaves(n, M->lvl_ptr_up.size() - 1);
-	sweepFreeKernel<T, LO><<<wLo, WAVE, 0, s>>>(n, M->d_order_lo, a->d_start, a->d_positions, vals, rhs, y, sc.words, sc.words + 2, doneFlag);
-	sweepFreeKernel<T, UP><<<wUp, WAVE, 0, s>>>(n, M->d_order_up, a->d_start, a->d_positions, vals, y, x, sc.words + 1, sc.words + 2, doneFlag);
+	sweepFreeKernel<T, LO, ONE_XCD><<<wLo, WAVE, 0, s>>>(n, M->d_order_lo, a->d_start, a->d_positions, vals, rhs, y, sc.words, sc.words + 2, doneFlag, limit, sc.words + 3);
+	sweepFreeKernel<T, UP, ONE_XCD><<<wUp, WAVE, 0, s>>>(n, M->d_order_up, a->d_start, a->d_positions, vals, y, x, sc.words + 1, sc.words + 2, doneFlag, limit, sc.words + 4);
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
 }
@@ -590,13 +630,18 @@ int precondTakeError(const smm_hip_precond* M, hipStream_t s) {
 	return SMM_HIP_OK;
 }
 
-static bool useFreeSweeps(const smm_precond_plan* plan) {
+// AUTO: the synchronisation-free sweeps; confined to one XCD when the levels are small (an average level of <= 2048 rows keeps the 32
+// CUs of one XCD busy, and a hop through that XCD's L2 is cheaper than one through the fabric: 2-D Poisson 1000^2 4.99 -> 4.18 ms per
+// apply), spread over the chip when they are large (3-D 108^3: 8.7 K-row levels need the bandwidth of all XCDs, 1.16 vs 1.86 ms)
+static int sweepModeOf(const smm_hip_precond* M) {
+	const smm_precond_plan* plan = M->plan;
 	int mode = plan->sweep;
 	if (mode == SMM_SWEEP_AUTO) {
-		mode = SMM_SWEEP_SYNCFREE;
+		const size_t levels = std::max<size_t>(1, std::min(M->lvl_ptr_lo.size(), M->lvl_ptr_up.size()) - 1);
+		mode = static_cast<size_t>(M->a->rows) / levels <= 2048 ? SMM_SWEEP_SYNCFREE_XCD : SMM_SWEEP_SYNCFREE;
 		if (const char* env = getenv("SMM_HIP_SWEEP")) mode = atoi(env);
 	}
-	return mode != SMM_SWEEP_LEVELS;
+	return mode;
 }
 
 template <typename T>
@@ -624,11 +669,19 @@ int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* don
 	}
 	const T* aVals = static_cast<const T*>(M->a->d_values);
 	const T* fVals = static_cast<const T*>(M->d_values);
-	if (useFreeSweeps(plan)) {
+	const int mode = sweepModeOf(M);
+	if (mode == SMM_SWEEP_SYNCFREE_XCD) {
 		switch (M->kind) {
-		case SMM_PRECOND_SGS: return runSweepsFree<T, SGS_LO, SGS_UP>(M, aVals, rhs, x, doneFlag, s);
-		case SMM_PRECOND_ILU0: return runSweepsFree<T, ILU_LO, ILU_UP>(M, fVals, rhs, x, doneFlag, s);
-		case SMM_PRECOND_IC0: return runSweepsFree<T, IC_LO, IC_UP>(M, fVals, rhs, x, doneFlag, s);
+		case SMM_PRECOND_SGS: return runSweepsFree<T, SGS_LO, SGS_UP, true>(M, aVals, rhs, x, doneFlag, s);
+		case SMM_PRECOND_ILU0: return runSweepsFree<T, ILU_LO, ILU_UP, true>(M, fVals, rhs, x, doneFlag, s);
+		case SMM_PRECOND_IC0: return runSweepsFree<T, IC_LO, IC_UP, true>(M, fVals, rhs, x, doneFlag, s);
+		default: break;
+		}
+	} else if (mode != SMM_SWEEP_LEVELS) {
+		switch (M->kind) {
+		case SMM_PRECOND_SGS: return runSweepsFree<T, SGS_LO, SGS_UP, false>(M, aVals, rhs, x, doneFlag, s);
+		case SMM_PRECOND_ILU0: return runSweepsFree<T, ILU_LO, ILU_UP, false>(M, fVals, rhs, x, doneFlag, s);
+		case SMM_PRECOND_IC0: return runSweepsFree<T, IC_LO, IC_UP, false>(M, fVals, rhs, x, doneFlag, s);
 		default: break;
 		}
 	}
@@ -735,6 +788,11 @@ static int createTyped(const smm_hip_csr* a, int kind, smm_hip_precond* M) {
 	SMM_TRY(uploadInts(orderLo, &M->d_order_lo, s));
 	SMM_TRY(uploadInts(orderUp, &M->d_order_up, s));
 	auto* plan = new smm_precond_plan();
+	{
+		long long longest = 0;
+		for (int i = 0; i < n; ++i) longest = std::max<long long>(longest, h.start[i + 1] - h.start[i]);
+		plan->passLimit = static_cast<unsigned>(std::min<long long>(0x7fffffffLL, (1LL << 21) + 64 * longest));
+	}
 	planGroups(M->lvl_ptr_lo, plan->lo.groups);
 	planGroups(M->lvl_ptr_up, plan->up.groups);
 	int st = uploadInts(M->lvl_ptr_lo, &plan->lo.d_lvlPtr, s);
@@ -853,12 +911,21 @@ int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower,
 }
 
 int smm_hip_precond_set_sweep(smm_hip_precond* M, int mode) {
-	if (!M || mode < SMM_SWEEP_AUTO || mode > SMM_SWEEP_SYNCFREE) {
+	if (!M || mode < SMM_SWEEP_AUTO || mode > SMM_SWEEP_SYNCFREE_XCD) {
 		setError("precond_set_sweep: null handle or unknown mode");
 		return SMM_HIP_ERR_INVALID;
 	}
 	if (M->plan) M->plan->sweep = mode;  // Jacobi / NONE have no sweeps: accepted, no effect
 	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_take_error(const smm_hip_precond* M, smm_hip_stream stream) {
+	if (!M) {
+		setError("precond_take_error: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	return precondTakeError(M, pickStream(stream));
 }
 
 int smm_hip_precond_apply_f32(const smm_hip_precond* M, const float* rhs, float* x) { return applyHost<float>(M, rhs, x); }

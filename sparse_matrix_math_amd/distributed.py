@@ -361,6 +361,8 @@ class HipOps:
         done, it = ctypes.c_int(), ctypes.c_int()
         res = (ctypes.c_float if self.suf == "f32" else ctypes.c_double)()
         self.check(self._result(self.ws, self._stream(), ctypes.byref(done), ctypes.byref(it), ctypes.byref(res)))
+        if self.has_precond:  # a triangular sweep that ran into its escape bound must not pass as a result (NaNs otherwise)
+            self.check(self.lib.smm_hip_precond_take_error(self.M._h, self._stream()))
         return done.value, it.value, res.value
 
     def close(self):

@@ -36,7 +36,7 @@ class SolverPreconditioner(enum.IntEnum):
 
 OP_ASSIGN, OP_ADD, OP_SUB = 0, 1, 2
 SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_PATTERN = 0, 1, 2, 3
-SWEEP_AUTO, SWEEP_LEVELS, SWEEP_SYNCFREE = 0, 1, 2
+SWEEP_AUTO, SWEEP_LEVELS, SWEEP_SYNCFREE, SWEEP_SYNCFREE_XCD = 0, 1, 2, 3
 
 _SUFFIX = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 _CT = {"f32": ctypes.c_float, "f64": ctypes.c_double}
@@ -120,6 +120,10 @@ class Preconditioner:
 
     def apply_dev(self, d_rhs, d_x, stream=None):
         check(_fn("smm_hip_precond_apply_dev", self.matrix._suf)(self._h, _dptr(d_rhs), _dptr(d_x), _dptr(stream)))
+
+    def take_error(self, stream=None):
+        """synchronises `stream`; raises when a triangular sweep applied on it failed to finish (apply_dev cannot report it)"""
+        check(_lib.load().smm_hip_precond_take_error(self._h, _dptr(stream)))
 
     def values(self):
         """factor values: diag (JACOBI) or the ILU0 / IC0 values on A's pattern"""

@@ -118,3 +118,106 @@ def test_concurrent_host_api_solves(smm, oracle):
     for st, x in results:
         assert st == 0
         np.testing.assert_allclose(x, x_ref, rtol=1e-7, atol=1e-9)
+
+
+def test_handle_destroyed_behind_an_async_launch_does_not_corrupt_it(smm, oracle):
+    """`_dev` entry points only enqueue, and destroy / __del__ hand buffers back to the caching allocator.  A block must not
+    be reused while a queued kernel still reads it: the matrix (library-owned copy of the arrays) is destroyed right behind an SpMV
+    that is still waiting in the stream, and a second matrix of the same size -- different values -- is created at once."""
+    import torch
+
+    from sparse_matrix_math_amd import host
+
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    csr1 = gen.banded_random_spd(300000, k=8, seed=1, max_offset=4000, dtype=np.float32)
+    csr2 = (csr1[0], csr1[1], (csr1[2] * np.float32(-3.0)).astype(np.float32))
+    n = len(csr1[0]) - 1
+    x = np.random.default_rng(1).uniform(-1, 1, n).astype(np.float32)
+    want = oracle.spmv(csr1, 0, None, x)
+    dx = torch.from_numpy(x).to(dev)
+    for _ in range(3):
+        y = torch.zeros(n, dtype=torch.float32, device=dev)
+        A = smm.CSRMatrix(n, n, *csr1)  # host arrays: the library owns the device copy
+        A.spmv_dev(0, None, dx, y, stream)  # builds the tile table, so that the next launches only enqueue
+        torch.cuda.synchronize()
+        big = torch.rand(96_000_000, device=dev)
+        for _ in range(6):
+            big = big * 1.0001 + 0.5  # ~100 ms of queued work ahead of the SpMV
+        y.zero_()
+        A.spmv_dev(0, None, dx, y, stream)
+        A.close()  # frees values / positions / start / tiles while the SpMV above is still queued
+        B = smm.CSRMatrix(n, n, *csr2)  # same sizes: the allocator would hand the same blocks out again
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+        y2 = torch.zeros(n, dtype=torch.float32, device=dev)
+        B.spmv_dev(0, None, dx, y2, stream)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y2.cpu().numpy(), -3.0 * want, rtol=2e-5, atol=6e-5)
+        B.close()
+        del big
+
+
+def test_dot_on_two_streams_at_once(smm):
+    """smm_hip_dot_dev keeps one partial-sum buffer per stream, so dots enqueued on different streams do not race"""
+    import torch
+
+    from sparse_matrix_math_amd import host
+
+    dev = torch.device("cuda:0")
+    n = 6_000_000
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    vecs = [torch.full((n,), float(k + 1), dtype=torch.float64, device=dev) for k in range(3)]
+    outs = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(20):
+        for k, st in enumerate(streams):
+            host.dot_dev(n, vecs[k], vecs[k], outs[k], np.float64, st.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert float(outs[k]) == float(n) * (k + 1) ** 2
+
+
+def test_sweeps_with_long_dependent_rows(smm, oracle):
+    """a dense lower-triangular block makes every row depend on all earlier ones with hundreds of entries per row -- the
+    case where waiting wavefronts poll far more often than the working one advances.  The sweeps must finish (escape bound scaled by
+    the longest row, smm_hip_precond_take_error clean) and stay bit-identical to the sequential sweeps."""
+    import torch
+
+    P = smm.SolverPreconditioner
+    rng = np.random.default_rng(11)
+    nb, n = 700, 1500
+    dense = np.zeros((n, n))
+    blk = rng.uniform(-0.5, 0.5, (nb, nb)) / nb
+    dense[:nb, :nb] = blk + blk.T  # symmetric dense block: lower AND upper sweeps are fully sequential over 700 rows
+    for i in range(n):
+        dense[i, i] = 4.0
+        if i + 1 < n:
+            dense[i, i + 1] = dense[i + 1, i] = -1.0
+    start = np.zeros(n + 1, dtype=np.int32)
+    pos, val = [], []
+    for r in range(n):
+        (c,) = np.nonzero(dense[r])
+        pos.extend(c.tolist())
+        val.extend(dense[r, c].tolist())
+        start[r + 1] = len(pos)
+    csr = (start, np.array(pos, dtype=np.int32), np.array(val, dtype=np.float64))
+    A = smm.CSRMatrix(n, n, *csr)
+    rhs = rng.uniform(-1, 1, n)
+    dev = torch.device("cuda:0")
+    for kind in (P.SYMMETRIC_GAUS_SEIDEL, P.ILU0):
+        M = A.getPreconditioner(kind)
+        assert max(M.levels()) >= nb
+        if kind == P.ILU0:
+            _, lu = oracle.ilu0_factorize(csr)
+            err, want = oracle.ilu0_apply(csr, lu, rhs)
+        else:
+            err, want = oracle.sgs_apply(csr, rhs)
+        assert err == 0
+        x = np.zeros(n)
+        assert M.apply(rhs, x) == 0
+        np.testing.assert_array_equal(x, want)
+        d_rhs, d_x = torch.from_numpy(rhs).to(dev), torch.zeros(n, dtype=torch.float64, device=dev)
+        M.apply_dev(d_rhs, d_x, torch.cuda.current_stream().cuda_stream)
+        M.take_error(torch.cuda.current_stream().cuda_stream)  # raises if a sweep tripped its bound
+        np.testing.assert_array_equal(d_x.cpu().numpy(), want)

@@ -115,7 +115,7 @@ def test_sweep_modes_bit_identical(smm, oracle, dtype):
     """the level-scheduled sweeps (one launch per level) and the synchronisation-free sweeps (one launch per sweep, rows wait
     on ready values) walk every row in the reference's order: same bits, and the oracle's sequential sweep's bits; sizes with
     thousands of wavefronts, hundreds of levels, levels smaller and larger than a wavefront"""
-    from sparse_matrix_math_amd.host import SWEEP_LEVELS, SWEEP_SYNCFREE
+    from sparse_matrix_math_amd.host import SWEEP_LEVELS, SWEEP_SYNCFREE, SWEEP_SYNCFREE_XCD
 
     P = smm.SolverPreconditioner
     cases = {
@@ -133,13 +133,14 @@ def test_sweep_modes_bit_identical(smm, oracle, dtype):
         for kind in kinds:
             M = A.getPreconditioner(kind)
             out = {}
-            for mode in (SWEEP_LEVELS, SWEEP_SYNCFREE):
+            for mode in (SWEEP_LEVELS, SWEEP_SYNCFREE, SWEEP_SYNCFREE_XCD):
                 M.set_sweep(mode)
                 x = np.full(rows, 7, dtype=dtype)
                 for _ in range(3):  # repeated applies reuse the ticket counters and the scratch vector
                     M.apply(rhs, x)
                 out[mode] = x
             np.testing.assert_array_equal(out[SWEEP_LEVELS], out[SWEEP_SYNCFREE], err_msg=f"{name} {kind}")
+            np.testing.assert_array_equal(out[SWEEP_LEVELS], out[SWEEP_SYNCFREE_XCD], err_msg=f"{name} {kind} one XCD")
             if kind == P.SYMMETRIC_GAUS_SEIDEL and rows <= 60_000:
                 np.testing.assert_array_equal(out[SWEEP_SYNCFREE], oracle.sgs_apply(csr, rhs)[1], err_msg=name)
 
@@ -147,7 +148,7 @@ def test_sweep_modes_bit_identical(smm, oracle, dtype):
 def test_sweep_modes_in_solver(smm):
     """a preconditioned BiCGStab / PCG solve gives the same bits whichever way the sweeps are launched; NaN / Inf in rhs travel
     through the synchronisation-free sweep (NaN is not the 'not ready yet' marker) instead of stalling it"""
-    from sparse_matrix_math_amd.host import SWEEP_LEVELS, SWEEP_SYNCFREE
+    from sparse_matrix_math_amd.host import SWEEP_LEVELS, SWEEP_SYNCFREE, SWEEP_SYNCFREE_XCD
 
     P = smm.SolverPreconditioner
     csr = gen.convdiff3d(30, 0.3, dtype=np.float64)

@@ -45,7 +45,7 @@ def main():
             M = A.getPreconditioner(kind)
             res = {}
             outs = {}
-            for mode, label in ((host.SWEEP_LEVELS, "levels"), (host.SWEEP_SYNCFREE, "syncfree")):
+            for mode, label in ((host.SWEEP_LEVELS, "levels"), (host.SWEEP_SYNCFREE, "syncfree"), (host.SWEEP_SYNCFREE_XCD, "onexcd")):
                 M.set_sweep(mode)
                 x = torch.zeros(n, dtype=torch.float64, device=dev)
                 M.apply_dev(rhs, x, stream)
@@ -57,9 +57,9 @@ def main():
                 torch.cuda.synchronize()
                 res[label] = e0.elapsed_time(e1) / args.reps
                 outs[label] = x
-            same = bool(torch.equal(outs["levels"], outs["syncfree"]))
+            same = bool(torch.equal(outs["levels"], outs["syncfree"])) and bool(torch.equal(outs["levels"], outs["onexcd"]))
             bytes_ = 2 * (nnz * 12 + (n + 1) * 4) + 5 * n * 8
-            print(f"{name} {kind.name}: levels {M.levels()}  level-scheduled {res['levels']:.3f} ms  sync-free {res['syncfree']:.3f} ms "
+            print(f"{name} {kind.name}: levels {M.levels()}  level-scheduled {res['levels']:.3f} ms  sync-free {res['syncfree']:.3f} ms  one-XCD {res['onexcd']:.3f} ms "
                   f"({bytes_ / res['syncfree'] / 1e6:.0f} GB/s)  identical {same}", flush=True)
 
 
