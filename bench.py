@@ -220,9 +220,14 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         d_pos.copy_((j * width + torch.minimum(r, width - 1)).clamp_(0, n - 1).to(torch.int32))
         del lens, j, width, r
         A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np_dtype)
+        # one lane per row: every family / lane count lands on the same time for this matrix, and the launches
+        # then carry a kernel name of their own (spmvStreamKernel<float, 1>) -- a rocprofv3 --stats of this command keeps the headline
+        # kernel's average (spmvStreamKernel<float, 2>) clean
+        A.set_kernel(2, 1)
         ms = time_spmv(A, n, td, 5)
         bts = spmv_bytes(n, n, nnz, s)
-        out["spmv_iid_columns"] = {"rows": n, "nnz": nnz, "dtype": args.dtype, "avg_launch_ms": ms, "gbps": bts / ms / 1e6, "frac": bts / ms / 1e6 / HBM_PEAK_GBPS,
+        out["spmv_iid_columns"] = {"rows": n, "nnz": nnz, "dtype": args.dtype, "lanes_per_row": 1, "avg_launch_ms": ms, "gbps": bts / ms / 1e6,
+                                   "frac": bts / ms / 1e6 / HBM_PEAK_GBPS,
                                    "note": "same shape and values as the bench matrix, columns i.i.d. uniform: every gather pulls its own 128-byte line"}
         A.close()
         del A, d_start, d_pos, d_val
@@ -396,7 +401,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(args),
-                "kernel": {2: "spmvStreamKernel", 3: "spmvPatternKernel"}.get(family, "spmvVectorKernel"),
+                "kernel": ("spmvTileKernel" if family == 2 and lanes in (2, 4) else {2: "spmvStreamKernel", 3: "spmvPatternKernel"}.get(family, "spmvVectorKernel")),
                 "algorithmic_bytes_per_launch": b_spmv,
                 "avg_launch_ms": spmv_avg_s * 1e3,
                 "launches": spmv_launches,

@@ -108,6 +108,7 @@ struct smm_hip_csr {
 	int stream_nnz_cap = 0;  // nonzeros / rows per tile the row blocks were cut for
 	int stream_max_rows = 0;
 	int stream_chunk_tiles = 0;  // tiles dealt to an XCD group at a time (0: one contiguous eighth per group)
+	int stream_mid_len = 0;      // nonzeros of the middle row (a typical row: sizes the gather batches of the TILE kernel)
 	std::mutex tileMutex;  // the tile table is built lazily by the first SpMV; concurrent solves on one matrix are allowed
 	// PATTERN family (opt-in, smm_spmv_pattern.hip): shared column offsets + one 64-bit mask per row, its own tile table
 	int pat_state = 0;  // 0 not analysed, 1 usable, -1 the matrix has no such pattern

@@ -23,6 +23,7 @@
 //
 // No MFMA: 2 flops per 8-12 bytes, the path is HBM-bound.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include <rocprim/device/device_scan.hpp>
@@ -442,6 +443,235 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// TILE kernel: the STREAM family's kernel for rows of up to ~128 nonzeros (L = 1, 2 or 4 pieces per row).
+//
+// Same data path as spmvStreamKernel (tile of whole rows -> 16-byte coalesced non-temporal loads -> LDS -> lane-per-row gathers),
+// two things changed, both measured on the benchmark matrix with tools/spmv_lab.hip (profiles/r02/spmv_variants.txt):
+//   * the L pieces of a row live in DIFFERENT waves: wave w gathers piece w % L of the 64 consecutive rows of row group w / L, so a
+//     gather instruction reads ONE window of 64 adjacent columns (256 B: 2-3 cache lines) instead of L windows of 64 / L columns --
+//     a quarter fewer L1->L2 requests (47.8 M vs 60.0 M on the benchmark matrix) and 64-lane-wide returns; the piece sums meet in LDS
+//     and are added left to right, exactly the order of the in-wave form: same bits;
+//   * no software pipelining inside the workgroup: a tile is loaded, stored to LDS and summed, then the next one.  A wave's loads
+//     return in order, so a gather issued behind the next tile's stream loads cannot return before them: the prefetch bought nothing
+//     (mode0 vs mode2 of the lab) and cost 32 VGPRs that are now free for deeper gather batches; the overlap comes from the other
+//     workgroups of the CU.
+// G (gathers in flight per lane and batch) is chosen per matrix so that a piece is walked in the fewest, evenly filled batches (a piece
+// of 26 entries: 2 x 13, not 3 x 8 + 2): the number of gather round trips per tile is what the tile time follows.
+// With L == 1 the mapping is the row-per-lane mapping of spmvStreamKernel and the sum is the reference's left-to-right sum (ref:1484-1489).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct TileCfg {
+	static constexpr int PIECE = 4 * TPB;
+	static constexpr int NVMAX = sizeof(T) == 4 ? 6 : 4;  // LDS per tile <= ~50 KB: three workgroups per CU
+	static constexpr int PAD = 16;
+};
+
+template <typename T, int L, int G>
+__global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int chunkTiles, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
+                                                      const int* __restrict__ positions, const T* __restrict__ values, int opFlags, const T* lhs,
+                                                      const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
+                                                      T* __restrict__ partials, const int* __restrict__ doneFlag) {
+	using Cfg = TileCfg<T>;
+	static_assert(L == 1 || L == 2 || L == 4, "pieces per row");
+	static_assert(G <= Cfg::PAD, "a batch may read G - 1 slots past its piece");
+	constexpr int NVMAX = Cfg::NVMAX;
+	const int op = opFlags & 0xFF;
+	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;
+	constexpr int GROUPS = TPB / WAVE / L;  // row groups of 64 rows
+	constexpr int RT = 64 * GROUPS;         // rows per tile
+	// LDS (sized by the host): sVal[cap + PAD] | sOff[cap + PAD] | sStart[RT + 4] | sPart[(L - 1) * RT] | red[4]
+	T* sVal = reinterpret_cast<T*>(smmDynLds);
+	unsigned* sOff = reinterpret_cast<unsigned*>(sVal + cap + Cfg::PAD);
+	int* sStart = reinterpret_cast<int*>(sOff + cap + Cfg::PAD);
+	T* sPart = reinterpret_cast<T*>(sStart + RT + 4);
+	T* red = sPart + (L > 1 ? (L - 1) * RT : 0);
+	if (doneFlag && *doneFlag) return;
+
+	const int t = threadIdx.x;
+	const int lane = t & (WAVE - 1);
+	const int wave = t >> 6;
+	const int piece = wave % L;
+	const int rl = (wave / L) * 64 + lane;  // this lane's row within the tile
+	const int nv = cap / Cfg::PIECE;
+	T acc0 = T(0), acc1 = T(0);
+	// every slot must always hold a valid byte offset: a batch may run past the end of its piece (those products are discarded)
+	for (int i = t; i < cap + Cfg::PAD; i += TPB) {
+		sOff[i] = 0u;
+		sVal[i] = T(0);
+	}
+	// XCD-aware work split, as in spmvStreamKernel
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int xcdGroup = blockIdx.x % nGroups;
+	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;
+	auto tileOf = [&](int j) {
+		const int c = j / chunkTiles;
+		const long long tIdx = (static_cast<long long>(c) * nGroups + xcdGroup) * chunkTiles + (j - c * chunkTiles);
+		return tIdx < nTiles ? static_cast<int>(tIdx) : nTiles;
+	};
+	const int stageLimit = (rowBlocks[nTiles].y & ~3) - cap;
+	int j = blockIdx.x / nGroups;
+	int tile = tileOf(j);
+	int2 m0 = make_int2(0, 0), m1 = make_int2(0, 0);
+	if (tile < nTiles) {
+		m0 = rowBlocks[tile];
+		m1 = rowBlocks[tile + 1];
+	}
+	__syncthreads();  // LDS initialised
+	while (tile < nTiles) {
+		const int r0 = m0.x, n0 = m0.y, r1 = m1.x, n1 = m1.y;
+		const int nrows = r1 - r0;
+		const int a0 = n0 & ~3;
+		const bool direct = n1 - n0 > cap - 3 || a0 > stageLimit;
+		if (!direct) {
+			// the tile's slices of positions[] / values[]: 16-byte coalesced non-temporal loads, straight on to LDS
+			i32x4 rp[NVMAX];
+			typename Pack16<T>::V rv[NVMAX * (sizeof(T) == 4 ? 1 : 2)];
+#pragma unroll
+			for (int v = 0; v < NVMAX; ++v) {
+				const int i = a0 + 4 * (t + v * TPB);
+				if (v < nv && i < n1) {
+					rp[v] = NT_LOAD(reinterpret_cast<const i32x4*>(positions + i));
+					if constexpr (sizeof(T) == 4) {
+						rv[v] = NT_LOAD(reinterpret_cast<const f32x4*>(values + i));
+					} else {
+						rv[2 * v] = NT_LOAD(reinterpret_cast<const f64x2*>(values + i));
+						rv[2 * v + 1] = NT_LOAD(reinterpret_cast<const f64x2*>(values + i + 2));
+					}
+				}
+			}
+			const int ps = t < nrows ? start[r0 + t] : 0;
+#pragma unroll
+			for (int v = 0; v < NVMAX; ++v) {
+				const int li = 4 * (t + v * TPB);
+				if (v < nv && a0 + li < n1) {
+					*reinterpret_cast<i32x4*>(sOff + li) = rp[v] * static_cast<int>(sizeof(T));
+					if constexpr (sizeof(T) == 4) {
+						*reinterpret_cast<f32x4*>(sVal + li) = rv[v];
+					} else {
+						*reinterpret_cast<f64x2*>(sVal + li) = rv[2 * v];
+						*reinterpret_cast<f64x2*>(sVal + li + 2) = rv[2 * v + 1];
+					}
+				}
+			}
+			if (t < nrows) sStart[t] = ps - a0;
+			if (t == 0) sStart[nrows] = n1 - a0;
+		}
+		ldsBarrier();  // the tile is in LDS
+		// descriptors of this workgroup's next tile (two short loads, in flight during the gathers)
+		j += groupSlots;
+		const int ntile = tileOf(j);
+		int2 m0n = make_int2(0, 0), m1n = make_int2(0, 0);
+		if (ntile < nTiles) {
+			m0n = rowBlocks[ntile];
+			m1n = rowBlocks[ntile + 1];
+		}
+		if (direct && nrows == 1) {
+			// an over-long row: wavefront 0 streams it straight from HBM
+			if (t < WAVE) {
+				T dot = T(0);
+				if constexpr (L == 1) {
+					for (int k0 = n0; k0 < n1; k0 += WAVE) {  // the reference's left-to-right order (ref:1484-1489)
+						const int k = k0 + lane;
+						const bool ok = k < n1;
+						const T v = ok ? values[k] : T(0);
+						const T xx = ok ? x[positions[k]] : T(0);
+						const int cnt = min(WAVE, n1 - k0);
+						for (int q = 0; q < cnt; ++q) dot = smmFma(readLane(v, q), readLane(xx, q), dot);
+					}
+				} else {
+					for (int k = n0 + lane; k < n1; k += WAVE) dot = smmFma(values[k], x[positions[k]], dot);
+					dot = groupSum<WAVE>(dot);
+				}
+				if (lane == 0) {
+					const T o = applyOp(op, lhs, r0, dot);
+					out[r0] = o;
+					if (dotMode == 2) acc0 += o * o;
+					if (dotMode) acc1 += o * w1[r0];
+				}
+			}
+		} else if (direct) {
+			// one of the last tiles of the matrix: one lane per row, left to right, straight from HBM
+			if (t < nrows) {
+				const int row = r0 + t;
+				const int e = start[row + 1];
+				T dot = T(0);
+				for (int k = start[row]; k < e; ++k) dot = smmFma(values[k], x[positions[k]], dot);
+				const T o = applyOp(op, lhs, row, dot);
+				out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		} else {
+			// ---- piece sums out of LDS: lane = row of the group, wave = (group, piece) ----
+			T dot = T(0);
+			int kb = 0, ke = 0;
+			if (rl < nrows) {
+				const int b = sStart[rl];
+				const int e = sStart[rl + 1];
+				kb = b;
+				ke = e;
+				if (L > 1) {
+					const int piecelen = (e - b + L - 1) / L;
+					kb = b + piece * piecelen;
+					ke = min(e, kb + piecelen);
+				}
+			}
+			for (int k = kb; k < ke; k += G) {
+				unsigned off[G];
+				T xv[G], vv[G];
+#pragma unroll
+				for (int u = 0; u < G; ++u) {
+					off[u] = sOff[k + u];
+					vv[u] = sVal[k + u];
+				}
+#pragma unroll
+				for (int u = 0; u < G; ++u) xv[u] = gatherX<T>(x, off[u]);
+				const int nvalid = ke - k;
+#pragma unroll
+				for (int u = 0; u < G; ++u) {
+					const T next = smmFma(vv[u], xv[u], dot);
+					dot = u < nvalid ? next : dot;
+				}
+			}
+			if (L > 1) {
+				// pieces of a row meet in LDS and are added left to right: ((p0 + p1) + p2) + p3
+				if (piece > 0 && rl < nrows) sPart[(piece - 1) * RT + rl] = dot;
+				ldsBarrier();
+				if (piece == 0 && rl < nrows) {
+#pragma unroll
+					for (int q = 1; q < L; ++q) dot += sPart[(q - 1) * RT + rl];
+				}
+			}
+			if (piece == 0 && rl < nrows) {
+				const int row = r0 + rl;
+				const T o = applyOp(op, lhs, row, dot);
+				if (ntOut) __builtin_nontemporal_store(o, out + row);
+				else out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		}
+		ldsBarrier();  // every lane is done with the LDS copy of this tile
+		tile = ntile;
+		m0 = m0n;
+		m1 = m1n;
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
+	}
+}
+
 // ---- tile table, built ON THE DEVICE -----------------------------------------------------------------------------------------
 // Rows are cut into tiles of <= capNnz nonzeros and <= maxRows whole rows (a row longer than capNnz is a tile of its own).  A
 // greedy cut from row 0 is a sequential chain over the whole matrix, so the row range is first divided at fixed seams -- the rows
@@ -494,6 +724,7 @@ __global__ void farColumnKernel(int rows, const int* __restrict__ start, const i
 	int far = 0;
 	for (int k = start[mid] + threadIdx.x; k < start[mid + 1]; k += blockDim.x) far = max(far, abs(positions[k] - mid));
 	if (far) atomicMax(info + 1, far);
+	if (threadIdx.x == 0) info[0] = start[mid + 1] - start[mid];  // length of a typical (interior) row
 }
 
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
@@ -520,11 +751,13 @@ int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 		SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
 		SMM_HIP_TRY(rocprim::exclusive_scan(temp.p, tempBytes, counts.p, counts.p, 0, static_cast<size_t>(nChunks) + 1, rocprim::plus<int>(), s));
 		if (rows > 0) farColumnKernel<<<1, 64, 0, s>>>(rows, m->d_start, m->d_positions, info);
-		int host[2] = {0, 0};
+		int host[2] = {0, 0}, midLen = 0;
 		SMM_HIP_TRY(hipMemcpyAsync(&host[0], counts.p + nChunks, sizeof(int), hipMemcpyDeviceToHost, s));
 		SMM_HIP_TRY(hipMemcpyAsync(&host[1], info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipMemcpyAsync(&midLen, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
 		SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream: the table's size decides the allocation and the grid
 		const int nTiles = host[0];
+		m->stream_mid_len = midLen;
 		SMM_TRY(devAlloc(reinterpret_cast<void**>(&m->d_rowblocks), (static_cast<size_t>(nTiles) + 1) * sizeof(int2)));
 		tileCutKernel<<<grid, 64, 0, s>>>(rows, m->d_start, capNnz, maxRows, chunkNnz, nChunks, nullptr, counts, reinterpret_cast<int2*>(m->d_rowblocks));
 		SMM_HIP_TRY(hipGetLastError());
@@ -545,9 +778,43 @@ int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 	return SMM_HIP_OK;
 }
 
+// Which kernel of the STREAM family: the TILE kernel for 2 or 4 pieces per row (benchmark matrix 0.825 -> 0.796 ms on one box,
+// profiles/r02/stream_kernels_ab.txt); with one lane per row (every stencil matrix) the two kernels map rows to lanes identically and
+// the pipelined one is 1-2 % faster (512^3 fp64 3.28 vs 3.33 ms), so it stays.  SMM_HIP_STREAM_VARIANT = 0 / 1 forces the pipelined /
+// the TILE kernel wherever it exists (A/B measurements).
+static bool useTileKernel(int lanes) {
+	static const int forced = [] {
+		const char* env = getenv("SMM_HIP_STREAM_VARIANT");
+		return env ? atoi(env) : -1;
+	}();
+	if (forced == 0) return false;
+	if (forced == 1) return lanes == 1 || lanes == 2 || lanes == 4;
+	return lanes == 2 || lanes == 4;
+}
+static int tileRows(int lanes) { return 64 * (TPB / WAVE / lanes); }
+
+// gathers per batch: a piece of p entries is walked in ceil(p / 16) batches of equal size (26 -> 2 x 13; 13 -> 1 x 13; 7 -> 1 x 7)
+static int tileBatch(const smm_hip_csr* m, int lanes) {
+	// a typical row: the middle row of the matrix (read when the tile table is built), else the mean
+	const double len = m->stream_mid_len > 0 ? m->stream_mid_len : (m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0);
+	const int p = std::max(1, static_cast<int>(std::ceil(len / lanes)));
+	const int nb = (p + 15) / 16;
+	int g = (p + nb - 1) / nb;
+	if (const char* env = getenv("SMM_HIP_TILE_BATCH")) g = atoi(env);  // tuning override
+	return std::max(4, std::min(16, g));
+}
+
 // LDS capacity (nonzeros) of a tile of TPB / lanes average rows, in staging passes of 1024
 template <typename T>
 static int streamCap(const smm_hip_csr* m, int lanes) {
+	if (useTileKernel(lanes)) {
+		const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0;
+		const double want = avg * tileRows(lanes) * 1.02 + 3;
+		int nv = static_cast<int>((want + TileCfg<T>::PIECE - 1) / TileCfg<T>::PIECE);
+		if (const char* env = getenv("SMM_HIP_STREAM_NV")) nv = atoi(env);
+		nv = std::max(1, std::min(nv, TileCfg<T>::NVMAX));
+		return nv * TileCfg<T>::PIECE;
+	}
 	const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0;
 	const int rowsPerTile = TPB / std::min(lanes, WAVE);
 	const double want = avg * rowsPerTile * 1.04 + 3;
@@ -597,9 +864,50 @@ static void launchVector(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 	                                            dotMode, w1, partials, doneFlag);
 }
 
+template <typename T, int L, int G>
+static void launchTileG(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+                        hipStream_t s) {
+	const int cap = m->stream_nnz_cap + 3;
+	const int rt = tileRows(L);
+	const size_t lds = static_cast<size_t>(cap + TileCfg<T>::PAD) * (sizeof(T) + 4) + (rt + 4) * sizeof(int) + static_cast<size_t>(L - 1) * rt * sizeof(T) +
+	                   4 * sizeof(T) + 32;
+	static bool raised = false;  // per instantiation: allow more than 64 KB of dynamic LDS where a tile needs it
+	if (lds > 64 * 1024 && !raised) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvTileKernel<T, L, G>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+		raised = true;
+	}
+	int perCU = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvTileKernel<T, L, G>, TPB, lds) != hipSuccess || perCU < 1) perCU = 3;
+	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	const int grid = std::max(1, std::min(std::min(m->n_rowblocks, numCUs() * perCU), NPART));
+	const int nGroups = std::min(8, grid);
+	const int chunkTiles = m->stream_chunk_tiles > 0 ? m->stream_chunk_tiles : (m->n_rowblocks + nGroups - 1) / nGroups;
+	spmvTileKernel<T, L, G><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, chunkTiles, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions,
+	                                             static_cast<const T*>(m->d_values), op | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1, partials, doneFlag);
+}
+
+template <typename T, int L>
+static void launchTile(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+                       hipStream_t s) {
+#define SMM_TILE_G(GV) \
+	case GV: launchTileG<T, L, GV>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	switch (tileBatch(m, L)) {
+		SMM_TILE_G(4) SMM_TILE_G(5) SMM_TILE_G(6) SMM_TILE_G(7) SMM_TILE_G(8) SMM_TILE_G(9) SMM_TILE_G(10) SMM_TILE_G(11) SMM_TILE_G(12)
+		SMM_TILE_G(13) SMM_TILE_G(14) SMM_TILE_G(15)
+	default: launchTileG<T, L, 16>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	}
+#undef SMM_TILE_G
+}
+
 template <typename T, int L>
 static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {
+	if constexpr (L == 1 || L == 2 || L == 4) {
+		if (useTileKernel(L)) {
+			launchTile<T, L>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s);
+			return;
+		}
+	}
 	const int cap = m->stream_nnz_cap + 3;
 	const size_t lds = static_cast<size_t>(cap + StreamCfg<T>::PAD) * (sizeof(T) + 4) + (TPB + 8) * sizeof(int) + 4 * sizeof(T) + 16;
 	// persistent grid = exactly the workgroups that are resident together (a larger grid would run in two uneven rounds)
@@ -653,7 +961,7 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	}
 	if (family == SMM_SPMV_STREAM) {
 		const int capNnz = streamCap<T>(m, L) - 3;
-		const int maxRows = TPB / std::min(L, WAVE);
+		const int maxRows = useTileKernel(L) ? tileRows(L) : TPB / std::min(L, WAVE);
 		std::lock_guard<std::mutex> lock(const_cast<smm_hip_csr*>(m)->tileMutex);
 		if (!m->d_rowblocks || m->stream_nnz_cap != capNnz || m->stream_max_rows != maxRows) {
 			SMM_TRY(buildRowBlocks(const_cast<smm_hip_csr*>(m), capNnz, maxRows, s));

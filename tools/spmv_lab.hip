@@ -81,7 +81,7 @@ __global__ __launch_bounds__(TPB) void labKernel(int nTiles, const int2* __restr
 	constexpr int CAP = NV * PIECE;
 	constexpr int PAD = G > 16 ? G : 16;
 	constexpr int RW = WAVE / L;
-	constexpr int RT = RW * (TPB / WAVE);
+	constexpr int RT = MODE >= 5 ? 64 * (TPB / WAVE) / L : RW * (TPB / WAVE);
 	constexpr bool RAWCOL = MODE == 3;  // LDS holds raw columns (LDS-DMA cannot scale them)
 	float* sVal = reinterpret_cast<float*>(labLds);
 	unsigned* sOff = reinterpret_cast<unsigned*>(sVal + CAP + PAD);
@@ -89,9 +89,13 @@ __global__ __launch_bounds__(TPB) void labKernel(int nTiles, const int2* __restr
 	const int t = threadIdx.x;
 	const int lane = t & (WAVE - 1);
 	const int wave = t >> 6;
-	const int rowInWave = lane % RW;
-	const int piece = lane / RW;
-	const int rl = wave * RW + rowInWave;
+	// MODE 5/6: a wave gathers ONE piece of 64 consecutive rows (a gather instruction then reads one 256-byte window of x instead of
+	// L windows of 256 / L bytes); the L pieces of a row sit in different waves and meet in LDS.  Rows per tile: 64 * (TPB / 64) / L.
+	constexpr bool XW = MODE >= 5;
+	const int rowInWave = XW ? lane : lane % RW;
+	const int piece = XW ? wave % L : lane / RW;
+	const int rl = XW ? (wave / L) * 64 + lane : wave * RW + rowInWave;
+	float* sPart = reinterpret_cast<float*>(sStart + RT + 8);  // XW: partial sums of pieces 1 .. L-1
 	for (int i = t; i < CAP + PAD; i += TPB) {
 		sOff[i] = 0u;
 		sVal[i] = 0.f;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(TPB) void labKernel(int nTiles, const int2* __restr
 			nm0 = rowBlocks[t1];
 			nm1 = rowBlocks[t1 + 1];
 		}
-		if (MODE <= 1) {
+		if (MODE <= 1 || MODE == 6) {
 			stageLoad(m0.y & ~3, m1.y);
 			if (t < m1.x - m0.x) ps = start[m0.x + t];
 		}
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(TPB) void labKernel(int nTiles, const int2* __restr
 		const int r0 = m0.x, n0 = m0.y, r1 = m1.x, n1 = m1.y;
 		const int nrows = r1 - r0;
 		const int a0 = n0 & ~3;
-		if (MODE == 2) {
+		if (MODE == 2 || MODE == 5) {
 			stageLoad(a0, n1);
 			if (t < nrows) ps = start[r0 + t];
 		}
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(TPB) void labKernel(int nTiles, const int2* __restr
 		const int2 m0n = nm0, m1n = nm1;
 		auto prefetchNext = [&]() {
 			if (ntile < nTiles) {
-				if (MODE <= 1) {
+				if (MODE <= 1 || MODE == 6) {
 					stageLoad(m0n.y & ~3, m1n.y);
 					if (t < m1n.x - m0n.x) ps = start[m0n.x + t];
 				}
@@ -236,7 +240,16 @@ __global__ __launch_bounds__(TPB) void labKernel(int nTiles, const int2* __restr
 				dot = u < nvalid ? next : dot;
 			}
 		}
-		if (L > 1) {
+		if (XW) {
+			if (L > 1) {
+				if (piece > 0) sPart[(piece - 1) * RT + rl] = dot;
+				ldsBarrier();
+				if (piece == 0) {
+#pragma unroll
+					for (int q = 1; q < L; ++q) dot += sPart[(q - 1) * RT + rl];
+				}
+			}
+		} else if (L > 1) {
 			float total = dot;
 #pragma unroll
 			for (int q = 1; q < L; ++q) total += __shfl(dot, rowInWave + q * RW, WAVE);
@@ -525,6 +538,70 @@ __global__ __launch_bounds__(256) void ceilPolicyKernel(int nTiles, const int2* 
 	if (acc == 123.456f || iacc == 0x7fffffff) out[blockIdx.x] = acc;
 }
 
+// 16-byte stream load with an explicit cache policy (FLAVOR): 0 the compiler's non-temporal load, 1 plain, 2 `sc0 sc1`, 3 `sc1`,
+// 4 `sc0 sc1 nt`.  The asm forms are invisible to the compiler's s_waitcnt bookkeeping: the caller waits with vmcnt(0) itself.
+template <int FLAVOR, typename V>
+__device__ __forceinline__ V streamLoad16(const V* p) {
+	if (FLAVOR == 0) return __builtin_nontemporal_load(p);
+	if (FLAVOR == 1) return *p;
+	V v;
+	if (FLAVOR == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+	if (FLAVOR == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+	if (FLAVOR == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+	return v;
+}
+
+// CEILING 3: stream + gathers (64-row windows, one piece per wave like ceilPolicyKernel) with the cache policy of the STREAM loads
+// as the knob: does any flavour keep the once-read matrix lines from displacing x[] lines in L2?
+template <int NOFFP, int FLAVOR>
+__global__ __launch_bounds__(256) void ceilFlavorKernel(int nTiles, const int2* __restrict__ rowBlocks, const int* __restrict__ positions,
+                                                        const float* __restrict__ values, const float* __restrict__ x, float* __restrict__ out,
+                                                        const int* __restrict__ offs, int nOffs, int nCols) {
+	const int t = threadIdx.x;
+	const int lane = t & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int half = wave & 1;
+	const int piece = wave >> 1;
+	const TileMap tm(nTiles);
+	float acc = 0.f;
+	int iacc = 0;
+	for (int j = blockIdx.x / tm.nGroups;; j += tm.groupSlots) {
+		const int tile = tm.tileOf(j);
+		if (tile >= nTiles) break;
+		const int2 m0 = rowBlocks[tile], m1 = rowBlocks[tile + 1];
+		const int a0 = m0.y & ~3, n1 = m1.y, r0 = m0.x, nrows = m1.x - m0.x;
+		i32x4 rp[4];
+		f32x4 rv[4];
+		float xv[NOFFP];
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			const int i = min(a0 + 4 * (t + v * 256), n1 & ~3);  // always a valid address: no divergence around the asm loads
+			rp[v] = streamLoad16<FLAVOR>(reinterpret_cast<const i32x4*>(positions + i));
+			rv[v] = streamLoad16<FLAVOR>(reinterpret_cast<const f32x4*>(values + i));
+		}
+		const int rl = 64 * half + lane;
+		const int row = r0 + rl;
+#pragma unroll
+		for (int u = 0; u < NOFFP; ++u) {
+			const int k = piece * NOFFP + u;
+			xv[u] = 0.f;
+			if (k < nOffs) {
+				const int col = row + offs[k];
+				if (rl < nrows && col >= 0 && col < nCols) xv[u] = x[col];
+			}
+		}
+		if (FLAVOR >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			iacc += rp[v].x ^ rp[v].y ^ rp[v].z ^ rp[v].w;
+			acc += rv[v].x + rv[v].y + rv[v].z + rv[v].w;
+		}
+#pragma unroll
+		for (int u = 0; u < NOFFP; ++u) acc += xv[u];
+	}
+	if (acc == 123.456f || iacc == 0x7fffffff) out[blockIdx.x] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------------------------
@@ -630,8 +707,8 @@ static void runLab(Ctx& c, int wgsPerCU = 0) {
 	std::snprintf(name, sizeof(name), "mode%d tpb%d nv%d L%d G%d wg%d", MODE, TPB, NV, L, G, wgsPerCU);
 	constexpr int CAP = NV * 4 * TPB;
 	constexpr int PAD = G > 16 ? G : 16;
-	constexpr int RT = (WAVE / L) * (TPB / WAVE);
-	const size_t lds = static_cast<size_t>(CAP + PAD) * 8 + (RT + 8) * sizeof(int) + 64;
+	constexpr int RT = MODE >= 5 ? 64 * (TPB / WAVE) / L : (WAVE / L) * (TPB / WAVE);
+	const size_t lds = static_cast<size_t>(CAP + PAD) * 8 + (RT + 8) * sizeof(int) + (MODE >= 5 ? L * RT * sizeof(float) : 0) + 64;
 	const Tiles& tl = c.get(CAP - 3, RT);
 	runVariant(c, name, labKernel<TPB, NV, L, G, MODE>, TPB, lds, wgsPerCU, tl, c.d_start, c.d_pos, c.d_val, c.d_x, c.d_y);
 }
@@ -708,6 +785,35 @@ static void runCeilPolicy(Ctx& c, int keepRows, int wgsPerCU, int streamToo) {
 	runVariant(c, name, ceilPolicyKernel<NOFFP>, 256, 0, wgsPerCU, tl, c.d_pos, c.d_val, c.d_x, c.d_y, d_offs, nOffs, c.rows, mask, streamToo);
 }
 
+static int* bandOffsets(Ctx& c, int* nOut) {
+	static int* d_offs = nullptr;
+	static int nOffs = 0;
+	if (!d_offs) {
+		const int mid = c.rows / 2;
+		nOffs = c.hs[mid + 1] - c.hs[mid];
+		std::vector<int> cols(nOffs);
+		CHECK(hipMemcpy(cols.data(), c.d_pos + c.hs[mid], sizeof(int) * nOffs, hipMemcpyDeviceToHost));
+		for (int& v : cols) v -= mid;
+		CHECK(hipMalloc(&d_offs, sizeof(int) * nOffs));
+		CHECK(hipMemcpy(d_offs, cols.data(), sizeof(int) * nOffs, hipMemcpyHostToDevice));
+	}
+	*nOut = nOffs;
+	return d_offs;
+}
+
+template <int FLAVOR>
+static void runCeilFlavor(Ctx& c, int wgsPerCU) {
+	static const char* names[] = {"nt (builtin)", "plain", "sc0 sc1", "sc1", "sc0 sc1 nt"};
+	char name[128];
+	std::snprintf(name, sizeof(name), "flavor stream loads %s wg%d", names[FLAVOR], wgsPerCU);
+	if (c.only && !std::strstr(name, c.only)) return;
+	int nOffs = 0;
+	int* d_offs = bandOffsets(c, &nOffs);
+	if (nOffs > 52) return;
+	const Tiles& tl = c.get(4093, 128);
+	runVariant(c, name, ceilFlavorKernel<26, FLAVOR>, 256, 0, wgsPerCU, tl, c.d_pos, c.d_val, c.d_x, c.d_y, d_offs, nOffs, c.rows);
+}
+
 int main(int argc, char** argv) {
 	Ctx c;
 	c.rows = argc > 1 ? std::atoi(argv[1]) : 10000000;
@@ -779,6 +885,34 @@ int main(int argc, char** argv) {
 #if LAB_SET == 1
 	runLab<256, 4, 2, 8, 0>(c);
 	runLab<256, 4, 2, 8, 2>(c);
+	// pieces in different waves: 64-row gathers
+	runLab<256, 6, 2, 13, 5>(c);
+	runLab<256, 6, 2, 13, 5>(c, 2);
+	runLab<256, 7, 2, 13, 5>(c);
+	runLab<256, 5, 2, 13, 5>(c);
+	runLab<256, 4, 2, 13, 5>(c);
+	runLab<256, 6, 2, 7, 5>(c);
+	runLab<256, 6, 2, 9, 5>(c);
+	runLab<256, 6, 2, 10, 5>(c);
+	runLab<256, 6, 2, 14, 5>(c);
+	runLab<256, 6, 2, 16, 5>(c);
+	runLab<384, 5, 3, 17, 5>(c);
+	runLab<384, 5, 3, 9, 5>(c);
+	runLab<512, 4, 4, 13, 5>(c);
+	runLab<512, 4, 4, 7, 5>(c);
+	runLab<512, 3, 4, 13, 5>(c);
+	runLab<256, 4, 4, 13, 5>(c);
+	runLab<256, 4, 4, 7, 5>(c);
+#ifdef LAB_MORE
+	runLab<256, 6, 2, 8, 5>(c);
+	runLab<256, 6, 2, 26, 5>(c);
+	runLab<256, 6, 2, 8, 6>(c);
+	runLab<256, 6, 2, 13, 6>(c);
+	runLab<128, 7, 2, 13, 5>(c);
+	runLab<128, 7, 2, 26, 5>(c);
+	runLab<512, 6, 2, 13, 5>(c);
+	runLab<512, 6, 4, 13, 5>(c);
+#endif
 #ifdef LAB_FULL  // measured in profiles/r02/spmv_variants.txt; every one of them lands between 0.82 and 1.02 ms
 	// --- the library's structure re-created, then one knob at a time ---
 	runLab<256, 4, 2, 8, 0>(c);
@@ -813,6 +947,12 @@ int main(int argc, char** argv) {
 	runCeil<3>(c);
 	runCeil<3>(c, 4);
 	runCeil<3>(c, 2);
+	// --- cache policy of the matrix stream beside the gathers ---
+	runCeilFlavor<0>(c, 4);
+	runCeilFlavor<1>(c, 4);
+	runCeilFlavor<2>(c, 4);
+	runCeilFlavor<3>(c, 4);
+	runCeilFlavor<4>(c, 4);
 	// --- per-window cache policy on the access stream ---
 	for (int wg : {0, 4, 2}) {
 		for (int keep : {1 << 30, 0, 4000, 12000, 20000, 31000, 40000, 50000, 60000, 80000}) runCeilPolicy(c, keep, wg, 1);
