@@ -25,6 +25,8 @@ class SmmHipError(RuntimeError):
 
 
 def library_path(fma=False):
+    if os.environ.get("SMM_HIP_LIBRARY"):  # A/B measurements of two builds of the library (tools/): never set in production
+        return os.environ["SMM_HIP_LIBRARY"]
     name = "libsmm_hip_fma.so" if fma else "libsmm_hip.so"
     return os.path.join(_HERE, "lib", name)
 

@@ -198,9 +198,11 @@ int ensureCsrReady(const smm_hip_csr* cm, hipStream_t s, bool streamKnown) {
 		const int grid = std::min(1024, (m->rows + 255) / 256);
 		countLeadingEmpty<<<grid, 256, 0, s>>>(m->rows, m->d_start, d_cnt);
 	}
-	int first = 0;
+	int first = 0, mid[2] = {0, 0};
 	SMM_HIP_TRY(hipMemcpyAsync(&first, d_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream only (8 bytes come back)
+	if (m->rows > 0) SMM_HIP_TRY(hipMemcpyAsync(mid, m->d_start + m->rows / 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream only (16 bytes come back)
+	m->stream_mid_len = mid[1] - mid[0];
 	devFree(d_cnt);
 	m->nnz = nnz;
 	m->firstActiveStart = first;
@@ -265,6 +267,7 @@ static int csrCreate(int rows, int cols, const int* start, const int* positions,
 				break;
 			}
 		}
+		if (rows > 0) m->stream_mid_len = start[rows / 2 + 1] - start[rows / 2];
 		chooseSpmvConfig(m);
 		m->ready = true;
 	}

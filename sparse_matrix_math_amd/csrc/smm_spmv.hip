@@ -463,9 +463,14 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 template <typename T>
 struct TileCfg {
 	static constexpr int PIECE = 4 * TPB;
-	static constexpr int NVMAX = sizeof(T) == 4 ? 6 : 4;  // LDS per tile <= ~50 KB: three workgroups per CU
+	static constexpr int NVMAX = sizeof(T) == 4 ? 7 : 5;  // staging passes of 1024 entries (the last one may be partial)
 	static constexpr int PAD = 16;
+	// three workgroups per CU: 160 KiB / 3, less the small arrays behind the tile
+	static constexpr int LDS_BUDGET = (160 * 1024) / 3 - 2048;
+	static constexpr int CAP_MAX = LDS_BUDGET / static_cast<int>(sizeof(T) + 4) - PAD;  // 6554 (fp32) / 4364 (fp64) nonzeros
 };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T, int L, int G>
 __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int chunkTiles, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
@@ -476,14 +481,17 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 	static_assert(L == 1 || L == 2 || L == 4, "pieces per row");
 	static_assert(G <= Cfg::PAD, "a batch may read G - 1 slots past its piece");
 	constexpr int NVMAX = Cfg::NVMAX;
+	// ({offset, value} pairs in ONE LDS array, read with a single ds_read_b64, were tried for fp32: 2-3 % slower -- tile_kernel_tuning.txt)
+	constexpr bool PAIRS = false;
 	const int op = opFlags & 0xFF;
 	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;
 	constexpr int GROUPS = TPB / WAVE / L;  // row groups of 64 rows
 	constexpr int RT = 64 * GROUPS;         // rows per tile
-	// LDS (sized by the host): sVal[cap + PAD] | sOff[cap + PAD] | sStart[RT + 4] | sPart[(L - 1) * RT] | red[4]
+	// LDS (sized by the host): tile [fp32: pairs[cap + PAD] | fp64: sVal[cap + PAD], sOff[cap + PAD]] | sStart[RT + 4] | sPart[(L - 1) * RT] | red[4]
+	uint2* sPair = reinterpret_cast<uint2*>(smmDynLds);
 	T* sVal = reinterpret_cast<T*>(smmDynLds);
 	unsigned* sOff = reinterpret_cast<unsigned*>(sVal + cap + Cfg::PAD);
-	int* sStart = reinterpret_cast<int*>(sOff + cap + Cfg::PAD);
+	int* sStart = PAIRS ? reinterpret_cast<int*>(sPair + cap + Cfg::PAD) : reinterpret_cast<int*>(sOff + cap + Cfg::PAD);
 	T* sPart = reinterpret_cast<T*>(sStart + RT + 4);
 	T* red = sPart + (L > 1 ? (L - 1) * RT : 0);
 	if (doneFlag && *doneFlag) return;
@@ -493,12 +501,16 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 	const int wave = t >> 6;
 	const int piece = wave % L;
 	const int rl = (wave / L) * 64 + lane;  // this lane's row within the tile
-	const int nv = cap / Cfg::PIECE;
+	const int nv = (cap + Cfg::PIECE - 1) / Cfg::PIECE;
 	T acc0 = T(0), acc1 = T(0);
 	// every slot must always hold a valid byte offset: a batch may run past the end of its piece (those products are discarded)
 	for (int i = t; i < cap + Cfg::PAD; i += TPB) {
-		sOff[i] = 0u;
-		sVal[i] = T(0);
+		if constexpr (PAIRS) {
+			sPair[i] = make_uint2(0u, 0u);
+		} else {
+			sOff[i] = 0u;
+			sVal[i] = T(0);
+		}
 	}
 	// XCD-aware work split, as in spmvStreamKernel
 	const int nGroups = min(8, static_cast<int>(gridDim.x));
@@ -509,7 +521,8 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 		const long long tIdx = (static_cast<long long>(c) * nGroups + xcdGroup) * chunkTiles + (j - c * chunkTiles);
 		return tIdx < nTiles ? static_cast<int>(tIdx) : nTiles;
 	};
-	const int stageLimit = (rowBlocks[nTiles].y & ~3) - cap;
+	// a tile is staged in whole 16-byte pieces from its aligned start: those may run (cap + 3 at most) past the tile, never past the arrays
+	const int stageLimit = (rowBlocks[nTiles].y & ~3) - (cap + 4);
 	int j = blockIdx.x / nGroups;
 	int tile = tileOf(j);
 	int2 m0 = make_int2(0, 0), m1 = make_int2(0, 0);
@@ -545,12 +558,27 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 			for (int v = 0; v < NVMAX; ++v) {
 				const int li = 4 * (t + v * TPB);
 				if (v < nv && a0 + li < n1) {
-					*reinterpret_cast<i32x4*>(sOff + li) = rp[v] * static_cast<int>(sizeof(T));
-					if constexpr (sizeof(T) == 4) {
-						*reinterpret_cast<f32x4*>(sVal + li) = rv[v];
+					const i32x4 bo = rp[v] * static_cast<int>(sizeof(T));  // byte offsets into x: a gather is base + 32-bit offset
+					if constexpr (PAIRS) {
+						u32x4 lo, hi;
+						lo.x = static_cast<unsigned>(bo.x);
+						lo.y = __float_as_uint(rv[v].x);
+						lo.z = static_cast<unsigned>(bo.y);
+						lo.w = __float_as_uint(rv[v].y);
+						hi.x = static_cast<unsigned>(bo.z);
+						hi.y = __float_as_uint(rv[v].z);
+						hi.z = static_cast<unsigned>(bo.w);
+						hi.w = __float_as_uint(rv[v].w);
+						*reinterpret_cast<u32x4*>(sPair + li) = lo;
+						*reinterpret_cast<u32x4*>(sPair + li + 2) = hi;
 					} else {
-						*reinterpret_cast<f64x2*>(sVal + li) = rv[2 * v];
-						*reinterpret_cast<f64x2*>(sVal + li + 2) = rv[2 * v + 1];
+						*reinterpret_cast<i32x4*>(sOff + li) = bo;
+						if constexpr (sizeof(T) == 4) {
+							*reinterpret_cast<f32x4*>(sVal + li) = rv[v];
+						} else {
+							*reinterpret_cast<f64x2*>(sVal + li) = rv[2 * v];
+							*reinterpret_cast<f64x2*>(sVal + li + 2) = rv[2 * v + 1];
+						}
 					}
 				}
 			}
@@ -622,8 +650,14 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 				T xv[G], vv[G];
 #pragma unroll
 				for (int u = 0; u < G; ++u) {
-					off[u] = sOff[k + u];
-					vv[u] = sVal[k + u];
+					if constexpr (PAIRS) {
+						const uint2 e2 = sPair[k + u];
+						off[u] = e2.x;
+						vv[u] = __uint_as_float(e2.y);
+					} else {
+						off[u] = sOff[k + u];
+						vv[u] = sVal[k + u];
+					}
 				}
 #pragma unroll
 				for (int u = 0; u < G; ++u) xv[u] = gatherX<T>(x, off[u]);
@@ -757,7 +791,7 @@ int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 		SMM_HIP_TRY(hipMemcpyAsync(&midLen, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
 		SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream: the table's size decides the allocation and the grid
 		const int nTiles = host[0];
-		m->stream_mid_len = midLen;
+		(void)midLen;  // (the length of the middle row is read by ensureCsrReady already: it sizes the tiles this table is cut for)
 		SMM_TRY(devAlloc(reinterpret_cast<void**>(&m->d_rowblocks), (static_cast<size_t>(nTiles) + 1) * sizeof(int2)));
 		tileCutKernel<<<grid, 64, 0, s>>>(rows, m->d_start, capNnz, maxRows, chunkNnz, nChunks, nullptr, counts, reinterpret_cast<int2*>(m->d_rowblocks));
 		SMM_HIP_TRY(hipGetLastError());
@@ -808,12 +842,14 @@ static int tileBatch(const smm_hip_csr* m, int lanes) {
 template <typename T>
 static int streamCap(const smm_hip_csr* m, int lanes) {
 	if (useTileKernel(lanes)) {
+		// exactly what tileRows() typical rows need (every lane of every wave then has a row), within the LDS budget of three
+		// workgroups per CU; a multiple of 4 so that the staged 16-byte pieces stay whole
 		const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0;
-		const double want = avg * tileRows(lanes) * 1.02 + 3;
-		int nv = static_cast<int>((want + TileCfg<T>::PIECE - 1) / TileCfg<T>::PIECE);
-		if (const char* env = getenv("SMM_HIP_STREAM_NV")) nv = atoi(env);
-		nv = std::max(1, std::min(nv, TileCfg<T>::NVMAX));
-		return nv * TileCfg<T>::PIECE;
+		const double len = std::max(avg, static_cast<double>(m->stream_mid_len));
+		int cap = static_cast<int>(len * tileRows(lanes)) + 8;
+		if (const char* env = getenv("SMM_HIP_STREAM_NV")) cap = atoi(env) * TileCfg<T>::PIECE;
+		cap = std::max(256, std::min(cap, TileCfg<T>::CAP_MAX));
+		return (cap + 3) & ~3;
 	}
 	const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0;
 	const int rowsPerTile = TPB / std::min(lanes, WAVE);
