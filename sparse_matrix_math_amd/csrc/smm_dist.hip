@@ -532,7 +532,9 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 			SMM_HIP_TRY(hipEventRecord(landed, cs));
 		}
 	}
-	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s));
+	// the local block runs while the halo is in flight; with RCCL the exchange is itself a kernel (a few workgroups per peer), and the
+	// persistent SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
+	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, landed ? SPMV_LEAVE_ROOM : 0));
 	if (landed) SMM_HIP_TRY(hipStreamWaitEvent(s, landed, 0));
 	return launchSpmv<T>(D->aRem, op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
 }
@@ -733,7 +735,16 @@ __global__ __launch_bounds__(TPB) void distCgP(int n, DistScal<T>* sc, int par, 
 }
 
 static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, NPART))); }
-static int pollInterval(int it) { return std::max(4, std::min(64, it / 4)); }
+// Leaving the loop early must be the SAME decision on every rank (a rank that stops issuing iterations while another goes on leaves the
+// other one alone in its next collective).  The `done` flag is formed from all-reduced -- hence identical -- numbers at the same
+// iteration on every rank, so a BLOCKING read of it at fixed iteration numbers is consistent; the asynchronous mailbox of the single-GPU
+// loops (whose answer depends on how far the host has run ahead) is not.  One pipeline drain every CHECK_EVERY iterations.
+constexpr int CHECK_EVERY = 16;
+static int readDone(const int* d_done, hipStream_t s, int* done) {
+	SMM_HIP_TRY(hipMemcpyAsync(done, d_done, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	return SMM_HIP_OK;
+}
 
 template <typename T>
 static int checkDist(const smm_hip_dist_csr* D, const char* who) {
@@ -799,17 +810,13 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	SMM_TRY(join(s, ev));
 	distBicgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc);
 
-	static thread_local DonePoller poller;
-	SMM_TRY(poller.init(s));
 	const int* doneFlag = &sc->done;
 	const int planned = std::max(1, maxIterations);  // do { } while: the body always runs once (ref:2232, 2277)
-	int nextCheck = 1;
 	for (int i = 0; i < planned; ++i) {
-		if (i == nextCheck) {
-			const int seen = poller.post(doneFlag);
-			if (seen < 0) return seen;
+		if (i > 0 && i % CHECK_EVERY == 0) {
+			int seen = 0;
+			SMM_TRY(readDone(doneFlag, s, &seen));
 			if (seen) break;
-			nextCheck = i + pollInterval(i);
 		}
 		const int par = i & 1;
 		// ap = [M^-1] A p ; ap.r0 (ref:2233-2243)
@@ -873,16 +880,12 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev));
 	SMM_TRY(join(s, ev));
 	distCgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc, eps);
-	static thread_local DonePoller poller;
-	SMM_TRY(poller.init(s));
 	const int* doneFlag = &sc->done;
-	int nextCheck = 0;
 	for (int i = 0; i < maxIterations; ++i) {
-		if (i == nextCheck) {
-			const int seen = poller.post(doneFlag);
-			if (seen < 0) return seen;
+		if (i % CHECK_EVERY == 0) {  // i == 0: the early exit of ref:2342-2344 costs nothing more than this read
+			int seen = 0;
+			SMM_TRY(readDone(doneFlag, s, &seen));
 			if (seen) break;
-			nextCheck = i + pollInterval(i);
 		}
 		const int par = i & 1;
 		SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, p, partsA, doneFlag, s));  // Ap = A p ; p.Ap, ref:2353-2354

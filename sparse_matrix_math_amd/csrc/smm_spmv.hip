@@ -915,11 +915,13 @@ static void launchTileG(const smm_hip_csr* m, int op, const T* lhs, const T* x, 
 	int perCU = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvTileKernel<T, L, G>, TPB, lds) != hipSuccess || perCU < 1) perCU = 3;
 	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
-	const int grid = std::max(1, std::min(std::min(m->n_rowblocks, numCUs() * perCU), NPART));
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
+	const int grid = std::max(1, std::min(std::min(m->n_rowblocks, cus * perCU), NPART));
 	const int nGroups = std::min(8, grid);
 	const int chunkTiles = m->stream_chunk_tiles > 0 ? m->stream_chunk_tiles : (m->n_rowblocks + nGroups - 1) / nGroups;
 	spmvTileKernel<T, L, G><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, chunkTiles, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions,
-	                                             static_cast<const T*>(m->d_values), op | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1, partials, doneFlag);
+	                                             static_cast<const T*>(m->d_values), (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1,
+	                                             partials, doneFlag);
 }
 
 template <typename T, int L>
@@ -950,11 +952,12 @@ static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 	int perCU = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvStreamKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
 	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
-	grid = std::max(1, std::min(std::min(m->n_rowblocks, numCUs() * perCU), NPART));
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
+	grid = std::max(1, std::min(std::min(m->n_rowblocks, cus * perCU), NPART));
 	const int nGroups = std::min(8, grid);
 	const int chunkTiles = m->stream_chunk_tiles > 0 ? m->stream_chunk_tiles : (m->n_rowblocks + nGroups - 1) / nGroups;
 	spmvStreamKernel<T, L><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, chunkTiles, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
-	                                            op | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1, partials, doneFlag);
+	                                            (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1, partials, doneFlag);
 }
 
 template <typename T>
@@ -981,7 +984,7 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		setError("spmv: fused dot needs w1 and partials");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if ((extraFlags & ~SPMV_FINISH) || ((extraFlags & SPMV_FINISH) && !dotMode)) {
+	if ((extraFlags & ~(SPMV_FINISH | SPMV_LEAVE_ROOM)) || ((extraFlags & SPMV_FINISH) && !dotMode)) {
 		setError("spmv: bad extra flags");
 		return SMM_HIP_ERR_INVALID;
 	}
