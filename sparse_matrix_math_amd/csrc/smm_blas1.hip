@@ -112,20 +112,19 @@ static int dotDev(int n, const T* a, const T* b, T* d_result, hipStream_t s) {
 		return SMM_HIP_ERR_INVALID;
 	}
 	// This entry point only enqueues, so its partial-sum buffer cannot go back to the allocator here.  One persistent buffer PER
-	// STREAM (and scalar type): calls on one stream are ordered by the stream, calls on different streams never share a buffer.
+	// STREAM (and scalar type): calls on different streams never share a buffer, calls on one stream are ordered by the stream -- and the
+	// two launches of a call are enqueued under one lock, so that calls made by several host threads on the SAME stream cannot interleave
+	// (A's partials, B's partials, A's sum).
 	static std::map<hipStream_t, T*> buffers;
 	static std::mutex mu;
-	T* partials = nullptr;
-	{
-		std::lock_guard<std::mutex> lock(mu);
-		auto it = buffers.find(s);
-		if (it == buffers.end()) {
-			T* p = nullptr;
-			SMM_TRY(devAlloc(reinterpret_cast<void**>(&p), NPART * sizeof(T)));
-			it = buffers.emplace(s, p).first;
-		}
-		partials = it->second;
+	std::lock_guard<std::mutex> lock(mu);
+	auto it = buffers.find(s);
+	if (it == buffers.end()) {
+		T* p = nullptr;
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&p), NPART * sizeof(T)));
+		it = buffers.emplace(s, p).first;
 	}
+	T* partials = it->second;
 	SMM_TRY(launchDotPartials<T>(n, a, b, partials, nullptr, s));
 	SMM_TRY(launchSumPartials<T>(partials, d_result, s));
 	return SMM_HIP_OK;
