@@ -421,11 +421,15 @@ class NativeComm:
         lib = _lib.load()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         ident = ctypes.create_string_buffer(128)
+        box = [None]
         if rank == 0:
-            _lib.check(lib.smm_hip_comm_unique_id(ident))
-        box = [ident.raw]
+            # a failure here (librccl not found ...) must reach every rank: the others are about to wait in the broadcast
+            status = lib.smm_hip_comm_unique_id(ident)
+            box = [ident.raw] if status == 0 else [RuntimeError(lib.smm_hip_last_error().decode("utf-8", "replace"))]
         if world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(box[0], Exception):
+            raise box[0]
         h = ctypes.c_void_p()
         _lib.check(lib.smm_hip_comm_create_rccl(rank, world, ctypes.create_string_buffer(box[0], 128), ctypes.byref(h)))
         return cls(h)
@@ -614,7 +618,14 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     b = torch.empty(hi - lo, dtype=t_dtype, device=dev)
     x = torch.zeros(hi - lo, dtype=t_dtype, device=dev)
     if driver == "native":
-        comm = NativeComm.gloo(dist) if staged else NativeComm.rccl(dist)
+        try:
+            comm = NativeComm.gloo(dist) if staged else NativeComm.rccl(dist)
+        except RuntimeError as e:  # raised on EVERY rank (see NativeComm.rccl): fall back together, loudly
+            import sys
+
+            print(f"rank {rank}: native communicator unavailable ({e}); using the Python driver over torch.distributed", file=sys.stderr)
+            driver = "python"
+    if driver == "native":
         comm.selftest()
         A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, np_dtype)
         del d_pos, d_val
