@@ -61,13 +61,18 @@ def spmv_bytes(rows, cols, nnz, s):
 
 
 def spmv_kernel_source_sha():
-    """sha256 over the sources the SpMV kernel is compiled from: a traffic measurement is only quoted for the kernel it was taken on"""
+    """sha256 over the CODE the SpMV kernel is compiled from (comments and white space stripped, so that a reworded comment does not
+    orphan a measurement): a traffic measurement is only quoted for the kernel it was taken on"""
     import hashlib
+    import re
 
     h = hashlib.sha256()
     for name in ("smm_spmv.hip", "smm_device.h", "smm_internal.h"):
-        with open(os.path.join(ROOT, "sparse_matrix_math_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "sparse_matrix_math_amd", "csrc", name), encoding="utf-8") as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # block comments
+        text = re.sub(r"//[^\n]*", "", text)                # line comments (no string literal of these files holds "//")
+        h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -450,8 +450,8 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 // two things changed, both measured on the benchmark matrix with tools/spmv_lab.hip (profiles/r02/spmv_variants.txt):
 //   * the L pieces of a row live in DIFFERENT waves: wave w gathers piece w % L of the 64 consecutive rows of row group w / L, so a
 //     gather instruction reads ONE window of 64 adjacent columns (256 B: 2-3 cache lines) instead of L windows of 64 / L columns --
-//     a quarter fewer L1->L2 requests (47.8 M vs 60.0 M on the benchmark matrix) and 64-lane-wide returns; the piece sums meet in LDS
-//     and are added left to right, exactly the order of the in-wave form: same bits;
+//     11 % fewer L1->L2 requests (53.2 M vs 59.8 M per launch on the benchmark matrix, profiles/r02/pmc_spmv_c3_summary.txt) and
+//     64-lane-wide returns; the piece sums meet in LDS and are added left to right, exactly the order of the in-wave form: same bits;
 //   * no software pipelining inside the workgroup: a tile is loaded, stored to LDS and summed, then the next one.  A wave's loads
 //     return in order, so a gather issued behind the next tile's stream loads cannot return before them: the prefetch bought nothing
 //     (mode0 vs mode2 of the lab) and cost 32 VGPRs that are now free for deeper gather batches; the overlap comes from the other

@@ -829,8 +829,17 @@ int main(int argc, char** argv) {
 	c.nnz = smm_hip_gen_banded_nnz(c.rows, K, SEED, MAXOFF);
 	const size_t slack = 64 * 1024;  // staging may run this far past the arrays (zero filled)
 	CHECK(hipMalloc(&c.d_start, sizeof(int) * (c.rows + 1)));
-	CHECK(hipMalloc(&c.d_pos, sizeof(int) * (c.nnz + slack)));
-	CHECK(hipMalloc(&c.d_val, sizeof(float) * (c.nnz + slack)));
+	// LAB_MATRIX_ALLOC: memory type of the matrix stream (0 default coarse-grained, 1 fine-grained, 3 uncached): does a stream that
+	// the L2 does not keep leave more room for x?
+	const int matFlag = std::getenv("LAB_MATRIX_ALLOC") ? std::atoi(std::getenv("LAB_MATRIX_ALLOC")) : 0;
+	if (matFlag) {
+		CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&c.d_pos), sizeof(int) * (c.nnz + slack), matFlag));
+		CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&c.d_val), sizeof(float) * (c.nnz + slack), matFlag));
+		std::printf("matrix stream allocated with hipExtMallocWithFlags(%d)\n", matFlag);
+	} else {
+		CHECK(hipMalloc(&c.d_pos, sizeof(int) * (c.nnz + slack)));
+		CHECK(hipMalloc(&c.d_val, sizeof(float) * (c.nnz + slack)));
+	}
 	CHECK(hipMemset(c.d_pos + c.nnz, 0, sizeof(int) * slack));
 	CHECK(hipMemset(c.d_val + c.nnz, 0, sizeof(float) * slack));
 	CHECK(hipMalloc(&c.d_x, sizeof(float) * c.rows));
