@@ -163,6 +163,18 @@ int smm_hip_cg_dev_f32(const smm_hip_csr* a, const float* d_b, const float* d_x0
 int smm_hip_cg_dev_f64(const smm_hip_csr* a, const double* d_b, const double* d_x0, double* d_x, int maxIterations, double eps,
                        const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm2);
 
+/* Register-resident ConjugateGradient (csrc/smm_resident.hip).  An unpreconditioned CG whose matrix fits the register file of the chip
+ * (rows <= 1024 * CUs * {4, 2, 1, 1} for rows of at most {5, 9, 16, 27} entries: BASELINE config 2 does) runs as ONE launch with the
+ * matrix held in registers and two grid-wide barriers per iteration, instead of three launches per iteration that re-read the matrix.
+ * Same algorithm, same per-row arithmetic; the global sums add the rows in a different (fixed) partition, so alpha / beta differ from the
+ * three-launch loop in the last bits.  mode: SMM_CG_RESIDENT_OFF never, _AUTO when it fits (default; falls back silently otherwise),
+ * _REQUIRE fail with SMM_HIP_ERR_INVALID when it does not apply (tests, measurements); any other value only queries.  Returns the
+ * previous mode.  Initial value from the environment variable SMM_HIP_CG_RESIDENT (0 / 1 / 2). */
+#define SMM_CG_RESIDENT_OFF 0
+#define SMM_CG_RESIDENT_AUTO 1
+#define SMM_CG_RESIDENT_REQUIRE 2
+int smm_hip_cg_resident(int mode);
+
 int smm_hip_bicgstab_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps,
                          const smm_hip_precond* M, int* solver_status, int* iterations, float* resnorm);
 int smm_hip_bicgstab_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps,

@@ -97,6 +97,7 @@ _PLAIN = {
     "smm_hip_gen_banded_nnz": (c_longlong, [c_int, c_int, c_ulonglong, c_int]),
     "smm_hip_gen_banded_row_start": (c_longlong, [c_int, c_int, c_ulonglong, c_int, c_int]),
     "smm_hip_partials_count": (c_int, []),
+    "smm_hip_cg_resident": (c_int, [c_int]),
     "smm_hip_bicgstab_ws_destroy": (c_int, [_P]),
     "smm_hip_cg_ws_status": (c_int, [_P, _P, POINTER(c_int)]),
     "smm_hip_bicgstab_ws_bind": (c_int, [_P, _P, _P, _P]),

@@ -109,6 +109,7 @@ struct smm_hip_csr {
 	int stream_max_rows = 0;
 	int stream_chunk_tiles = 0;  // tiles dealt to an XCD group at a time (0: one contiguous eighth per group)
 	int stream_mid_len = 0;      // nonzeros of the middle row (a typical row: sizes the gather batches of the TILE kernel)
+	int max_row_len = -1;        // longest row, found on first demand (smm_resident.hip)
 	std::mutex tileMutex;  // the tile table is built lazily by the first SpMV; concurrent solves on one matrix are allowed
 	// PATTERN family (opt-in, smm_spmv_pattern.hip): shared column offsets + one 64-bit mask per row, its own tile table
 	int pat_state = 0;  // 0 not analysed, 1 usable, -1 the matrix has no such pattern
@@ -181,6 +182,11 @@ template <typename T>
 int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
                       const int* doneFlag, hipStream_t s);
 void chooseSpmvConfig(smm_hip_csr* m);
+
+// register-resident ConjugateGradient (smm_resident.hip): *handled = false when the matrix does not fit the register file
+template <typename T>
+int cgResidentTry(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations, T eps, hipStream_t s, int* status, int* iterations,
+                  T* resnorm2, bool* handled);
 
 // partials[0..NPART) = per-block sums of a[i]*b[i]
 template <typename T>

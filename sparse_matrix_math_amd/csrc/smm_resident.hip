@@ -1,0 +1,508 @@
+// smm_resident.hip -- ConjugateGradient (ref:2316-2398) for matrices that fit the chip's REGISTER FILE: one launch per solve.
+//
+// Why (BASELINE config 2, the 1000 x 1000 Poisson matrix, fp64): the whole problem -- 60 MB of matrix, four 8 MB vectors -- is
+// smaller than the 128 MB of vector registers of an MI355X (256 CUs x 512 KB), yet the three-launch iteration of cgDev
+// (smm_solvers.hip) streams the matrix from the Infinity Cache every iteration: 41 us per iteration, of which ~5 us are kernel
+// boundaries and the rest is moving 150 MB that never change.  Here every lane keeps R whole rows of the matrix (values and
+// positions, padded to K entries) and its rows of x, r and p in registers for the whole solve; one workgroup of 1024 lanes per CU
+// (16 waves x 128 VGPRs = the CU's register file).  Per iteration only p has to cross workgroups (the gathers of A p), and two
+// scalars (p.Ap, r.r) have to be summed over the chip: two grid-wide barriers per iteration, nothing else.
+//
+//   * p is never exchanged as such: a third barrier would be needed between "beta known" and "p gathered".  Instead every owner
+//     publishes r (before the r.r barrier) and its previous p, and a consumer forms p_new[c] = beta p_old[c] + r[c] itself for
+//     every column it gathers -- the same expression on the same operands as the owner's own update, hence the same bits.
+//   * barriers are XCD-hierarchical (MI355X_MICROARCH.md, barrier-xcd): workgroups arrive on a counter of their XCD, the last
+//     arriver of an XCD writes that L2's dirty lines back (one agent-scope release per XCD), arrives on the top counter, waits
+//     for the 8 leaders and opens a generation word for its XCD; every workgroup then acquires at agent scope.  Every wait is
+//     bounded (poll count): a timed-out solve reports it and the caller falls back to the three-launch loop; the kernel
+//     writes x into a scratch vector that is copied out only after a clean run.
+//   * the partial sums of a reduction are one slot per workgroup, added by every workgroup in the same fixed order (lane t takes
+//     slot t, wave butterflies, 16 wave sums left to right): all workgroups get the same bits and leave the loop together.
+//   * a row's dot product is formed left to right with _smm_fma exactly like the one-lane-per-row SpMV (smm_spmv.hip), so A p is
+//     bit-identical to the library's SpMV; the global sums use a different partition of the rows than cgDev's, so alpha / beta
+//     differ from cgDev's in the last bits (tests/test_gpu_resident.py bounds the difference; same tolerance as cgDev vs the
+//     oracle).
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+
+#include "smm_device.h"
+#include "smm_internal.h"
+
+namespace smm {
+
+constexpr int RTPB = 1024;     // lanes per workgroup: one workgroup per CU
+constexpr int RWAVES = RTPB / WAVE;
+constexpr int MAX_XCD = 8;
+
+struct ResidentSync {  // zeroed before every launch; every word that is polled sits on a 128-byte line of its own
+	unsigned census[32];
+	unsigned top[32];
+	unsigned timeout[32];
+	unsigned pop[MAX_XCD][32];
+	unsigned arrive[MAX_XCD][32];
+	unsigned gen[MAX_XCD][32];
+};
+
+template <typename T>
+struct ResidentOut {
+	T res;
+	int iters;
+	int status;
+	int timedOut;
+	int pad;
+};
+
+template <typename T>
+struct ResidentArgs {
+	int n;
+	int maxIterations;
+	int nnzAny;  // the matrix has at least one entry
+	T eps;
+	const int* start;
+	const int* positions;
+	const T* values;
+	const T* b;
+	const T* x0;
+	T* x;
+	T* pb[2];   // p of the previous iteration, double-buffered by iteration parity
+	T* rg;      // r of this iteration
+	T* parts;   // [2][gridDim.x] partial sums: p.Ap, r.r
+	ResidentSync* sync;
+	ResidentOut<T>* out;
+	long long waitTicks;  // bound of one wait, in polls (a poll is a load + s_sleep, ~0.5-1 us; polls do not advance while the queue is switched out)
+};
+
+__device__ __forceinline__ int residentXcc() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0x7; }
+
+// one lane polls `word` until it reaches `target`; false when the bound expired or another workgroup already gave up
+__device__ __forceinline__ bool waitAtLeast(unsigned* word, unsigned target, unsigned* timeoutWord, long long waitTicks) {
+	for (long long spins = 0;; ++spins) {
+		if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+		__builtin_amdgcn_s_sleep(1);
+		if ((spins & 255) == 255) {
+			if (__hip_atomic_load(timeoutWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+			if (spins > waitTicks) {
+				__hip_atomic_store(timeoutWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return false;
+			}
+		}
+	}
+}
+
+struct BarrierState {
+	unsigned epoch;  // barriers passed so far + 1
+	unsigned pop;    // workgroups on this XCD
+	unsigned nx;     // XCDs that hold at least one workgroup
+	int xcc;
+};
+
+// Grid-wide barrier.  Called by all RTPB lanes of every workgroup.  Everything a workgroup stored before the call is visible to plain
+// loads of every workgroup after it.  Returns false (in all lanes) when a wait timed out.
+__device__ __forceinline__ bool gridBarrier(ResidentSync* sy, BarrierState& st, int* sOk, long long waitTicks) {
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		bool ok;
+		const unsigned e = st.epoch;
+		const unsigned before = __hip_atomic_fetch_add(&sy->arrive[st.xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (before + 1 == st.pop * e) {
+			// last workgroup of this XCD: one write-back of the XCD's L2 publishes the stores of all its workgroups
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__hip_atomic_fetch_add(&sy->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			ok = waitAtLeast(&sy->top[0], st.nx * e, &sy->timeout[0], waitTicks);
+			__hip_atomic_store(&sy->gen[st.xcc][0], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			ok = waitAtLeast(&sy->gen[st.xcc][0], e, &sy->timeout[0], waitTicks);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		*sOk = ok ? 1 : 0;
+	}
+	__syncthreads();
+	st.epoch += 1;
+	return *sOk != 0;
+}
+
+// sum over the workgroup, the same value in every lane.  Order: butterfly inside each wave, then the 16 wave sums left to right.
+template <typename T>
+__device__ __forceinline__ T blockSumAll(T v, T* lds /* RWAVES + 1 */) {
+	v = groupSum<WAVE>(v);
+	if ((threadIdx.x & (WAVE - 1)) == 0) lds[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		T s = lds[0];
+#pragma unroll
+		for (int w = 1; w < RWAVES; ++w) s += lds[w];
+		lds[RWAVES] = s;
+	}
+	__syncthreads();
+	const T r = lds[RWAVES];
+	__syncthreads();
+	return r;
+}
+
+// total of the per-workgroup partial sums (slot t by lane t), the same bits in every workgroup
+template <typename T>
+__device__ __forceinline__ T sumSlots(const T* slots, T* lds) {
+	T v = T(0);
+	if (threadIdx.x < gridDim.x) v = __hip_atomic_load(slots + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return blockSumAll(v, lds);
+}
+
+template <typename T, int R, int K>
+__global__ __launch_bounds__(RTPB) void cgResidentKernel(ResidentArgs<T> a) {
+	__shared__ T sRed[RWAVES + 1];
+	__shared__ int sOk;
+	__shared__ unsigned sCensus[2];
+	// positions and row lengths live in LDS, lane-interleaved (entry e of lane t at [e * RTPB + t]: conflict-free): together with the
+	// values they would not fit 128 registers per lane
+	extern __shared__ int sDyn[];
+	int* const sCol = sDyn;                 // [R * K][RTPB]
+	int* const sLen = sDyn + R * K * RTPB;  // [R][RTPB]
+	T* const sX = reinterpret_cast<T*>(sDyn + R * (K + 1) * RTPB);  // [R][RTPB]: x is only ever updated in place
+	ResidentSync* const sy = a.sync;
+	const int n = a.n;
+	const int tid = threadIdx.x;
+	const int chunk0 = blockIdx.x * (R * RTPB);
+
+	// ---- census: which XCD am I on, how many workgroups live there, how many XCDs are populated --------------------------
+	BarrierState st;
+	st.xcc = residentXcc();
+	st.epoch = 1;
+	if (tid == 0) {
+		__hip_atomic_fetch_add(&sy->pop[st.xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_fetch_add(&sy->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+
+	// ---- the matrix rows of this lane, into registers -----------------------------------------------------------------------
+	T val[R][K];
+	T rr[R], pr[R];
+#pragma unroll
+	for (int j = 0; j < R; ++j) {
+		const int row = chunk0 + j * RTPB + tid;
+		int b0 = 0, l = 0;
+		if (row < n) {
+			b0 = a.start[row];
+			l = a.start[row + 1] - b0;
+		}
+		sLen[j * RTPB + tid] = l;
+		// r = b - A x0 (ref:2337), x = x0, p starts at 0 (beta = 0 makes the first "p = beta p + r" a copy, ref:2340)
+		T dot = T(0);
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const bool on = k < l;
+			const int e = on ? b0 + k : 0;  // a padded entry reads entry 0 of the arrays (l > 0 somewhere, or nothing is read at all)
+			const T v = a.nnzAny ? a.values[e] : T(0);
+			const int c = a.nnzAny ? a.positions[e] : 0;
+			val[j][k] = on ? v : T(0);
+			sCol[(j * K + k) * RTPB + tid] = on ? c : 0;
+			const T next = smmFma(v, a.x0[on ? c : 0], dot);
+			dot = on ? next : dot;
+		}
+		sX[j * RTPB + tid] = row < n ? a.x0[row] : T(0);
+		rr[j] = row < n ? a.b[row] - dot : T(0);
+		pr[j] = T(0);
+		if (row < n) {
+			a.pb[0][row] = T(0);
+			a.rg[row] = rr[j];
+		}
+		asm volatile("" ::: "memory");
+	}
+	T acc = T(0);
+#pragma unroll
+	for (int j = 0; j < R; ++j) acc += rr[j] * rr[j];
+	T s = blockSumAll(acc, sRed);
+	T* const partsA = a.parts;
+	T* const partsC = a.parts + gridDim.x;
+	if (tid == 0) __hip_atomic_store(partsC + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+	// census wait (flat), then the first real barrier
+	if (tid == 0) {
+		const bool ok = waitAtLeast(&sy->census[0], gridDim.x, &sy->timeout[0], a.waitTicks);
+		unsigned nx = 0, mine = 0;
+		for (int x = 0; x < MAX_XCD; ++x) {
+			const unsigned p = __hip_atomic_load(&sy->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			nx += p != 0;
+			if (x == st.xcc) mine = p;
+		}
+		sCensus[0] = ok ? mine : 0;
+		sCensus[1] = nx;
+	}
+	__syncthreads();
+	st.pop = sCensus[0];
+	st.nx = sCensus[1];
+	bool alive = st.pop != 0;
+	if (alive) alive = gridBarrier(sy, st, &sOk, a.waitTicks);
+
+	int iters = 0;
+	int status = SMM_SOLVER_MAX_ITERATIONS_REACHED;
+	T res = T(0);
+	if (alive) {
+		T rrOld = sumSlots(partsC, sRed);
+		res = rrOld;
+		const T eps2 = a.eps * a.eps;
+		if (eps2 > rrOld) {
+			status = SMM_SOLVER_SUCCESS;  // ref:2341-2344: x untouched
+		} else {
+			T beta = T(0);
+			for (int it = 0; it < a.maxIterations; ++it) {
+				const T* const pOld = a.pb[it & 1];
+				T* const pNew = a.pb[(it & 1) ^ 1];
+				const T* const rg = a.rg;
+				// p = beta p + r (ref:2391-2393), kept and published for the gathers of the NEXT iteration
+#pragma unroll
+				for (int j = 0; j < R; ++j) {
+					const int row = chunk0 + j * RTPB + tid;
+					pr[j] = smmFma(beta, pr[j], rr[j]);
+					if (row < n) pNew[row] = pr[j];
+				}
+				// Ap = A p (ref:2353) with p[c] = beta pOld[c] + r[c] formed on the fly; p.Ap (ref:2354)
+				T ap[R];
+				acc = T(0);
+#pragma unroll
+				for (int j = 0; j < R; ++j) {
+					T dot = T(0);
+					const int l = sLen[j * RTPB + tid];
+#pragma unroll
+					for (int k = 0; k < K; ++k) {
+						// loads are unconditional (a padded entry gathers column 0) so that a row's gathers are in flight together;
+						// the padded entries are dropped by a select, not by a multiplication with 0 (0 x inf, -0 + 0)
+						const int c = sCol[(j * K + k) * RTPB + tid];
+						const T pc = smmFma(beta, pOld[c], rg[c]);
+						const T next = smmFma(val[j][k], pc, dot);
+						dot = k < l ? next : dot;
+					}
+					ap[j] = dot;
+					acc += pr[j] * dot;
+					asm volatile("" ::: "memory");  // one row's gathers at a time: the registers are spoken for
+				}
+				s = blockSumAll(acc, sRed);
+				if (tid == 0) __hip_atomic_store(partsA + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (!gridBarrier(sy, st, &sOk, a.waitTicks)) {
+					alive = false;
+					break;
+				}
+				const T alpha = rrOld / sumSlots(partsA, sRed);  // ref:2358
+				// x = alpha p + x ; r = -alpha Ap + r ; r.r (ref:2371-2375)
+				acc = T(0);
+#pragma unroll
+				for (int j = 0; j < R; ++j) {
+					const int row = chunk0 + j * RTPB + tid;
+					sX[j * RTPB + tid] = smmFma(alpha, pr[j], sX[j * RTPB + tid]);
+					rr[j] = smmFma(-alpha, ap[j], rr[j]);
+					if (row < n) a.rg[row] = rr[j];
+					acc += rr[j] * rr[j];
+				}
+				s = blockSumAll(acc, sRed);
+				if (tid == 0) __hip_atomic_store(partsC + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (!gridBarrier(sy, st, &sOk, a.waitTicks)) {
+					alive = false;
+					break;
+				}
+				const T rrNew = sumSlots(partsC, sRed);
+				iters = it + 1;
+				res = rrNew;
+				if (eps2 > rrNew) {  // ref:2377-2380
+					status = SMM_SOLVER_SUCCESS;
+					break;
+				}
+				beta = rrNew / rrOld;  // ref:2381
+				rrOld = rrNew;
+			}
+		}
+	}
+	if (alive && iters > 0) {
+#pragma unroll
+		for (int j = 0; j < R; ++j) {
+			const int row = chunk0 + j * RTPB + tid;
+			if (row < n) a.x[row] = sX[j * RTPB + tid];
+		}
+	}
+	if (blockIdx.x == 0 && tid == 0) {
+		a.out->res = res;
+		a.out->iters = iters;
+		a.out->status = status;
+		a.out->timedOut = alive ? 0 : 1;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxRowLenKernel(int rows, const int* __restrict__ start, int* __restrict__ out) {
+	int m = 0;
+	for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < rows; i += static_cast<long long>(gridDim.x) * blockDim.x) {
+		m = max(m, start[i + 1] - start[i]);
+	}
+#pragma unroll
+	for (int o = WAVE / 2; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, WAVE));
+	if ((threadIdx.x & (WAVE - 1)) == 0 && m > 0) atomicMax(out, m);
+}
+
+static int maxRowLen(const smm_hip_csr* cm, hipStream_t s, int* out) {
+	auto* m = const_cast<smm_hip_csr*>(cm);
+	std::lock_guard<std::mutex> lock(m->readyMutex);
+	if (m->max_row_len < 0) {
+		DevBuf<int> d;
+		SMM_TRY(d.alloc(1));
+		SMM_HIP_TRY(hipMemsetAsync(d, 0, sizeof(int), s));
+		if (m->rows > 0) maxRowLenKernel<<<std::min(2048, (m->rows + 255) / 256), 256, 0, s>>>(m->rows, m->d_start, d);
+		int h = 0;
+		SMM_HIP_TRY(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		m->max_row_len = h;
+	}
+	*out = m->max_row_len;
+	return SMM_HIP_OK;
+}
+
+// SMM_CG_RESIDENT_OFF / AUTO / REQUIRE; the environment variable SMM_HIP_CG_RESIDENT sets the initial value
+static std::atomic<int>& residentModeRef() {
+	static std::atomic<int> mode{[] {
+		const char* e = getenv("SMM_HIP_CG_RESIDENT");
+		const int v = e ? atoi(e) : SMM_CG_RESIDENT_AUTO;
+		return v < SMM_CG_RESIDENT_OFF || v > SMM_CG_RESIDENT_REQUIRE ? SMM_CG_RESIDENT_AUTO : v;
+	}()};
+	return mode;
+}
+static int residentMode() { return residentModeRef().load(); }
+
+static std::mutex g_residentMutex;  // two grid-barrier kernels must never share the chip: each would wait for CUs the other holds
+
+template <typename T>
+static size_t residentLds(int R, int K) { return static_cast<size_t>(R) * RTPB * ((K + 1) * sizeof(int) + sizeof(T)); }
+
+template <typename T, int R, int K>
+static int launchResident(const ResidentArgs<T>& args, int grid, hipStream_t s) {
+	static const int fits = [] {
+		int perCU = 0;
+		if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cgResidentKernel<T, R, K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                        static_cast<int>(residentLds<T>(R, K))) != hipSuccess)
+			return 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, cgResidentKernel<T, R, K>, RTPB, residentLds<T>(R, K)) != hipSuccess) return 0;
+		return perCU;
+	}();
+	if (fits < 1) return SMM_HIP_ERR_INVALID;
+	cgResidentKernel<T, R, K><<<grid, RTPB, residentLds<T>(R, K), s>>>(args);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+// the (rows per lane, entries per row) shapes that are compiled; registers: R * (K * (sizeof(T) / 4 + 1) + 5 * sizeof(T) / 4) + ~25
+template <typename T>
+static int dispatchResident(int R, int K, const ResidentArgs<T>& args, int grid, hipStream_t s) {
+#define SMM_RES_CASE(RR, KK) \
+	if (R == RR && K == KK) return launchResident<T, RR, KK>(args, grid, s);
+	SMM_RES_CASE(1, 5)
+	SMM_RES_CASE(2, 5)
+	SMM_RES_CASE(4, 5)
+	SMM_RES_CASE(1, 9)
+	SMM_RES_CASE(2, 9)
+	SMM_RES_CASE(1, 16)
+	SMM_RES_CASE(1, 27)
+#undef SMM_RES_CASE
+	return SMM_HIP_ERR_INVALID;
+}
+
+// Tries the register-resident solve.  *handled = false (and nothing written) when the matrix does not fit, the mode is off, or the
+// launch gave up at a barrier; the caller then runs the three-launch loop.
+template <typename T>
+int cgResidentTry(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations, T eps, hipStream_t s, int* status, int* iterations,
+                  T* resnorm2, bool* handled) {
+	*handled = false;
+	const int mode = residentMode();
+	if (mode == SMM_CG_RESIDENT_OFF) return SMM_HIP_OK;
+	// under SMM_CG_RESIDENT_REQUIRE (tests, measurements) "does not apply" is an error instead of a silent fall-back
+	auto notApplicable = [mode](const char* why) {
+		if (mode != SMM_CG_RESIDENT_REQUIRE) return static_cast<int>(SMM_HIP_OK);
+		setError("cg: the register-resident solve was required but %s", why);
+		return static_cast<int>(SMM_HIP_ERR_INVALID);
+	};
+	const int n = a->rows;
+	if (n <= 0 || maxIterations == 0) return SMM_HIP_OK;  // nothing to iterate: the general path handles the corner cases
+	const int cus = numCUs();
+	if (static_cast<long long>(n) > static_cast<long long>(cus) * 4 * RTPB) return notApplicable("the matrix has too many rows");
+	int longest = 0;
+	SMM_TRY(maxRowLen(a, s, &longest));
+	static const int KS[] = {5, 9, 16, 27};
+	static const int RMAX[] = {4, 2, 1, 1};
+	int K = 0, R = 0;
+	for (int i = 0; i < 4 && !K; ++i) {
+		if (longest > KS[i]) continue;
+		// fewest rows per lane that still fit the chip: more workgroups take part
+		for (int r = 1; r <= RMAX[i]; r *= 2) {
+			if (static_cast<long long>(n) <= static_cast<long long>(cus) * r * RTPB) {
+				K = KS[i];
+				R = r;
+				break;
+			}
+		}
+		if (!K) return notApplicable("rows of this length do not fit the register file");  // wider shapes hold fewer rows still
+	}
+	if (!K) return notApplicable("its longest row has more than 27 entries");
+	const int grid = (n + R * RTPB - 1) / (R * RTPB);
+
+	DevBuf<T> pb0, pb1, rg, parts, xOut;
+	DevBuf<ResidentSync> sync;
+	DevBuf<ResidentOut<T>> out;
+	SMM_TRY(pb0.alloc(n));
+	SMM_TRY(pb1.alloc(n));
+	SMM_TRY(rg.alloc(n));
+	SMM_TRY(xOut.alloc(n));
+	SMM_TRY(parts.alloc(2 * static_cast<size_t>(grid)));
+	SMM_TRY(sync.alloc(1));
+	SMM_TRY(out.alloc(1));
+	ResidentArgs<T> args;
+	args.n = n;
+	args.maxIterations = maxIterations == -1 ? n : maxIterations;  // ref:2345-2347
+	args.eps = eps;
+	args.nnzAny = a->nnz > 0 ? 1 : 0;
+	args.start = a->d_start;
+	args.positions = a->d_positions;
+	args.values = static_cast<const T*>(a->d_values);
+	args.b = b;
+	args.x0 = x0;
+	args.x = xOut;
+	args.pb[0] = pb0;
+	args.pb[1] = pb1;
+	args.rg = rg;
+	args.parts = parts;
+	args.sync = sync;
+	args.out = out;
+	args.waitTicks = 1LL << 22;  // a few seconds
+	ResidentOut<T> h;
+	unsigned gaveUp = 0;
+	{
+		std::lock_guard<std::mutex> lock(g_residentMutex);
+		SMM_HIP_TRY(hipMemsetAsync(sync, 0, sizeof(ResidentSync), s));
+		const int st = dispatchResident<T>(R, K, args, grid, s);
+		if (st != SMM_HIP_OK) return notApplicable("the kernel does not fit a CU of this device");
+		SMM_HIP_TRY(hipMemcpyAsync(&h, out, sizeof(h), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipMemcpyAsync(&gaveUp, &sync.p->timeout[0], sizeof(unsigned), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
+	if (h.timedOut || gaveUp) return notApplicable("a grid barrier timed out (is another persistent kernel holding CUs?)");
+	if (h.iters > 0) SMM_HIP_TRY(hipMemcpyAsync(x, xOut.p, static_cast<size_t>(n) * sizeof(T), hipMemcpyDeviceToDevice, s));
+	if (status) *status = h.status;
+	if (iterations) *iterations = h.iters;
+	if (resnorm2) *resnorm2 = h.res;
+	*handled = true;
+	return SMM_HIP_OK;
+}
+
+}  // namespace smm
+
+extern "C" int smm_hip_cg_resident(int mode) {
+	const int before = smm::residentModeRef().load();
+	if (mode >= SMM_CG_RESIDENT_OFF && mode <= SMM_CG_RESIDENT_REQUIRE) smm::residentModeRef().store(mode);
+	return before;
+}
+
+namespace smm {
+
+template int cgResidentTry<float>(const smm_hip_csr*, const float*, const float*, float*, int, float, hipStream_t, int*, int*, float*, bool*);
+template int cgResidentTry<double>(const smm_hip_csr*, const double*, const double*, double*, int, double, hipStream_t, int*, int*, double*, bool*);
+
+}  // namespace smm

@@ -432,6 +432,13 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 		setError("cg: null vector");
 		return SMM_HIP_ERR_INVALID;
 	}
+	if (!pcg) {
+		// a matrix that fits the chip's register file is solved in one launch (smm_resident.hip)
+		bool handled = false;
+		SMM_TRY(ensureCsrReady(a, s, true));
+		SMM_TRY(cgResidentTry<T>(a, b, x0, x, maxIterations, eps, s, status, iterations, resnorm2, &handled));
+		if (handled) return SMM_HIP_OK;
+	}
 	DevBuf<T> r, p, Ap, z, parts, parts2;
 	DevBuf<Scal<T>> sc;
 	SMM_TRY(r.alloc(n));

@@ -304,6 +304,14 @@ def cg_dev(a, d_b, d_x0, d_x, maxIterations, eps, M=None, stream=None):
     return SolverStatus(st.value), it.value, res.value
 
 
+CG_RESIDENT_OFF, CG_RESIDENT_AUTO, CG_RESIDENT_REQUIRE = 0, 1, 2
+
+
+def cg_resident(mode=-1):
+    """sets (0 off, 1 auto, 2 require) or only queries (-1) the register-resident CG path; returns the previous mode"""
+    return int(_lib.load().smm_hip_cg_resident(int(mode)))
+
+
 def bicgstab_dev(a, d_b, d_x, maxIterations, eps, M=None, stream=None):
     """device-pointer BiCGStab; returns (SolverStatus, iterations, resnorm).  Synchronises `stream`."""
     suf = a._suf

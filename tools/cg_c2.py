@@ -13,8 +13,10 @@ host.gen_poisson2d_dev(N, N, ds, dp, dv, np.float64, stream)
 A = smm.CSRMatrix.from_device(n, n, ds, dp, dv, np.float64)
 ones = torch.ones(n, dtype=torch.float64, device=dev); b = torch.empty_like(ones)
 A.spmv_dev(0, None, ones, b, stream)
-for maxit, eps, label in ((-1, 1e-6, "converged tol 1e-6"), (500, 0.0, "fixed 500")):
-    for rep in range(2):
-        x = torch.zeros(n, dtype=torch.float64, device=dev); torch.cuda.synchronize(); t0 = time.perf_counter()
-        st, it, res = host.cg_dev(A, b, x, x, maxit, eps, None, stream); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"CG {label}: status {int(st)} iterations {it} in {dt*1e3:.1f} ms -> {it/dt:.0f} it/s, {dt/it*1e6:.1f} us/it, max|x-1| {float((x-1).abs().max()):.2e}")
+for mode, mname in ((host.CG_RESIDENT_OFF, "three launches per iteration"), (host.CG_RESIDENT_REQUIRE, "register-resident, one launch")):
+    host.cg_resident(mode)
+    for maxit, eps, label in ((-1, 1e-6, "converged tol 1e-6"), (500, 0.0, "fixed 500"), (5000, 0.0, "fixed 5000")):
+        for rep in range(3):
+            x = torch.zeros(n, dtype=torch.float64, device=dev); torch.cuda.synchronize(); t0 = time.perf_counter()
+            st, it, res = host.cg_dev(A, b, x, x, maxit, eps, None, stream); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"CG [{mname}] {label}: status {int(st)} iterations {it} in {dt*1e3:.1f} ms -> {it/dt:.0f} it/s, {dt/it*1e6:.1f} us/it, max|x-1| {float((x-1).abs().max()):.2e}", flush=True)
