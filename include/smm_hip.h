@@ -164,7 +164,7 @@ int smm_hip_cg_dev_f64(const smm_hip_csr* a, const double* d_b, const double* d_
                        const smm_hip_precond* M, smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm2);
 
 /* Register-resident ConjugateGradient (csrc/smm_resident.hip).  An unpreconditioned CG whose matrix fits the register file of the chip
- * (rows <= 1024 * CUs * {4, 2, 1, 1} for rows of at most {5, 9, 16, 27} entries: BASELINE config 2 does) runs as ONE launch with the
+ * (rows <= 512 * CUs * {8, 4, 2, 1} for rows of at most {5, 9, 16, 27} entries: BASELINE config 2 does) runs as ONE launch with the
  * matrix held in registers and two grid-wide barriers per iteration, instead of three launches per iteration that re-read the matrix.
  * Same algorithm, same per-row arithmetic; the global sums add the rows in a different (fixed) partition, so alpha / beta differ from the
  * three-launch loop in the last bits.  mode: SMM_CG_RESIDENT_OFF never, _AUTO when it fits (default; falls back silently otherwise),

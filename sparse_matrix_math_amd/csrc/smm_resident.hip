@@ -3,25 +3,31 @@
 // Why (BASELINE config 2, the 1000 x 1000 Poisson matrix, fp64): the whole problem -- 60 MB of matrix, four 8 MB vectors -- is
 // smaller than the 128 MB of vector registers of an MI355X (256 CUs x 512 KB), yet the three-launch iteration of cgDev
 // (smm_solvers.hip) streams the matrix from the Infinity Cache every iteration: 41 us per iteration, of which ~5 us are kernel
-// boundaries and the rest is moving 150 MB that never change.  Here every lane keeps R whole rows of the matrix (values and
-// positions, padded to K entries) and its rows of x, r and p in registers for the whole solve; one workgroup of 1024 lanes per CU
-// (16 waves x 128 VGPRs = the CU's register file).  Per iteration only p has to cross workgroups (the gathers of A p), and two
-// scalars (p.Ap, r.r) have to be summed over the chip: two grid-wide barriers per iteration, nothing else.
+// boundaries and the rest is moving 150 MB that never change.  Here every lane keeps R whole rows of the matrix (values, padded to K
+// entries) and its rows of r and p in registers for the whole solve; one workgroup of 512 lanes per CU (8 waves x 256 VGPRs = the
+// CU's register file); the positions, x and the workgroup's own slice of p sit in the CU's 160 KB of LDS.  Per iteration only the
+// part of p that ANOTHER workgroup gathers has to cross workgroups, and two scalars (p.Ap, r.r) have to be summed over the chip:
+// two grid-wide barriers per iteration, nothing else.
 //
-//   * p is never exchanged as such: a third barrier would be needed between "beta known" and "p gathered".  Instead every owner
+//   * p is never exchanged as such: a third barrier would be needed between "beta known" and "p gathered".  Instead an owner
 //     publishes r (before the r.r barrier) and its previous p, and a consumer forms p_new[c] = beta p_old[c] + r[c] itself for
-//     every column it gathers -- the same expression on the same operands as the owner's own update, hence the same bits.
+//     every foreign column it gathers -- the same expression on the same operands as the owner's own update, hence the same bits.
+//     Columns of the workgroup's own chunk are read from LDS; a wave none of whose lanes needs a foreign column for an entry
+//     skips that entry's two loads (on a banded matrix nine waves in ten do); only rows that some other workgroup gathers
+//     (found once, at set-up: `needed`) are published at all.
 //   * barriers are XCD-hierarchical (MI355X_MICROARCH.md, barrier-xcd): workgroups arrive on a counter of their XCD, the last
 //     arriver of an XCD writes that L2's dirty lines back (one agent-scope release per XCD), arrives on the top counter, waits
 //     for the 8 leaders and opens a generation word for its XCD; every workgroup then acquires at agent scope.  Every wait is
 //     bounded (poll count): a timed-out solve reports it and the caller falls back to the three-launch loop; the kernel
 //     writes x into a scratch vector that is copied out only after a clean run.
 //   * the partial sums of a reduction are one slot per workgroup, added by every workgroup in the same fixed order (lane t takes
-//     slot t, wave butterflies, 16 wave sums left to right): all workgroups get the same bits and leave the loop together.
+//     slot t, wave butterflies, 8 wave sums left to right): all workgroups get the same bits and leave the loop together.
 //   * a row's dot product is formed left to right with _smm_fma exactly like the one-lane-per-row SpMV (smm_spmv.hip), so A p is
 //     bit-identical to the library's SpMV; the global sums use a different partition of the rows than cgDev's, so alpha / beta
-//     differ from cgDev's in the last bits (tests/test_gpu_resident.py bounds the difference; same tolerance as cgDev vs the
-//     oracle).
+//     differ from cgDev's in the last bits (tests/test_gpu_resident.py: <= 1e-5 relative in fp32, <= 2e-14 in fp64, the same
+//     iteration counts).
+//
+// Measured on config 2 (tools/cg_c2.py, profiles/r02/cg_config2.txt): see DESIGN.md section 3.4.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -31,7 +37,7 @@
 
 namespace smm {
 
-constexpr int RTPB = 1024;     // lanes per workgroup: one workgroup per CU
+constexpr int RTPB = 512;      // lanes per workgroup: one workgroup per CU, 2 waves per SIMD, up to 256 VGPRs per lane
 constexpr int RWAVES = RTPB / WAVE;
 constexpr int MAX_XCD = 8;
 
@@ -68,8 +74,12 @@ struct ResidentArgs {
 	T* pb[2];   // p of the previous iteration, double-buffered by iteration parity
 	T* rg;      // r of this iteration
 	T* parts;   // [2][gridDim.x] partial sums: p.Ap, r.r
+	int* needed;  // [n], zeroed: needed[c] != 0 when a workgroup other than c's owner gathers column c
 	ResidentSync* sync;
 	ResidentOut<T>* out;
+#ifdef SMM_RESIDENT_LAB
+	int lab;  // measurement builds only (tools/run_resident_lab.sh): 1 no gathers, 2 no barrier waits, 4 no published stores, 8 no global sums
+#endif
 	long long waitTicks;  // bound of one wait, in polls (a poll is a load + s_sleep, ~0.5-1 us; polls do not advance while the queue is switched out)
 };
 
@@ -99,7 +109,16 @@ struct BarrierState {
 
 // Grid-wide barrier.  Called by all RTPB lanes of every workgroup.  Everything a workgroup stored before the call is visible to plain
 // loads of every workgroup after it.  Returns false (in all lanes) when a wait timed out.
+// RELEASE: the workgroups stored with plain stores (the XCD's last arriver writes the L2 back); false when everything that has to be
+// seen was stored write-through (agent-scope atomic stores), which needs no write-back.
+template <bool RELEASE>
 __device__ __forceinline__ bool gridBarrier(ResidentSync* sy, BarrierState& st, int* sOk, long long waitTicks) {
+#ifdef SMM_RESIDENT_LAB
+	if (waitTicks < 0) {  // lab: no grid-wide wait at all (wrong results; what do the barriers cost?)
+		__syncthreads();
+		return true;
+	}
+#endif
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
 	__syncthreads();
 	if (threadIdx.x == 0) {
@@ -108,8 +127,10 @@ __device__ __forceinline__ bool gridBarrier(ResidentSync* sy, BarrierState& st, 
 		const unsigned before = __hip_atomic_fetch_add(&sy->arrive[st.xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (before + 1 == st.pop * e) {
 			// last workgroup of this XCD: one write-back of the XCD's L2 publishes the stores of all its workgroups
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (RELEASE) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
 			__hip_atomic_fetch_add(&sy->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			ok = waitAtLeast(&sy->top[0], st.nx * e, &sy->timeout[0], waitTicks);
 			__hip_atomic_store(&sy->gen[st.xcc][0], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -123,6 +144,20 @@ __device__ __forceinline__ bool gridBarrier(ResidentSync* sy, BarrierState& st, 
 	__syncthreads();
 	st.epoch += 1;
 	return *sOk != 0;
+}
+
+// How the rows other workgroups gather are stored inside the loop.  Write-through (agent-scope atomic store = global_store ... sc1): the
+// bytes leave for the memory side at once and the barrier needs no L2 write-back; plain: they stay dirty in the L2 until the XCD's last
+// arriver writes the L2 back.  Measured on config 2 (profiles/r02/resident_lab.txt): SMM_RESIDENT_PLAIN_PUBLISH builds are the plain form.
+#ifdef SMM_RESIDENT_PLAIN_PUBLISH
+constexpr bool PLAIN_PUBLISH = true;
+#else
+constexpr bool PLAIN_PUBLISH = false;
+#endif
+template <typename T>
+__device__ __forceinline__ void publish(T* p, T v) {
+	if (PLAIN_PUBLISH) *p = v;
+	else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // sum over the workgroup, the same value in every lane.  Order: butterfly inside each wave, then the 16 wave sums left to right.
@@ -151,17 +186,28 @@ __device__ __forceinline__ T sumSlots(const T* slots, T* lds) {
 	return blockSumAll(v, lds);
 }
 
+#ifdef SMM_RESIDENT_LAB  // measurement builds (tools/run_resident_lab.sh): parts of an iteration can be switched off
+#define PUBLISH(j) (((pubMask >> (j)) & 1u) != 0 && !(a.lab & 4))
+#define GATHERS (!(a.lab & 1))
+#else
+#define PUBLISH(j) (((pubMask >> (j)) & 1u) != 0)
+#define GATHERS true
+#endif
+
 template <typename T, int R, int K>
 __global__ __launch_bounds__(RTPB) void cgResidentKernel(ResidentArgs<T> a) {
 	__shared__ T sRed[RWAVES + 1];
 	__shared__ int sOk;
 	__shared__ unsigned sCensus[2];
-	// positions and row lengths live in LDS, lane-interleaved (entry e of lane t at [e * RTPB + t]: conflict-free): together with the
-	// values they would not fit 128 registers per lane
+	// Positions, row lengths, x and p of the workgroup's rows live in LDS, lane-interleaved (entry e of lane t at [e * RTPB + t]:
+	// conflict-free); together with the values they would not fit the registers of a lane.  A position is stored ENCODED: a column
+	// inside this workgroup's chunk as its index in the chunk (>= 0: its p is read from sP), any other column c as -(c + 1) (its p is
+	// formed from the published vectors).
 	extern __shared__ int sDyn[];
-	int* const sCol = sDyn;                 // [R * K][RTPB]
-	int* const sLen = sDyn + R * K * RTPB;  // [R][RTPB]
-	T* const sX = reinterpret_cast<T*>(sDyn + R * (K + 1) * RTPB);  // [R][RTPB]: x is only ever updated in place
+	int* const sCol = sDyn;                                                     // [R * K][RTPB]
+	T* const sX = reinterpret_cast<T*>(sDyn + R * K * RTPB);                    // [R][RTPB]: x is only ever updated in place
+	T* const sP = sX + R * RTPB;                                                // [R][RTPB] = p of rows chunk0 .. chunk0 + R * RTPB
+	unsigned char* const sLen = reinterpret_cast<unsigned char*>(sP + R * RTPB);  // [R][RTPB]
 	ResidentSync* const sy = a.sync;
 	const int n = a.n;
 	const int tid = threadIdx.x;
@@ -187,7 +233,7 @@ __global__ __launch_bounds__(RTPB) void cgResidentKernel(ResidentArgs<T> a) {
 			b0 = a.start[row];
 			l = a.start[row + 1] - b0;
 		}
-		sLen[j * RTPB + tid] = l;
+		sLen[j * RTPB + tid] = static_cast<unsigned char>(l);
 		// r = b - A x0 (ref:2337), x = x0, p starts at 0 (beta = 0 makes the first "p = beta p + r" a copy, ref:2340)
 		T dot = T(0);
 #pragma unroll
@@ -197,7 +243,10 @@ __global__ __launch_bounds__(RTPB) void cgResidentKernel(ResidentArgs<T> a) {
 			const T v = a.nnzAny ? a.values[e] : T(0);
 			const int c = a.nnzAny ? a.positions[e] : 0;
 			val[j][k] = on ? v : T(0);
-			sCol[(j * K + k) * RTPB + tid] = on ? c : 0;
+			const unsigned local = static_cast<unsigned>(c - chunk0);
+			const bool mine = !on || local < static_cast<unsigned>(R * RTPB);
+			sCol[(j * K + k) * RTPB + tid] = on ? (mine ? static_cast<int>(local) : -(c + 1)) : 0;
+			if (!mine) a.needed[c] = 1;  // that row's owner must publish it (several lanes may store the same 1)
 			const T next = smmFma(v, a.x0[on ? c : 0], dot);
 			dot = on ? next : dot;
 		}
@@ -234,7 +283,15 @@ __global__ __launch_bounds__(RTPB) void cgResidentKernel(ResidentArgs<T> a) {
 	st.pop = sCensus[0];
 	st.nx = sCensus[1];
 	bool alive = st.pop != 0;
-	if (alive) alive = gridBarrier(sy, st, &sOk, a.waitTicks);
+	if (alive) alive = gridBarrier<true>(sy, st, &sOk, a.waitTicks);
+	// which of my rows does another workgroup gather?  Only those are published from now on.
+	unsigned pubMask = 0;
+#pragma unroll
+	for (int j = 0; j < R; ++j) {
+		const int row = chunk0 + j * RTPB + tid;
+		if (row < n && a.needed[row] != 0) pubMask |= 1u << j;
+	}
+	const int safeRow = min(chunk0 + tid, n - 1);  // where a lane that needs no published value points its (discarded) load
 
 	int iters = 0;
 	int status = SMM_SOLVER_MAX_ITERATIONS_REACHED;
@@ -251,28 +308,60 @@ __global__ __launch_bounds__(RTPB) void cgResidentKernel(ResidentArgs<T> a) {
 				const T* const pOld = a.pb[it & 1];
 				T* const pNew = a.pb[(it & 1) ^ 1];
 				const T* const rg = a.rg;
-				// p = beta p + r (ref:2391-2393), kept and published for the gathers of the NEXT iteration
+				// p = beta p + r (ref:2391-2393): kept in registers, shared with the workgroup through LDS, and -- the rows another
+				// workgroup gathers -- published for the gathers of the NEXT iteration
+				// (the row index is laundered through an empty asm in every phase: otherwise the compiler keeps the 64-bit addresses of
+				// all R rows in all three published vectors alive across the whole loop, ~6 registers per row that the values need)
+				int base = chunk0 + tid;
+				asm volatile("" : "+v"(base));
 #pragma unroll
 				for (int j = 0; j < R; ++j) {
-					const int row = chunk0 + j * RTPB + tid;
+					const int row = base + j * RTPB;
 					pr[j] = smmFma(beta, pr[j], rr[j]);
-					if (row < n) pNew[row] = pr[j];
+					sP[j * RTPB + tid] = pr[j];
+					if (row < n && PUBLISH(j)) publish(pNew + row, pr[j]);
 				}
-				// Ap = A p (ref:2353) with p[c] = beta pOld[c] + r[c] formed on the fly; p.Ap (ref:2354)
+				__syncthreads();
+				// Ap = A p (ref:2353); p.Ap (ref:2354).  p of a column of this chunk comes from LDS; of any other column it is formed on
+				// the fly as beta pOld[c] + r[c] -- the owner's expression on the owner's operands.  A wave in which no lane needs a
+				// published value for entry k skips those two loads altogether (most waves of a banded matrix do).
 				T ap[R];
 				acc = T(0);
 #pragma unroll
 				for (int j = 0; j < R; ++j) {
 					T dot = T(0);
 					const int l = sLen[j * RTPB + tid];
+					// G entries of the row at a time: their (at most 2 G) gathers are in flight together
+					constexpr int G = sizeof(T) == 8 ? 3 : 9;  // (8 rows x 5 doubles per lane leave room for 3)
 #pragma unroll
-					for (int k = 0; k < K; ++k) {
-						// loads are unconditional (a padded entry gathers column 0) so that a row's gathers are in flight together;
-						// the padded entries are dropped by a select, not by a multiplication with 0 (0 x inf, -0 + 0)
-						const int c = sCol[(j * K + k) * RTPB + tid];
-						const T pc = smmFma(beta, pOld[c], rg[c]);
-						const T next = smmFma(val[j][k], pc, dot);
-						dot = k < l ? next : dot;
+					for (int k0 = 0; k0 < K; k0 += G) {
+						int enc[G];
+						T po[G], rv[G];
+#pragma unroll
+						for (int g = 0; g < G; ++g) {
+							if (k0 + g < K) {
+								enc[g] = sCol[(j * K + k0 + g) * RTPB + tid];
+								const bool need = enc[g] < 0 && GATHERS;
+								po[g] = T(0);
+								rv[g] = T(0);
+								if (__builtin_amdgcn_ballot_w64(need) != 0) {
+									// unconditional inside (a lane that does not need the value reads its own row and drops it)
+									const int cg = need ? -enc[g] - 1 : safeRow;
+									po[g] = pOld[cg];
+									rv[g] = rg[cg];
+								}
+							}
+						}
+#pragma unroll
+						for (int g = 0; g < G; ++g) {
+							if (k0 + g < K) {
+								const bool inside = enc[g] >= 0;
+								const T mine = sP[inside ? enc[g] : 0];
+								const T pc = inside ? mine : smmFma(beta, po[g], rv[g]);
+								const T next = smmFma(val[j][k0 + g], pc, dot);
+								dot = k0 + g < l ? next : dot;  // padded entries are dropped by a select, not by a multiplication with 0
+							}
+						}
 					}
 					ap[j] = dot;
 					acc += pr[j] * dot;
@@ -280,28 +369,38 @@ __global__ __launch_bounds__(RTPB) void cgResidentKernel(ResidentArgs<T> a) {
 				}
 				s = blockSumAll(acc, sRed);
 				if (tid == 0) __hip_atomic_store(partsA + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (!gridBarrier(sy, st, &sOk, a.waitTicks)) {
+				if (!gridBarrier<PLAIN_PUBLISH>(sy, st, &sOk, a.waitTicks)) {
 					alive = false;
 					break;
 				}
+#ifdef SMM_RESIDENT_LAB
+				const T alpha = rrOld / ((a.lab & 8) ? T(1) : sumSlots(partsA, sRed));
+#else
 				const T alpha = rrOld / sumSlots(partsA, sRed);  // ref:2358
+#endif
 				// x = alpha p + x ; r = -alpha Ap + r ; r.r (ref:2371-2375)
 				acc = T(0);
+				base = chunk0 + tid;
+				asm volatile("" : "+v"(base));
 #pragma unroll
 				for (int j = 0; j < R; ++j) {
-					const int row = chunk0 + j * RTPB + tid;
+					const int row = base + j * RTPB;
 					sX[j * RTPB + tid] = smmFma(alpha, pr[j], sX[j * RTPB + tid]);
 					rr[j] = smmFma(-alpha, ap[j], rr[j]);
-					if (row < n) a.rg[row] = rr[j];
+					if (row < n && PUBLISH(j)) publish(a.rg + row, rr[j]);
 					acc += rr[j] * rr[j];
 				}
 				s = blockSumAll(acc, sRed);
 				if (tid == 0) __hip_atomic_store(partsC + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (!gridBarrier(sy, st, &sOk, a.waitTicks)) {
+				if (!gridBarrier<PLAIN_PUBLISH>(sy, st, &sOk, a.waitTicks)) {
 					alive = false;
 					break;
 				}
+#ifdef SMM_RESIDENT_LAB
+				const T rrNew = (a.lab & 8) ? T(1) : sumSlots(partsC, sRed);
+#else
 				const T rrNew = sumSlots(partsC, sRed);
+#endif
 				iters = it + 1;
 				res = rrNew;
 				if (eps2 > rrNew) {  // ref:2377-2380
@@ -372,7 +471,7 @@ static int residentMode() { return residentModeRef().load(); }
 static std::mutex g_residentMutex;  // two grid-barrier kernels must never share the chip: each would wait for CUs the other holds
 
 template <typename T>
-static size_t residentLds(int R, int K) { return static_cast<size_t>(R) * RTPB * ((K + 1) * sizeof(int) + sizeof(T)); }
+static size_t residentLds(int R, int K) { return static_cast<size_t>(R) * RTPB * (K * sizeof(int) + 2 * sizeof(T) + 1); }
 
 template <typename T, int R, int K>
 static int launchResident(const ResidentArgs<T>& args, int grid, hipStream_t s) {
@@ -398,10 +497,16 @@ static int dispatchResident(int R, int K, const ResidentArgs<T>& args, int grid,
 	SMM_RES_CASE(1, 5)
 	SMM_RES_CASE(2, 5)
 	SMM_RES_CASE(4, 5)
+	SMM_RES_CASE(8, 5)
 	SMM_RES_CASE(1, 9)
 	SMM_RES_CASE(2, 9)
+	SMM_RES_CASE(4, 9)
 	SMM_RES_CASE(1, 16)
+	SMM_RES_CASE(2, 16)
 	SMM_RES_CASE(1, 27)
+	if constexpr (sizeof(T) == 4) {
+		SMM_RES_CASE(2, 27)
+	}
 #undef SMM_RES_CASE
 	return SMM_HIP_ERR_INVALID;
 }
@@ -423,11 +528,11 @@ int cgResidentTry(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIt
 	const int n = a->rows;
 	if (n <= 0 || maxIterations == 0) return SMM_HIP_OK;  // nothing to iterate: the general path handles the corner cases
 	const int cus = numCUs();
-	if (static_cast<long long>(n) > static_cast<long long>(cus) * 4 * RTPB) return notApplicable("the matrix has too many rows");
+	if (static_cast<long long>(n) > static_cast<long long>(cus) * 8 * RTPB) return notApplicable("the matrix has too many rows");
 	int longest = 0;
 	SMM_TRY(maxRowLen(a, s, &longest));
 	static const int KS[] = {5, 9, 16, 27};
-	static const int RMAX[] = {4, 2, 1, 1};
+	const int RMAX[] = {8, 4, 2, sizeof(T) == 4 ? 2 : 1};
 	int K = 0, R = 0;
 	for (int i = 0; i < 4 && !K; ++i) {
 		if (longest > KS[i]) continue;
@@ -446,6 +551,8 @@ int cgResidentTry(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIt
 
 	DevBuf<T> pb0, pb1, rg, parts, xOut;
 	DevBuf<ResidentSync> sync;
+	DevBuf<int> needed;
+	SMM_TRY(needed.alloc(n));
 	DevBuf<ResidentOut<T>> out;
 	SMM_TRY(pb0.alloc(n));
 	SMM_TRY(pb1.alloc(n));
@@ -470,13 +577,19 @@ int cgResidentTry(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIt
 	args.rg = rg;
 	args.parts = parts;
 	args.sync = sync;
+	args.needed = needed;
 	args.out = out;
 	args.waitTicks = 1LL << 22;  // a few seconds
+#ifdef SMM_RESIDENT_LAB
+	args.lab = getenv("SMM_RESIDENT_LAB") ? atoi(getenv("SMM_RESIDENT_LAB")) : 0;
+	if (args.lab & 2) args.waitTicks = -1;
+#endif
 	ResidentOut<T> h;
 	unsigned gaveUp = 0;
 	{
 		std::lock_guard<std::mutex> lock(g_residentMutex);
 		SMM_HIP_TRY(hipMemsetAsync(sync, 0, sizeof(ResidentSync), s));
+		SMM_HIP_TRY(hipMemsetAsync(needed, 0, static_cast<size_t>(n) * sizeof(int), s));
 		const int st = dispatchResident<T>(R, K, args, grid, s);
 		if (st != SMM_HIP_OK) return notApplicable("the kernel does not fit a CU of this device");
 		SMM_HIP_TRY(hipMemcpyAsync(&h, out, sizeof(h), hipMemcpyDeviceToHost, s));

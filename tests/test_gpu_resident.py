@@ -42,16 +42,21 @@ def random_spd(n, per_row, seed, dtype):
 
 def cases(dtype):
     out = {
-        "poisson2d_300 (1 row/lane, 5)": gen.poisson2d(300, dtype=dtype),
-        "poisson2d_600x700 (2 rows/lane, 5)": gen.poisson2d(600, 700, dtype=dtype),
-        "poisson2d_777 (4 rows/lane, 5)": gen.poisson2d(777, dtype=dtype),
-        "poisson3d_40 (1 row/lane, 9)": gen.poisson3d(40, dtype=dtype),
-        "poisson3d_70 (2 rows/lane, 9)": gen.poisson3d(70, dtype=dtype),
+        # (rows per lane, entries per row) on 256 CUs x 512 lanes
+        "poisson2d_300 (1, 5)": gen.poisson2d(300, dtype=dtype),
+        "poisson2d_450 (2, 5)": gen.poisson2d(450, dtype=dtype),
+        "poisson2d_600x700 (4, 5)": gen.poisson2d(600, 700, dtype=dtype),
+        "poisson2d_777 (8, 5)": gen.poisson2d(777, dtype=dtype),
+        "poisson3d_40 (1, 9)": gen.poisson3d(40, dtype=dtype),
+        "poisson3d_60 (2, 9)": gen.poisson3d(60, dtype=dtype),
+        "poisson3d_70 (4, 9)": gen.poisson3d(70, dtype=dtype),
         "ragged_spd_16": random_spd(20000, 4, 3, dtype),
+        "ragged_spd_16 (2, 16)": random_spd(200000, 3, 3, dtype),
         "ragged_spd_27": random_spd(9000, 10, 5, dtype),
         "tiny_3": (np.array([0, 2, 5, 7], dtype=np.int32), np.array([0, 1, 0, 1, 2, 1, 2], dtype=np.int32),
                    np.array([4, -1, -1, 4, -1, -1, 4], dtype=dtype)),
     }
+    assert 9 < np.diff(out["ragged_spd_16 (2, 16)"][0]).max() <= 16
     lens16 = np.diff(out["ragged_spd_16"][0]).max()
     lens27 = np.diff(out["ragged_spd_27"][0]).max()
     assert 9 < lens16 <= 16 and 16 < lens27 <= 27, (lens16, lens27)
@@ -174,7 +179,7 @@ def test_fallback_when_the_matrix_does_not_fit(smm, oracle, modes):
 
 
 def test_config2_runs_resident(smm, modes):
-    """BASELINE config 2 (1000 x 1000 Poisson, fp64) fits: 4 rows per lane on 245 of the 256 CUs"""
+    """BASELINE config 2 (1000 x 1000 Poisson, fp64) fits: 8 rows per lane on 245 of the 256 CUs"""
     host.cg_resident(host.CG_RESIDENT_REQUIRE)
     csr = gen.poisson2d(1000, dtype=np.float64)
     n = 1000 * 1000

@@ -13,7 +13,9 @@ host.gen_poisson2d_dev(N, N, ds, dp, dv, np.float64, stream)
 A = smm.CSRMatrix.from_device(n, n, ds, dp, dv, np.float64)
 ones = torch.ones(n, dtype=torch.float64, device=dev); b = torch.empty_like(ones)
 A.spmv_dev(0, None, ones, b, stream)
-for mode, mname in ((host.CG_RESIDENT_OFF, "three launches per iteration"), (host.CG_RESIDENT_REQUIRE, "register-resident, one launch")):
+MODES = ((host.CG_RESIDENT_OFF, "three launches per iteration"), (host.CG_RESIDENT_REQUIRE, "register-resident, one launch"))
+if "resident" in sys.argv[1:]: MODES = MODES[1:]
+for mode, mname in MODES:
     host.cg_resident(mode)
     for maxit, eps, label in ((-1, 1e-6, "converged tol 1e-6"), (500, 0.0, "fixed 500"), (5000, 0.0, "fixed 5000")):
         for rep in range(3):
