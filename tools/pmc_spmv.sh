@@ -14,9 +14,12 @@ PASSES=(
  "write:WRITE_SIZE"
  "tcp:TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
  "ta:TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"
+ "ea:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
 )
+# PMC_ONLY="tcc ea": run only these passes
 for P in "${PASSES[@]}"; do
   NAME=${P%%:*}; CTR=${P#*:}
+  if [ -n "${PMC_ONLY:-}" ] && ! echo " $PMC_ONLY " | grep -q " $NAME "; then continue; fi
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $CTR -d $OUT/$NAME --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/spmv_sweep.py "$@" > $OUT/$NAME.log 2>&1
   echo "pass $NAME exit $?"
 done

@@ -68,7 +68,7 @@ def main():
         d_pos.copy_(rows_of)
         del rows_of, lens
     A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, npd)
-    x = torch.rand(n, dtype=td, device=dev)
+    x = torch.rand(n, dtype=td, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
     y = torch.empty(n, dtype=td, device=dev)
     bytes_ = nnz * (s + 4) + (n + 1) * 4 + 2 * n * s
     print(f"matrix {args.matrix} rows {n} nnz {nnz} ({nnz / n:.1f}/row) {args.dtype}: B_spmv = {bytes_ / 1e9:.3f} GB; default kernel {A.get_kernel()}")
@@ -85,7 +85,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
-        print(f"family {fam} lanes {lanes:2d}: {ms:8.4f} ms  {bytes_ / ms / 1e6:8.1f} GB/s  {100 * bytes_ / ms / 1e6 / 8000:5.1f} % of 8 TB/s", flush=True)
+        # a checksum of y: the same bits whatever order the tiles are walked in (A/B runs of tile orders compare these)
+        chk = int(torch.sum(y.view(torch.int32 if args.dtype == "f32" else torch.int64).to(torch.int64) & 0xFFFFFF).item())
+        print(f"family {fam} lanes {lanes:2d}: {ms:8.4f} ms  {bytes_ / ms / 1e6:8.1f} GB/s  {100 * bytes_ / ms / 1e6 / 8000:5.1f} % of 8 TB/s  y-checksum {chk}", flush=True)
 
 
 if __name__ == "__main__":
