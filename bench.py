@@ -258,6 +258,39 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
     except Exception as e:  # noqa: BLE001
         out["spmv_laplacian512_f64"] = {"skipped": str(e)[:200]}
     torch.cuda.empty_cache()
+    # (c) BASELINE config 2: CG on the 1000 x 1000 Poisson matrix, fp64, tol 1e-6 -- the register-resident solve (one launch,
+    # csrc/smm_resident.hip) and the three-launch loop, wall time of the whole call
+    before = host.cg_resident(-1)
+    try:
+        N = 1000
+        n, nnz = N * N, host.gen_poisson2d_nnz(N, N)
+        d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+        d_val = torch.empty(nnz, dtype=torch.float64, device=dev)
+        host.gen_poisson2d_dev(N, N, d_start, d_pos, d_val, np.float64, stream)
+        A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np.float64)
+        ones = torch.ones(n, dtype=torch.float64, device=dev)
+        b = torch.empty_like(ones)
+        A.spmv_dev(0, None, ones, b, stream)
+        leg = {"rows": n, "nnz": nnz, "dtype": "f64", "tol": 1e-6}
+        for mode, name in ((host.CG_RESIDENT_AUTO, "auto"), (host.CG_RESIDENT_OFF, "three_launch_loop")):
+            host.cg_resident(mode)
+            for _ in range(2):
+                x = torch.zeros(n, dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st, it, _res = host.cg_dev(A, b, x, x, -1, 1e-6, None, stream)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            leg[name] = {"status": int(st), "iterations": it, "ms": dt * 1e3, "us_per_iteration": dt / max(it, 1) * 1e6,
+                         "max_abs_err_vs_ones": float((x - 1).abs().max())}
+        out["cg_poisson1000_f64"] = leg
+        A.close()
+        del A, d_start, d_pos, d_val
+    except Exception as e:  # noqa: BLE001
+        out["cg_poisson1000_f64"] = {"skipped": str(e)[:200]}
+    host.cg_resident(before)
+    torch.cuda.empty_cache()
     return out
 
 
