@@ -157,13 +157,27 @@ def load(fma=False):
         )
     _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(path)
+    older_build = bool(os.environ.get("SMM_HIP_LIBRARY"))  # A/B measurements against an earlier build: entry points it lacks are skipped
+
+    def symbol(name):
+        try:
+            return getattr(lib, name)
+        except AttributeError:
+            if older_build:
+                return None
+            raise
+
     for name, (res, args) in _PLAIN.items():
-        fn = getattr(lib, name)
+        fn = symbol(name)
+        if fn is None:
+            continue
         fn.restype = res
         fn.argtypes = args
     for base, (res, args) in _TYPED.items():
         for suf, ct in (("f32", c_float), ("f64", c_double)):
-            fn = getattr(lib, f"{base}_{suf}")
+            fn = symbol(f"{base}_{suf}")
+            if fn is None:
+                continue
             fn.restype = res
             apply_t = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(ct), POINTER(ct))
             fn.argtypes = [ct if a == "T" else POINTER(ct) if a == "PT" else apply_t if a == "APPLY" else a for a in args]

@@ -9,12 +9,15 @@
 // Runs of small levels are executed by a single 1024-lane workgroup with a workgroup barrier between levels
 // (no launch per level); a large level gets a multi-workgroup launch of its own.
 //
-// Factorisation (ILU0 / IC0) is setup work and runs on the host at create time; only the values it produces
-// live on the device.
+// Set-up (structural checks, the level sets, the ILU0 / IC0 factorisation) runs on the device as well, at create time: the level sets
+// by a synchronisation-free propagation kernel, the factorisation level by level with one wavefront per row.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <memory>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "smm_device.h"
 #include "smm_internal.h"
@@ -347,134 +350,236 @@ __global__ __launch_bounds__(TPB) void extractDiagKernel(int rows, const int* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// host-side analysis
+// Set-up on the device: structural checks, level sets of both sweeps, ILU(0) / IC(0) factorisation.  Nothing of the matrix is
+// copied to the host; what comes back are a few words (error flags, the number of levels, the longest row) and the level pointers.
 // ---------------------------------------------------------------------------------------------------------
-struct HostCsr {
-	int rows = 0;
-	std::vector<int> start, positions;
-};
-
-// level sets of the strictly-lower (lower=true) or strictly-upper part of the pattern
-static void buildLevels(const HostCsr& h, bool lower, std::vector<int>& order, std::vector<int>& lvlPtr) {
-	const int n = h.rows;
-	std::vector<int> level(static_cast<size_t>(n), 0);
-	int maxLevel = -1;
-	if (lower) {
-		for (int i = 0; i < n; ++i) {
-			int lv = 0;
-			for (int k = h.start[i]; k < h.start[i + 1] && h.positions[k] < i; ++k) {
-				lv = std::max(lv, level[h.positions[k]] + 1);
-			}
-			level[i] = lv;
-			maxLevel = std::max(maxLevel, lv);
-		}
-	} else {
-		for (int i = n - 1; i >= 0; --i) {
-			int lv = 0;
-			for (int k = h.start[i + 1] - 1; k >= h.start[i] && h.positions[k] > i; --k) {
-				lv = std::max(lv, level[h.positions[k]] + 1);
-			}
-			level[i] = lv;
-			maxLevel = std::max(maxLevel, lv);
-		}
-	}
-	lvlPtr.assign(static_cast<size_t>(maxLevel + 2), 0);
-	for (int i = 0; i < n; ++i) lvlPtr[level[i] + 1]++;
-	for (int l = 0; l <= maxLevel; ++l) lvlPtr[l + 1] += lvlPtr[l];
-	order.resize(static_cast<size_t>(n));
-	std::vector<int> cursor(lvlPtr.begin(), lvlPtr.end() - 1);
-	for (int i = 0; i < n; ++i) order[cursor[level[i]]++] = i;
-}
-
-// every row non-empty, diagonal stored; with checkMagnitude also |d| >= 1e-5 (ref:1666-1693)
+// every row non-empty with its diagonal stored; with checkMagnitude also |d| >= 1e-5 (ref:1666-1693).  info[0] |= 1 on a violation,
+// info[1] = longest row
 template <typename T>
-static bool diagonalOk(const HostCsr& h, const std::vector<T>& vals, bool checkMagnitude) {
-	for (int i = 0; i < h.rows; ++i) {
+__global__ __launch_bounds__(TPB) void rowCheckKernel(int n, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
+                                                      int checkMagnitude, int* info) {
+	int longest = 0;
+	bool bad = false;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		const int b = start[i], e = start[i + 1];
+		longest = max(longest, e - b);
 		bool found = false;
-		for (int k = h.start[i]; k < h.start[i + 1]; ++k) {
-			if (h.positions[k] == i) {
-				found = !checkMagnitude || std::fabs(vals[k]) >= T(1e-5);
+		for (int k = b; k < e; ++k) {
+			if (positions[k] == i) {
+				const T v = vals[k];
+				found = !checkMagnitude || (v < T(0) ? -v : v) >= T(1e-5);
 				break;
 			}
 		}
-		if (!found) return false;
+		bad = bad || !found;
 	}
-	return true;
+#pragma unroll
+	for (int o = WAVE / 2; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o, WAVE));
+	if ((threadIdx.x & (WAVE - 1)) == 0 && longest > 0) atomicMax(info + 1, longest);
+	if (bad) atomicOr(info, 1);
 }
 
-// ILU(0), IKJ ordering on A's pattern (Saad, Iterative Methods for Sparse Linear Systems, Alg. 10.4): unit-lower L
-// and U share one value array.  l_ik = a_ik * (1/u_kk) as ref:1767 intends.  false on a missing / tiny pivot.
-template <typename T>
-static bool factorIlu0(const HostCsr& h, std::vector<T>& lu) {
-	const int n = h.rows;
-	std::vector<int> where(static_cast<size_t>(n), -1);
-	std::vector<T> pivotInv(static_cast<size_t>(n));
-	for (int i = 0; i < n; ++i) {
-		const int rb = h.start[i], re = h.start[i + 1];
-		for (int q = rb; q < re; ++q) where[h.positions[q]] = q;
-		int q = rb;
-		for (; q < re && h.positions[q] < i; ++q) {
-			const int k = h.positions[q];
-			const T lik = lu[q] * pivotInv[k];
-			lu[q] = lik;
-			for (int u = h.start[k + 1] - 1; u >= h.start[k] && h.positions[u] > k; --u) {
-				const int target = where[h.positions[u]];
-				if (target != -1) lu[target] -= lik * lu[u];
+// Level sets of the strictly-lower (LOWER) or strictly-upper part of the pattern: level[i] = 1 + the largest level among the rows that
+// row i reads (0 if it reads none) -- the longest path to i in the dependency DAG.  One launch: rows are taken in the natural order
+// (descending for the upper part) from a ticket counter, a lane walks its row's triangular entries and, where the level of a column is
+// not known yet (-1), stops and polls again on the next pass of the wave-wide loop; a finished row publishes its level with one store
+// that is value and ready flag at once -- the scheme of the synchronisation-free sweeps below, with the same freedom from deadlock
+// (a row reads only rows that drew earlier tickets; nobody waits inside a pass).  words: [0] ticket, [2] error.
+template <bool LOWER>
+__global__ __launch_bounds__(TPB) void levelFreeKernel(int n, const int* __restrict__ start, const int* __restrict__ positions, int* level, int* words,
+                                                       unsigned passLimit) {
+	const int lane = threadIdx.x & (WAVE - 1);
+	constexpr int DIR = LOWER ? 1 : -1;
+	for (;;) {
+		int chunk = 0;
+		if (lane == 0) chunk = atomicAdd(words, 1);
+		chunk = __builtin_amdgcn_readfirstlane(chunk);
+		const long long base = static_cast<long long>(chunk) * WAVE;
+		if (base >= n) return;
+		bool pending = base + lane < n;
+		int row = 0, k = 0, stop = 0, lv = 0;
+		if (pending) {
+			row = LOWER ? static_cast<int>(base + lane) : n - 1 - static_cast<int>(base + lane);
+			k = LOWER ? start[row] : start[row + 1] - 1;
+			stop = LOWER ? start[row + 1] : start[row] - 1;
+		}
+		unsigned passes = 0;
+		while (__ballot(pending) != 0ull) {
+			if (pending) {
+				// one entry per pass (the shape of the sweeps' loop: nobody waits, or loops, inside a pass)
+				const bool inside = LOWER ? k < stop : k > stop;
+				const int col = inside ? positions[k] : row;
+				if (!(inside && (LOWER ? col < row : col > row))) {  // end of the triangular part (ref:1673-1694 stop at the diagonal too)
+					__hip_atomic_store(level + row, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					pending = false;
+				} else {
+					const int d = __hip_atomic_load(level + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (d >= 0) {  // known: take it and move on; otherwise poll again on the next pass
+						lv = max(lv, d + 1);
+						k += DIR;
+					}
+				}
+			}
+			if (++passes > passLimit && pending) {  // cannot happen; guarantees that the grid drains
+				atomicOr(words + 2, 1);
+				__hip_atomic_store(level + row, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				pending = false;
 			}
 		}
-		const bool ok = q < re && h.positions[q] == i && std::fabs(lu[q]) >= T(1e-6);
-		if (ok) pivotInv[i] = T(1.0) / lu[q];
-		for (int c = rb; c < re; ++c) where[h.positions[c]] = -1;
-		if (!ok) return false;
+		// (the largest level is found by a kernel of its own, maxLevelKernel: a wave reduction + "if (lane == 0) atomicMax" at this
+		// place made hipcc 7.2 emit a loop in which lanes 1 .. 63 re-enter the chunk forever)
 	}
-	return true;
 }
 
-// IC(0): A ~ L L^T with L's values stored at A's lower positions and mirrored into the upper ones, column by
-// column like ref:1839-1928 (the rows j>i that hold column i are the columns >i of row i for a symmetric pattern).
+__global__ __launch_bounds__(TPB) void maxLevelKernel(int n, const int* __restrict__ level, int* out) {
+	int top = 0;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) top = max(top, level[i]);
+#pragma unroll
+	for (int o = WAVE / 2; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o, WAVE));
+	if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(out, top);
+}
+
+__global__ __launch_bounds__(TPB) void iotaKernel(int n, int* out) {
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) out[i] = static_cast<int>(i);
+}
+
+// sortedLevel[] ascending: lvlPtr[l] = first index of level l (every level 0 .. nLevels-1 holds at least one row), lvlPtr[nLevels] = n
+__global__ __launch_bounds__(TPB) void levelPtrKernel(int n, int nLevels, const int* __restrict__ sortedLevel, int* __restrict__ lvlPtr) {
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * TPB) {
+		if (i == 0 || sortedLevel[i] != sortedLevel[i - 1]) lvlPtr[sortedLevel[i]] = static_cast<int>(i);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) lvlPtr[nLevels] = n;
+}
+
+// position of column c among positions[b .. e) (ascending), or -1
+__device__ __forceinline__ int findColumn(const int* __restrict__ positions, int b, int e, int c) {
+	int lo = b, hi = e;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (positions[mid] < c) lo = mid + 1;
+		else hi = mid;
+	}
+	return lo < e && positions[lo] == c ? lo : -1;
+}
+
+// ILU(0), IKJ ordering on A's pattern (Saad, Iterative Methods for Sparse Linear Systems, Alg. 10.4), one row by one WAVEFRONT: unit-lower
+// L and U share one value array.  l_ik = a_ik * (1/u_kk) as ref:1767 intends.  The elimination steps of a row (its lower entries k,
+// ascending) are sequential; inside a step the lanes share the entries of row k's U part -- every entry of the row is touched at most
+// once per step, so the result does not depend on how the step is shared out: the same bits as the sequential loop.  The rows k are final
+// (earlier levels).  A missing / tiny pivot raises *err (the create call then fails: reordering would be needed, ref:1741-1746).
 template <typename T>
-static bool factorIc0(const HostCsr& h, const std::vector<T>& a, std::vector<T>& ic) {
-	const int n = h.rows;
-	std::vector<int> filled(static_cast<size_t>(n), 0);
-	std::vector<int> where(static_cast<size_t>(n), -1);
-	for (int i = 0; i < n; ++i) {
-		const int rb = h.start[i], re = h.start[i + 1];
-		if (rb == re) return false;
-		for (int q = rb; q < re; ++q) where[h.positions[q]] = q;
-		T acc = T(0);
-		int dq = rb;
-		while (dq < re && h.positions[dq] < i) {
-			acc += ic[dq] * ic[dq];
-			++dq;
+__device__ __forceinline__ void iluRowWave(int row, const int* __restrict__ start, const int* __restrict__ positions, T* lu, T* pivotInv, int* err) {
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int rb = start[row], re = start[row + 1];
+	int q = rb;
+	for (; q < re; ++q) {
+		const int k = positions[q];
+		if (k >= row) break;
+		const T lik = lu[q] * pivotInv[k];
+		const int ke = start[k + 1];
+		const int dk = findColumn(positions, start[k], ke, k);  // the diagonal of row k (rowCheckKernel made sure of it)
+		for (int u = dk + 1 + lane; u < ke; u += WAVE) {
+			const int target = findColumn(positions, rb, re, positions[u]);
+			if (target != -1) lu[target] = lu[target] - lik * lu[u];
 		}
-		if (dq >= re || h.positions[dq] != i) return false;
-		const T under = a[dq] - acc;
-		if (!(under > T(0))) return false;
-		const T d = std::sqrt(under);
-		ic[rb + filled[i]] = d;
-		filled[i]++;
-		const T dinv = T(1) / d;
-		for (int q = dq + 1; q < re; ++q) {
-			const int j = h.positions[q];
-			const int jb = h.start[j], je = h.start[j + 1];
-			const int slot = jb + filled[j];
-			if (slot >= je || h.positions[slot] != i) continue;
-			T sum = T(0);
-			int k = jb;
-			while (k < je && h.positions[k] < i) {
-				const int mine = where[h.positions[k]];
-				if (mine != -1) sum += ic[mine] * ic[k];
-				++k;
+		if (lane == 0) lu[q] = lik;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's updates are in place before the next step reads lu[q + 1]
+	}
+	const T piv = q < re ? lu[q] : T(0);
+	const bool ok = q < re && positions[q] == row && (piv < T(0) ? -piv : piv) >= T(1e-6);
+	if (lane == 0) {
+		pivotInv[row] = ok ? T(1.0) / piv : T(0);
+		if (!ok) atomicOr(err, 1);
+	}
+}
+
+// IC(0): A ~ L L^T with L's values stored at A's lower positions and mirrored into the upper ones -- ref:1839-1928 computes it column
+// by column; this is the same arithmetic row by row (up-looking), one row by one wavefront: l_ji = (a_ji - sum_{k<i} l_ik l_jk) / d_i
+// with the sum in ascending k over row j's entries, d_j = sqrt(a_jj - sum_k l_jk^2) in ascending k.  The lanes share the look-ups of a
+// sum (64 entries of row j at a time) and the products are then added one after the other in entry order: the operands and the order of
+// every sum are the reference's, so are the bits (tests: assert_array_equal against the reference's factor).  Row i (< j) is final when
+// row j starts (earlier level).  *err: bit 0 not positive definite on the pattern (ref:1871-1878) or diagonal missing, bit 1 pattern not
+// symmetric.
+template <typename T>
+__device__ __forceinline__ void ic0RowWave(int j, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ a, T* ic, T* dinv,
+                                           int* err) {
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int jb = start[j], je = start[j + 1];
+	T acc = T(0);
+	int k = jb;
+	for (; k < je; ++k) {
+		const int i = positions[k];
+		if (i >= j) break;
+		const int ib = start[i], ie = start[i + 1];
+		const int mirror = findColumn(positions, ib, ie, j);
+		if (mirror == -1) {  // row i does not hold column j: not a symmetric pattern
+			if (lane == 0) atomicOr(err, 2);
+			continue;
+		}
+		T sum = T(0);
+		for (int kk0 = jb; kk0 < k; kk0 += WAVE) {
+			const int kk = kk0 + lane;
+			const int mine = kk < k ? findColumn(positions, ib, ie, positions[kk]) : -1;
+			const T prod = mine != -1 ? ic[mine] * ic[kk] : T(0);
+			unsigned long long has = __ballot(mine != -1);
+			while (has != 0ull) {  // in entry order
+				const int t = __builtin_ctzll(has);
+				sum += __shfl(prod, t, WAVE);
+				has &= has - 1ull;
 			}
-			const T lji = (a[k] - sum) * dinv;
+		}
+		const T lji = (a[k] - sum) * dinv[i];
+		if (lane == 0) {
 			ic[k] = lji;
-			ic[rb + filled[i]] = lji;
-			filled[i]++;
-			filled[j]++;
+			ic[mirror] = lji;
 		}
-		for (int q = rb; q < re; ++q) where[h.positions[q]] = -1;
+		acc += lji * lji;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // l_ji is in place before the next entry's sum reads it
 	}
-	return true;
+	if (k >= je || positions[k] != j) {
+		if (lane == 0) {
+			atomicOr(err, 1);
+			dinv[j] = T(0);
+		}
+		return;
+	}
+	const T under = a[k] - acc;
+	const T d = sqrt(under);
+	if (lane == 0) {
+		if (!(under > T(0))) atomicOr(err, 1);
+		ic[k] = d;
+		dinv[j] = T(1) / d;
+	}
+}
+
+// KIND: SMM_PRECOND_ILU0 or SMM_PRECOND_IC0.  One large level / a run of small levels inside one workgroup, like the sweeps; one
+// wavefront per row (a row of a dense block costs O(length^2) look-ups: one lane per row took minutes on tests/test_gpu_misc.py's
+// 700-row dense block).
+template <typename T, int KIND>
+__device__ __forceinline__ void factorRowWave(int row, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ a, T* f, T* piv,
+                                              int* err) {
+	if (KIND == SMM_PRECOND_ILU0) iluRowWave<T>(row, start, positions, f, piv, err);
+	else ic0RowWave<T>(row, start, positions, a, f, piv, err);
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(TPB) void factorLevelKernel(const int* __restrict__ order, int begin, int count, const int* __restrict__ start,
+                                                         const int* __restrict__ positions, const T* __restrict__ a, T* f, T* piv, int* err) {
+	const int r = blockIdx.x * (TPB / WAVE) + (threadIdx.x >> 6);
+	if (r < count) factorRowWave<T, KIND>(order[begin + r], start, positions, a, f, piv, err);
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(SMALL_LEVEL) void factorChainKernel(const int* __restrict__ order, const int* __restrict__ lvlPtr, int l0, int l1,
+                                                                 const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ a,
+                                                                 T* f, T* piv, int* err) {
+	for (int l = l0; l < l1; ++l) {
+		const int begin = lvlPtr[l];
+		const int count = lvlPtr[l + 1] - begin;
+		for (int r = threadIdx.x >> 6; r < count; r += SMALL_LEVEL / WAVE) factorRowWave<T, KIND>(order[begin + r], start, positions, a, f, piv, err);
+		__threadfence_block();
+		__syncthreads();
+	}
 }
 
 struct SweepPlan {
@@ -707,9 +812,77 @@ int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* don
 template int precondApplyDev<float>(const smm_hip_precond*, const float*, float*, const int*, hipStream_t);
 template int precondApplyDev<double>(const smm_hip_precond*, const double*, double*, const int*, hipStream_t);
 
-static int uploadInts(const std::vector<int>& v, int** d, hipStream_t s) {
-	SMM_TRY(devAlloc(reinterpret_cast<void**>(d), std::max<size_t>(1, v.size()) * sizeof(int)));
-	if (!v.empty()) SMM_HIP_TRY(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s));
+// level sets of one sweep, on the device: d_order (rows sorted by level, ascending row inside a level), the level pointers on the host
+// (the launch plan is made from them) and on the device (the chained kernels read them)
+template <bool LOWER>
+static int buildLevelsDevice(const smm_hip_csr* a, unsigned passLimit, hipStream_t s, int** d_order, std::vector<int>& lvlPtr, int** d_lvlPtr) {
+	const int n = a->rows;
+	*d_order = nullptr;
+	*d_lvlPtr = nullptr;
+	lvlPtr.assign(1, 0);
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(d_order), static_cast<size_t>(std::max(1, n)) * sizeof(int)));
+	if (n == 0) {
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(d_lvlPtr), sizeof(int)));
+		SMM_HIP_TRY(hipMemsetAsync(*d_lvlPtr, 0, sizeof(int), s));
+		return SMM_HIP_OK;
+	}
+	DevBuf<int> level, sorted, rowsIn, words;
+	SMM_TRY(level.alloc(n));
+	SMM_TRY(sorted.alloc(n));
+	SMM_TRY(rowsIn.alloc(n));
+	SMM_TRY(words.alloc(4));
+	SMM_HIP_TRY(hipMemsetAsync(level, 0xFF, static_cast<size_t>(n) * sizeof(int), s));  // -1: not known yet
+	SMM_HIP_TRY(hipMemsetAsync(words, 0, 4 * sizeof(int), s));
+	const int waves = std::min((n + WAVE - 1) / WAVE, numCUs() * 32);
+	levelFreeKernel<LOWER><<<(waves + TPB / WAVE - 1) / (TPB / WAVE), TPB, 0, s>>>(n, a->d_start, a->d_positions, level, words, passLimit);
+	const int grid = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
+	maxLevelKernel<<<grid, TPB, 0, s>>>(n, level, words.p + 1);
+	iotaKernel<<<grid, TPB, 0, s>>>(n, rowsIn);
+	int h[4] = {0, 0, 0, 0};
+	SMM_HIP_TRY(hipMemcpyAsync(h, words, sizeof(h), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (h[2]) {
+		setError("preconditioner: the level analysis ran into its pass limit");
+		return SMM_HIP_ERR_HIP;
+	}
+	const int nLevels = h[1] + 1;
+	int bits = 1;
+	while ((1ll << bits) <= h[1]) ++bits;
+	size_t tempBytes = 0;
+	SMM_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tempBytes, level.p, sorted.p, rowsIn.p, *d_order, static_cast<size_t>(n), 0, bits, s));
+	DevBuf<char> temp;
+	SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
+	SMM_HIP_TRY(rocprim::radix_sort_pairs(temp.p, tempBytes, level.p, sorted.p, rowsIn.p, *d_order, static_cast<size_t>(n), 0, bits, s));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(d_lvlPtr), (static_cast<size_t>(nLevels) + 1) * sizeof(int)));
+	levelPtrKernel<<<grid, TPB, 0, s>>>(n, nLevels, sorted, *d_lvlPtr);
+	lvlPtr.resize(static_cast<size_t>(nLevels) + 1);
+	SMM_HIP_TRY(hipMemcpyAsync(lvlPtr.data(), *d_lvlPtr, lvlPtr.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // the scratch buffers go back to the allocator when this scope ends
+	return SMM_HIP_OK;
+}
+
+// ILU(0) / IC(0) on the device, level by level in the order of the lower sweep (a row is eliminated with rows of earlier levels only)
+template <typename T, int KIND>
+static int factorDevice(const smm_hip_csr* a, const SweepPlan& plan, const int* d_order, const std::vector<int>& lvlPtr, T* f, int* herr, hipStream_t s) {
+	const int n = a->rows;
+	DevBuf<T> piv;
+	DevBuf<int> err;
+	SMM_TRY(piv.alloc(std::max(1, n)));
+	SMM_TRY(err.alloc(1));
+	SMM_HIP_TRY(hipMemsetAsync(err, 0, sizeof(int), s));
+	const T* aVals = static_cast<const T*>(a->d_values);
+	for (const auto& g : plan.groups) {
+		if (g.chain) {
+			factorChainKernel<T, KIND><<<1, SMALL_LEVEL, 0, s>>>(d_order, plan.d_lvlPtr, g.l0, g.l1, a->d_start, a->d_positions, aVals, f, piv.p, err.p);
+		} else {
+			const int begin = lvlPtr[g.l0];
+			const int count = lvlPtr[g.l0 + 1] - begin;
+			factorLevelKernel<T, KIND><<<(count + TPB / WAVE - 1) / (TPB / WAVE), TPB, 0, s>>>(d_order, begin, count, a->d_start, a->d_positions, aVals, f, piv.p, err.p);
+		}
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	SMM_HIP_TRY(hipMemcpyAsync(herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
 	return SMM_HIP_OK;
 }
 
@@ -737,7 +910,7 @@ static int createTyped(const smm_hip_csr* a, int kind, smm_hip_precond* M) {
 		}
 		return SMM_HIP_OK;
 	}
-	// SGS / ILU0 / IC0: analysis on the host
+	// SGS / ILU0 / IC0: analysis (and factorisation) on the device
 	if (a->rows != a->cols) {
 		setError("preconditioner needs a square matrix");
 		return SMM_HIP_ERR_INVALID;
@@ -746,63 +919,52 @@ static int createTyped(const smm_hip_csr* a, int kind, smm_hip_precond* M) {
 		setError("preconditioner: matrix has leading empty rows (firstActiveStart != 0)");
 		return SMM_HIP_ERR_PRECOND;
 	}
-	HostCsr h;
-	h.rows = n;
-	h.start.resize(static_cast<size_t>(n) + 1);
-	h.positions.resize(static_cast<size_t>(a->nnz));
-	std::vector<T> vals(static_cast<size_t>(a->nnz));
-	SMM_HIP_TRY(hipMemcpyAsync(h.start.data(), a->d_start, h.start.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-	if (a->nnz) {
-		SMM_HIP_TRY(hipMemcpyAsync(h.positions.data(), a->d_positions, h.positions.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipMemcpyAsync(vals.data(), a->d_values, vals.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+	int info[2] = {0, 0};  // structural error, longest row
+	{
+		DevBuf<int> dinfo;
+		SMM_TRY(dinfo.alloc(2));
+		SMM_HIP_TRY(hipMemsetAsync(dinfo, 0, 2 * sizeof(int), s));
+		if (n) {
+			const int grid = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
+			rowCheckKernel<T><<<grid, TPB, 0, s>>>(n, a->d_start, a->d_positions, static_cast<const T*>(a->d_values), kind == SMM_PRECOND_SGS ? 1 : 0, dinfo);
+		}
+		SMM_HIP_TRY(hipMemcpyAsync(info, dinfo, sizeof(info), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
 	}
-	SMM_HIP_TRY(hipStreamSynchronize(s));
-	if (!diagonalOk<T>(h, vals, kind == SMM_PRECOND_SGS)) {
+	if (info[0]) {
 		setError("preconditioner: empty row, missing diagonal or |d|<1e-5");
 		return SMM_HIP_ERR_PRECOND;
 	}
-	if (kind == SMM_PRECOND_ILU0) {
-		std::vector<T> lu(vals);
-		if (!factorIlu0<T>(h, lu)) {
-			setError("ilu0: zero / missing pivot (reordering would be needed, ref:1741-1746)");
-			return SMM_HIP_ERR_PRECOND;
-		}
-		SMM_TRY(devAlloc(&M->d_values, std::max<size_t>(1, lu.size()) * sizeof(T)));
-		M->n_values = lu.size();
-		if (!lu.empty()) SMM_HIP_TRY(hipMemcpyAsync(M->d_values, lu.data(), lu.size() * sizeof(T), hipMemcpyHostToDevice, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));
-	} else if (kind == SMM_PRECOND_IC0) {
-		std::vector<T> ic(vals.size(), T(0));
-		if (!factorIc0<T>(h, vals, ic)) {
-			setError("ic0: matrix is not symmetric positive definite on its pattern (ref:1871-1878)");
-			return SMM_HIP_ERR_PRECOND;
-		}
-		SMM_TRY(devAlloc(&M->d_values, std::max<size_t>(1, ic.size()) * sizeof(T)));
-		M->n_values = ic.size();
-		if (!ic.empty()) SMM_HIP_TRY(hipMemcpyAsync(M->d_values, ic.data(), ic.size() * sizeof(T), hipMemcpyHostToDevice, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));
-	}
-	std::vector<int> orderLo, orderUp;
-	buildLevels(h, true, orderLo, M->lvl_ptr_lo);
-	buildLevels(h, false, orderUp, M->lvl_ptr_up);
-	SMM_TRY(uploadInts(orderLo, &M->d_order_lo, s));
-	SMM_TRY(uploadInts(orderUp, &M->d_order_up, s));
 	auto* plan = new smm_precond_plan();
-	{
-		long long longest = 0;
-		for (int i = 0; i < n; ++i) longest = std::max<long long>(longest, h.start[i + 1] - h.start[i]);
-		plan->passLimit = static_cast<unsigned>(std::min<long long>(0x7fffffffLL, (1LL << 21) + 64 * longest));
-	}
+	M->plan = plan;  // (smm_hip_precond_destroy releases it together with whatever the steps below have allocated so far)
+	plan->passLimit = static_cast<unsigned>(std::min<long long>(0x7fffffffLL, (1LL << 21) + 64LL * info[1]));
+	SMM_TRY(buildLevelsDevice<true>(a, plan->passLimit, s, &M->d_order_lo, M->lvl_ptr_lo, &plan->lo.d_lvlPtr));
+	SMM_TRY(buildLevelsDevice<false>(a, plan->passLimit, s, &M->d_order_up, M->lvl_ptr_up, &plan->up.d_lvlPtr));
 	planGroups(M->lvl_ptr_lo, plan->lo.groups);
 	planGroups(M->lvl_ptr_up, plan->up.groups);
-	int st = uploadInts(M->lvl_ptr_lo, &plan->lo.d_lvlPtr, s);
-	if (st == SMM_HIP_OK) st = uploadInts(M->lvl_ptr_up, &plan->up.d_lvlPtr, s);
-	if (st != SMM_HIP_OK) {
-		delete plan;
-		return st;
+	if (kind == SMM_PRECOND_ILU0 || kind == SMM_PRECOND_IC0) {
+		const size_t nnz = static_cast<size_t>(a->nnz);
+		SMM_TRY(devAlloc(&M->d_values, std::max<size_t>(1, nnz) * sizeof(T)));
+		M->n_values = nnz;
+		int herr = 0;
+		if (kind == SMM_PRECOND_ILU0) {
+			if (nnz) SMM_HIP_TRY(hipMemcpyAsync(M->d_values, a->d_values, nnz * sizeof(T), hipMemcpyDeviceToDevice, s));
+			SMM_TRY((factorDevice<T, SMM_PRECOND_ILU0>(a, plan->lo, M->d_order_lo, M->lvl_ptr_lo, static_cast<T*>(M->d_values), &herr, s)));
+			if (herr) {
+				setError("ilu0: zero / missing pivot (reordering would be needed, ref:1741-1746)");
+				return SMM_HIP_ERR_PRECOND;
+			}
+		} else {
+			if (nnz) SMM_HIP_TRY(hipMemsetAsync(M->d_values, 0, nnz * sizeof(T), s));
+			SMM_TRY((factorDevice<T, SMM_PRECOND_IC0>(a, plan->lo, M->d_order_lo, M->lvl_ptr_lo, static_cast<T*>(M->d_values), &herr, s)));
+			if (herr) {
+				setError(herr & 1 ? "ic0: matrix is not symmetric positive definite on its pattern (ref:1871-1878)"
+				                  : "ic0: the pattern of the matrix is not symmetric");
+				return SMM_HIP_ERR_PRECOND;
+			}
+		}
 	}
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	M->plan = plan;
 	return SMM_HIP_OK;
 }
 
