@@ -67,7 +67,7 @@ def spmv_kernel_source_sha():
     import re
 
     h = hashlib.sha256()
-    for name in ("smm_spmv.hip", "smm_device.h", "smm_internal.h"):
+    for name in ("smm_spmv.hip", "smm_device.h"):  # (not smm_internal.h: it changes with every unrelated entry point)
         with open(os.path.join(ROOT, "sparse_matrix_math_amd", "csrc", name), encoding="utf-8") as f:
             text = f.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # block comments
