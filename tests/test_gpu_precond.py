@@ -104,6 +104,17 @@ def test_structural_failures(smm):
     A = smm.CSRMatrix(2, 2, np.array([0, 2, 4], dtype=np.int32), np.array([0, 1, 0, 1], dtype=np.int32), np.array([1.0, 2.0, 2.0, 1.0]))
     with pytest.raises(smm.SmmHipError):  # not positive definite
         A.getPreconditioner(P.IC0)
+    # IC0 on a pattern that is not symmetric (row 2 holds column 0, row 0 does not hold column 2): refused, not factorised into garbage
+    A = smm.CSRMatrix(3, 3, np.array([0, 2, 4, 7], dtype=np.int32), np.array([0, 1, 0, 1, 0, 1, 2], dtype=np.int32),
+                      np.array([4.0, -1.0, -1.0, 4.0, -1.0, -1.0, 4.0]))
+    with pytest.raises(smm.SmmHipError) as e:
+        A.getPreconditioner(P.IC0)
+    assert e.value.code == -4 and "symmetric" in str(e.value)
+    # ILU0 with a pivot that cancels to zero: [[1, 1], [1, 1]] -> u_11 = 1 - 1 * 1 = 0 (ref:1741-1746: reordering would be needed)
+    A = smm.CSRMatrix(2, 2, np.array([0, 2, 4], dtype=np.int32), np.array([0, 1, 0, 1], dtype=np.int32), np.array([1.0, 1.0, 1.0, 1.0]))
+    with pytest.raises(smm.SmmHipError) as e:
+        A.getPreconditioner(P.ILU0)
+    assert e.value.code == -4
     M = smm.CSRMatrix(2, 2, np.array([0, 1, 2], dtype=np.int32), np.array([0, 1], dtype=np.int32), np.array([2.0, 4.0])).getPreconditioner(P.JACOBI)
     v = np.ones(2)
     with pytest.raises(smm.SmmHipError):  # rhs must not alias x (ref:1667)
