@@ -164,6 +164,9 @@ constexpr int SPMV_FINISH = 0x200;
 // launch-side only (never reaches a kernel): size the persistent grid for all but 8 CUs, so that a kernel of another stream (an RCCL
 // exchange running beside the local block of a distributed SpMV) finds free workgroup slots
 constexpr int SPMV_LEAVE_ROOM = 0x400;
+// launch-side: out[i] = (A x)[i] / lhs[i] (op must be SMM_OP_ASSIGN).  Reaches the kernels as the internal operation SPMV_OP_DIV.
+constexpr int SPMV_DIV_LHS = 0x800;
+constexpr int SPMV_OP_DIV = 3;
 constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer
 constexpr int PARTS_LEN = 2 * NPART + 4;   // elements of a finishing buffer: 2 x NPART partials, 2 totals, 8 bytes for the ticket
 template <typename T>

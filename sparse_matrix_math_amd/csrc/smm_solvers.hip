@@ -536,7 +536,10 @@ struct HostApplier {
 
 template <typename T, typename Applier>
 static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const bool precondition, const Applier& apply, hipStream_t s,
-                        int* status, int* iterations, T* resnorm) {
+                        int* status, int* iterations, T* resnorm, const T* jacobiDiag = nullptr) {
+	// jacobiDiag: M is the library's Jacobi preconditioner and its apply (x = rhs / diag, smm_precond.hip) is folded into the rows of the
+	// SpMV that precedes it -- the same division on the same operands, so the same bits as SpMV + apply -- which lets the preconditioned
+	// loop use the fused dots of the unpreconditioned one: no apply launches, no dot launches, no extra vector passes.
 	const int n = a->rows;
 	maxIterations = std::min(maxIterations, n);  // ref:2200
 	if (maxIterations == -1) maxIterations = n;  // ref:2201-2203
@@ -583,7 +586,9 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 			if (seen) break;
 			nextCheck = i + checkInterval(i);
 		}
-		if (precondition) {
+		if (jacobiDiag) {
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, jacobiDiag, p, ap, 1, r0, parts, doneFlag, s, SPMV_DIV_LHS));  // ref:2234-2235 + 2243 fused
+		} else if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
 			SMM_TRY(apply(scratch, ap, doneFlag, s));                                                          // ref:2235
 			SMM_TRY(launchDotPartials<T>(n, ap, r0, parts, doneFlag, s));                                      // ref:2243
@@ -592,7 +597,9 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 		}
 		// alpha, omega and beta are formed inside the three update kernels that consume them (no scalar launches)
 		SMM_LAUNCH_UPDATE(bicgFusedS, updateNT(n, sizeof(T), 3), gridFor(n), s, n, sc, i & 1, parts, ap, r, sv);
-		if (precondition) {
+		if (jacobiDiag) {
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, jacobiDiag, sv, as, 2, sv, parts, doneFlag, s, SPMV_DIV_LHS));  // ref:2250-2251 + 2256-2261 fused
+		} else if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
 			SMM_TRY(apply(scratch, as, doneFlag, s));                                                           // ref:2251
 			dot2Partials<T><<<NPART, TPB, 0, s>>>(n, as, sv, parts, parts.p + NPART, doneFlag);                 // ref:2259, 2261
@@ -639,7 +646,9 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 		return SMM_HIP_ERR_INVALID;
 	}
 	const DevApplier<T> apply{M};
-	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm)));
+	SMM_TRY(ensureCsrReady(a, s, true));
+	const T* jacobiDiag = precondition && M->kind == SMM_PRECOND_JACOBI && a->family != SMM_SPMV_PATTERN ? static_cast<const T*>(M->d_values) : nullptr;
+	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm, jacobiDiag)));
 	return precondition ? precondTakeError(M, s) : SMM_HIP_OK;
 }
 

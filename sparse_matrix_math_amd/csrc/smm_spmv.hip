@@ -50,6 +50,7 @@ template <typename T>
 __device__ __forceinline__ T applyOp(int op, const T* __restrict__ lhs, int row, T dot) {
 	if (op == SMM_OP_ASSIGN) return dot;
 	const T l = lhs[row];
+	if (op == SPMV_OP_DIV) return dot / l;  // internal (SPMV_DIV_LHS): the Jacobi apply x = rhs / diag (smm_precond.hip) folded into the row
 	return op == SMM_OP_ADD ? l + dot : l - dot;
 }
 
@@ -984,9 +985,17 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		setError("spmv: fused dot needs w1 and partials");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if ((extraFlags & ~(SPMV_FINISH | SPMV_LEAVE_ROOM)) || ((extraFlags & SPMV_FINISH) && !dotMode)) {
+	if ((extraFlags & ~(SPMV_FINISH | SPMV_LEAVE_ROOM | SPMV_DIV_LHS)) || ((extraFlags & SPMV_FINISH) && !dotMode)) {
 		setError("spmv: bad extra flags");
 		return SMM_HIP_ERR_INVALID;
+	}
+	if (extraFlags & SPMV_DIV_LHS) {  // out = (A x) / lhs, row by row
+		if (op != SMM_OP_ASSIGN || (m->rows > 0 && !lhs) || m->family == SMM_SPMV_PATTERN) {
+			setError("spmv: the divide-by-lhs form needs SMM_OP_ASSIGN, a divisor vector and a family other than PATTERN");
+			return SMM_HIP_ERR_INVALID;
+		}
+		op = SPMV_OP_DIV;
+		extraFlags &= ~SPMV_DIV_LHS;
 	}
 	if (m->rows == 0 && !dotMode) return SMM_HIP_OK;
 	op |= extraFlags;  // the kernels split `op` into the operation (low byte) and flags
