@@ -206,3 +206,46 @@ def test_sweep_modes_in_solver(smm):
     np.testing.assert_array_equal(outs[0][ok], outs[1][ok])
     with pytest.raises(smm.SmmHipError):
         M.set_sweep(9)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ic0_and_ilu0_long_rows_match_oracle(smm, oracle, dtype):
+    """rows far longer than a wavefront (the device factorisation shares a row's work over 64 lanes in batches): a dense symmetric
+    positive definite block of 200 rows inside a banded matrix -- factor values and one apply bit-identical to the oracle's
+    sequential algorithms (the oracle's IC0 is pinned to the real reference bit for bit, tests/test_oracle.py)"""
+    P = smm.SolverPreconditioner
+    rng = np.random.default_rng(21)
+    nb, n = 200, 600
+    dense = np.zeros((n, n))
+    blk = rng.uniform(-0.5, 0.5, (nb, nb)) / nb
+    dense[100:100 + nb, 100:100 + nb] = blk + blk.T
+    for i in range(n):
+        dense[i, i] = 3.0
+        if i + 1 < n:
+            dense[i, i + 1] = dense[i + 1, i] = -1.0
+        if i + 7 < n:
+            dense[i, i + 7] = dense[i + 7, i] = -0.25
+    start = np.zeros(n + 1, dtype=np.int32)
+    pos, val = [], []
+    for r in range(n):
+        (c,) = np.nonzero(dense[r])
+        pos.extend(c.tolist())
+        val.extend(dense[r, c].tolist())
+        start[r + 1] = len(pos)
+    csr = (start, np.array(pos, dtype=np.int32), np.array(val, dtype=dtype))
+    assert np.diff(start).max() > 3 * 64
+    A = make(smm, csr)
+    rhs = rng.uniform(-1, 1, n).astype(dtype)
+    x = np.zeros(n, dtype=dtype)
+    e, ic = oracle.ic0_factorize(csr)
+    assert e == 0
+    M = A.getPreconditioner(P.IC0)
+    np.testing.assert_array_equal(M.values(), ic)
+    M.apply(rhs, x)
+    np.testing.assert_array_equal(x, oracle.ic0_apply(csr, ic, rhs)[1])
+    e, lu = oracle.ilu0_factorize(csr)
+    assert e == 0
+    M = A.getPreconditioner(P.ILU0)
+    np.testing.assert_array_equal(M.values(), lu)
+    M.apply(rhs, x)
+    np.testing.assert_array_equal(x, oracle.ilu0_apply(csr, lu, rhs)[1])
