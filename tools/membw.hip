@@ -206,6 +206,70 @@ __global__ __launch_bounds__(256) void tileKernel(const f32x4* __restrict__ a, c
 	if (acc == 123.456f) sink[0] = acc;
 }
 
+
+// The same skeleton with a workgroup taking KC CONSECUTIVE tiles at a time (instead of every slots-th tile) and, WMODE 1, keeping their
+// results in LDS until the KC * 2 KB of y they cover can be written in one go with 16-byte non-temporal stores (WMODE 0: 8 bytes per lane
+// after every tile, as the SpMV does).  Question: is the high price of the SpMV's out[] stream (profiles/r02/membw.txt) a matter of how
+// large and how contiguous the written pieces are?
+template <int NV, int KC, int WMODE>
+__global__ __launch_bounds__(256) void tileChunkKernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, int nTiles, float* __restrict__ sink,
+                                                       double* __restrict__ y) {
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	float* sa = lds;
+	float* sb = lds + NV * 1024 + 16;
+	double* sy = reinterpret_cast<double*>(lds + 2 * (NV * 1024 + 16));
+	const int t = threadIdx.x;
+	const int g = blockIdx.x % 8;
+	const int slots = (gridDim.x - g + 7) / 8;
+	const int per = (nTiles + 7) / 8;
+	const int s = blockIdx.x / 8;
+	const int end = min(nTiles, (g + 1) * per);
+	auto tileOf = [&](int j) { return g * per + ((j / KC) * slots + s) * KC + j % KC; };
+	f32x4 ra[NV], rb[NV];
+	auto load = [&](int tl) {
+		const long long base = static_cast<long long>(tl) * NV * 256;
+#pragma unroll
+		for (int v = 0; v < NV; ++v) {
+			ra[v] = __builtin_nontemporal_load(a + base + v * 256 + t);
+			rb[v] = __builtin_nontemporal_load(b + base + v * 256 + t);
+		}
+	};
+	float acc = 0.f;
+	int j = 0;
+	int tile = tileOf(0);
+	if (tile < end) load(tile);
+	while (tile < end) {
+		const int next = tileOf(j + 1);
+#pragma unroll
+		for (int v = 0; v < NV; ++v) {
+			*reinterpret_cast<f32x4*>(sa + 4 * (v * 256 + t)) = ra[v];
+			*reinterpret_cast<f32x4*>(sb + 4 * (v * 256 + t)) = rb[v];
+		}
+		__syncthreads();
+		if (next < end) load(next);
+		const int k0 = t * (NV * 4);
+#pragma unroll
+		for (int u = 0; u < NV * 4; ++u) acc += sa[k0 + u] * sb[k0 + u];
+		if (WMODE == 0) {
+			__builtin_nontemporal_store(static_cast<double>(acc), y + static_cast<long long>(tile) * 256 + t);
+		} else {
+			const int slot = j % KC;
+			sy[slot * 256 + t] = acc;
+			const bool last = slot == KC - 1 || next >= end || next != tile + 1;
+			if (last) {
+				__syncthreads();
+				const int pieces = (slot + 1) * 128;  // 16-byte pieces of the chunk's results
+				f64x2* dst = reinterpret_cast<f64x2*>(y + static_cast<long long>(tile - slot) * 256);
+				for (int q = t; q < pieces; q += 256) __builtin_nontemporal_store(reinterpret_cast<const f64x2*>(sy)[q], dst + q);
+			}
+		}
+		__syncthreads();
+		tile = next;
+		++j;
+	}
+	if (acc == 123.456f) sink[0] = acc;
+}
+
 template <typename F>
 static double timeIt(F launch, int reps) {
 	hipEvent_t e0, e1;
@@ -291,6 +355,18 @@ int main() {
 				const double m4 = timeIt([&] { tileKernel<2, 4, true><<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
 				const double m5 = timeIt([&] { tileKernel<2, 5, true><<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
 				std::printf("tile skeleton NV=2 wgs/CU=%d: read only %.3f ms | + %.2f GB written, plain stores %.3f ms | non-temporal stores %.3f ms | 16-byte stores via LDS %.3f ms | same nt %.3f ms\n", perCU, m1, wbytes / 1e9, m2, m3, m4, m5);
+			}
+			for (int perCU : {4, 6}) {
+				const int nTiles = static_cast<int>(n16 / 512);
+				const double wbytes = nTiles * 256.0 * 8;
+				auto run = [&](auto kern, int kc) {
+					const size_t ldsBytes = (2 * (2 * 1024 + 16)) * sizeof(float) + static_cast<size_t>(kc) * 256 * sizeof(double);
+					return timeIt([&] { kern<<<cus * perCU, 256, ldsBytes>>>(a, b, nTiles, sink, y); }, 10);
+				};
+				std::printf("tile skeleton NV=2 wgs/CU=%d, %.2f GB written, workgroup takes KC consecutive tiles; 8-byte nt stores per tile / KC x 2 KB from LDS at once:"
+				            "  KC=1 %.3f / %.3f ms | KC=4 %.3f / %.3f ms | KC=8 %.3f / %.3f ms | KC=16 %.3f / %.3f ms\n", perCU, wbytes / 1e9,
+				            run(tileChunkKernel<2, 1, 0>, 1), run(tileChunkKernel<2, 1, 1>, 1), run(tileChunkKernel<2, 4, 0>, 4), run(tileChunkKernel<2, 4, 1>, 4),
+				            run(tileChunkKernel<2, 8, 0>, 8), run(tileChunkKernel<2, 8, 1>, 8), run(tileChunkKernel<2, 16, 0>, 16), run(tileChunkKernel<2, 16, 1>, 16));
 			}
 			CHECK(hipFree(y));
 		}
