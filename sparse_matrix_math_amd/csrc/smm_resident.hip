@@ -160,7 +160,7 @@ __device__ __forceinline__ void publish(T* p, T v) {
 	else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sum over the workgroup, the same value in every lane.  Order: butterfly inside each wave, then the 16 wave sums left to right.
+// sum over the workgroup, the same value in every lane.  Order: butterfly inside each wave, then the RWAVES wave sums left to right.
 template <typename T>
 __device__ __forceinline__ T blockSumAll(T v, T* lds /* RWAVES + 1 */) {
 	v = groupSum<WAVE>(v);
