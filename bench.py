@@ -291,6 +291,43 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         out["cg_poisson1000_f64"] = {"skipped": str(e)[:200]}
     host.cg_resident(before)
     torch.cuda.empty_cache()
+    # (d) BASELINE config 5's stand-in: BiCGStab on the non-symmetric convection-diffusion matrix 108^3 (1.26 M rows, fp64) to 1e-8, without a
+    # preconditioner and with the library's Jacobi / ILU0 (create time and solve time)
+    try:
+        N = 108
+        n, nnz = N ** 3, host.gen_stencil3d_nnz(N, N, N)
+        d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+        d_val = torch.empty(nnz, dtype=torch.float64, device=dev)
+        host.gen_stencil3d_dev(N, N, N, 6.0, -1.3, -0.7, d_start, d_pos, d_val, np.float64, stream)
+        A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np.float64)
+        ones = torch.ones(n, dtype=torch.float64, device=dev)
+        b = torch.empty_like(ones)
+        A.spmv_dev(0, None, ones, b, stream)
+        leg = {"rows": n, "nnz": nnz, "dtype": "f64", "tol": 1e-8}
+        P = smm.SolverPreconditioner
+        for name, kind in (("none", None), ("jacobi", P.JACOBI), ("ilu0", P.ILU0)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            M = A.getPreconditioner(kind) if kind is not None else None
+            tc = time.perf_counter() - t0
+            for _ in range(2):
+                x = torch.zeros(n, dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st, it, _res = host.bicgstab_dev(A, b, x, -1, 1e-8, M, stream)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            leg[name] = {"status": int(st), "iterations": it, "solve_ms": dt * 1e3, "create_ms": tc * 1e3,
+                         "max_abs_err_vs_ones": float((x - 1).abs().max())}
+            if M is not None:
+                M.close()
+        out["bicgstab_convdiff108_f64"] = leg
+        A.close()
+        del A, d_start, d_pos, d_val
+    except Exception as e:  # noqa: BLE001
+        out["bicgstab_convdiff108_f64"] = {"skipped": str(e)[:200]}
+    torch.cuda.empty_cache()
     return out
 
 
