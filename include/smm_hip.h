@@ -65,6 +65,14 @@ extern "C" {
 #define SMM_PRECOND_ILU0 2
 #define SMM_PRECOND_SGS 3
 #define SMM_PRECOND_IC0 4
+/* Block-diagonal forms (additions, no counterpart in the reference).  The rows are cut into contiguous blocks; M is the ILU0 /
+ * SGS preconditioner of the block-diagonal part of A: an entry that couples two blocks is dropped from M only (the solver keeps
+ * multiplying with all of A).  Inside a block the arithmetic is the global preconditioner's, entry for entry -- BLOCK_SGS is
+ * SGSPreconditioner::apply (ref:1658-1713) of the block-diagonal matrix, and with one block covering all rows both kinds give the
+ * global preconditioner's bits.  What it buys on MI355X: a block is factorised and swept by ONE wavefront out of LDS, all blocks at
+ * once, one launch per apply -- no dependency chain across the chip (csrc/smm_precond_block.hip). */
+#define SMM_PRECOND_BLOCK_ILU0 5
+#define SMM_PRECOND_BLOCK_SGS 6
 
 #define SMM_DTYPE_F32 0
 #define SMM_DTYPE_F64 1
@@ -205,6 +213,12 @@ int smm_hip_bicgsymmetric_f64(const smm_hip_csr* a, double* b, double* x, int ma
  * The matrix must outlive the preconditioner (the reference holds a const CSRMatrix&).  Structural failures
  * (missing or |d|<1e-5 diagonal, empty row, non-SPD IC0 pivot) return SMM_HIP_ERR_PRECOND. */
 int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out);
+/* The block kinds with a chosen block size: blocks of at most block_rows rows (64 .. 2048; 0 = the default, 1024) and at most 8192
+ * stored entries, cut greedily from row 0; smm_hip_precond_create uses the default.  The cut is a property of the handle:
+ * smm_hip_precond_block_bounds returns the nblocks + 1 row numbers (bounds[0] = 0, bounds[nblocks] = rows). */
+int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows, smm_hip_precond** out);
+int smm_hip_precond_block_count(const smm_hip_precond* M, int* nblocks);
+int smm_hip_precond_block_bounds(const smm_hip_precond* M, int* bounds, size_t count);
 int smm_hip_precond_destroy(smm_hip_precond* M);
 int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower, int* levels_upper);
 /* How the two triangular sweeps of SGS / ILU0 / IC0 run (same numbers bit for bit either way):
@@ -225,7 +239,8 @@ int smm_hip_precond_apply_dev_f64(const smm_hip_precond* M, const double* d_rhs,
  * it then publishes NaN and raises a sticky flag).  This call synchronises `stream`, returns SMM_HIP_ERR_HIP when a sweep applied on it
  * since the last call tripped the bound, and clears the flag.  The solver entry points call it themselves before they return. */
 int smm_hip_precond_take_error(const smm_hip_precond* M, smm_hip_stream stream);
-/* copies the factor values (ILU0 / IC0: nnz values on A's pattern; JACOBI: rows diagonal entries) to the host */
+/* copies the factor values (ILU0 / IC0 / BLOCK_ILU0: nnz values on A's pattern -- for BLOCK_ILU0 the entries that couple two blocks
+ * keep A's value; JACOBI: rows diagonal entries) to the host */
 int smm_hip_precond_values_f32(const smm_hip_precond* M, float* out, size_t count);
 int smm_hip_precond_values_f64(const smm_hip_precond* M, double* out, size_t count);
 

@@ -198,7 +198,8 @@ private:
 	int denseRowCount = 0, denseColCount = 0;
 };
 
-enum class SolverPreconditioner { NONE, SYMMETRIC_GAUS_SEIDEL, ILU0, JACOBI /* addition */ };  // ref:1002-1006
+// ref:1002-1006; JACOBI and the BLOCK_ forms (ILU0 / SGS of the block-diagonal part of A, smm_hip.h) are additions
+enum class SolverPreconditioner { NONE, SYMMETRIC_GAUS_SEIDEL, ILU0, JACOBI, BLOCK_ILU0, BLOCK_SGS };
 enum class SolverStatus { SUCCESS = 0, DIVERGED, MAX_ITERATIONS_REACHED };                       // ref:2010-2014
 
 // ---- CSRMatrix<T> (ref:1010-1641) -------------------------------------------------------------------------------------------
@@ -291,6 +292,18 @@ public:
 		IC0Preconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_IC0) {}
 		IC0Preconditioner(IC0Preconditioner&&) noexcept = default;
 	};
+	// additions: ILU0 / SGS of the block-diagonal part of A (blocks of <= 1024 rows; smm_hip.h, SMM_PRECOND_BLOCK_*)
+	class BlockILU0Preconditioner : public PreconditionerBase {
+	public:
+		BlockILU0Preconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_BLOCK_ILU0) {}
+		BlockILU0Preconditioner(BlockILU0Preconditioner&&) noexcept = default;
+		int validate() noexcept { return this->init(); }
+	};
+	class BlockSGSPreconditioner : public PreconditionerBase {
+	public:
+		BlockSGSPreconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_BLOCK_SGS) {}
+		BlockSGSPreconditioner(BlockSGSPreconditioner&&) noexcept = default;
+	};
 
 	CSRMatrix() noexcept = default;
 	CSRMatrix(const TripletMatrix<T>& triplet) noexcept { init(triplet); }
@@ -371,6 +384,10 @@ public:
 			return SGSPreconditioner(*this);
 		} else if constexpr (precond == SolverPreconditioner::ILU0) {
 			return ILU0Preconditioner(*this);
+		} else if constexpr (precond == SolverPreconditioner::BLOCK_ILU0) {
+			return BlockILU0Preconditioner(*this);
+		} else if constexpr (precond == SolverPreconditioner::BLOCK_SGS) {
+			return BlockSGSPreconditioner(*this);
 		} else {
 			return JacobiPreconditioner(*this);
 		}

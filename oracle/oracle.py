@@ -18,6 +18,7 @@ ORACLE_FMA_LIB = os.path.join(_HERE, "_build", "libsmm_oracle_fma.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libsmm_ref.so")
 
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_ILU0, PRECOND_SGS = 0, 1, 2, 3
+PRECOND_BLOCK_ILU0, PRECOND_BLOCK_SGS = 5, 6
 OP_ASSIGN, OP_ADD, OP_SUB = 0, 1, 2
 
 _SUF = {np.dtype(np.float32): ("f32", c_float), np.dtype(np.float64): ("f64", c_double)}
@@ -32,6 +33,18 @@ def build(ref=True):
 
 def _p(a):
     return a.ctypes.data_as(c_void_p) if a is not None else c_void_p(0)
+
+
+def block_diagonal_part(csr, bounds):
+    """(A with every entry that couples two row blocks removed, mask of the kept entries); bounds: nblocks + 1 row numbers"""
+    start, pos, val = csr
+    n = len(start) - 1
+    bounds = np.asarray(bounds)
+    rowof = np.repeat(np.arange(n), np.diff(start))
+    keep = (np.searchsorted(bounds, rowof, side="right") - 1) == (np.searchsorted(bounds, pos, side="right") - 1)
+    s2 = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rowof[keep], minlength=n), out=s2[1:])
+    return (s2, pos[keep].copy(), val[keep].copy()), keep
 
 
 def _c(a, dtype):
@@ -166,6 +179,43 @@ class Oracle:
                 ctypes.byref(res))
         return st, x, it.value, res.value
 
+    # ---- block preconditioners: the global algorithm on the block-diagonal part of A (bounds: nblocks + 1 row numbers) ----
+    def block_ilu0_factorize(self, csr, bounds):
+        start, pos, val = csr
+        bounds = _c(bounds, np.int32)
+        lu = np.zeros_like(val)
+        fn, _ = self._f("block_ilu0_factorize", val.dtype)
+        err = fn(c_int(len(start) - 1), _p(start), _p(pos), _p(val), c_int(len(bounds) - 1), _p(bounds), _p(lu))
+        return err, lu
+
+    def block_ilu0_apply(self, csr, bounds, lu, rhs):
+        start, pos, val = csr
+        bounds = _c(bounds, np.int32)
+        x = np.zeros_like(rhs)
+        fn, _ = self._f("block_ilu0_apply", val.dtype)
+        err = fn(c_int(len(start) - 1), _p(start), _p(pos), _p(lu), c_int(len(bounds) - 1), _p(bounds), _p(rhs), _p(x))
+        return err, x
+
+    def block_sgs_apply(self, csr, bounds, rhs):
+        start, pos, val = csr
+        bounds = _c(bounds, np.int32)
+        x = np.zeros_like(rhs)
+        fn, _ = self._f("block_sgs_apply", val.dtype)
+        err = fn(c_int(len(start) - 1), _p(start), _p(pos), _p(val), c_int(len(bounds) - 1), _p(bounds), _p(rhs), _p(x))
+        return err, x
+
+    def bicgstab_block(self, csr, b, x0, maxit, eps, precond, bounds, precond_values=None):
+        start, pos, val = csr
+        bounds = _c(bounds, np.int32)
+        x = x0.copy()
+        bb = b.copy()
+        it = c_int()
+        fn, ct = self._f("bicgstab_block", val.dtype)
+        res = ct()
+        st = fn(c_int(len(start) - 1), _p(start), _p(pos), _p(val), _p(bb), _p(x), c_int(maxit), ct(eps), c_int(precond), _p(precond_values),
+                c_int(len(bounds) - 1), _p(bounds), ctypes.byref(it), ctypes.byref(res))
+        return st, x, it.value, res.value
+
     def omp_threads(self):
         return self.lib.smm_oracle_omp_max_threads()
 
@@ -246,6 +296,14 @@ class Reference:
         bb = b.copy()
         fn, ct = self._f("bicgsymmetric", m.dtype)
         st = fn(m.h, _p(bb), _p(x), c_int(maxit), ct(eps))
+        return st, x
+
+    def bicgstab_sgs_of(self, m, m_precond, b, x0, maxit, eps):
+        """BiCGStab<SGSPreconditioner> on m with the SGS preconditioner of ANOTHER matrix (its block-diagonal part)"""
+        x = x0.copy()
+        bb = b.copy()
+        fn, ct = self._f("bicgstab_sgs_of", m.dtype)
+        st = fn(m.h, m_precond.h, _p(bb), _p(x), c_int(maxit), ct(eps))
         return st, x
 
     def sgs_apply(self, m, rhs):

@@ -98,9 +98,27 @@ int bicgstab(void* h, T* b, T* x, int maxIterations, T eps, int precond, const T
 	return -1;
 }
 
+// The reference's own BiCGStab template with the reference's own SGSPreconditioner taken from ANOTHER matrix (`hm`): with hm = the
+// block-diagonal part of A this is what SMM_PRECOND_BLOCK_SGS must reproduce.  The template takes any preconditioner object (:2191-2199).
+template <typename T>
+int bicgstabSgsOf(void* h, void* hm, T* b, T* x, int maxIterations, T eps) {
+	auto* a = static_cast<SMM::CSRMatrix<T>*>(h);
+	auto* m = static_cast<SMM::CSRMatrix<T>*>(hm);
+	using SGS = typename SMM::CSRMatrix<T>::SGSPreconditioner;
+	const SGS M = m->template getPreconditioner<SMM::SolverPreconditioner::SYMMETRIC_GAUS_SEIDEL>();
+	return static_cast<int>(SMM::BiCGStab<SGS, T>(*a, b, x, maxIterations, eps, M));
+}
+
 }  // namespace
 
 extern "C" {
+
+int ref_bicgstab_sgs_of_f32(void* h, void* hm, float* b, float* x, int maxIterations, float eps) {
+	return bicgstabSgsOf<float>(h, hm, b, x, maxIterations, eps);
+}
+int ref_bicgstab_sgs_of_f64(void* h, void* hm, double* b, double* x, int maxIterations, double eps) {
+	return bicgstabSgsOf<double>(h, hm, b, x, maxIterations, eps);
+}
 
 void* ref_csr_create_f32(int rows, int cols, const int* start, const int* positions, const float* values) {
 	return makeCsr<float>(rows, cols, start, positions, values);

@@ -10,6 +10,8 @@
  * bit-for-bit against the real reference header compiled in the build container (oracle/_ref, see
  * oracle/Makefile and tests/test_oracle_vs_reference.py) and against the reference's own known-answer
  * tests (test/cpp/csr.cpp:314,354,448,500; test/cpp/cg.cpp:55).
+ * block_sgs: the reference's SGS on the block-diagonal part of A -- pinned by running the real reference on that
+ * derived matrix (tests/test_oracle.py::test_block_sgs_is_reference_sgs_of_block_diagonal).  block_ilu0: unpinned like ilu0.
  * PARITY UNPINNED for jacobi and ilu0: the reference has no Jacobi preconditioner and its ILU0 is
  * declared but unusable (apply undefined, include/sparse_matrix_math.h:1199; factorize returns 2 on every
  * valid matrix, :1743-1746, :1777-1780).  Those two follow the textbook algorithm (Saad, Iterative Methods
@@ -36,7 +38,11 @@ enum { SMM_ORACLE_OP_ASSIGN = 0, SMM_ORACLE_OP_ADD = 1, SMM_ORACLE_OP_SUB = 2 };
 
 /* Preconditioner selector for bicgstab (0 = IDPreconditioner :1166-1170, 3 = SGSPreconditioner :1173-1186;
  * 1 and 2 are the additions north_star asks for) */
-enum { SMM_ORACLE_PRECOND_NONE = 0, SMM_ORACLE_PRECOND_JACOBI = 1, SMM_ORACLE_PRECOND_ILU0 = 2, SMM_ORACLE_PRECOND_SGS = 3 };
+enum {
+	SMM_ORACLE_PRECOND_NONE = 0, SMM_ORACLE_PRECOND_JACOBI = 1, SMM_ORACLE_PRECOND_ILU0 = 2, SMM_ORACLE_PRECOND_SGS = 3,
+	/* block-diagonal variants (additions): the global algorithm on the block-diagonal part of A, see smm_oracle_impl.inc */
+	SMM_ORACLE_PRECOND_BLOCK_ILU0 = 5, SMM_ORACLE_PRECOND_BLOCK_SGS = 6
+};
 
 #define SMM_ORACLE_DECLARE(T, S)                                                                                   \
 	void smm_oracle_spmv_##S(int rows, const int* start, const int* positions, const T* values, int op,           \
@@ -59,6 +65,16 @@ enum { SMM_ORACLE_PRECOND_NONE = 0, SMM_ORACLE_PRECOND_JACOBI = 1, SMM_ORACLE_PR
 	                                  T* luval);                                                                   \
 	int smm_oracle_ilu0_apply_##S(int rows, const int* start, const int* positions, const T* luval,               \
 	                              const T* rhs, T* x);                                                             \
+	int smm_oracle_block_ilu0_factorize_##S(int rows, const int* start, const int* positions, const T* values,    \
+	                                        int nblocks, const int* bounds, T* luval);                             \
+	int smm_oracle_block_ilu0_apply_##S(int rows, const int* start, const int* positions, const T* luval,         \
+	                                    int nblocks, const int* bounds, const T* rhs, T* x);                       \
+	int smm_oracle_block_sgs_apply_##S(int rows, const int* start, const int* positions, const T* values,         \
+	                                   int nblocks, const int* bounds, const T* rhs, T* x);                        \
+	int smm_oracle_block_of_##S(int nblocks, const int* bounds, int row);                                          \
+	int smm_oracle_bicgstab_block_##S(int rows, const int* start, const int* positions, const T* values, T* b,    \
+	                                  T* x, int maxIterations, T eps, int precond, const T* precond_values,        \
+	                                  int nblocks, const int* bounds, int* iterations, T* resnorm);                \
 	int smm_oracle_ic0_factorize_##S(int rows, const int* start, const int* positions, const T* values,           \
 	                                 T* ic0val);                                                                   \
 	int smm_oracle_ic0_apply_##S(int rows, const int* start, const int* positions, const T* ic0val,               \

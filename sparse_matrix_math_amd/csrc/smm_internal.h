@@ -133,6 +133,7 @@ struct smm_hip_precond {
 	int* d_order_up = nullptr;
 	std::vector<int> lvl_ptr_lo, lvl_ptr_up;  // host: level l covers order[lvl_ptr[l] .. lvl_ptr[l+1])
 	struct smm_precond_plan* plan = nullptr;  // launch groups of the two sweeps (smm_precond.hip)
+	struct smm_precond_block* blk = nullptr;  // BLOCK_ILU0 / BLOCK_SGS: row blocks + packed sweep records (smm_precond_block.hip)
 };
 
 namespace smm {
@@ -176,6 +177,9 @@ inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
 }
 
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s);
+// greedy cut of the rows into runs of <= capNnz stored entries and <= maxRows rows, on the device: tiles[0 .. nTiles] = {first row,
+// start[first row]}, closed by {rows, nnz}; allocated with devAlloc, owned by the caller; synchronises `s`
+int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows, hipStream_t s, int2** tiles, int* nTiles);
 // streamKnown: `s` is the stream the caller orders its work on (the `_dev` entry points); otherwise (host-side queries and set-up
 // calls that have no stream) the whole device is drained first and the library's own stream is used
 int ensureCsrReady(const smm_hip_csr* m, hipStream_t s, bool streamKnown);
@@ -278,5 +282,16 @@ template <typename T>
 int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* doneFlag, hipStream_t s);
 // sticky error of the synchronisation-free sweeps applied on `s`; synchronises `s`.  M may be null.
 int precondTakeError(const smm_hip_precond* M, hipStream_t s);
+
+// block preconditioners (smm_precond_block.hip)
+inline bool isBlockKind(int kind) { return kind == SMM_PRECOND_BLOCK_ILU0 || kind == SMM_PRECOND_BLOCK_SGS; }
+template <typename T>
+int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_precond* M);
+// x = M^-1 rhs; dotMode / w1 / partials: dot products of x fused into the epilogue, as in launchSpmv (partials: 2 * NPART elements)
+template <typename T>
+int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s);
+void blockDestroy(struct smm_precond_block* B);
+void blockLevels(const struct smm_precond_block* B, int* lo, int* up);
+int blockDefaultRows();
 
 }  // namespace smm

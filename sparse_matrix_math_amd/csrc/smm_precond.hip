@@ -761,6 +761,7 @@ int precondApplyDev(const smm_hip_precond* M, const T* rhs, T* x, const int* don
 		setError("precond_apply: null vector or rhs aliases x");
 		return SMM_HIP_ERR_INVALID;
 	}
+	if (isBlockKind(M->kind)) return blockApplyDev<T>(M, rhs, x, 0, nullptr, nullptr, doneFlag, s);
 	if (M->kind == SMM_PRECOND_JACOBI) {
 		const int grid = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
 		jacobiApplyKernel<T><<<grid, TPB, 0, s>>>(n, static_cast<const T*>(M->d_values), rhs, x, doneFlag);
@@ -1014,13 +1015,13 @@ using namespace smm;
 
 extern "C" {
 
-int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out) {
+static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, smm_hip_precond** out) {
 	if (!a || !out) {
 		setError("precond_create: null argument");
 		return SMM_HIP_ERR_INVALID;
 	}
 	*out = nullptr;
-	if (kind < SMM_PRECOND_NONE || kind > SMM_PRECOND_IC0) {
+	if (kind < SMM_PRECOND_NONE || kind > SMM_PRECOND_BLOCK_SGS) {
 		setError("precond_create: unknown kind %d", kind);
 		return SMM_HIP_ERR_INVALID;
 	}
@@ -1031,7 +1032,9 @@ int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out
 	M->dtype = a->dtype;
 	M->a = a;
 	int st = SMM_HIP_OK;
-	if (kind != SMM_PRECOND_NONE) {
+	if (isBlockKind(kind)) {
+		st = a->dtype == SMM_DTYPE_F32 ? blockCreateTyped<float>(a, kind, blockRows, M) : blockCreateTyped<double>(a, kind, blockRows, M);
+	} else if (kind != SMM_PRECOND_NONE) {
 		st = a->dtype == SMM_DTYPE_F32 ? createTyped<float>(a, kind, M) : createTyped<double>(a, kind, M);
 	}
 	if (st != SMM_HIP_OK) {
@@ -1042,8 +1045,23 @@ int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out
 	return SMM_HIP_OK;
 }
 
+int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out) { return precondCreate(a, kind, blockDefaultRows(), out); }
+
+int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows, smm_hip_precond** out) {
+	if (!isBlockKind(kind)) {
+		setError("precond_create_block: kind %d is not a block preconditioner", kind);
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (block_rows != 0 && (block_rows < 64 || block_rows > 2048)) {
+		setError("precond_create_block: block_rows must be 0 (default) or 64 .. 2048");
+		return SMM_HIP_ERR_INVALID;
+	}
+	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), out);
+}
+
 int smm_hip_precond_destroy(smm_hip_precond* M) {
 	if (!M) return SMM_HIP_OK;
+	blockDestroy(M->blk);
 	smm_precond_plan* plan = M->plan;
 	if (plan) {
 		devFree(plan->lo.d_lvlPtr);
@@ -1067,6 +1085,10 @@ int smm_hip_precond_info(const smm_hip_precond* M, int* kind, int* levels_lower,
 		return SMM_HIP_ERR_INVALID;
 	}
 	if (kind) *kind = M->kind;
+	if (M->blk) {  // block kinds: the deepest block
+		blockLevels(M->blk, levels_lower, levels_upper);
+		return SMM_HIP_OK;
+	}
 	if (levels_lower) *levels_lower = M->lvl_ptr_lo.empty() ? 0 : static_cast<int>(M->lvl_ptr_lo.size()) - 1;
 	if (levels_upper) *levels_upper = M->lvl_ptr_up.empty() ? 0 : static_cast<int>(M->lvl_ptr_up.size()) - 1;
 	return SMM_HIP_OK;

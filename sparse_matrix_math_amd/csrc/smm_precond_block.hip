@@ -1,0 +1,991 @@
+// smm_precond_block.hip -- BLOCK_ILU0 / BLOCK_SGS: the ILU(0) / Symmetric Gauss-Seidel preconditioner of the block-diagonal part of A,
+// one WAVEFRONT per block, the block's vector in LDS, one launch per apply.
+//
+// Why (profiles/r02/sweep_timing.txt): the exact global sweeps of smm_precond.hip pay one fabric round trip (1.2-1.8 us) per
+// dependency level -- 644 of them per apply on the 108^3 convection-diffusion problem -- and lose to the unpreconditioned solve.  Here
+// the rows are cut into contiguous blocks (<= 1024 rows, <= 8192 stored entries), couplings between blocks are dropped from M only, and
+// every dependency of a sweep stays inside one wavefront: a level costs one LDS round trip (~60 ns), all blocks run at the same time.
+//
+// Per block, built once at create time (all on the device):
+//   * the dependency levels of the lower and of the upper sweep, rows sorted by level, cut into CHUNKS of 64 sorted rows;
+//   * for ILU0 the factorisation of the block (IKJ on the block's pattern, one lane per row, level by level, out of LDS);
+//   * one fixed-size RECORD per (chunk, lane) and sweep: {row, level, count | columns (16-bit, local) | diagonal | values} of that
+//     row's first KREG in-block entries in the order the sequential sweep visits them; rows with more entries continue in an
+//     overflow list.  Records of a chunk are adjacent, so a wavefront streams them with 8-byte loads, D chunks ahead of their use.
+// Apply (blkApplyKernel): a wavefront loads its block's slice of rhs into LDS, walks the lower chunks and then the upper ones, and
+// inside a chunk the levels one after the other: the lanes whose row is in that level read the x[] they need from LDS, run the
+// row's multiply-adds in the sequential order and store the row's result -- the LDS pipeline of a wavefront is in order, so a later
+// level sees it without any barrier.  Same operands, same order, same roundings as the sequential sweeps over the block-diagonal
+// matrix (the tests compare bit for bit with the CPU restatement of exactly that), and BLOCK_SGS thereby the reference's SGSPreconditioner::apply
+// (ref:1658-1713) on that matrix.  The dot products BiCGStab needs of the result ride in the epilogue.
+#include <algorithm>
+#include <cmath>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "smm_device.h"
+#include "smm_internal.h"
+
+struct smm_precond_block {
+	int nBlocks = 0;
+	int blockRows = 0;      // the cut: at most this many rows ...
+	int capNnz = 0;         // ... and this many stored entries per block
+	int kreg = 2;           // in-block entries per row and sweep that live in the records
+	bool overflow = false;  // some row has more than kreg: the rest is in the overflow lists
+	int levelsLo = 0, levelsUp = 0;  // deepest block
+	long long nChunks = 0;
+	int2* d_bounds = nullptr;  // [nBlocks + 1] {first row, start[first row]}
+	int* d_chunk0 = nullptr;   // [nBlocks + 1] chunks in front of block b
+	unsigned* d_recLo = nullptr;
+	unsigned* d_recUp = nullptr;
+	int* d_ovPtrLo = nullptr;  // [nChunks * 64 + 1] when overflow
+	int* d_ovPtrUp = nullptr;
+	unsigned short* d_ovColLo = nullptr;
+	unsigned short* d_ovColUp = nullptr;
+	void* d_ovValLo = nullptr;
+	void* d_ovValUp = nullptr;
+	std::vector<int> hostBounds;  // filled on first query
+	std::mutex boundsMutex;
+};
+
+namespace smm {
+
+constexpr int BLK_TPB = 256;            // set-up kernels: one workgroup per block
+constexpr int BLK_DEFAULT_ROWS = 1024;
+constexpr int BLK_MIN_ROWS = 64;
+constexpr int BLK_MAX_ROWS = 2048;
+constexpr int BLK_CAP_NNZ = 8192;
+constexpr unsigned BLK_NOROW = 0xFFFu;  // row field of a padding lane
+constexpr unsigned short BLK_UNKNOWN = 0xFFFFu;
+
+enum BlkMode { B_ILU_LO = 0, B_ILU_UP = 1, B_SGS_LO = 2, B_SGS_UP = 3 };
+
+// record of one (chunk, lane): dwords {meta | ceil(KREG / 2) column pairs | [diagonal] | KREG values}, padded to an even count
+template <typename T, bool HASD, int KREG>
+struct RecLayout {
+	static constexpr int VW = sizeof(T) / 4;
+	static constexpr int COLW = (KREG + 1) / 2;
+	static constexpr int DIAG_AT = 1 + COLW;
+	static constexpr int VAL_AT = DIAG_AT + (HASD ? VW : 0);
+	static constexpr int RAW = VAL_AT + VW * KREG;
+	static constexpr int DW = (RAW + 1) & ~1;
+};
+
+template <typename T>
+__device__ __forceinline__ T fromWords(const unsigned* w) {
+	T v;
+	if (sizeof(T) == 4) {
+		__builtin_memcpy(&v, w, 4);
+	} else {
+		const unsigned long long b = static_cast<unsigned long long>(w[0]) | (static_cast<unsigned long long>(w[1]) << 32);
+		__builtin_memcpy(&v, &b, 8);
+	}
+	return v;
+}
+template <typename T>
+__device__ __forceinline__ void toWords(T v, unsigned* w) {
+	if (sizeof(T) == 4) {
+		__builtin_memcpy(w, &v, 4);
+	} else {
+		unsigned long long b;
+		__builtin_memcpy(&b, &v, 8);
+		w[0] = static_cast<unsigned>(b);
+		w[1] = static_cast<unsigned>(b >> 32);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// apply
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct BlkApplyArgs {
+	int nBlocks;
+	const int2* bounds;
+	const int* chunk0;
+	const unsigned* recLo;
+	const unsigned* recUp;
+	const int* ovPtrLo;
+	const int* ovPtrUp;
+	const unsigned short* ovColLo;
+	const unsigned short* ovColUp;
+	const T* ovValLo;
+	const T* ovValUp;
+	const T* rhs;
+	T* x;
+	int dotMode;  // 0 none; 1: x.w1 -> partials[0..NPART); 2: x.x -> partials[0..NPART), x.w1 -> partials[NPART..2 NPART)
+	const T* w1;
+	T* partials;
+	const int* doneFlag;
+};
+
+template <int DW>
+__device__ __forceinline__ void loadRec(unsigned (&w)[DW], const uint2* p) {
+#pragma unroll
+	for (int i = 0; i < DW / 2; ++i) {
+		const uint2 v = p[i];
+		w[2 * i] = v.x;
+		w[2 * i + 1] = v.y;
+	}
+}
+
+// one sweep of one block: nc chunks of records starting at `rec` (the block's first chunk, lane 0); xs = the block's vector in LDS
+template <typename T, int MODE, int KREG, bool OV, int D>
+__device__ __forceinline__ void blkSweep(const unsigned* __restrict__ rec, long long recIndex0, int nc, T* xs, const int* __restrict__ ovPtr,
+                                         const unsigned short* __restrict__ ovCol, const T* __restrict__ ovVal) {
+	constexpr bool LOWER = MODE == B_ILU_LO || MODE == B_SGS_LO;
+	constexpr bool HASD = MODE != B_ILU_LO;
+	using L = RecLayout<T, HASD, KREG>;
+	constexpr int DW = L::DW;
+	const int lane = threadIdx.x;
+	const uint2* base = reinterpret_cast<const uint2*>(rec) + static_cast<size_t>(lane) * (DW / 2);
+	constexpr size_t CHUNK_STRIDE = static_cast<size_t>(WAVE) * (DW / 2);  // in uint2
+	// Register sets: chunk c lives in set c % (2 D) and is loaded D chunks before its use into the set chunk c - D has just left --
+	// so a set is never reloaded while it is read, no register is copied at the loop's back edge, and the wait in front of a
+	// chunk's first use counts only the younger loads (the D chunks behind it stay in flight).
+	constexpr int U = 2 * D;
+	unsigned ring[U][DW];
+	// Every load is issued unconditionally (past the end: the last chunk again), so that the number of loads in flight is the same
+	// on every path and the compiler can wait with a count instead of draining the queue.
+#pragma unroll
+	for (int d = 0; d < D; ++d) loadRec<DW>(ring[d], base + static_cast<size_t>(min(d, nc - 1)) * CHUNK_STRIDE);
+	for (int c0 = 0; c0 < nc; c0 += U) {
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int c = c0 + u;
+			loadRec<DW>(ring[(u + D) % U], base + static_cast<size_t>(min(c + D, nc - 1)) * CHUNK_STRIDE);
+			if (c < nc) {
+				const unsigned(&w)[DW] = ring[u];
+				const unsigned meta = w[0];
+				const unsigned row = meta & 0xFFFu;
+				const int lvl = static_cast<int>((meta >> 12) & 0xFFFu);
+				const int n = static_cast<int>(meta >> 24);  // in-block entries of this sweep, capped at 255
+				const bool valid = row != BLK_NOROW;
+				const int lFirst = __builtin_amdgcn_readfirstlane(lvl);
+				const int lLast = __builtin_amdgcn_readlane(lvl, WAVE - 1);
+				const T own = valid ? xs[row] : T(0);  // rhs (lower sweep) or y (upper sweep) of the lane's row: no other row writes it
+				for (int lv = lFirst; lv <= lLast; ++lv) {
+					if (valid && lvl == lv) {
+						T xv[KREG];
+#pragma unroll
+						for (int k = 0; k < KREG; ++k) {
+							if (k < n) {
+								const unsigned col = (w[1 + k / 2] >> (16 * (k & 1))) & 0xFFFFu;
+								xv[k] = xs[col];
+							}
+						}
+						T acc = MODE == B_SGS_UP ? T(0) : own;
+#pragma unroll
+						for (int k = 0; k < KREG; ++k) {
+							if (k < n) {
+								const T val = fromWords<T>(&w[L::VAL_AT + L::VW * k]);
+								acc = MODE == B_SGS_UP ? smmFma(val, xv[k], acc) : smmFma(-val, xv[k], acc);  // ref:1706 / ref:1686
+							}
+						}
+						if (OV && n > KREG) {  // the tail of a long row, straight from memory (slow path)
+							const long long g = recIndex0 + static_cast<long long>(c) * WAVE + lane;
+							for (int e = ovPtr[g]; e < ovPtr[g + 1]; ++e) {
+								const T val = ovVal[e];
+								const T xo = xs[ovCol[e]];
+								acc = MODE == B_SGS_UP ? smmFma(val, xo, acc) : smmFma(-val, xo, acc);
+							}
+						}
+						T result;
+						if (MODE == B_ILU_LO) {
+							result = acc;
+						} else {
+							const T diag = fromWords<T>(&w[L::DIAG_AT]);
+							if (MODE == B_SGS_UP) result = own - acc / diag;  // ref:1710
+							else result = acc / diag;                          // ref:1694; ILU: U x = y
+						}
+						xs[row] = result;
+					}
+				}
+			}
+		}
+	}
+	(void)LOWER;
+}
+
+template <typename T, int KIND, int KREG, bool OV, int D>
+__global__ __launch_bounds__(WAVE) void blkApplyKernel(const BlkApplyArgs<T> a) {
+	extern __shared__ __align__(16) unsigned char blkLds[];
+	T* xs = reinterpret_cast<T*>(blkLds);
+	if (a.doneFlag && *a.doneFlag) return;
+	constexpr int LO = KIND == SMM_PRECOND_BLOCK_ILU0 ? B_ILU_LO : B_SGS_LO;
+	constexpr int UP = KIND == SMM_PRECOND_BLOCK_ILU0 ? B_ILU_UP : B_SGS_UP;
+	using LL = RecLayout<T, LO != B_ILU_LO, KREG>;
+	using LU = RecLayout<T, true, KREG>;
+	const int lane = threadIdx.x;
+	T acc0 = T(0), acc1 = T(0);
+	for (int b = blockIdx.x; b < a.nBlocks; b += gridDim.x) {
+		const int r0 = a.bounds[b].x;
+		const int nb = a.bounds[b + 1].x - r0;
+		const int nc = (nb + WAVE - 1) / WAVE;
+		const long long rec0 = static_cast<long long>(a.chunk0[b]) * WAVE;
+		for (int i = lane; i < nb; i += WAVE) xs[i] = a.rhs[r0 + i];
+		blkSweep<T, LO, KREG, OV, D>(a.recLo + rec0 * LL::DW, rec0, nc, xs, a.ovPtrLo, a.ovColLo, a.ovValLo);
+		blkSweep<T, UP, KREG, OV, D>(a.recUp + rec0 * LU::DW, rec0, nc, xs, a.ovPtrUp, a.ovColUp, a.ovValUp);
+		if (a.dotMode == 0) {
+			for (int i = lane; i < nb; i += WAVE) a.x[r0 + i] = xs[i];
+		} else {
+			for (int i = lane; i < nb; i += WAVE) {
+				const T v = xs[i];
+				a.x[r0 + i] = v;
+				const T w = a.w1[r0 + i];
+				if (a.dotMode == 2) {
+					acc0 += v * v;
+					acc1 += v * w;
+				} else {
+					acc0 += v * w;
+				}
+			}
+		}
+	}
+	if (a.dotMode != 0) {
+		acc0 = groupSum<WAVE>(acc0);
+		if (a.dotMode == 2) acc1 = groupSum<WAVE>(acc1);
+		if (lane == 0) {
+			a.partials[blockIdx.x] = acc0;
+			if (a.dotMode == 2) a.partials[NPART + blockIdx.x] = acc1;
+		}
+		// every slot is (re)written by every launch: idle slots hold 0
+		for (int i = gridDim.x + blockIdx.x * WAVE + lane; i < NPART; i += gridDim.x * WAVE) {
+			a.partials[i] = T(0);
+			if (a.dotMode == 2) a.partials[NPART + i] = T(0);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// set-up
+// ---------------------------------------------------------------------------------------------------------
+__global__ void blkChunkCountKernel(int nBlocks, const int2* __restrict__ bounds, int* __restrict__ counts) {
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < nBlocks) counts[b] = (bounds[b + 1].x - bounds[b].x + WAVE - 1) / WAVE;
+	if (b == nBlocks) counts[b] = 0;
+}
+
+// exclusive scan of v over the 256 threads of a workgroup; *total = the sum.  scratch: 8 ints of LDS.
+__device__ __forceinline__ int blockExclusiveScan256(int v, int* scratch, int* total) {
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int wave = threadIdx.x >> 6;
+	int incl = v;
+#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) {
+		const int t = __shfl_up(incl, o, WAVE);
+		if (lane >= o) incl += t;
+	}
+	if (lane == WAVE - 1) scratch[wave] = incl;
+	__syncthreads();
+	int offset = 0;
+	for (int k = 0; k < wave; ++k) offset += scratch[k];
+	const int all = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+	__syncthreads();
+	*total = all;
+	return offset + incl - v;
+}
+
+// first index in positions[lo .. hi) with positions[.] >= key
+__device__ __forceinline__ int lowerBoundCol(const int* __restrict__ positions, int lo, int hi, int key) {
+	while (lo < hi) {
+		const int mid = lo + (hi - lo) / 2;
+		if (positions[mid] < key) lo = mid + 1;
+		else hi = mid;
+	}
+	return lo;
+}
+
+// The block's own CSR (entries whose column lies inside the block, columns local) in LDS.  ROWS_PER_THREAD * 256 >= blockRows.
+struct BlkStage {
+	int* lptr;             // [maxRows + 1]
+	int* ibG;              // [maxRows]   global index of the first in-block entry of the row
+	unsigned short* nlow;  // [maxRows]   in-block entries left of the diagonal
+	unsigned short* lcol;  // [cap]
+};
+
+// returns bit 0: some row of this thread has no diagonal entry (or is empty), bit 1 (checkMagnitude): |d| < 1e-5; fills st.lptr / ibG / nlow / lcol (and lval when LVAL is not null)
+template <typename T>
+__device__ int stageBlock(const BlkStage& st, T* lval, int r0, int nb, const int* __restrict__ start, const int* __restrict__ positions,
+                          const T* __restrict__ vals, int* scanScratch, int checkMagnitude = 0) {
+	constexpr int RPT = BLK_MAX_ROWS / BLK_TPB;  // 8 consecutive rows per thread
+	const int t = threadIdx.x;
+	int cnt[RPT], ib[RPT];
+	int mine = 0;
+#pragma unroll
+	for (int j = 0; j < RPT; ++j) {
+		const int i = t * RPT + j;
+		cnt[j] = 0;
+		ib[j] = 0;
+		if (i < nb) {
+			const int b = start[r0 + i], e = start[r0 + i + 1];
+			const int lo = lowerBoundCol(positions, b, e, r0);
+			const int hi = lowerBoundCol(positions, lo, e, r0 + nb);
+			ib[j] = lo;
+			cnt[j] = hi - lo;
+		}
+		mine += cnt[j];
+	}
+	int total = 0;
+	int at = blockExclusiveScan256(mine, scanScratch, &total);
+	int bad = 0;
+#pragma unroll
+	for (int j = 0; j < RPT; ++j) {
+		const int i = t * RPT + j;
+		if (i < nb) {
+			st.lptr[i] = at;
+			st.ibG[i] = ib[j];
+			int low = 0;
+			bool diag = false;
+			for (int e = 0; e < cnt[j]; ++e) {
+				const int c = positions[ib[j] + e] - r0;
+				st.lcol[at + e] = static_cast<unsigned short>(c);
+				if (lval) lval[at + e] = vals[ib[j] + e];
+				low += c < i ? 1 : 0;
+				if (c == i) {
+					diag = true;
+					if (checkMagnitude) {  // |d| >= 1e-5, ref:1691-1693
+						const T d = vals[ib[j] + e];
+						if ((d < T(0) ? -d : d) < T(1e-5)) bad |= 2;
+					}
+				}
+			}
+			st.nlow[i] = static_cast<unsigned short>(low);
+			if (!diag) bad |= 1;
+			at += cnt[j];
+		}
+	}
+	if (t == 0) st.lptr[nb] = total;
+	__syncthreads();
+	return bad;
+}
+
+// Levels of one sweep by ONE wavefront (call with the first 64 threads): rows in the sweep's natural order, 64 at a time; a lane
+// consumes the entries of its row whose level is known, and publishes its own level once all are -- a later pass of the same
+// wavefront sees it (LDS is in order for a wavefront).  The first unfinished lane always finishes within a pass: <= 64 passes per
+// chunk.  Returns the largest level (>= 2^20: the pass bound tripped).
+template <bool LOWER>
+__device__ int blkLevels(const BlkStage& st, int nb, unsigned short* lvl) {
+	const int lane = threadIdx.x & (WAVE - 1);
+	int top = 0;
+	for (int c = 0; c * WAVE < nb; ++c) {
+		const int q = c * WAVE + lane;
+		bool pending = q < nb;
+		const int i = LOWER ? q : nb - 1 - q;
+		int k = 0, kEnd = 0, lv = 0;
+		if (pending) {
+			if (LOWER) {
+				k = st.lptr[i];
+				kEnd = k + st.nlow[i];
+			} else {
+				k = st.lptr[i + 1] - 1;
+				kEnd = st.lptr[i] + st.nlow[i];  // the diagonal: entries (kEnd, lptr[i+1]) are the upper part
+			}
+		}
+		for (int pass = 0; pass <= WAVE && __ballot(pending) != 0ull; ++pass) {
+			if (pending) {
+				while (LOWER ? k < kEnd : k > kEnd) {
+					const unsigned short d = lvl[st.lcol[k]];
+					if (d == BLK_UNKNOWN) break;
+					lv = max(lv, static_cast<int>(d) + 1);
+					k += LOWER ? 1 : -1;
+				}
+				if (LOWER ? k >= kEnd : k <= kEnd) {
+					lvl[i] = static_cast<unsigned short>(lv);
+					pending = false;
+				}
+			}
+		}
+		if (pending) {  // cannot happen (see above); never leave a row without a level
+			lvl[i] = static_cast<unsigned short>(lv);
+			top = 1 << 20;
+		}
+		top = max(top, lv);
+	}
+#pragma unroll
+	for (int o = WAVE / 2; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o, WAVE));
+	return top;
+}
+
+// rows sorted by level (all 256 threads): hist[] is scratch of maxRows + 1 ints; ord[q] = row at sorted position q
+__device__ void blkSortByLevel(int nb, const unsigned short* lvl, int* hist, unsigned short* ord, int* scanScratch) {
+	constexpr int RPT = BLK_MAX_ROWS / BLK_TPB;
+	const int t = threadIdx.x;
+	for (int i = t; i <= nb; i += BLK_TPB) hist[i] = 0;
+	__syncthreads();
+	for (int i = t; i < nb; i += BLK_TPB) atomicAdd(&hist[lvl[i]], 1);
+	__syncthreads();
+	int h[RPT];
+	int mine = 0;
+#pragma unroll
+	for (int j = 0; j < RPT; ++j) {
+		const int i = t * RPT + j;
+		h[j] = i < nb ? hist[i] : 0;
+		mine += h[j];
+	}
+	int total = 0;
+	int at = blockExclusiveScan256(mine, scanScratch, &total);
+#pragma unroll
+	for (int j = 0; j < RPT; ++j) {
+		const int i = t * RPT + j;
+		if (i < nb) hist[i] = at;
+		at += h[j];
+	}
+	__syncthreads();
+	for (int i = t; i < nb; i += BLK_TPB) {
+		const int q = atomicAdd(&hist[lvl[i]], 1);
+		ord[q] = static_cast<unsigned short>(i);
+	}
+	__syncthreads();
+}
+
+// LDS carve-up shared by the two set-up kernels
+__device__ __forceinline__ unsigned char* carve(unsigned char*& p, size_t bytes) {
+	unsigned char* q = p;
+	p += (bytes + 15) & ~static_cast<size_t>(15);
+	return q;
+}
+static size_t carveSize(size_t bytes) { return (bytes + 15) & ~static_cast<size_t>(15); }
+
+// info: [0] most lower entries of a row, [1] most upper entries, [2] error bits (1: empty row / missing diagonal, 2: |d| < 1e-5 for
+// SGS), [3] deepest lower sweep, [4] deepest upper sweep (levels)
+template <typename T>
+__global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
+                                                           const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
+                                                           int checkMagnitude, unsigned* __restrict__ metaLo, unsigned* __restrict__ metaUp,
+                                                           unsigned short* __restrict__ nEntLo, unsigned short* __restrict__ nEntUp, int* info) {
+	extern __shared__ __align__(16) unsigned char blkLds[];
+	unsigned char* p = blkLds;
+	BlkStage st;
+	st.lptr = reinterpret_cast<int*>(carve(p, (maxRows + 1) * sizeof(int)));
+	st.ibG = reinterpret_cast<int*>(carve(p, maxRows * sizeof(int)));
+	st.nlow = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
+	st.lcol = reinterpret_cast<unsigned short*>(carve(p, cap * sizeof(unsigned short)));
+	unsigned short* lvlLo = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
+	unsigned short* lvlUp = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
+	unsigned short* ord = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
+	int* hist = reinterpret_cast<int*>(carve(p, (maxRows + 1) * sizeof(int)));
+	int* scanScratch = reinterpret_cast<int*>(carve(p, 8 * sizeof(int)));
+	int* tops = reinterpret_cast<int*>(carve(p, 4 * sizeof(int)));
+
+	const int b = blockIdx.x;
+	const int r0 = bounds[b].x;
+	const int nb = bounds[b + 1].x - r0;
+	const int nc = (nb + WAVE - 1) / WAVE;
+	const long long rec0 = static_cast<long long>(chunk0[b]) * WAVE;
+	const int t = threadIdx.x;
+
+	const int bad = stageBlock<T>(st, nullptr, r0, nb, start, positions, vals, scanScratch, checkMagnitude);
+	if (bad) atomicOr(info + 2, bad);
+	for (int i = t; i < nb; i += BLK_TPB) {
+		lvlLo[i] = BLK_UNKNOWN;
+		lvlUp[i] = BLK_UNKNOWN;
+	}
+	// a missing diagonal makes nlow / the upper part meaningless: the create call fails anyway, skip the analysis
+	if (__syncthreads_or(bad & 1) != 0) return;
+	if (t < WAVE) {  // two wavefronts, one sweep each, at the same time
+		const int top = blkLevels<true>(st, nb, lvlLo);
+		if (t == 0) tops[0] = top;
+	} else if (t < 2 * WAVE) {
+		const int top = blkLevels<false>(st, nb, lvlUp);
+		if (t == WAVE) tops[1] = top;
+	}
+	__syncthreads();
+	if (t == 0) {
+		if (tops[0] >= (1 << 20) || tops[1] >= (1 << 20)) atomicOr(info + 2, 8);
+		atomicMax(info + 3, (tops[0] & 0xFFFFF) + 1);
+		atomicMax(info + 4, (tops[1] & 0xFFFFF) + 1);
+	}
+	int mostLo = 0, mostUp = 0;
+	// lower sweep: sorted order, meta, entry counts
+	blkSortByLevel(nb, lvlLo, hist, ord, scanScratch);
+	for (int q = t; q < nc * WAVE; q += BLK_TPB) {
+		unsigned meta;
+		int n = 0;
+		if (q < nb) {
+			const int row = ord[q];
+			n = st.nlow[row];
+			meta = static_cast<unsigned>(row) | (static_cast<unsigned>(lvlLo[row]) << 12) | (static_cast<unsigned>(min(n, 255)) << 24);
+		} else {
+			meta = BLK_NOROW | (static_cast<unsigned>(lvlLo[ord[nb - 1]]) << 12);
+		}
+		metaLo[rec0 + q] = meta;
+		nEntLo[rec0 + q] = static_cast<unsigned short>(n);
+		mostLo = max(mostLo, n);
+	}
+	__syncthreads();
+	blkSortByLevel(nb, lvlUp, hist, ord, scanScratch);
+	for (int q = t; q < nc * WAVE; q += BLK_TPB) {
+		unsigned meta;
+		int n = 0;
+		if (q < nb) {
+			const int row = ord[q];
+			n = st.lptr[row + 1] - st.lptr[row] - st.nlow[row] - 1;
+			meta = static_cast<unsigned>(row) | (static_cast<unsigned>(lvlUp[row]) << 12) | (static_cast<unsigned>(min(n, 255)) << 24);
+		} else {
+			meta = BLK_NOROW | (static_cast<unsigned>(lvlUp[ord[nb - 1]]) << 12);
+		}
+		metaUp[rec0 + q] = meta;
+		nEntUp[rec0 + q] = static_cast<unsigned short>(n);
+		mostUp = max(mostUp, n);
+	}
+#pragma unroll
+	for (int o = WAVE / 2; o > 0; o >>= 1) {
+		mostLo = max(mostLo, __shfl_xor(mostLo, o, WAVE));
+		mostUp = max(mostUp, __shfl_xor(mostUp, o, WAVE));
+	}
+	if ((t & (WAVE - 1)) == 0) {
+		if (mostLo) atomicMax(info + 0, mostLo);
+		if (mostUp) atomicMax(info + 1, mostUp);
+	}
+}
+
+// entries beyond the KREG a record holds
+__global__ void blkOverflowCountKernel(long long n, int kreg, const unsigned short* __restrict__ nEnt, int* __restrict__ counts) {
+	const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n) counts[i] = max(0, static_cast<int>(nEnt[i]) - kreg);
+	if (i == n) counts[i] = 0;
+}
+
+// ILU(0) of one row of the block, by one lane, out of LDS: IKJ on the block's pattern (Saad, Alg. 10.4), the arithmetic of
+// the sequential textbook loop: l_ik = a_ik * (1 / u_kk); a_ij -= l_ik * u_kj for the j both rows hold.  Row k (an earlier level)
+// is final.  Both rows are ascending, so the search for column j in row i is a merge walk.
+template <typename T>
+__device__ __forceinline__ bool blkIluRow(const BlkStage& st, T* lval, T* pinv, int i) {
+	const int rb = st.lptr[i], re = st.lptr[i + 1];
+	const int kd = rb + st.nlow[i];
+	for (int q = rb; q < kd; ++q) {
+		const int k = st.lcol[q];
+		const T lik = lval[q] * pinv[k];
+		lval[q] = lik;
+		int tgt = q + 1;
+		for (int u = st.lptr[k] + st.nlow[k] + 1; u < st.lptr[k + 1]; ++u) {
+			const int c = st.lcol[u];
+			while (tgt < re && st.lcol[tgt] < c) ++tgt;
+			if (tgt < re && st.lcol[tgt] == c) lval[tgt] = lval[tgt] - lik * lval[u];
+		}
+	}
+	const T piv = lval[kd];
+	const bool ok = (piv < T(0) ? -piv : piv) >= T(1e-6);
+	pinv[i] = ok ? T(1.0) / piv : T(0);
+	return ok;
+}
+
+// factorise (ILU0) and write the records of both sweeps.  err: bit 2 = zero / tiny pivot.
+template <typename T, int KIND, int KREG, bool OV>
+__global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
+                                                        const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
+                                                        const unsigned* __restrict__ metaLo, const unsigned* __restrict__ metaUp, T* __restrict__ lu,
+                                                        unsigned* __restrict__ recLo, unsigned* __restrict__ recUp, const int* __restrict__ ovPtrLo,
+                                                        const int* __restrict__ ovPtrUp, unsigned short* __restrict__ ovColLo,
+                                                        unsigned short* __restrict__ ovColUp, T* __restrict__ ovValLo, T* __restrict__ ovValUp, int* info) {
+	extern __shared__ __align__(16) unsigned char blkLds[];
+	unsigned char* p = blkLds;
+	BlkStage st;
+	st.lptr = reinterpret_cast<int*>(carve(p, (maxRows + 1) * sizeof(int)));
+	st.ibG = reinterpret_cast<int*>(carve(p, maxRows * sizeof(int)));
+	st.nlow = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
+	st.lcol = reinterpret_cast<unsigned short*>(carve(p, cap * sizeof(unsigned short)));
+	T* lval = reinterpret_cast<T*>(carve(p, cap * sizeof(T)));
+	T* pinv = reinterpret_cast<T*>(carve(p, maxRows * sizeof(T)));
+	int* scanScratch = reinterpret_cast<int*>(carve(p, 8 * sizeof(int)));
+
+	constexpr bool ILU = KIND == SMM_PRECOND_BLOCK_ILU0;
+	const int b = blockIdx.x;
+	const int r0 = bounds[b].x;
+	const int nb = bounds[b + 1].x - r0;
+	const int nc = (nb + WAVE - 1) / WAVE;
+	const long long rec0 = static_cast<long long>(chunk0[b]) * WAVE;
+	const int t = threadIdx.x;
+
+	stageBlock<T>(st, lval, r0, nb, start, positions, vals, scanScratch);  // (the analysis kernel has already vetted the structure)
+	if (ILU) {
+		if (t < WAVE) {
+			bool allOk = true;
+			for (int c = 0; c < nc; ++c) {
+				const unsigned meta = metaLo[rec0 + static_cast<long long>(c) * WAVE + t];
+				const unsigned row = meta & 0xFFFu;
+				const int lvl = static_cast<int>((meta >> 12) & 0xFFFu);
+				const bool valid = row != BLK_NOROW;
+				const int lFirst = __builtin_amdgcn_readfirstlane(lvl);
+				const int lLast = __builtin_amdgcn_readlane(lvl, WAVE - 1);
+				for (int lv = lFirst; lv <= lLast; ++lv) {
+					if (valid && lvl == lv) allOk = blkIluRow<T>(st, lval, pinv, static_cast<int>(row)) && allOk;
+				}
+			}
+			if (!allOk) atomicOr(info + 2, 4);
+		}
+		__syncthreads();
+		// the factor on A's pattern (smm_hip_precond_values): in-block entries only, the rest keeps A's value
+		for (int i = t; i < nb; i += BLK_TPB) {
+			const int g = st.ibG[i], l = st.lptr[i], cnt = st.lptr[i + 1] - l;
+			for (int e = 0; e < cnt; ++e) lu[g + e] = lval[l + e];
+		}
+	}
+	using LL = RecLayout<T, !ILU, KREG>;
+	using LU = RecLayout<T, true, KREG>;
+	for (int q = t; q < nc * WAVE; q += BLK_TPB) {
+		const long long g = rec0 + q;
+		{  // lower sweep: entries left of the diagonal, ascending
+			unsigned w[LL::DW];
+#pragma unroll
+			for (int i = 0; i < LL::DW; ++i) w[i] = 0u;
+			const unsigned meta = metaLo[g];
+			w[0] = meta;
+			const unsigned row = meta & 0xFFFu;
+			if (row != BLK_NOROW) {
+				const int rb = st.lptr[row];
+				const int n = st.nlow[row];
+#pragma unroll
+				for (int k = 0; k < KREG; ++k) {
+					if (k < n) {
+						w[1 + k / 2] |= static_cast<unsigned>(st.lcol[rb + k]) << (16 * (k & 1));
+						toWords<T>(lval[rb + k], &w[LL::VAL_AT + LL::VW * k]);
+					}
+				}
+				if (!ILU) toWords<T>(lval[rb + n], &w[LL::DIAG_AT]);
+				if (OV && n > KREG) {
+					int at = ovPtrLo[g];
+					for (int k = KREG; k < n; ++k, ++at) {
+						ovColLo[at] = st.lcol[rb + k];
+						ovValLo[at] = lval[rb + k];
+					}
+				}
+			}
+			unsigned* out = recLo + g * LL::DW;
+#pragma unroll
+			for (int i = 0; i < LL::DW; ++i) out[i] = w[i];
+		}
+		{  // upper sweep: entries right of the diagonal, descending
+			unsigned w[LU::DW];
+#pragma unroll
+			for (int i = 0; i < LU::DW; ++i) w[i] = 0u;
+			const unsigned meta = metaUp[g];
+			w[0] = meta;
+			const unsigned row = meta & 0xFFFu;
+			if (row != BLK_NOROW) {
+				const int re = st.lptr[row + 1];
+				const int kd = st.lptr[row] + st.nlow[row];
+				const int n = re - kd - 1;
+#pragma unroll
+				for (int k = 0; k < KREG; ++k) {
+					if (k < n) {
+						w[1 + k / 2] |= static_cast<unsigned>(st.lcol[re - 1 - k]) << (16 * (k & 1));
+						toWords<T>(lval[re - 1 - k], &w[LU::VAL_AT + LU::VW * k]);
+					}
+				}
+				toWords<T>(lval[kd], &w[LU::DIAG_AT]);
+				if (OV && n > KREG) {
+					int at = ovPtrUp[g];
+					for (int k = KREG; k < n; ++k, ++at) {
+						ovColUp[at] = st.lcol[re - 1 - k];
+						ovValUp[at] = lval[re - 1 - k];
+					}
+				}
+			}
+			unsigned* out = recUp + g * LU::DW;
+#pragma unroll
+			for (int i = 0; i < LU::DW; ++i) out[i] = w[i];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static size_t analyzeLds(int maxRows, int cap) {
+	return carveSize((maxRows + 1) * sizeof(int)) + carveSize(maxRows * sizeof(int)) + carveSize(maxRows * 2) + carveSize(static_cast<size_t>(cap) * 2) +
+	       3 * carveSize(maxRows * 2) + carveSize((maxRows + 1) * sizeof(int)) + carveSize(8 * sizeof(int)) + carveSize(4 * sizeof(int));
+}
+template <typename T>
+static size_t packLds(int maxRows, int cap) {
+	return carveSize((maxRows + 1) * sizeof(int)) + carveSize(maxRows * sizeof(int)) + carveSize(maxRows * 2) + carveSize(static_cast<size_t>(cap) * 2) +
+	       carveSize(static_cast<size_t>(cap) * sizeof(T)) + carveSize(maxRows * sizeof(T)) + carveSize(8 * sizeof(int));
+}
+
+template <typename T, int KIND, int KREG, bool OV>
+static int packTyped(const smm_hip_csr* a, smm_hip_precond* M, const unsigned* metaLo, const unsigned* metaUp, int* d_info, hipStream_t s) {
+	smm_precond_block* B = M->blk;
+	const size_t lds = packLds<T>(B->blockRows, B->capNnz);
+	auto kernel = blkPackKernel<T, KIND, KREG, OV>;
+	SMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+	kernel<<<B->nBlocks, BLK_TPB, lds, s>>>(B->blockRows, B->capNnz, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
+	                                       metaLo, metaUp, static_cast<T*>(M->d_values), B->d_recLo, B->d_recUp, B->d_ovPtrLo, B->d_ovPtrUp, B->d_ovColLo,
+	                                       B->d_ovColUp, static_cast<T*>(B->d_ovValLo), static_cast<T*>(B->d_ovValUp), d_info);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T, int KIND>
+static int packKind(const smm_hip_csr* a, smm_hip_precond* M, const unsigned* metaLo, const unsigned* metaUp, int* d_info, hipStream_t s) {
+	const smm_precond_block* B = M->blk;
+	if (B->overflow) return packTyped<T, KIND, 8, true>(a, M, metaLo, metaUp, d_info, s);
+	switch (B->kreg) {
+	case 2: return packTyped<T, KIND, 2, false>(a, M, metaLo, metaUp, d_info, s);
+	case 4: return packTyped<T, KIND, 4, false>(a, M, metaLo, metaUp, d_info, s);
+	default: return packTyped<T, KIND, 8, false>(a, M, metaLo, metaUp, d_info, s);
+	}
+}
+
+static int exclusiveScanInPlace(int* d, size_t n, hipStream_t s) {
+	size_t tempBytes = 0;
+	SMM_HIP_TRY(rocprim::exclusive_scan(nullptr, tempBytes, d, d, 0, n, rocprim::plus<int>(), s));
+	DevBuf<char> temp;
+	SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
+	SMM_HIP_TRY(rocprim::exclusive_scan(temp.p, tempBytes, d, d, 0, n, rocprim::plus<int>(), s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // temp goes back to the allocator
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_precond* M) {
+	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipDeviceSynchronize());  // the matrix may still be being written on a caller's stream
+	const int n = a->rows;
+	if (a->rows != a->cols) {
+		setError("preconditioner needs a square matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (a->firstActiveStart != 0 && n > 0) {  // ref:1666-1670
+		setError("preconditioner: matrix has leading empty rows (firstActiveStart != 0)");
+		return SMM_HIP_ERR_PRECOND;
+	}
+	auto* B = new smm_precond_block();
+	M->blk = B;  // (smm_hip_precond_destroy releases whatever the steps below have allocated so far)
+	B->blockRows = blockRows;
+	B->capNnz = BLK_CAP_NNZ;
+	if (n == 0) return SMM_HIP_OK;
+	SMM_TRY(cutRows(a->d_start, n, a->nnz, B->capNnz, B->blockRows, s, &B->d_bounds, &B->nBlocks));
+	const int nBlocks = B->nBlocks;
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_chunk0), (static_cast<size_t>(nBlocks) + 1) * sizeof(int)));
+	blkChunkCountKernel<<<(nBlocks + 1 + 255) / 256, 256, 0, s>>>(nBlocks, B->d_bounds, B->d_chunk0);
+	SMM_TRY(exclusiveScanInPlace(B->d_chunk0, static_cast<size_t>(nBlocks) + 1, s));
+	int nChunks = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&nChunks, B->d_chunk0 + nBlocks, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	B->nChunks = nChunks;
+	const size_t nRec = static_cast<size_t>(nChunks) * WAVE;
+
+	DevBuf<unsigned> metaLo, metaUp;
+	DevBuf<unsigned short> nEntLo, nEntUp;
+	DevBuf<int> info;
+	SMM_TRY(metaLo.alloc(nRec));
+	SMM_TRY(metaUp.alloc(nRec));
+	SMM_TRY(nEntLo.alloc(nRec));
+	SMM_TRY(nEntUp.alloc(nRec));
+	SMM_TRY(info.alloc(8));
+	SMM_HIP_TRY(hipMemsetAsync(info, 0, 8 * sizeof(int), s));
+	{
+		const size_t lds = analyzeLds(B->blockRows, B->capNnz);
+		auto kernel = blkAnalyzeKernel<T>;
+		SMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+		kernel<<<nBlocks, BLK_TPB, lds, s>>>(B->blockRows, B->capNnz, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
+		                                    kind == SMM_PRECOND_BLOCK_SGS ? 1 : 0, metaLo, metaUp, nEntLo, nEntUp, info);
+		SMM_HIP_TRY(hipGetLastError());
+	}
+	int h[8] = {0};
+	SMM_HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (h[2] & 8) {
+		setError("block preconditioner: the level analysis of a block did not finish");
+		return SMM_HIP_ERR_HIP;
+	}
+	if (h[2]) {
+		setError("block preconditioner: empty row, missing diagonal or |d|<1e-5");
+		return SMM_HIP_ERR_PRECOND;
+	}
+	B->levelsLo = h[3];
+	B->levelsUp = h[4];
+	const int most = std::max(h[0], h[1]);
+	B->kreg = most <= 2 ? 2 : most <= 4 ? 4 : 8;
+	B->overflow = most > 8;
+	if (const char* env = getenv("SMM_HIP_BLOCK_KREG")) {  // testing: force the overflow path on matrices with short rows
+		const int k = atoi(env);
+		if (k == 2 || k == 4 || k == 8) {
+			B->kreg = std::max(B->kreg, k);
+		} else if (k == -8) {
+			B->kreg = 8;
+			B->overflow = true;
+		}
+	}
+	if (B->overflow) {
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_ovPtrLo), (nRec + 1) * sizeof(int)));
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_ovPtrUp), (nRec + 1) * sizeof(int)));
+		const int grid = static_cast<int>((nRec + 1 + 255) / 256);
+		blkOverflowCountKernel<<<grid, 256, 0, s>>>(static_cast<long long>(nRec), B->kreg, nEntLo, B->d_ovPtrLo);
+		blkOverflowCountKernel<<<grid, 256, 0, s>>>(static_cast<long long>(nRec), B->kreg, nEntUp, B->d_ovPtrUp);
+		SMM_TRY(exclusiveScanInPlace(B->d_ovPtrLo, nRec + 1, s));
+		SMM_TRY(exclusiveScanInPlace(B->d_ovPtrUp, nRec + 1, s));
+		int tot[2] = {0, 0};
+		SMM_HIP_TRY(hipMemcpyAsync(&tot[0], B->d_ovPtrLo + nRec, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipMemcpyAsync(&tot[1], B->d_ovPtrUp + nRec, sizeof(int), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_ovColLo), std::max<size_t>(1, tot[0]) * sizeof(unsigned short)));
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_ovColUp), std::max<size_t>(1, tot[1]) * sizeof(unsigned short)));
+		SMM_TRY(devAlloc(&B->d_ovValLo, std::max<size_t>(1, tot[0]) * sizeof(T)));
+		SMM_TRY(devAlloc(&B->d_ovValUp, std::max<size_t>(1, tot[1]) * sizeof(T)));
+	}
+	const bool ilu = kind == SMM_PRECOND_BLOCK_ILU0;
+	size_t dwLo = 0, dwUp = 0;
+	switch (B->kreg) {
+	case 2:
+		dwLo = ilu ? RecLayout<T, false, 2>::DW : RecLayout<T, true, 2>::DW;
+		dwUp = RecLayout<T, true, 2>::DW;
+		break;
+	case 4:
+		dwLo = ilu ? RecLayout<T, false, 4>::DW : RecLayout<T, true, 4>::DW;
+		dwUp = RecLayout<T, true, 4>::DW;
+		break;
+	default:
+		dwLo = ilu ? RecLayout<T, false, 8>::DW : RecLayout<T, true, 8>::DW;
+		dwUp = RecLayout<T, true, 8>::DW;
+		break;
+	}
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_recLo), std::max<size_t>(1, nRec * dwLo) * sizeof(unsigned)));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_recUp), std::max<size_t>(1, nRec * dwUp) * sizeof(unsigned)));
+	if (ilu) {
+		const size_t nnz = static_cast<size_t>(a->nnz);
+		SMM_TRY(devAlloc(&M->d_values, std::max<size_t>(1, nnz) * sizeof(T)));
+		M->n_values = nnz;
+		if (nnz) SMM_HIP_TRY(hipMemcpyAsync(M->d_values, a->d_values, nnz * sizeof(T), hipMemcpyDeviceToDevice, s));
+		SMM_TRY((packKind<T, SMM_PRECOND_BLOCK_ILU0>(a, M, metaLo, metaUp, info, s)));
+	} else {
+		SMM_TRY((packKind<T, SMM_PRECOND_BLOCK_SGS>(a, M, metaLo, metaUp, info, s)));
+	}
+	SMM_HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // also: the scratch buffers go back to the allocator when this scope ends
+	if (h[2] & 4) {
+		setError("block ilu0: zero / tiny pivot (reordering would be needed, ref:1741-1746)");
+		return SMM_HIP_ERR_PRECOND;
+	}
+	return SMM_HIP_OK;
+}
+
+template int blockCreateTyped<float>(const smm_hip_csr*, int, int, smm_hip_precond*);
+template int blockCreateTyped<double>(const smm_hip_csr*, int, int, smm_hip_precond*);
+
+template <typename T, int KIND, int KREG, bool OV>
+static int launchBlkApply(const smm_hip_precond* M, const BlkApplyArgs<T>& args, hipStream_t s) {
+	const smm_precond_block* B = M->blk;
+	constexpr int D = KREG <= 2 ? 4 : 2;
+	const int grid = std::min(B->nBlocks, NPART);
+	const size_t lds = static_cast<size_t>(B->blockRows) * sizeof(T);
+	blkApplyKernel<T, KIND, KREG, OV, D><<<grid, WAVE, lds, s>>>(args);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T, int KIND>
+static int launchBlkApplyKind(const smm_hip_precond* M, const BlkApplyArgs<T>& args, hipStream_t s) {
+	const smm_precond_block* B = M->blk;
+	if (B->overflow) return launchBlkApply<T, KIND, 8, true>(M, args, s);
+	switch (B->kreg) {
+	case 2: return launchBlkApply<T, KIND, 2, false>(M, args, s);
+	case 4: return launchBlkApply<T, KIND, 4, false>(M, args, s);
+	default: return launchBlkApply<T, KIND, 8, false>(M, args, s);
+	}
+}
+
+// x = M^-1 rhs with the dot products of x fused into the epilogue (dotMode as in launchSpmv; partials: 2 * NPART elements)
+template <typename T>
+int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s) {
+	const smm_precond_block* B = M->blk;
+	if (!B) {
+		setError("precond_apply: block preconditioner without its tables");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (B->nBlocks == 0) return SMM_HIP_OK;
+	BlkApplyArgs<T> args;
+	args.nBlocks = B->nBlocks;
+	args.bounds = B->d_bounds;
+	args.chunk0 = B->d_chunk0;
+	args.recLo = B->d_recLo;
+	args.recUp = B->d_recUp;
+	args.ovPtrLo = B->d_ovPtrLo;
+	args.ovPtrUp = B->d_ovPtrUp;
+	args.ovColLo = B->d_ovColLo;
+	args.ovColUp = B->d_ovColUp;
+	args.ovValLo = static_cast<const T*>(B->d_ovValLo);
+	args.ovValUp = static_cast<const T*>(B->d_ovValUp);
+	args.rhs = rhs;
+	args.x = x;
+	args.dotMode = dotMode;
+	args.w1 = w1;
+	args.partials = partials;
+	args.doneFlag = doneFlag;
+	if (M->kind == SMM_PRECOND_BLOCK_ILU0) return launchBlkApplyKind<T, SMM_PRECOND_BLOCK_ILU0>(M, args, s);
+	return launchBlkApplyKind<T, SMM_PRECOND_BLOCK_SGS>(M, args, s);
+}
+
+template int blockApplyDev<float>(const smm_hip_precond*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
+template int blockApplyDev<double>(const smm_hip_precond*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
+
+void blockDestroy(smm_precond_block* B) {
+	if (!B) return;
+	devFree(B->d_bounds);
+	devFree(B->d_chunk0);
+	devFree(B->d_recLo);
+	devFree(B->d_recUp);
+	devFree(B->d_ovPtrLo);
+	devFree(B->d_ovPtrUp);
+	devFree(B->d_ovColLo);
+	devFree(B->d_ovColUp);
+	devFree(B->d_ovValLo);
+	devFree(B->d_ovValUp);
+	delete B;
+}
+
+void blockLevels(const smm_precond_block* B, int* lo, int* up) {
+	if (lo) *lo = B ? B->levelsLo : 0;
+	if (up) *up = B ? B->levelsUp : 0;
+}
+
+int blockDefaultRows() {
+	int rows = BLK_DEFAULT_ROWS;
+	if (const char* env = getenv("SMM_HIP_BLOCK_ROWS")) rows = atoi(env);
+	return std::max(BLK_MIN_ROWS, std::min(BLK_MAX_ROWS, rows));
+}
+
+}  // namespace smm
+
+using namespace smm;
+
+extern "C" {
+
+int smm_hip_precond_block_count(const smm_hip_precond* M, int* nblocks) {
+	if (!M || !M->blk || !nblocks) {
+		setError("precond_block_count: not a block preconditioner");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*nblocks = M->blk->nBlocks;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_block_bounds(const smm_hip_precond* M, int* bounds, size_t count) {
+	if (!M || !M->blk || !bounds) {
+		setError("precond_block_bounds: not a block preconditioner");
+		return SMM_HIP_ERR_INVALID;
+	}
+	smm_precond_block* B = M->blk;
+	if (count != static_cast<size_t>(B->nBlocks) + 1) {
+		setError("precond_block_bounds: %d blocks need %d entries", B->nBlocks, B->nBlocks + 1);
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	std::lock_guard<std::mutex> lock(B->boundsMutex);
+	if (B->hostBounds.empty()) {
+		if (B->nBlocks == 0) {
+			B->hostBounds.assign(1, 0);
+		} else {
+			std::vector<int2> tmp(static_cast<size_t>(B->nBlocks) + 1);
+			hipStream_t s = libStream();
+			SMM_HIP_TRY(hipMemcpyAsync(tmp.data(), B->d_bounds, tmp.size() * sizeof(int2), hipMemcpyDeviceToHost, s));
+			SMM_HIP_TRY(hipStreamSynchronize(s));
+			B->hostBounds.resize(tmp.size());
+			for (size_t i = 0; i < tmp.size(); ++i) B->hostBounds[i] = tmp[i].x;
+		}
+	}
+	std::copy(B->hostBounds.begin(), B->hostBounds.end(), bounds);
+	return SMM_HIP_OK;
+}
+
+}  // extern "C"

@@ -536,10 +536,12 @@ struct HostApplier {
 
 template <typename T, typename Applier>
 static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const bool precondition, const Applier& apply, hipStream_t s,
-                        int* status, int* iterations, T* resnorm, const T* jacobiDiag = nullptr) {
+                        int* status, int* iterations, T* resnorm, const T* jacobiDiag = nullptr, const smm_hip_precond* blockM = nullptr) {
 	// jacobiDiag: M is the library's Jacobi preconditioner and its apply (x = rhs / diag, smm_precond.hip) is folded into the rows of the
 	// SpMV that precedes it -- the same division on the same operands, so the same bits as SpMV + apply -- which lets the preconditioned
 	// loop use the fused dots of the unpreconditioned one: no apply launches, no dot launches, no extra vector passes.
+	// blockM: M is a block preconditioner (smm_precond_block.hip): its one-launch apply forms the dot products of its result in its
+	// own epilogue, so the loop needs no dot launches either.
 	const int n = a->rows;
 	maxIterations = std::min(maxIterations, n);  // ref:2200
 	if (maxIterations == -1) maxIterations = n;  // ref:2201-2203
@@ -588,6 +590,9 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 		}
 		if (jacobiDiag) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, jacobiDiag, p, ap, 1, r0, parts, doneFlag, s, SPMV_DIV_LHS));  // ref:2234-2235 + 2243 fused
+		} else if (blockM) {
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
+			SMM_TRY(blockApplyDev<T>(blockM, scratch, ap, 1, r0, parts, doneFlag, s));                         // ref:2235 + 2243 fused
 		} else if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
 			SMM_TRY(apply(scratch, ap, doneFlag, s));                                                          // ref:2235
@@ -599,6 +604,9 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 		SMM_LAUNCH_UPDATE(bicgFusedS, updateNT(n, sizeof(T), 3), gridFor(n), s, n, sc, i & 1, parts, ap, r, sv);
 		if (jacobiDiag) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, jacobiDiag, sv, as, 2, sv, parts, doneFlag, s, SPMV_DIV_LHS));  // ref:2250-2251 + 2256-2261 fused
+		} else if (blockM) {
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
+			SMM_TRY(blockApplyDev<T>(blockM, scratch, as, 2, sv, parts, doneFlag, s));                          // ref:2251 + 2259, 2261 fused
 		} else if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
 			SMM_TRY(apply(scratch, as, doneFlag, s));                                                           // ref:2251
@@ -642,13 +650,14 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	SMM_TRY(bicgstabCheck<T>(a, b, x));
 	const bool precondition = M != nullptr && M->kind != SMM_PRECOND_NONE;  // ref:2209
 	if (precondition && (M->a != a || M->kind == SMM_PRECOND_IC0)) {
-		setError("bicgstab: preconditioner must be JACOBI / ILU0 / SGS created for this matrix");
+		setError("bicgstab: preconditioner must be JACOBI / ILU0 / SGS / BLOCK_ILU0 / BLOCK_SGS created for this matrix");
 		return SMM_HIP_ERR_INVALID;
 	}
 	const DevApplier<T> apply{M};
 	SMM_TRY(ensureCsrReady(a, s, true));
 	const T* jacobiDiag = precondition && M->kind == SMM_PRECOND_JACOBI && a->family != SMM_SPMV_PATTERN ? static_cast<const T*>(M->d_values) : nullptr;
-	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm, jacobiDiag)));
+	const smm_hip_precond* blockM = precondition && isBlockKind(M->kind) ? M : nullptr;
+	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm, jacobiDiag, blockM)));
 	return precondition ? precondTakeError(M, s) : SMM_HIP_OK;
 }
 

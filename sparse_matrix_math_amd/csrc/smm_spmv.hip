@@ -762,6 +762,34 @@ __global__ void farColumnKernel(int rows, const int* __restrict__ start, const i
 	if (threadIdx.x == 0) info[0] = start[mid + 1] - start[mid];  // length of a typical (interior) row
 }
 
+// The cut itself: tiles[0 .. *nTiles] = {first row, start[first row]} with the closing sentinel {rows, nnz}; the table is allocated here
+// (devAlloc) and owned by the caller.  Also used for the row blocks of the block preconditioners (smm_precond_block.hip).
+int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows, hipStream_t s, int2** tiles, int* nTiles) {
+	*tiles = nullptr;
+	*nTiles = 0;
+	const long long chunkNnz = static_cast<long long>(TILES_PER_CHUNK) * capNnz;
+	const int nChunks = static_cast<int>(nnz / chunkNnz) + 1;
+	DevBuf<int> counts;
+	SMM_TRY(counts.alloc(static_cast<size_t>(nChunks) + 1));
+	SMM_HIP_TRY(hipMemsetAsync(counts, 0, (static_cast<size_t>(nChunks) + 1) * sizeof(int), s));
+	const int grid = (nChunks + 63) / 64;
+	tileCutKernel<<<grid, 64, 0, s>>>(rows, d_start, capNnz, maxRows, chunkNnz, nChunks, counts, nullptr, nullptr);
+	size_t tempBytes = 0;
+	SMM_HIP_TRY(rocprim::exclusive_scan(nullptr, tempBytes, counts.p, counts.p, 0, static_cast<size_t>(nChunks) + 1, rocprim::plus<int>(), s));
+	DevBuf<char> temp;
+	SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
+	SMM_HIP_TRY(rocprim::exclusive_scan(temp.p, tempBytes, counts.p, counts.p, 0, static_cast<size_t>(nChunks) + 1, rocprim::plus<int>(), s));
+	int n = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&n, counts.p + nChunks, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream: the table's size decides the allocation and the grid
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(tiles), (static_cast<size_t>(n) + 1) * sizeof(int2)));
+	tileCutKernel<<<grid, 64, 0, s>>>(rows, d_start, capNnz, maxRows, chunkNnz, nChunks, nullptr, counts, *tiles);
+	SMM_HIP_TRY(hipGetLastError());
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // the scratch buffers above go back to the allocator when this scope ends
+	*nTiles = n;
+	return SMM_HIP_OK;
+}
+
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 	const int rows = m->rows;
 	devFree(m->d_rowblocks);
@@ -770,44 +798,26 @@ int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 	m->stream_nnz_cap = capNnz;
 	m->stream_max_rows = maxRows;
 	m->stream_chunk_tiles = 0;
-	const long long chunkNnz = static_cast<long long>(TILES_PER_CHUNK) * capNnz;
-	const int nChunks = static_cast<int>(m->nnz / chunkNnz) + 1;
-	DevBuf<int> counts, info;
-	SMM_TRY(counts.alloc(static_cast<size_t>(nChunks) + 1));
+	DevBuf<int> info;
 	SMM_TRY(info.alloc(2));
-	SMM_HIP_TRY(hipMemsetAsync(counts, 0, (static_cast<size_t>(nChunks) + 1) * sizeof(int), s));
 	SMM_HIP_TRY(hipMemsetAsync(info, 0, 2 * sizeof(int), s));
-	const int grid = (nChunks + 63) / 64;
-	tileCutKernel<<<grid, 64, 0, s>>>(rows, m->d_start, capNnz, maxRows, chunkNnz, nChunks, counts, nullptr, nullptr);
-	{
-		size_t tempBytes = 0;
-		SMM_HIP_TRY(rocprim::exclusive_scan(nullptr, tempBytes, counts.p, counts.p, 0, static_cast<size_t>(nChunks) + 1, rocprim::plus<int>(), s));
-		DevBuf<char> temp;
-		SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
-		SMM_HIP_TRY(rocprim::exclusive_scan(temp.p, tempBytes, counts.p, counts.p, 0, static_cast<size_t>(nChunks) + 1, rocprim::plus<int>(), s));
-		if (rows > 0) farColumnKernel<<<1, 64, 0, s>>>(rows, m->d_start, m->d_positions, info);
-		int host[2] = {0, 0}, midLen = 0;
-		SMM_HIP_TRY(hipMemcpyAsync(&host[0], counts.p + nChunks, sizeof(int), hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipMemcpyAsync(&host[1], info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipMemcpyAsync(&midLen, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream: the table's size decides the allocation and the grid
-		const int nTiles = host[0];
-		(void)midLen;  // (the length of the middle row is read by ensureCsrReady already: it sizes the tiles this table is cut for)
-		SMM_TRY(devAlloc(reinterpret_cast<void**>(&m->d_rowblocks), (static_cast<size_t>(nTiles) + 1) * sizeof(int2)));
-		tileCutKernel<<<grid, 64, 0, s>>>(rows, m->d_start, capNnz, maxRows, chunkNnz, nChunks, nullptr, counts, reinterpret_cast<int2*>(m->d_rowblocks));
-		SMM_HIP_TRY(hipGetLastError());
-		m->n_rowblocks = nTiles;
-		// How the tiles are dealt to the 8 XCDs.  The farthest column a middle row touches tells how far apart (in rows) two uses of
-		// the same x[] line are.  When that distance is many tiles but a small fraction of the matrix (3-D stencils: one grid plane),
-		// the tiles are dealt one such span per XCD, round-robin, so the 8 XCDs sweep 8 adjacent planes together instead of 8 regions
-		// a gigabyte apart: measured -8 % on the 512^3 Laplacian (3.55 -> 3.28 ms), neutral on smaller grids; with far offsets that are
-		// a large fraction of the matrix (the banded-random benchmark matrix) contiguous eighths are best (tools/sweep_chunk.sh).
-		if (rows > 0 && nTiles > 0) {
-			const double rowsPerTile = static_cast<double>(rows) / nTiles;
-			const long long farTiles = static_cast<long long>(host[1] / rowsPerTile);
-			if (farTiles >= 256 && farTiles * 32 <= nTiles) m->stream_chunk_tiles = static_cast<int>(farTiles);
-		}
-		SMM_HIP_TRY(hipStreamSynchronize(s));  // the scratch buffers above go back to the allocator when this scope ends
+	if (rows > 0) farColumnKernel<<<1, 64, 0, s>>>(rows, m->d_start, m->d_positions, info);
+	int far = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&far, info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+	int2* tiles = nullptr;
+	int nTiles = 0;
+	SMM_TRY(cutRows(m->d_start, rows, m->nnz, capNnz, maxRows, s, &tiles, &nTiles));  // synchronises s: `far` has arrived
+	m->d_rowblocks = reinterpret_cast<int*>(tiles);
+	m->n_rowblocks = nTiles;
+	// How the tiles are dealt to the 8 XCDs.  The farthest column a middle row touches tells how far apart (in rows) two uses of
+	// the same x[] line are.  When that distance is many tiles but a small fraction of the matrix (3-D stencils: one grid plane),
+	// the tiles are dealt one such span per XCD, round-robin, so the 8 XCDs sweep 8 adjacent planes together instead of 8 regions
+	// a gigabyte apart: measured -8 % on the 512^3 Laplacian (3.55 -> 3.28 ms), neutral on smaller grids; with far offsets that are
+	// a large fraction of the matrix (the banded-random benchmark matrix) contiguous eighths are best (tools/sweep_chunk.sh).
+	if (rows > 0 && nTiles > 0) {
+		const double rowsPerTile = static_cast<double>(rows) / nTiles;
+		const long long farTiles = static_cast<long long>(far / rowsPerTile);
+		if (farTiles >= 256 && farTiles * 32 <= nTiles) m->stream_chunk_tiles = static_cast<int>(farTiles);
 	}
 	if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) m->stream_chunk_tiles = std::max(0, atoi(env));  // tuning override
 	return SMM_HIP_OK;

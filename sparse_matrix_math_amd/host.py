@@ -25,13 +25,15 @@ class SolverStatus(enum.IntEnum):  # ref:2010-2014
 
 
 class SolverPreconditioner(enum.IntEnum):
-    """ref:1002-1006 has NONE, SYMMETRIC_GAUS_SEIDEL (sic) and ILU0; JACOBI and IC0 are additions.  Values are the
-    SMM_PRECOND_* codes of the C ABI."""
+    """ref:1002-1006 has NONE, SYMMETRIC_GAUS_SEIDEL (sic) and ILU0; JACOBI, IC0 and the BLOCK_ forms (ILU0 / SGS of the
+    block-diagonal part of A, one wavefront per block) are additions.  Values are the SMM_PRECOND_* codes of the C ABI."""
     NONE = 0
     JACOBI = 1
     ILU0 = 2
     SYMMETRIC_GAUS_SEIDEL = 3
     IC0 = 4
+    BLOCK_ILU0 = 5
+    BLOCK_SGS = 6
 
 
 OP_ASSIGN, OP_ADD, OP_SUB = 0, 1, 2
@@ -106,11 +108,22 @@ def profile_read(reset=True):
 class Preconditioner:
     """`int apply(const T* rhs, T* x) const` (ref:1173-1235).  Created by CSRMatrix.getPreconditioner."""
 
-    def __init__(self, matrix, kind):
+    def __init__(self, matrix, kind, block_rows=None):
         self.matrix = matrix  # keeps the matrix alive (the reference holds a const CSRMatrix&)
         self.kind = SolverPreconditioner(kind)
         self._h = ctypes.c_void_p()
-        check(_lib.load().smm_hip_precond_create(matrix._h, int(kind), ctypes.byref(self._h)))
+        if block_rows is None:
+            check(_lib.load().smm_hip_precond_create(matrix._h, int(kind), ctypes.byref(self._h)))
+        else:  # BLOCK_ILU0 / BLOCK_SGS with a chosen block size
+            check(_lib.load().smm_hip_precond_create_block(matrix._h, int(kind), int(block_rows), ctypes.byref(self._h)))
+
+    def block_bounds(self):
+        """BLOCK_ kinds: the nblocks + 1 row numbers at which the rows were cut"""
+        n = ctypes.c_int()
+        check(_lib.load().smm_hip_precond_block_count(self._h, ctypes.byref(n)))
+        out = np.zeros(n.value + 1, dtype=np.int32)
+        check(_lib.load().smm_hip_precond_block_bounds(self._h, out.ctypes.data_as(ctypes.c_void_p), out.size))
+        return out
 
     def apply(self, rhs, x):
         suf = self.matrix._suf
@@ -126,7 +139,7 @@ class Preconditioner:
         check(_lib.load().smm_hip_precond_take_error(self._h, _dptr(stream)))
 
     def values(self):
-        """factor values: diag (JACOBI) or the ILU0 / IC0 values on A's pattern"""
+        """factor values: diag (JACOBI) or the ILU0 / IC0 / BLOCK_ILU0 values on A's pattern"""
         count = self.matrix.rows if self.kind == SolverPreconditioner.JACOBI else self.matrix.nnz
         out = np.empty(count, dtype=self.matrix.dtype)
         check(_fn("smm_hip_precond_values", self.matrix._suf)(self._h, _host(out, self.matrix.dtype, "out"), count))
@@ -229,8 +242,8 @@ class CSRMatrix:
     def spmv_dev(self, op, d_lhs, d_x, d_out, stream=None):
         check(_fn("smm_hip_spmv_dev", self._suf)(self._h, int(op), _dptr(d_lhs), _dptr(d_x), _dptr(d_out), _dptr(stream)))
 
-    def getPreconditioner(self, kind):  # ref:1643-1651
-        return Preconditioner(self, kind)
+    def getPreconditioner(self, kind, block_rows=None):  # ref:1643-1651; block_rows: BLOCK_ kinds only (None = default)
+        return Preconditioner(self, kind, block_rows)
 
     def close(self):
         if self._h:

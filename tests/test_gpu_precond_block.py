@@ -1,0 +1,211 @@
+"""GPU parity of the block preconditioners (csrc/smm_precond_block.hip: one wavefront per block, the block's vector in LDS):
+apply and factor bit-identical to the oracle's sequential sweeps over the block-diagonal part of A (smm_oracle_block_*), BLOCK_SGS
+bit-identical to what the REAL reference computes for that construction (tests/golden/reference_outputs_v3.npz), BiCGStab with them
+within the solver tolerance of the oracle / the reference at fixed iterations."""
+import os
+
+import numpy as np
+import pytest
+from test_oracle_block import golden_v3  # noqa: F401  (fixture)
+
+from oracle.gen_golden_v3 import bounds_sets, matrices, rhs_of
+from oracle.oracle import PRECOND_BLOCK_ILU0, PRECOND_BLOCK_SGS
+from sparse_matrix_math_amd import generators as gen
+
+pytestmark = pytest.mark.gpu
+DTYPES = [np.float32, np.float64]
+TOL = {np.dtype(np.float32): 3e-4, np.dtype(np.float64): 1e-10}
+
+
+def make(smm, csr):
+    rows = len(csr[0]) - 1
+    return smm.CSRMatrix(rows, rows, *csr)
+
+
+def check_bounds(bounds, rows, block_rows, csr):
+    assert bounds[0] == 0 and bounds[-1] == rows
+    sizes = np.diff(bounds)
+    assert (sizes >= 1).all() and sizes.max() <= block_rows
+    nnz = csr[0][bounds[1:]] - csr[0][bounds[:-1]]
+    assert (nnz[sizes > 1] <= 8192).all()
+
+
+def compare_with_oracle(smm, oracle, csr, block_rows, dtype, seed=5):
+    """factor + apply of both kinds against the oracle on the library's own cut; returns the cut"""
+    P = smm.SolverPreconditioner
+    rows = len(csr[0]) - 1
+    A = make(smm, csr)
+    rhs = np.random.default_rng(seed).uniform(-1, 1, rows).astype(dtype)
+    I = A.getPreconditioner(P.BLOCK_ILU0, block_rows)
+    bounds = I.block_bounds()
+    check_bounds(bounds, rows, block_rows or 1024, csr)
+    err, lu = oracle.block_ilu0_factorize(csr, bounds)
+    assert err == 0
+    np.testing.assert_array_equal(I.values(), lu)
+    x = np.zeros(rows, dtype=dtype)
+    assert I.apply(rhs, x) == 0
+    np.testing.assert_array_equal(x, oracle.block_ilu0_apply(csr, bounds, lu, rhs)[1])
+    S = A.getPreconditioner(P.BLOCK_SGS, block_rows)
+    np.testing.assert_array_equal(S.block_bounds(), bounds)
+    x2 = np.zeros(rows, dtype=dtype)
+    assert S.apply(rhs, x2) == 0
+    np.testing.assert_array_equal(x2, oracle.block_sgs_apply(csr, bounds, rhs)[1])
+    return bounds
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_block_apply_and_factor_bit_identical_to_oracle(smm, oracle, dtype):
+    cases = [
+        (gen.convdiff3d(24, 0.3, dtype=dtype), None),
+        (gen.convdiff3d(24, 0.3, dtype=dtype), 64),
+        (gen.convdiff3d(14, 0.3, dtype=dtype), 2048),
+        (gen.poisson2d(70, dtype=dtype), 256),
+        (gen.banded_random_spd(3000, k=3, seed=3, max_offset=40, dtype=dtype), 128),     # up to 3 + 3 in-block entries: 4 per record
+        (gen.banded_random_spd(3000, k=7, seed=5, max_offset=60, dtype=dtype), 512),     # up to 7 + 7: 8 per record
+        (gen.banded_random_spd(4000, k=12, seed=11, max_offset=90, dtype=dtype), None),  # 12 + 12: records + overflow lists
+        (gen.random_rows(900, 900, 2, 25, seed=9, dtype=dtype, diag_dominant=True), 300),
+        (gen.poisson2d(5, dtype=dtype), None),  # 25 rows: a single partly filled chunk
+    ]
+    for csr, block_rows in cases:
+        compare_with_oracle(smm, oracle, csr, block_rows, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_block_sgs_bit_identical_to_the_reference_on_the_block_diagonal(smm, golden_v3, dtype):  # noqa: F811
+    """uniform cuts that the library's greedy cut reproduces (rows only: these blocks stay far below 8192 entries)"""
+    P = smm.SolverPreconditioner
+    dn = np.dtype(dtype).name
+    for mname, csr in matrices(dtype).items():
+        rows = len(csr[0]) - 1
+        A = make(smm, csr)
+        rhs = rhs_of(rows, dtype)
+        b = gen.row_sums(csr[0], csr[2])
+        for bname, block_rows in (("u64", 64), ("u256", 256)) + ((("one", 2048),) if rows <= 2048 and csr[0][-1] <= 8192 else ()):
+            if mname == "banded_2000" and bname == "u256":
+                continue  # 256 rows x 51 entries exceed the 8192-entry cap: the library cuts those blocks shorter
+            M = A.getPreconditioner(P.BLOCK_SGS, block_rows)
+            np.testing.assert_array_equal(M.block_bounds(), bounds_sets(rows)[bname])
+            tag = f"block_sgs/{mname}/{bname}/{dn}"
+            x = np.zeros(rows, dtype=dtype)
+            assert M.apply(rhs, x) == 0
+            np.testing.assert_array_equal(x, golden_v3[f"{tag}/apply/x"], err_msg=tag)
+            for maxit in (1, 3, 10):
+                xs = np.zeros(rows, dtype=dtype)
+                info = {}
+                st = smm.BiCGStab(A, b, xs, maxit, dtype(1e-30), M, info=info)
+                ref = golden_v3[f"{tag}/bicgstab/{maxit}/x"]
+                assert int(st) == int(golden_v3[f"{tag}/bicgstab/{maxit}/status"]) and info["iterations"] == maxit
+                assert np.abs(xs - ref).max() <= TOL[np.dtype(dtype)] * max(1.0, np.abs(ref).max()), (tag, maxit)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_one_block_is_the_global_preconditioner(smm, oracle, dtype):
+    P = smm.SolverPreconditioner
+    csr = gen.convdiff3d(12, 0.3, dtype=dtype)  # 1728 rows, 11 664 entries: over the entry cap -> two blocks; 10^3 fits one
+    csr1 = gen.convdiff3d(10, 0.3, dtype=dtype)
+    rows = len(csr1[0]) - 1
+    A = make(smm, csr1)
+    rhs = rhs_of(rows, dtype)
+    for kind_b, kind_g in ((P.BLOCK_ILU0, P.ILU0), (P.BLOCK_SGS, P.SYMMETRIC_GAUS_SEIDEL)):
+        B = A.getPreconditioner(kind_b, 2048)
+        np.testing.assert_array_equal(B.block_bounds(), [0, rows])
+        G = A.getPreconditioner(kind_g)
+        xb, xg = np.zeros(rows, dtype=dtype), np.zeros(rows, dtype=dtype)
+        B.apply(rhs, xb)
+        G.apply(rhs, xg)
+        np.testing.assert_array_equal(xb, xg)
+        assert B.levels() == G.levels()
+    assert len(make(smm, csr).getPreconditioner(P.BLOCK_ILU0, 2048).block_bounds()) == 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bicgstab_with_block_preconditioners_matches_oracle(smm, oracle, dtype):
+    P = smm.SolverPreconditioner
+    tol = TOL[np.dtype(dtype)]
+    for csr, block_rows in ((gen.convdiff3d(20, 0.3, dtype=dtype), None), (gen.poisson2d(60, dtype=dtype), 128)):
+        rows = len(csr[0]) - 1
+        A = make(smm, csr)
+        b = gen.row_sums(csr[0], csr[2])
+        for kind, okind in ((P.BLOCK_ILU0, PRECOND_BLOCK_ILU0), (P.BLOCK_SGS, PRECOND_BLOCK_SGS)):
+            M = A.getPreconditioner(kind, block_rows)
+            bounds = M.block_bounds()
+            pv = oracle.block_ilu0_factorize(csr, bounds)[1] if kind == P.BLOCK_ILU0 else None
+            for maxit in (1, 3, 10):
+                x = np.zeros(rows, dtype=dtype)
+                info = {}
+                st = smm.BiCGStab(A, b, x, maxit, dtype(1e-30), M, info=info)
+                st_o, x_o, it_o, _ = oracle.bicgstab_block(csr, b, np.zeros(rows, dtype=dtype), maxit, dtype(1e-30), okind, bounds, pv)
+                assert int(st) == st_o and info["iterations"] == it_o == maxit
+                assert np.abs(x - x_o).max() <= tol * max(1.0, np.abs(x_o).max()), (kind, maxit)
+            # converged: same iteration count (+-1: the dot products are summed in another order), x = 1
+            eps = dtype(1e-4 if dtype == np.float32 else 1e-9)
+            x = np.zeros(rows, dtype=dtype)
+            info = {}
+            st = smm.BiCGStab(A, b, x, -1, eps, M, info=info)
+            st_o, x_o, it_o, _ = oracle.bicgstab_block(csr, b, np.zeros(rows, dtype=dtype), -1, eps, okind, bounds, pv)
+            assert int(st) == st_o == 0 and abs(info["iterations"] - it_o) <= 1, (info, it_o)
+            np.testing.assert_allclose(x, np.ones(rows), atol=50 * float(eps))
+
+
+@pytest.mark.parametrize("n,dtype", [(108, np.float64), (1000, np.float64)])
+def test_block_preconditioners_at_config_sizes(smm, oracle, n, dtype):
+    """BASELINE config 5's stand-in (convection-diffusion 108^3) and configs 1 / 2's matrix (Poisson 1000^2) at full size: apply and
+    factor bit-identical to the oracle, the preconditioned solve against the oracle's"""
+    P = smm.SolverPreconditioner
+    csr = gen.convdiff3d(108, 0.3, dtype=dtype) if n == 108 else gen.poisson2d(1000, dtype=dtype)
+    rows = len(csr[0]) - 1
+    bounds = compare_with_oracle(smm, oracle, csr, None, dtype)
+    A = make(smm, csr)
+    b = gen.row_sums(csr[0], csr[2])
+    M = A.getPreconditioner(P.BLOCK_ILU0)
+    lu = oracle.block_ilu0_factorize(csr, bounds)[1]
+    x = np.zeros(rows, dtype=dtype)
+    info = {}
+    st = smm.BiCGStab(A, b, x, 20, dtype(1e-30), M, info=info)
+    st_o, x_o, it_o, _ = oracle.bicgstab_block(csr, b, np.zeros(rows, dtype=dtype), 20, dtype(1e-30), PRECOND_BLOCK_ILU0, bounds, lu)
+    assert int(st) == st_o and info["iterations"] == it_o == 20
+    assert np.abs(x - x_o).max() <= 1e-9 * max(1.0, np.abs(x_o).max())
+
+
+def test_block_apply_is_repeatable_and_asynchronous(smm):
+    """device-pointer apply on the caller's stream, twice: same bits; and the fused-dot epilogue leaves x unchanged"""
+    torch = pytest.importorskip("torch")
+    P = smm.SolverPreconditioner
+    csr = gen.convdiff3d(30, 0.3, dtype=np.float64)
+    rows = len(csr[0]) - 1
+    A = make(smm, csr)
+    M = A.getPreconditioner(P.BLOCK_ILU0)
+    rhs = torch.rand(rows, dtype=torch.float64, device="cuda")
+    x1 = torch.zeros_like(rhs)
+    x2 = torch.zeros_like(rhs)
+    s = torch.cuda.current_stream().cuda_stream
+    M.apply_dev(rhs, x1, s)
+    M.apply_dev(rhs, x2, s)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x2)
+    host = np.zeros(rows)
+    M.apply(rhs.cpu().numpy(), host)
+    np.testing.assert_array_equal(host, x1.cpu().numpy())
+
+
+def test_block_preconditioner_structural_failures(smm):
+    P = smm.SolverPreconditioner
+    start, pos, val = gen.poisson2d(12, dtype=np.float64)
+    rows = len(start) - 1
+    rowof = np.repeat(np.arange(rows), np.diff(start))
+    keep = ~((pos == rowof) & (rowof == 77))  # row 77 loses its diagonal
+    s2 = np.zeros(rows + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rowof[keep], minlength=rows), out=s2[1:])
+    A = smm.CSRMatrix(rows, rows, s2, pos[keep].copy(), val[keep].copy())
+    for kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
+        with pytest.raises(Exception):
+            A.getPreconditioner(kind, 64)
+    tiny = val.copy()
+    tiny[(pos == rowof) & (rowof == 5)] = 1e-7  # |d| < 1e-5: SGS refuses (ref:1691-1693), ILU0's pivot is tiny as well
+    A2 = smm.CSRMatrix(rows, rows, start, pos, tiny)
+    with pytest.raises(Exception):
+        A2.getPreconditioner(P.BLOCK_SGS, 64)
+    with pytest.raises(Exception):
+        A.getPreconditioner(P.BLOCK_ILU0, 32)  # block_rows out of range
+    with pytest.raises(Exception):
+        A.getPreconditioner(P.JACOBI, 64)  # not a block kind
