@@ -130,7 +130,9 @@ def test_bicgstab_with_block_preconditioners_matches_oracle(smm, oracle, dtype):
             M = A.getPreconditioner(kind, block_rows)
             bounds = M.block_bounds()
             pv = oracle.block_ilu0_factorize(csr, bounds)[1] if kind == P.BLOCK_ILU0 else None
-            for maxit in (1, 3, 10):
+            # (few iterations: with these strong preconditioners the fp32 solve reaches round-off within ~10 passes, after which the
+            # iterates follow the summation order of the dot products, not the algorithm)
+            for maxit in (1, 2, 4):
                 x = np.zeros(rows, dtype=dtype)
                 info = {}
                 st = smm.BiCGStab(A, b, x, maxit, dtype(1e-30), M, info=info)
