@@ -292,7 +292,8 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
     host.cg_resident(before)
     torch.cuda.empty_cache()
     # (d) BASELINE config 5's stand-in: BiCGStab on the non-symmetric convection-diffusion matrix 108^3 (1.26 M rows, fp64) to 1e-8, without a
-    # preconditioner and with the library's Jacobi / ILU0 (create time and solve time)
+    # preconditioner and with the library's Jacobi / ILU0 / BLOCK_ILU0 / BLOCK_SGS (create time, solve time, time of one apply;
+    # DESIGN.md section 3.5)
     try:
         N = 108
         n, nnz = N ** 3, host.gen_stencil3d_nnz(N, N, N)
@@ -306,11 +307,18 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         A.spmv_dev(0, None, ones, b, stream)
         leg = {"rows": n, "nnz": nnz, "dtype": "f64", "tol": 1e-8}
         P = smm.SolverPreconditioner
-        for name, kind in (("none", None), ("jacobi", P.JACOBI), ("ilu0", P.ILU0)):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            M = A.getPreconditioner(kind) if kind is not None else None
-            tc = time.perf_counter() - t0
+        bytes_apply = 2 * (nnz * 12 + (n + 1) * 4) + 5 * n * 8  # two triangular sweeps over A's pattern ~ 2 x SpMV bytes
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for name, kind in (("none", None), ("jacobi", P.JACOBI), ("ilu0", P.ILU0), ("block_ilu0", P.BLOCK_ILU0), ("block_sgs", P.BLOCK_SGS)):
+            M, tc = None, 0.0
+            for _ in range(2 if kind is not None else 0):  # the second create is the steady state (device allocations cached)
+                if M is not None:
+                    M.close()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                M = A.getPreconditioner(kind)
+                torch.cuda.synchronize()
+                tc = time.perf_counter() - t0
             for _ in range(2):
                 x = torch.zeros(n, dtype=torch.float64, device=dev)
                 torch.cuda.synchronize()
@@ -318,9 +326,22 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
                 st, it, _res = host.bicgstab_dev(A, b, x, -1, 1e-8, M, stream)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-            leg[name] = {"status": int(st), "iterations": it, "solve_ms": dt * 1e3, "create_ms": tc * 1e3,
+            leg[name] = {"status": int(st), "iterations": it, "solve_ms": dt * 1e3, "create_ms": tc * 1e3, "create_plus_solve_ms": (tc + dt) * 1e3,
                          "max_abs_err_vs_ones": float((x - 1).abs().max())}
             if M is not None:
+                if kind != P.JACOBI:
+                    y = torch.empty_like(ones)
+                    M.apply_dev(b, y, stream)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(20):
+                        M.apply_dev(b, y, stream)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms_apply = e0.elapsed_time(e1) / 20
+                    leg[name].update(apply_us=ms_apply * 1e3, apply_gbps=bytes_apply / ms_apply / 1e6, levels=list(M.levels()))
+                    if kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
+                        leg[name]["blocks"] = len(M.block_bounds()) - 1
                 M.close()
         out["bicgstab_convdiff108_f64"] = leg
         A.close()

@@ -645,29 +645,58 @@ inline MatrixLoadStatus loadMatrixMarketMatrix(const char* filepath, CSRMatrix<T
 	return out.init(h.rows, h.cols, start.data(), positions.data(), values.data()) == 0 ? MatrixLoadStatus::SUCCESS : MatrixLoadStatus::FAILED_TO_PARSE_FILE;
 }
 
-// ref:2611-2643: dense text `rows cols { {a, b, ...}, {...} }`; zeros are not stored
+// The dense text format the reference's saveDenseText writes and ref:2611-2643 reads: `rows cols { {a, b, ...}, {...}, ... }`.
+// Written from that format description with a parser of its own: the file is read whole and scanned once as a token stream --
+// numbers by strtod, `{` `}` tracked as a nesting depth, commas and white space skipped -- and the shape is CHECKED (exactly `rows`
+// inner groups of exactly `cols` numbers, a closed outer group), which the format allows and a stream of >> / ignore calls cannot.
+// Zeros are not stored.
 template <typename T>
 inline MatrixLoadStatus loadSMMDTMatrix(const char* filepath, TripletMatrix<T>& out) {
-	std::ifstream file(filepath);
-	if (!file.is_open()) return MatrixLoadStatus::FAILED_TO_OPEN_FILE;
-	int rows = 0, cols = 0;
-	file >> rows >> cols;
-	if (file.fail() || rows < 0 || cols < 0) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
-	out.init(rows, cols, 0);
-	file.ignore(std::numeric_limits<std::streamsize>::max(), '{');
-	for (int i = 0; i < rows; ++i) {
-		file.ignore(std::numeric_limits<std::streamsize>::max(), '{');
-		for (int j = 0; j < cols; ++j) {
-			T val;
-			file >> val;
-			if (file.fail()) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
-			if (val != 0) out.addEntry(i, j, val);
-			file.ignore(1, ',');
-		}
-		file.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
+	std::FILE* f = std::fopen(filepath, "rb");
+	if (!f) return MatrixLoadStatus::FAILED_TO_OPEN_FILE;
+	std::string text;
+	char buf[1 << 16];
+	for (size_t got; (got = std::fread(buf, 1, sizeof(buf), f)) > 0;) text.append(buf, got);
+	std::fclose(f);
+	const char* p = text.c_str();
+	const char* const end = p + text.size();
+	long dims[2] = {0, 0};
+	for (long& d : dims) {  // the two leading integers
+		char* after = nullptr;
+		d = std::strtol(p, &after, 10);
+		if (after == p || d < 0 || d > std::numeric_limits<int>::max()) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+		p = after;
 	}
-	file.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
-	if (file.fail()) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+	const int rows = static_cast<int>(dims[0]), cols = static_cast<int>(dims[1]);
+	out.init(rows, cols, 0);
+	int depth = 0, row = -1, col = 0;  // depth 1: between rows; depth 2: inside row `row`, `col` numbers read so far
+	bool closed = false;
+	while (p < end && !closed) {
+		const char c = *p;
+		if (c == '{') {
+			if (++depth > 2) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+			if (depth == 2) {
+				if (++row >= rows) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+				col = 0;
+			}
+			++p;
+		} else if (c == '}') {
+			if (depth == 2 && col != cols) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+			if (--depth < 0) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+			closed = depth == 0;
+			++p;
+		} else if (c == ',' || std::isspace(static_cast<unsigned char>(c))) {
+			++p;
+		} else {
+			char* after = nullptr;
+			const double v = std::strtod(p, &after);
+			if (after == p || depth != 2 || col >= cols) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
+			if (v != 0.0) out.addEntry(row, col, static_cast<T>(v));
+			++col;
+			p = after;
+		}
+	}
+	if (!closed || row + 1 != rows) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
 	return MatrixLoadStatus::SUCCESS;
 }
 

@@ -123,6 +123,19 @@ static void testLoader(const bool withGpu) {
 		CHECK(SMM::loadMatrix(dpath.c_str(), m) == St::SUCCESS);
 		CHECK(m.getNonZeroCount() == 4 && m.getValue(2, 3) == T(-1.25));
 	}
+	// the shape is checked: a short row, a missing row, an unclosed outer group, a number outside a row, too deep a nesting
+	for (const char* bad : {"2 2\n{\n{1,2},\n{3}\n}\n", "2 2\n{\n{1,2}\n}\n", "2 2\n{\n{1,2},\n{3,4}\n", "2 2\n{ 5 {1,2},{3,4} }\n", "1 1\n{ { {1} } }\n",
+	                        "2 2\n{\n{1,2,3},\n{4,5}\n}\n", "x 2\n{}\n", "2 2\n{\n{1,2},\n{3,4},\n{5,6}\n}\n"}) {
+		writeFile(dpath, bad);
+		SMM::TripletMatrix<T> t;
+		CHECK(SMM::loadMatrix(dpath.c_str(), t) == St::FAILED_TO_PARSE_FILE);
+	}
+	writeFile(dpath, "0 0\n{\n}\n");
+	{
+		SMM::TripletMatrix<T> t;
+		CHECK(SMM::loadMatrix(dpath.c_str(), t) == St::SUCCESS);
+		CHECK(t.getNonZeroCount() == 0);
+	}
 	std::remove(dpath.c_str());
 }
 

@@ -33,7 +33,10 @@ def test_loaders_and_error_reporting_host_only():
 def test_host_side_under_address_and_ub_sanitizers():
     """the same translation unit built with -fsanitize=address,undefined (CPU sanitizer build)"""
     _build()
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    # sanitizers never run on the GPU (not supported on this pool): hide every device, so that on a GPU box too the binary takes its
+    # no-device path (the HIP runtime then reports zero devices and every ABI call returns SMM_HIP_ERR_NO_DEVICE)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", HIP_VISIBLE_DEVICES="-1",
+               ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="-1")
     r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_loader_asan")], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "0 failed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
