@@ -265,6 +265,23 @@ __global__ __launch_bounds__(TPB) void labKernel(int nTiles, const int2* __restr
 
 // ---------------------------------------------------------------------------------------------------------------------
 // MODE 4: NP producer waves (LDS-DMA into a ring of NS tile slots) + NC consumer waves (gathers and row sums)
+//
+// On record: the FIRST run of this mode ended in "Memory access fault by GPU node-2 ... on address 0x791c6c566000" (r02,
+// gpurun_out/lab1_ring.log, before the first configuration printed a line).  That source was never committed -- the lab entered git at
+// 4da9802 with the guards below already in -- so the faulting line cannot be quoted from a diff; what the surviving artefacts say:
+//   * the address is page-aligned and nothing was printed: a read that ran off the END of a global allocation into the next, unmapped
+//     page, in the very first launch.  LDS accesses cannot raise this fault (ring slot indexing (kk % NS) * SLOT and the PAD over-read of
+//     a gather batch stay inside the workgroup's LDS allocation or return zeros; they would have shown as wrong sums, and every later run
+//     printed `ok`), and out[] is only written for rl < nrows.
+//   * the only global accesses of this mode that can leave their buffer are the producer's LDS-DMA reads of positions[] / values[]:
+//     a producer issues whole slots -- CAP entries from a0 = rowBlocks[tile].y & ~3, whatever the tile really holds -- and runs NS - 1
+//     tiles AHEAD of the consumers, i.e. it issues slots for kk >= myTiles too.  For those TileMap::tileOf() returns nTiles, whose table
+//     entry is the closing sentinel {rows, nnz}: a DMA of CAP (4096-8192) entries starting AT nnz, 16-32 KB past the arrays, where the
+//     modes 0-3 over-read less than one 4 KB piece.  With the arrays allocated with the small slack those modes needed, that read ends in
+//     an unmapped page.
+// Both guards are in the committed source: issue() clamps to the workgroup's last real tile (`min(kk, myTiles - 1)`, a dummy reload
+// whose slot no consumer reads) and skips everything when myTiles == 0, and main() allocates positions[] / values[] with 64 K entries
+// of zero-filled slack (> CAP for every configuration: static_assert below), so even the last tile's own over-read stays mapped.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void waitVm() {
@@ -282,6 +299,7 @@ __global__ __launch_bounds__((NP + NC) * WAVE) void labRingKernel(int nTiles, co
 	constexpr int IPT = 2 * CHUNKS / NP;   // LDS-DMA instructions per tile and producer wave
 	static_assert(2 * CHUNKS % NP == 0, "chunks must divide over the producer waves");
 	static_assert((NS - 1) * IPT <= 60, "vmcnt is a 6-bit counter");
+	static_assert(CAP + 256 <= 64 * 1024, "a slot's DMA may start at the last entry: it must stay inside the slack main() allocates behind the arrays");
 	// ring: slot s = sOff[CAP + PAD] then sVal[CAP]; a batch of G entries may read past the end of its piece: what it finds there must
 	// be a valid column (the zeroed PAD), never value bits; one more PAD behind the last slot
 	constexpr int SLOT = 2 * CAP + PAD;
