@@ -125,6 +125,10 @@ int smm_hip_csr_info(const smm_hip_csr* m, int* rows, int* cols, int* nnz, int* 
 /* Force a SpMV kernel family / lanes-per-row (0 = heuristic).  Tuning knob, not needed for correctness. */
 int smm_hip_csr_set_kernel(smm_hip_csr* m, int family, int lanes_per_row);
 int smm_hip_csr_get_kernel(const smm_hip_csr* m, int* family, int* lanes_per_row);
+/* The STREAM family's tile table as the last SpMV built it (0 tiles before the first SpMV or for the other families): number of
+ * tiles, the nonzeros / rows a tile was cut for, and whether the launches go to spmvTileKernel (1: the pieces of a row in different
+ * waves -- 2 or 4 lanes per row, the benchmark matrix) or to the pipelined spmvStreamKernel (0).  Diagnostics for tests and benches. */
+int smm_hip_csr_tile_info(const smm_hip_csr* m, int* tiles, int* tile_nnz_cap, int* tile_max_rows, int* tile_kernel);
 /* Times the candidate SpMV configurations on this matrix and keeps the fastest. */
 int smm_hip_csr_autotune(smm_hip_csr* m);
 
@@ -271,6 +275,16 @@ int smm_hip_spmv_fused_dev_f32(const smm_hip_csr* m, int op, const float* d_lhs,
                                const float* d_w1, float* d_partials, smm_hip_stream stream);
 int smm_hip_spmv_fused_dev_f64(const smm_hip_csr* m, int op, const double* d_lhs, const double* d_x, double* d_out, int dot_mode,
                                const double* d_w1, double* d_partials, smm_hip_stream stream);
+/* The same with the reduction FINISHED in the launch: the workgroup that ends last adds the partial sums (same fixed order, same bits as
+ * a separate summing kernel) and leaves the totals at d_finish[smm_hip_finish_totals_offset() + {0, 1}] (dot_mode 1: out.w1; dot_mode 2:
+ * out.out, out.w1).  d_finish: smm_hip_finish_len() elements, zeroed ONCE by the caller before the first use (it carries the arrival
+ * counter between launches); one buffer per stream.  What the row-partitioned solvers all-reduce right behind their SpMV. */
+int smm_hip_finish_len(void);
+int smm_hip_finish_totals_offset(void);
+int smm_hip_spmv_fused_finish_dev_f32(const smm_hip_csr* m, int op, const float* d_lhs, const float* d_x, float* d_out, int dot_mode,
+                                      const float* d_w1, float* d_finish, smm_hip_stream stream);
+int smm_hip_spmv_fused_finish_dev_f64(const smm_hip_csr* m, int op, const double* d_lhs, const double* d_x, double* d_out, int dot_mode,
+                                      const double* d_w1, double* d_finish, smm_hip_stream stream);
 /* workspace for n local rows: owns r, r0, ap, as, the partial-sum buffer, `sums` (4 scalars) and the recurrence state */
 int smm_hip_bicgstab_ws_create_f32(int n, smm_hip_bicgstab_ws** out);
 int smm_hip_bicgstab_ws_create_f64(int n, smm_hip_bicgstab_ws** out);

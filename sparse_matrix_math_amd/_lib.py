@@ -61,6 +61,7 @@ _TYPED = {
     "smm_hip_gen_banded_dev": (c_int, [c_int, c_int, c_ulonglong, c_int, "T", _P, _P, _P, _P]),
     "smm_hip_gen_banded_rows_dev": (c_int, [c_int, c_int, c_ulonglong, c_int, "T", c_int, c_int, _P, _P, _P, _P]),
     "smm_hip_spmv_fused_dev": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    "smm_hip_spmv_fused_finish_dev": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "smm_hip_bicgstab_ws_create": (c_int, [c_int, POINTER(_P)]),
     "smm_hip_bicgstab_ws_stage": (c_int, [_P, c_int, _P, "T", _P]),
     "smm_hip_cg_ws_stage": (c_int, [_P, c_int, _P, _P, "T", _P]),
@@ -87,6 +88,7 @@ _PLAIN = {
     "smm_hip_csr_set_kernel": (c_int, [_P, c_int, c_int]),
     "smm_hip_csr_get_kernel": (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
     "smm_hip_csr_autotune": (c_int, [_P]),
+    "smm_hip_csr_tile_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "smm_hip_precond_create": (c_int, [_P, c_int, POINTER(_P)]),
     "smm_hip_precond_create_block": (c_int, [_P, c_int, c_int, POINTER(_P)]),
     "smm_hip_precond_block_count": (c_int, [_P, POINTER(c_int)]),
@@ -100,6 +102,8 @@ _PLAIN = {
     "smm_hip_gen_banded_nnz": (c_longlong, [c_int, c_int, c_ulonglong, c_int]),
     "smm_hip_gen_banded_row_start": (c_longlong, [c_int, c_int, c_ulonglong, c_int, c_int]),
     "smm_hip_partials_count": (c_int, []),
+    "smm_hip_finish_len": (c_int, []),
+    "smm_hip_finish_totals_offset": (c_int, []),
     "smm_hip_cg_resident": (c_int, [c_int]),
     "smm_hip_bicgstab_ws_destroy": (c_int, [_P]),
     "smm_hip_cg_ws_status": (c_int, [_P, _P, POINTER(c_int)]),

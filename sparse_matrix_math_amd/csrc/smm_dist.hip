@@ -525,6 +525,7 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 	hipEvent_t landed = nullptr;
 	if (exchange) {
 		hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;  // the callback kind blocks anyway
+		noteStream(cs);
 		SMM_TRY(orderAfter(c, s, cs));
 		SMM_TRY(commExchange<T>(c, ext, D->sends, D->recvs, cs));
 		if (cs != s) {
@@ -548,6 +549,7 @@ static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t
 	if (c->kind == SMM_COMM_SELF) return SMM_HIP_OK;
 	T* totals = parts + PARTS_TOTALS;
 	if (c->kind == SMM_COMM_HOST) return commAllreduce<T>(c, totals, count, s);
+	noteStream(c->stream);
 	SMM_TRY(orderAfter(c, s, c->stream));
 	SMM_TRY(commAllreduce<T>(c, totals, count, c->stream));
 	*joined = takeEvent(c);

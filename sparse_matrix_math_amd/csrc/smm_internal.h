@@ -42,7 +42,12 @@ int ensureInit();
 hipStream_t libStream();
 // `_dev` entry points follow plain HIP semantics: the handle is a hipStream_t and NULL is the null (default) stream --
 // which is also what torch.cuda.current_stream().cuda_stream is for PyTorch's default stream
-inline hipStream_t pickStream(smm_hip_stream s) { return static_cast<hipStream_t>(s); }
+// (the allocator is told: a block freed later becomes reusable only after an event recorded on this stream has completed)
+void noteStream(hipStream_t s);
+inline hipStream_t pickStream(smm_hip_stream s) {
+	noteStream(static_cast<hipStream_t>(s));
+	return static_cast<hipStream_t>(s);
+}
 int numCUs();
 
 // caching device allocator (solver temporaries are allocated per call like the reference's SMM::Vector,

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restr
 		int used = W;  // entries of the window already consumed (W: load the next window)
 		unsigned passes = 0;
 		while (__ballot(pending) != 0ull) {
+			bool moved = false;
 			if (pending) {
 				if (used == W) {
 #pragma unroll
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restr
 							else result = acc / value;                            // ILU_UP, IC_LO (ref:1818), IC_UP (ref:1834)
 							publishX<T, ONE_XCD>(out, row, result);
 							pending = false;
+							moved = true;
 						} else if (xb[u] != SweepBits<T>::SENT) {
 							T xv;
 							__builtin_memcpy(&xv, &xb[u], sizeof(T));
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restr
 								acc = acc - prod;
 							}
 							used = u + 1;
+							moved = true;
 						} else {
 							stopped = true;  // not final yet: poll again on the next pass
 						}
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(TPB) void sweepFreeKernel(int n, const int* __restr
 				}
 				if (pending && used == W) k += DIR * W;
 			}
+			if (__ballot(moved) != 0ull) passes = 0;  // the bound counts passes without progress of any lane (pure waiting), like levelFreeKernel's
 			if (++passes > passLimit && pending) {  // cannot happen; guarantees that the grid drains
 				atomicOr(err, 1);
 				publishX<T, ONE_XCD>(out, row, __builtin_nanf(""));
@@ -403,8 +407,9 @@ __global__ __launch_bounds__(TPB) void levelFreeKernel(int n, const int* __restr
 			k = LOWER ? start[row] : start[row + 1] - 1;
 			stop = LOWER ? start[row + 1] : start[row] - 1;
 		}
-		unsigned passes = 0;
+		unsigned passes = 0;  // passes since a lane of this wavefront last moved on
 		while (__ballot(pending) != 0ull) {
+			bool moved = false;
 			if (pending) {
 				// one entry per pass (the shape of the sweeps' loop: nobody waits, or loops, inside a pass)
 				const bool inside = LOWER ? k < stop : k > stop;
@@ -412,14 +417,20 @@ __global__ __launch_bounds__(TPB) void levelFreeKernel(int n, const int* __restr
 				if (!(inside && (LOWER ? col < row : col > row))) {  // end of the triangular part (ref:1673-1694 stop at the diagonal too)
 					__hip_atomic_store(level + row, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					pending = false;
+					moved = true;
 				} else {
 					const int d = __hip_atomic_load(level + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					if (d >= 0) {  // known: take it and move on; otherwise poll again on the next pass
 						lv = max(lv, d + 1);
 						k += DIR;
+						moved = true;
 					}
 				}
 			}
+			// The escape bound counts passes WITHOUT progress: a wavefront that consumes an entry or finishes a row starts afresh, so what
+			// is bounded is the pure wait for the rows in front of it -- at most the chunks of the other resident wavefronts, each a
+			// bounded number of passes (buildLevelsDevice sizes passLimit for exactly that) -- not the depth of the matrix's DAG.
+			if (__ballot(moved) != 0ull) passes = 0;
 			if (++passes > passLimit && pending) {  // cannot happen; guarantees that the grid drains
 				atomicOr(words + 2, 1);
 				__hip_atomic_store(level + row, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -816,7 +827,7 @@ template int precondApplyDev<double>(const smm_hip_precond*, const double*, doub
 // level sets of one sweep, on the device: d_order (rows sorted by level, ascending row inside a level), the level pointers on the host
 // (the launch plan is made from them) and on the device (the chained kernels read them)
 template <bool LOWER>
-static int buildLevelsDevice(const smm_hip_csr* a, unsigned passLimit, hipStream_t s, int** d_order, std::vector<int>& lvlPtr, int** d_lvlPtr) {
+static int buildLevelsDevice(const smm_hip_csr* a, unsigned passLimit, int maxRowLen, hipStream_t s, int** d_order, std::vector<int>& lvlPtr, int** d_lvlPtr) {
 	const int n = a->rows;
 	*d_order = nullptr;
 	*d_lvlPtr = nullptr;
@@ -834,8 +845,15 @@ static int buildLevelsDevice(const smm_hip_csr* a, unsigned passLimit, hipStream
 	SMM_TRY(words.alloc(4));
 	SMM_HIP_TRY(hipMemsetAsync(level, 0xFF, static_cast<size_t>(n) * sizeof(int), s));  // -1: not known yet
 	SMM_HIP_TRY(hipMemsetAsync(words, 0, 4 * sizeof(int), s));
-	const int waves = std::min((n + WAVE - 1) / WAVE, numCUs() * 32);
-	levelFreeKernel<LOWER><<<(waves + TPB / WAVE - 1) / (TPB / WAVE), TPB, 0, s>>>(n, a->d_start, a->d_positions, level, words, passLimit);
+	// Resident wavefronts only (8 per CU), and the escape bound follows from their number: the wavefront that drew the last of the
+	// first `waves` tickets may have to wait for every chunk in front of it, each of which needs at most 64 rows x (longest row + 2)
+	// passes once ITS predecessors are done (a pure chain -- a tridiagonal matrix, a dense band -- is the worst case; the r02 bound,
+	// 2^21 + 64 x longest row for up to 8192 wavefronts, left a factor 2 for a tridiagonal matrix and none for a 50-entry band).
+	const int waves = std::min((n + WAVE - 1) / WAVE, numCUs() * 8);
+	const unsigned long long perChunk = 64ull * (static_cast<unsigned long long>(maxRowLen) + 2ull);
+	const unsigned levelLimit = static_cast<unsigned>(std::min<unsigned long long>(0x7fffffffull, (1ull << 21) + 8ull * static_cast<unsigned long long>(waves) * perChunk));
+	(void)passLimit;
+	levelFreeKernel<LOWER><<<(waves + TPB / WAVE - 1) / (TPB / WAVE), TPB, 0, s>>>(n, a->d_start, a->d_positions, level, words, levelLimit);
 	const int grid = static_cast<int>(std::min<long long>((n + TPB - 1LL) / TPB, numCUs() * 8LL));
 	maxLevelKernel<<<grid, TPB, 0, s>>>(n, level, words.p + 1);
 	iotaKernel<<<grid, TPB, 0, s>>>(n, rowsIn);
@@ -939,8 +957,8 @@ static int createTyped(const smm_hip_csr* a, int kind, smm_hip_precond* M) {
 	auto* plan = new smm_precond_plan();
 	M->plan = plan;  // (smm_hip_precond_destroy releases it together with whatever the steps below have allocated so far)
 	plan->passLimit = static_cast<unsigned>(std::min<long long>(0x7fffffffLL, (1LL << 21) + 64LL * info[1]));
-	SMM_TRY(buildLevelsDevice<true>(a, plan->passLimit, s, &M->d_order_lo, M->lvl_ptr_lo, &plan->lo.d_lvlPtr));
-	SMM_TRY(buildLevelsDevice<false>(a, plan->passLimit, s, &M->d_order_up, M->lvl_ptr_up, &plan->up.d_lvlPtr));
+	SMM_TRY(buildLevelsDevice<true>(a, plan->passLimit, info[1], s, &M->d_order_lo, M->lvl_ptr_lo, &plan->lo.d_lvlPtr));
+	SMM_TRY(buildLevelsDevice<false>(a, plan->passLimit, info[1], s, &M->d_order_up, M->lvl_ptr_up, &plan->up.d_lvlPtr));
 	planGroups(M->lvl_ptr_lo, plan->lo.groups);
 	planGroups(M->lvl_ptr_up, plan->up.groups);
 	if (kind == SMM_PRECOND_ILU0 || kind == SMM_PRECOND_IC0) {

@@ -579,7 +579,11 @@ int cgResidentTry(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIt
 	args.sync = sync;
 	args.needed = needed;
 	args.out = out;
-	args.waitTicks = 1LL << 22;  // a few seconds
+	// Every barrier wait is bounded.  REQUIRE (tests, measurements) waits a few seconds; AUTO gives up after a fraction of that: a
+	// plain launch cannot reserve the CUs (a cooperative launch only checks the grid against the occupancy query, it does not wait for
+	// CUs another stream or process holds -- MI355X_MICROARCH.md, coop-launch), so when workgroups are not co-resident the honest move
+	// is to fall back quickly, and -- below -- to stop trying for the rest of the process.
+	args.waitTicks = mode == SMM_CG_RESIDENT_REQUIRE ? 1LL << 22 : 1LL << 19;
 #ifdef SMM_RESIDENT_LAB
 	args.lab = getenv("SMM_RESIDENT_LAB") ? atoi(getenv("SMM_RESIDENT_LAB")) : 0;
 	if (args.lab & 2) args.waitTicks = -1;
@@ -596,7 +600,17 @@ int cgResidentTry(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIt
 		SMM_HIP_TRY(hipMemcpyAsync(&gaveUp, &sync.p->timeout[0], sizeof(unsigned), hipMemcpyDeviceToHost, s));
 		SMM_HIP_TRY(hipStreamSynchronize(s));
 	}
-	if (h.timedOut || gaveUp) return notApplicable("a grid barrier timed out (is another persistent kernel holding CUs?)");
+	if (h.timedOut || gaveUp) {
+		if (mode == SMM_CG_RESIDENT_AUTO) {
+			// remember it: the CUs this solve needs all at once are shared with somebody; every later AUTO solve would pay the same stall
+			int expected = SMM_CG_RESIDENT_AUTO;
+			if (residentModeRef().compare_exchange_strong(expected, SMM_CG_RESIDENT_OFF)) {
+				fprintf(stderr, "libsmm_hip: the register-resident ConjugateGradient gave up at a grid barrier (CUs held by another stream or process?); "
+				                "switched off for this process (smm_hip_cg_resident / SMM_HIP_CG_RESIDENT turn it back on)\n");
+			}
+		}
+		return notApplicable("a grid barrier timed out (is another persistent kernel holding CUs?)");
+	}
 	if (h.iters > 0) SMM_HIP_TRY(hipMemcpyAsync(x, xOut.p, static_cast<size_t>(n) * sizeof(T), hipMemcpyDeviceToDevice, s));
 	if (status) *status = h.status;
 	if (iterations) *iterations = h.iters;

@@ -73,29 +73,110 @@ int numCUs() { return g_cus > 0 ? g_cus : 256; }
 
 // ---- caching allocator: free blocks keyed by size, reused exactly --------------------------------------
 // Every `_dev` entry point is asynchronous on the caller's stream, and handles are destroyed (Python __del__, error returns)
-// while kernels that read their buffers may still be queued.  A freed block therefore first goes to a QUARANTINE list; it
-// becomes reusable only after a hipDeviceSynchronize() issued after the free -- paid once, by the first allocation that wants
-// a quarantined block, and releasing the whole quarantine.  (hipFree would have synchronised implicitly; so does this, but
-// once per batch of frees instead of once per block.)  In the steady state of solve-after-solve the device is idle at that
-// point (a solve ends with a stream synchronise), so the synchronise costs microseconds.
+// while kernels that read their buffers may still be queued.  A freed block therefore first goes to a QUARANTINE.  The quarantine
+// is kept in EPOCHS: when an allocation wants a quarantined size, the blocks freed so far are closed into an epoch and one event is
+// recorded on every stream the library has been given work on since the previous close (noteStream); an epoch's blocks become
+// reusable once all its events have completed -- work enqueued BEFORE the free on any of those streams is then done.  Nothing
+// drains the device: other threads' streams and the communicator's side stream keep running (r02 called hipDeviceSynchronize here,
+// once per solve).  Only when the wanted size sits in an epoch that has not completed yet does the allocation wait -- for that epoch's
+// events alone; in the steady state of solve-after-solve a solve ends with a stream synchronise, so they have.
 static std::mutex g_allocMutex;
-static std::multimap<size_t, void*> g_free;        // safe to hand out
-static std::multimap<size_t, void*> g_quarantine;  // freed, but work that uses them may still be queued on some stream
+static std::multimap<size_t, void*> g_free;  // safe to hand out
 static std::map<void*, size_t> g_live;
+struct QuarantineEpoch {
+	unsigned long long id = 0;
+	std::multimap<size_t, void*> blocks;
+	std::vector<hipEvent_t> events;
+	bool drainInstead = false;  // an event could not be recorded (a stream destroyed meanwhile): fall back to a device drain
+};
+static std::multimap<size_t, void*> g_open;       // freed since the last close
+static std::vector<QuarantineEpoch> g_epochs;     // closed, oldest first
+static std::vector<hipStream_t> g_recentStreams;  // streams given work since the last close (small: linear search)
+static std::vector<hipEvent_t> g_eventPool;
+static std::mutex g_streamMutex;
 
-static bool releaseQuarantineLocked(std::unique_lock<std::mutex>& lock) {
-	if (g_quarantine.empty()) return false;
-	std::multimap<size_t, void*> batch;
-	batch.swap(g_quarantine);  // blocks freed from here on wait for the next synchronise
-	lock.unlock();
-	const hipError_t e = hipDeviceSynchronize();
-	lock.lock();
-	if (e != hipSuccess) {
-		g_quarantine.insert(batch.begin(), batch.end());
-		return false;
+void noteStream(hipStream_t s) {
+	std::lock_guard<std::mutex> lock(g_streamMutex);
+	for (hipStream_t k : g_recentStreams) {
+		if (k == s) return;
 	}
-	g_free.insert(batch.begin(), batch.end());
-	return true;
+	g_recentStreams.push_back(s);
+}
+
+static void closeEpochLocked() {
+	if (g_open.empty()) return;
+	static unsigned long long nextId = 1;
+	QuarantineEpoch ep;
+	ep.id = nextId++;
+	ep.blocks.swap(g_open);
+	std::vector<hipStream_t> streams;
+	{
+		std::lock_guard<std::mutex> lock(g_streamMutex);
+		streams.swap(g_recentStreams);
+	}
+	bool haveLib = false;
+	for (hipStream_t k : streams) haveLib = haveLib || k == g_stream;
+	if (!haveLib && g_stream) streams.push_back(g_stream);  // the host-pointer entry points run here
+	for (hipStream_t k : streams) {
+		hipEvent_t ev = nullptr;
+		if (!g_eventPool.empty()) {
+			ev = g_eventPool.back();
+			g_eventPool.pop_back();
+		} else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+			ep.drainInstead = true;
+			continue;
+		}
+		if (hipEventRecord(ev, k) != hipSuccess) {
+			(void)hipGetLastError();
+			g_eventPool.push_back(ev);
+			ep.drainInstead = true;
+			continue;
+		}
+		ep.events.push_back(ev);
+	}
+	g_epochs.push_back(std::move(ep));
+}
+
+// moves the blocks of every completed epoch (oldest first, in order) to the free list; with `waitFor` != 0 it first waits for the
+// oldest epoch that holds a block of that size
+static void reapEpochsLocked(std::unique_lock<std::mutex>& lock, size_t waitFor) {
+	while (!g_epochs.empty()) {
+		QuarantineEpoch& ep = g_epochs.front();
+		bool done = !ep.drainInstead;
+		for (hipEvent_t ev : ep.events) {
+			if (!done) break;
+			done = hipEventQuery(ev) == hipSuccess;
+		}
+		if (!done) {
+			bool wanted = false;
+			if (waitFor) {
+				for (const auto& e : g_epochs) wanted = wanted || e.blocks.count(waitFor) != 0;
+			}
+			if (!wanted) return;
+			// wait for the front epoch only (epochs complete in order as far as one stream is concerned); unlock meanwhile
+			const std::vector<hipEvent_t> events = ep.events;
+			const bool drain = ep.drainInstead;
+			const unsigned long long id = ep.id;
+			lock.unlock();
+			if (drain) (void)hipDeviceSynchronize();
+			for (hipEvent_t ev : events) (void)hipEventSynchronize(ev);
+			lock.lock();
+			if (g_epochs.empty() || g_epochs.front().id != id) continue;  // another thread reaped it meanwhile
+		}
+		QuarantineEpoch finished = std::move(g_epochs.front());
+		g_epochs.erase(g_epochs.begin());
+		g_free.insert(finished.blocks.begin(), finished.blocks.end());
+		g_eventPool.insert(g_eventPool.end(), finished.events.begin(), finished.events.end());
+		if (waitFor && g_free.count(waitFor)) return;
+	}
+}
+
+static bool quarantineHoldsLocked(size_t bytes) {
+	if (g_open.count(bytes)) return true;
+	for (const auto& e : g_epochs) {
+		if (e.blocks.count(bytes)) return true;
+	}
+	return false;
 }
 
 int devAlloc(void** p, size_t bytes) {
@@ -103,7 +184,11 @@ int devAlloc(void** p, size_t bytes) {
 	{
 		std::unique_lock<std::mutex> lock(g_allocMutex);
 		auto it = g_free.find(bytes);
-		if (it == g_free.end() && g_quarantine.count(bytes) && releaseQuarantineLocked(lock)) it = g_free.find(bytes);
+		if (it == g_free.end() && quarantineHoldsLocked(bytes)) {
+			closeEpochLocked();
+			reapEpochsLocked(lock, bytes);
+			it = g_free.find(bytes);
+		}
 		if (it != g_free.end()) {
 			*p = it->second;
 			g_free.erase(it);
@@ -133,13 +218,20 @@ void devFree(void* p) {
 		hipFree(p);  // synchronises implicitly
 		return;
 	}
-	g_quarantine.emplace(it->second, p);
+	g_open.emplace(it->second, p);
 	g_live.erase(it);
 }
 
 void devTrim() {
+	(void)hipDeviceSynchronize();  // everything queued anywhere is done: every quarantined block is free
 	std::unique_lock<std::mutex> lock(g_allocMutex);
-	releaseQuarantineLocked(lock);
+	g_free.insert(g_open.begin(), g_open.end());
+	g_open.clear();
+	for (auto& ep : g_epochs) {
+		g_free.insert(ep.blocks.begin(), ep.blocks.end());
+		g_eventPool.insert(g_eventPool.end(), ep.events.begin(), ep.events.end());
+	}
+	g_epochs.clear();
 	for (auto& kv : g_free) hipFree(kv.second);
 	g_free.clear();
 }
@@ -189,8 +281,9 @@ int ensureCsrReady(const smm_hip_csr* cm, hipStream_t s, bool streamKnown) {
 		SMM_HIP_TRY(hipDeviceSynchronize());
 		s = libStream();
 	}
-	int* d_cnt = nullptr;
-	SMM_TRY(devAlloc(reinterpret_cast<void**>(&d_cnt), sizeof(int)));
+	DevBuf<int> cnt;  // (released on every return path)
+	SMM_TRY(cnt.alloc(1));
+	int* d_cnt = cnt.p;
 	SMM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), s));
 	int nnz = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(&nnz, m->d_start + m->rows, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -203,7 +296,6 @@ int ensureCsrReady(const smm_hip_csr* cm, hipStream_t s, bool streamKnown) {
 	if (m->rows > 0) SMM_HIP_TRY(hipMemcpyAsync(mid, m->d_start + m->rows / 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));  // the caller's stream only (16 bytes come back)
 	m->stream_mid_len = mid[1] - mid[0];
-	devFree(d_cnt);
 	m->nnz = nnz;
 	m->firstActiveStart = first;
 	if (!m->kernelForced) chooseSpmvConfig(m);

@@ -1165,6 +1165,21 @@ int smm_hip_csr_get_kernel(const smm_hip_csr* m, int* family, int* lanes_per_row
 	return SMM_HIP_OK;
 }
 
+int smm_hip_csr_tile_info(const smm_hip_csr* m, int* tiles, int* tile_nnz_cap, int* tile_max_rows, int* tile_kernel) {
+	if (!m) {
+		setError("csr_tile_info: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	SMM_TRY(ensureCsrReady(m, nullptr, false));
+	std::lock_guard<std::mutex> lock(const_cast<smm_hip_csr*>(m)->tileMutex);
+	if (tiles) *tiles = m->d_rowblocks ? m->n_rowblocks : 0;
+	if (tile_nnz_cap) *tile_nnz_cap = m->d_rowblocks ? m->stream_nnz_cap : 0;
+	if (tile_max_rows) *tile_max_rows = m->d_rowblocks ? m->stream_max_rows : 0;
+	if (tile_kernel) *tile_kernel = m->family == SMM_SPMV_STREAM && useTileKernel(m->lanes) ? 1 : 0;
+	return SMM_HIP_OK;
+}
+
 int smm_hip_csr_autotune(smm_hip_csr* m) {
 	if (!m) {
 		setError("csr_autotune: null matrix");

@@ -392,6 +392,28 @@ int smm_hip_spmv_fused_dev_f64(const smm_hip_csr* m, int op, const double* d_lhs
 	return launchSpmv<double>(m, op, d_lhs, d_x, d_out, dot_mode, d_w1, d_partials, nullptr, pickStream(stream));
 }
 
+int smm_hip_finish_len(void) { return PARTS_LEN; }
+int smm_hip_finish_totals_offset(void) { return PARTS_TOTALS; }
+
+int smm_hip_spmv_fused_finish_dev_f32(const smm_hip_csr* m, int op, const float* d_lhs, const float* d_x, float* d_out, int dot_mode, const float* d_w1,
+                                      float* d_finish, smm_hip_stream stream) {
+	if (!m || !d_finish || dot_mode < 1 || dot_mode > 2) {
+		setError("spmv_fused_finish: null matrix / buffer, or dot_mode not 1 or 2");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	return launchSpmv<float>(m, op, d_lhs, d_x, d_out, dot_mode, d_w1, d_finish, nullptr, pickStream(stream), SPMV_FINISH);
+}
+int smm_hip_spmv_fused_finish_dev_f64(const smm_hip_csr* m, int op, const double* d_lhs, const double* d_x, double* d_out, int dot_mode, const double* d_w1,
+                                      double* d_finish, smm_hip_stream stream) {
+	if (!m || !d_finish || dot_mode < 1 || dot_mode > 2) {
+		setError("spmv_fused_finish: null matrix / buffer, or dot_mode not 1 or 2");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	return launchSpmv<double>(m, op, d_lhs, d_x, d_out, dot_mode, d_w1, d_finish, nullptr, pickStream(stream), SPMV_FINISH);
+}
+
 int smm_hip_bicgstab_ws_create_f32(int n, smm_hip_bicgstab_ws** out) { return wsCreate<float>(n, out); }
 int smm_hip_bicgstab_ws_create_f64(int n, smm_hip_bicgstab_ws** out) { return wsCreate<double>(n, out); }
 

@@ -86,6 +86,18 @@ def device_info():
     return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
 
 
+def partials_count():
+    return _lib.load().smm_hip_partials_count()
+
+
+def finish_len():
+    return _lib.load().smm_hip_finish_len()
+
+
+def finish_totals_offset():
+    return _lib.load().smm_hip_finish_totals_offset()
+
+
 def uses_std_fma():
     return bool(_lib.load().smm_hip_uses_std_fma())
 
@@ -241,6 +253,19 @@ class CSRMatrix:
 
     def spmv_dev(self, op, d_lhs, d_x, d_out, stream=None):
         check(_fn("smm_hip_spmv_dev", self._suf)(self._h, int(op), _dptr(d_lhs), _dptr(d_x), _dptr(d_out), _dptr(stream)))
+
+    def tile_info(self):
+        """(tiles, nonzeros per tile, rows per tile, 1 if spmvTileKernel serves the launches) of the STREAM family's tile table"""
+        v = [ctypes.c_int() for _ in range(4)]
+        check(_lib.load().smm_hip_csr_tile_info(self._h, *[ctypes.byref(c) for c in v]))
+        return tuple(c.value for c in v)
+
+    def spmv_fused_dev(self, op, d_lhs, d_x, d_out, dot_mode, d_w1, d_partials, stream=None, finish=False):
+        """SpMV with the dot products of the fresh out[] in its epilogue (dot_mode 1: out.w1; 2: out.out and out.w1).  finish=False:
+        d_partials receives 2 x partials_count() per-workgroup sums; finish=True: d_partials is a finishing buffer of finish_len()
+        elements (zeroed once) and the totals land at finish_totals_offset() + {0, 1}"""
+        name = "smm_hip_spmv_fused_finish_dev" if finish else "smm_hip_spmv_fused_dev"
+        check(_fn(name, self._suf)(self._h, int(op), _dptr(d_lhs), _dptr(d_x), _dptr(d_out), int(dot_mode), _dptr(d_w1), _dptr(d_partials), _dptr(stream)))
 
     def getPreconditioner(self, kind, block_rows=None):  # ref:1643-1651; block_rows: BLOCK_ kinds only (None = default)
         return Preconditioner(self, kind, block_rows)

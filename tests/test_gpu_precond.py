@@ -249,3 +249,40 @@ def test_ic0_and_ilu0_long_rows_match_oracle(smm, oracle, dtype):
     np.testing.assert_array_equal(M.values(), lu)
     M.apply(rhs, x)
     np.testing.assert_array_equal(x, oracle.ilu0_apply(csr, lu, rhs)[1])
+
+
+def _band_lower_chain(n, width, dtype):
+    """rows i hold columns i-width .. i+1: every row waits for its `width` predecessors -- a pure dependency chain with long rows"""
+    offs = np.arange(-width, 2)
+    cols = np.arange(n)[:, None] + offs[None, :]
+    ok = (cols >= 0) & (cols < n)
+    start = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(ok.sum(axis=1), out=start[1:])
+    pos = cols[ok].astype(np.int32)
+    val = np.broadcast_to(np.where(offs == 0, 2.0 * width + 4.0, -1.0)[None, :], cols.shape)[ok].astype(dtype)
+    return start, pos, val
+
+
+@pytest.mark.parametrize("case", ["tridiagonal_1m", "band40_200k"])
+def test_deep_chains_do_not_trip_the_escape_bound(smm, oracle, case):
+    """the level analysis is one synchronisation-free launch whose escape bound must not depend on the depth of the DAG.
+    A tridiagonal matrix of a million rows (a million levels) and a 40-wide band (200 000 levels, 42-entry rows): create, levels, apply
+    bit-identical to the oracle's sequential sweeps."""
+    dtype = np.float64
+    P = smm.SolverPreconditioner
+    n, width = (1_000_000, 1) if case == "tridiagonal_1m" else (200_000, 40)
+    csr = _band_lower_chain(n, width, dtype)
+    A = make(smm, csr)
+    rhs = np.random.default_rng(3).uniform(-1, 1, n).astype(dtype)
+    for kind in (P.SYMMETRIC_GAUS_SEIDEL, P.ILU0):
+        M = A.getPreconditioner(kind)
+        assert M.levels() == (n, n)  # both sweeps: one row per level
+        x = np.zeros(n, dtype=dtype)
+        assert M.apply(rhs, x) == 0
+        if kind == P.ILU0:
+            e, lu = oracle.ilu0_factorize(csr)
+            assert e == 0
+            np.testing.assert_array_equal(M.values(), lu)
+            np.testing.assert_array_equal(x, oracle.ilu0_apply(csr, lu, rhs)[1])
+        else:
+            np.testing.assert_array_equal(x, oracle.sgs_apply(csr, rhs)[1])

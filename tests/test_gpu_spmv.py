@@ -188,3 +188,83 @@ def test_full_size_properties(smm, dtype, n, k):
     A.spmv_dev(2, w, u, w, stream)
     torch.cuda.synchronize()
     assert float((w - (v - base)).abs().max()) <= 1e3 * np.finfo(dtype).eps
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_headline_kernel_against_oracle_at_scale(smm, oracle, dtype):
+    """The instantiation the bench's number of record comes from -- AUTO on a matrix of BASELINE config 3's shape (k = 25 random offsets
+    on both sides, ~51 entries per row) resolves to spmvTileKernel<T, 2, 13> -- with a persistent walk over thousands of tiles (XCD
+    chunking, the directly streamed last tiles), against the ORACLE row by row: rMult / rMultAdd / rMultSub, the fused-dot epilogue with
+    and without the in-launch finish, and 20 BiCGStab iterations."""
+    import torch
+
+    n, k = 300_000, 25
+    csr = gen.banded_random_spd(n, k=k, seed=0x5EED, max_offset=1 << 15, dtype=dtype)
+    start, pos, val = csr
+    assert 49 <= (start[n // 2 + 1] - start[n // 2]) <= 51
+    A = make(smm, csr)
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    lhs = rng.uniform(-1, 1, n).astype(dtype)
+    out = np.zeros(n, dtype=dtype)
+    A.rMult(x, out)  # the first SpMV cuts the tile table
+    assert A.get_kernel() == (2, 2)  # STREAM family, 2 pieces per row
+    tiles, cap, max_rows, tile_kernel = A.tile_info()
+    assert tile_kernel == 1 and tiles >= 2000 and max_rows == 128, (tiles, cap, max_rows, tile_kernel)
+    tail = slice(n - 4 * max_rows, n)  # the last tiles start within one tile capacity of the end of the arrays: streamed, not staged
+    for op, call in ((OP_ASSIGN, lambda o: A.rMult(x, o)), (OP_ADD, lambda o: A.rMultAdd(lhs, x, o)), (OP_SUB, lambda o: A.rMultSub(lhs, x, o))):
+        out = np.full(n, 7, dtype=dtype)
+        call(out)
+        ref = oracle.spmv(csr, op, lhs if op else None, x)
+        err = np.abs(out.astype(np.float64) - ref)
+        bnd = bound(csr, x, dtype, lhs if op else None)
+        assert np.all(err <= bnd), (op, int(np.argmax(err - bnd)))
+        assert np.all(err[tail] <= bnd[tail])
+    # in place (out aliases lhs, csr.cpp:295-300)
+    inpl = lhs.copy()
+    A.rMultSub(inpl, x, inpl)
+    assert np.all(np.abs(inpl.astype(np.float64) - oracle.spmv(csr, OP_SUB, lhs, x)) <= bound(csr, x, dtype, lhs))
+    # fused dot products of the fresh out[]: per-workgroup partial sums, and the totals finished inside the launch
+    dev = torch.device("cuda:0")
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    stream = torch.cuda.current_stream().cuda_stream
+    dx, dw = torch.from_numpy(x).to(dev), torch.from_numpy(lhs).to(dev)
+    dout = torch.empty(n, dtype=td, device=dev)
+    P = smm.host.partials_count()
+    ref = oracle.spmv(csr, OP_ASSIGN, None, x).astype(np.float64)
+    want_oo, want_ow = float(ref @ ref), float(ref @ lhs.astype(np.float64))
+    tol = 4 * n * np.finfo(dtype).eps
+    for mode in (1, 2):
+        parts = torch.full((2 * P,), float("nan"), dtype=td, device=dev)
+        A.spmv_fused_dev(OP_ASSIGN, None, dx, dout, mode, dw, parts, stream)
+        fin = torch.zeros(smm.host.finish_len(), dtype=td, device=dev)
+        for _ in range(2):  # twice: the arrival counter must be back at zero for the second launch
+            A.spmv_fused_dev(OP_ASSIGN, None, dx, dout, mode, dw, fin, stream, finish=True)
+        torch.cuda.synchronize()
+        assert np.all(np.abs(dout.cpu().numpy().astype(np.float64) - ref) <= bound(csr, x, dtype))
+        sums = parts.cpu().numpy().astype(np.float64)
+        off = smm.host.finish_totals_offset()
+        totals = fin.cpu().numpy()
+        if mode == 1:
+            got = (sums[:P].sum(),)
+            want = (want_ow,)
+        else:
+            got = (sums[:P].sum(), sums[P:].sum())
+            want = (want_oo, want_ow)
+        for i, (g, w) in enumerate(zip(got, want)):
+            scale = float(np.abs(ref * (ref if (mode == 2 and i == 0) else lhs)).sum())
+            assert abs(g - w) <= tol * scale, (mode, i, g, w)
+            assert abs(float(totals[off + i]) - w) <= tol * scale, (mode, i, totals[off + i], w)
+            # the finished total is the sum of the same partials in the fixed order of the separate summing kernel
+            assert abs(float(totals[off + i]) - g) <= 2048 * np.finfo(dtype).eps * scale
+    # 20 BiCGStab iterations against the oracle (b = A x_true: b = A 1 is degenerate on this matrix, DESIGN.md section 6)
+    x_true = rng.uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, OP_ASSIGN, None, x_true)
+    xs = np.zeros(n, dtype=dtype)
+    info = {}
+    st = smm.BiCGStab(A, b, xs, 20, dtype(1e-30), info=info)
+    st_o, x_o, it_o, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 20, dtype(1e-30))
+    assert int(st) == st_o and info["iterations"] == it_o == 20
+    tol_x = 3e-4 if dtype == np.float32 else 1e-10
+    assert np.abs(xs - x_o).max() <= tol_x * np.abs(x_o).max()
+    assert np.abs(xs - x_true).max() <= 1e-4 * np.abs(x_true).max()  # (sanity: 20 passes bring this well-conditioned system to ~1e-6)
