@@ -998,6 +998,7 @@ int smm_hip_comm_destroy(smm_hip_comm* c) {
 	if (!c) return SMM_HIP_OK;
 	if (c->stream) {
 		hipStreamSynchronize(c->stream);
+		forgetStream(c->stream);
 		hipStreamDestroy(c->stream);
 	}
 	for (hipEvent_t e : c->events) {

@@ -44,6 +44,7 @@ hipStream_t libStream();
 // which is also what torch.cuda.current_stream().cuda_stream is for PyTorch's default stream
 // (the allocator is told: a block freed later becomes reusable only after an event recorded on this stream has completed)
 void noteStream(hipStream_t s);
+void forgetStream(hipStream_t s);  // before the library destroys a stream of its own
 inline hipStream_t pickStream(smm_hip_stream s) {
 	noteStream(static_cast<hipStream_t>(s));
 	return static_cast<hipStream_t>(s);

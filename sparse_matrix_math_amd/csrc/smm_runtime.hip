@@ -1,6 +1,7 @@
 // smm_runtime.hip -- device selection, error text, library stream, caching allocator, CSR handles.
 #include <cstdarg>
 #include <map>
+#include <thread>
 
 #include "smm_internal.h"
 
@@ -46,6 +47,7 @@ static int initLocked(int device) {
 	SMM_HIP_TRY(hipGetDeviceProperties(&prop, device));
 	g_cus = prop.multiProcessorCount;
 	if (g_stream) {
+		forgetStream(g_stream);
 		hipStreamDestroy(g_stream);
 		g_stream = nullptr;
 	}
@@ -75,8 +77,9 @@ int numCUs() { return g_cus > 0 ? g_cus : 256; }
 // Every `_dev` entry point is asynchronous on the caller's stream, and handles are destroyed (Python __del__, error returns)
 // while kernels that read their buffers may still be queued.  A freed block therefore first goes to a QUARANTINE.  The quarantine
 // is kept in EPOCHS: when an allocation wants a quarantined size, the blocks freed so far are closed into an epoch and one event is
-// recorded on every stream the library has been given work on since the previous close (noteStream); an epoch's blocks become
-// reusable once all its events have completed -- work enqueued BEFORE the free on any of those streams is then done.  Nothing
+// recorded on EVERY stream the library has ever been given work on (noteStream; a handful -- and never only the "recent" ones: a
+// `_dev` call notes its stream when it starts and frees its temporaries when it returns, with its kernels still queued); an epoch's
+// blocks become reusable once all its events have completed -- work enqueued BEFORE the free on any of those streams is then done.  Nothing
 // drains the device: other threads' streams and the communicator's side stream keep running (r02 called hipDeviceSynchronize here,
 // once per solve).  Only when the wanted size sits in an epoch that has not completed yet does the allocation wait -- for that epoch's
 // events alone; in the steady state of solve-after-solve a solve ends with a stream synchronise, so they have.
@@ -91,7 +94,7 @@ struct QuarantineEpoch {
 };
 static std::multimap<size_t, void*> g_open;       // freed since the last close
 static std::vector<QuarantineEpoch> g_epochs;     // closed, oldest first
-static std::vector<hipStream_t> g_recentStreams;  // streams given work since the last close (small: linear search)
+static std::vector<hipStream_t> g_recentStreams;  // every stream the library has been given work on (small: linear search)
 static std::vector<hipEvent_t> g_eventPool;
 static std::mutex g_streamMutex;
 
@@ -103,6 +106,17 @@ void noteStream(hipStream_t s) {
 	g_recentStreams.push_back(s);
 }
 
+// a stream of the library's own that is about to be destroyed (already synchronised by its owner)
+void forgetStream(hipStream_t s) {
+	std::lock_guard<std::mutex> lock(g_streamMutex);
+	for (size_t i = 0; i < g_recentStreams.size(); ++i) {
+		if (g_recentStreams[i] == s) {
+			g_recentStreams.erase(g_recentStreams.begin() + static_cast<long>(i));
+			return;
+		}
+	}
+}
+
 static void closeEpochLocked() {
 	if (g_open.empty()) return;
 	static unsigned long long nextId = 1;
@@ -112,7 +126,7 @@ static void closeEpochLocked() {
 	std::vector<hipStream_t> streams;
 	{
 		std::lock_guard<std::mutex> lock(g_streamMutex);
-		streams.swap(g_recentStreams);
+		streams = g_recentStreams;
 	}
 	bool haveLib = false;
 	for (hipStream_t k : streams) haveLib = haveLib || k == g_stream;
@@ -126,10 +140,11 @@ static void closeEpochLocked() {
 			ep.drainInstead = true;
 			continue;
 		}
-		if (hipEventRecord(ev, k) != hipSuccess) {
+		if (hipEventRecord(ev, k) != hipSuccess) {  // a stream its owner has destroyed meanwhile: drain once, then forget it
 			(void)hipGetLastError();
 			g_eventPool.push_back(ev);
 			ep.drainInstead = true;
+			forgetStream(k);
 			continue;
 		}
 		ep.events.push_back(ev);
@@ -145,7 +160,7 @@ static void reapEpochsLocked(std::unique_lock<std::mutex>& lock, size_t waitFor)
 		bool done = !ep.drainInstead;
 		for (hipEvent_t ev : ep.events) {
 			if (!done) break;
-			done = hipEventQuery(ev) == hipSuccess;
+			done = hipEventQuery(ev) != hipErrorNotReady;  // (an error state does not come back: treat the event as over)
 		}
 		if (!done) {
 			bool wanted = false;
@@ -153,15 +168,27 @@ static void reapEpochsLocked(std::unique_lock<std::mutex>& lock, size_t waitFor)
 				for (const auto& e : g_epochs) wanted = wanted || e.blocks.count(waitFor) != 0;
 			}
 			if (!wanted) return;
-			// wait for the front epoch only (epochs complete in order as far as one stream is concerned); unlock meanwhile
-			const std::vector<hipEvent_t> events = ep.events;
-			const bool drain = ep.drainInstead;
+			// Wait for the front epoch only, by POLLING its events under the lock with the lock released in between: another thread may
+			// reap this epoch meanwhile and hand its events back to the pool, where the next close records them again -- an event a
+			// thread is blocked on in hipEventSynchronize must not be re-recorded under it, so nobody blocks on one.
 			const unsigned long long id = ep.id;
-			lock.unlock();
-			if (drain) (void)hipDeviceSynchronize();
-			for (hipEvent_t ev : events) (void)hipEventSynchronize(ev);
-			lock.lock();
-			if (g_epochs.empty() || g_epochs.front().id != id) continue;  // another thread reaped it meanwhile
+			if (ep.drainInstead) {
+				lock.unlock();
+				(void)hipDeviceSynchronize();
+				lock.lock();
+				if (g_epochs.empty() || g_epochs.front().id != id) continue;
+				g_epochs.front().drainInstead = false;
+			}
+			for (;;) {
+				if (g_epochs.empty() || g_epochs.front().id != id) break;  // another thread reaped it meanwhile
+				bool all = true;
+				for (hipEvent_t ev : g_epochs.front().events) all = all && hipEventQuery(ev) != hipErrorNotReady;
+				if (all) break;
+				lock.unlock();
+				std::this_thread::yield();
+				lock.lock();
+			}
+			if (g_epochs.empty() || g_epochs.front().id != id) continue;
 		}
 		QuarantineEpoch finished = std::move(g_epochs.front());
 		g_epochs.erase(g_epochs.begin());
@@ -383,7 +410,10 @@ int smm_hip_shutdown(void) {
 	if (!g_inited) return SMM_HIP_OK;
 	hipDeviceSynchronize();
 	devTrim();
-	if (g_stream) hipStreamDestroy(g_stream);
+	if (g_stream) {
+		forgetStream(g_stream);
+		hipStreamDestroy(g_stream);
+	}
 	g_stream = nullptr;
 	g_inited = false;
 	g_device = -1;
