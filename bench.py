@@ -432,6 +432,23 @@ def main():
         from sparse_matrix_math_amd import distributed as dsm
 
         result = dsm.bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype)
+        if rank == 0 and args.cpu_seconds > 0:
+            # the CPU baseline belongs to the WORKLOAD, not to the partition: rank 0 builds the whole matrix once more on its GPU, hands it
+            # to the host and times the bounded sample exactly as the one-GPU run does (the other ranks wait in the all-reduce below)
+            nnz = host.gen_banded_nnz(n, args.band_k, args.seed, args.max_offset)
+            f_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            f_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+            f_val = torch.empty(nnz, dtype=t_dtype, device=dev)
+            host.gen_banded_dev(n, args.band_k, args.seed, args.max_offset, f_start, f_pos, f_val, np_dtype, stream, diag_shift=args.diag_shift)
+            F = smm.CSRMatrix.from_device(n, n, f_start, f_pos, f_val, np_dtype)
+            f_x = torch.rand(n, dtype=t_dtype, device=dev, generator=torch.Generator(device=dev).manual_seed(args.seed)) + 0.5
+            f_b = torch.empty(n, dtype=t_dtype, device=dev)
+            F.spmv_dev(0, None, f_x, f_b, stream)
+            torch.cuda.synchronize()
+            result["cpu_baseline"] = cpu_baseline(args, np_dtype, f_start.cpu().numpy(), f_pos.cpu().numpy(), f_val.cpu().numpy(), f_b.cpu().numpy(),
+                                                  args.cpu_seconds)
+            F.close()
+            del F, f_start, f_pos, f_val, f_x, f_b
     else:
         nnz = host.gen_banded_nnz(n, args.band_k, args.seed, args.max_offset)
         d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)

@@ -349,6 +349,12 @@ int smm_hip_comm_create_host(int rank, int world, smm_hip_host_allreduce_fn allr
 int smm_hip_comm_create_self(smm_hip_comm** out);
 int smm_hip_comm_destroy(smm_hip_comm* comm);
 int smm_hip_comm_info(const smm_hip_comm* comm, int* rank, int* world, int* kind);
+/* the communicator's size as RCCL itself reports it (ncclCommCount); 0 for the other kinds */
+int smm_hip_comm_rccl_ranks(const smm_hip_comm* comm, int* count);
+/* Failure containment: ncclCommInitRank and every wait on a stream that carries RCCL work are bounded by SMM_HIP_COMM_TIMEOUT_S
+ * seconds (environment, default 180); on a time-out -- or on any failure inside a distributed call -- the communicator is aborted
+ * (ncclCommAbort), the call returns SMM_HIP_ERR_COMM and every later call on it fails at once: the peers then run into their own
+ * bounded wait instead of hanging in the next collective.  The process should exit. */
 /* runs every collective the solvers use once and checks the results (collective) */
 int smm_hip_comm_selftest(smm_hip_comm* comm);
 /* bounds[0..world]: contiguous row ranges with ~equal nonzeros, from a host start[rows+1] */

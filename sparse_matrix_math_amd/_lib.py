@@ -116,6 +116,7 @@ _PLAIN = {
     "smm_hip_comm_destroy": (c_int, [_P]),
     "smm_hip_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "smm_hip_comm_selftest": (c_int, [_P]),
+    "smm_hip_comm_rccl_ranks": (c_int, [_P, POINTER(c_int)]),
     "smm_hip_partition_rows_by_nnz": (c_int, [_P, c_int, c_int, _P]),
     "smm_hip_dist_csr_destroy": (c_int, [_P]),
     "smm_hip_dist_csr_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_longlong), POINTER(c_longlong)]),

@@ -24,7 +24,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <thread>
 
 #include <rccl/rccl.h>  // types and prototypes only: every call goes through dlsym'd pointers
 #include <rocprim/device/device_scan.hpp>
@@ -50,6 +54,9 @@ struct RcclApi {
 	decltype(&ncclGroupStart) GroupStart = nullptr;
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	// optional (older libraries): resolved when present
+	decltype(&ncclCommAbort) CommAbort = nullptr;
+	decltype(&ncclCommCount) CommCount = nullptr;
 };
 
 static RcclApi* rccl() {
@@ -84,6 +91,8 @@ static RcclApi* rccl() {
 	SMM_RCCL_SYM(GroupEnd)
 	SMM_RCCL_SYM(GetErrorString)
 #undef SMM_RCCL_SYM
+	api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
+	api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(h, "ncclCommCount"));
 	api.handle = h;
 	return &api;
 }
@@ -119,13 +128,17 @@ struct smm_hip_comm {
 	size_t pinnedBytes = 0;
 	long long* d_i64 = nullptr;  // set-up reductions
 	size_t i64Count = 0;
+	bool broken = false;  // aborted after a failure or a time-out: every further call fails at once
 };
 
 namespace smm {
 
 static hipEvent_t takeEvent(smm_hip_comm* c) {
 	if (c->events.empty()) {
-		c->events.resize(64);
+		// between two drains of the pipeline (every CHECK_EVERY = 16 iterations) a BiCGStab loop records ~10 events per iteration; an event
+		// re-recorded while an earlier wait on it is still queued is legal (a wait refers to the record that preceded it), but the pool is
+		// sized so that it does not happen
+		c->events.resize(256);
 		for (auto& e : c->events) {
 			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
 		}
@@ -133,6 +146,67 @@ static hipEvent_t takeEvent(smm_hip_comm* c) {
 	hipEvent_t e = c->events[c->nextEvent];
 	c->nextEvent = (c->nextEvent + 1) % c->events.size();
 	return e;
+}
+
+// ---- failure containment (a collective that a peer never joins would otherwise block this rank for ever) ---------------------
+// Every wait of the row-partitioned code on a stream that may carry RCCL work goes through boundedSync: the stream is POLLED, and
+// after SMM_HIP_COMM_TIMEOUT_S seconds (default 180) the communicator is aborted (ncclCommAbort: queued collectives of this rank are
+// torn down instead of waiting for a peer that is gone) and the call fails with SMM_HIP_ERR_COMM.  Any other failure inside a
+// distributed call aborts the communicator too (guardComm), so that the peers run into THEIR bounded wait instead of hanging in the
+// next collective.  The process is expected to exit then (bench.py does, with a non-zero status).
+static double commTimeoutSeconds() {
+	static const double t = [] {
+		const char* env = getenv("SMM_HIP_COMM_TIMEOUT_S");
+		const double v = env ? atof(env) : 180.0;
+		return v > 0 ? v : 180.0;
+	}();
+	return t;
+}
+
+static void commAbort(smm_hip_comm* c) {
+	if (!c || c->broken) return;
+	c->broken = true;
+	if (c->kind == SMM_COMM_RCCL && c->nccl) {
+		RcclApi* api = rccl();
+		if (api && api->CommAbort) api->CommAbort(c->nccl);
+		c->nccl = nullptr;  // (without ncclCommAbort the handle is leaked rather than destroyed: ncclCommDestroy would wait for the peers)
+	}
+}
+
+static int boundedSync(smm_hip_comm* c, hipStream_t s) {
+	if (!c || c->kind != SMM_COMM_RCCL) {
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		return SMM_HIP_OK;
+	}
+	const auto t0 = std::chrono::steady_clock::now();
+	for (unsigned spins = 0;; ++spins) {
+		const hipError_t q = hipStreamQuery(s);
+		if (q == hipSuccess) return SMM_HIP_OK;
+		if (q != hipErrorNotReady) {
+			commAbort(c);
+			return hipFail(q, "hipStreamQuery", __FILE__, __LINE__);
+		}
+		if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));  // (the first polls spin: short waits stay short)
+		if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > commTimeoutSeconds()) {
+			commAbort(c);
+			setError("comm: rank %d waited %.0f s for a collective to complete (a peer missing or failed?); communicator aborted", c->rank,
+			         commTimeoutSeconds());
+			return SMM_HIP_ERR_COMM;
+		}
+	}
+}
+
+static int guardComm(smm_hip_comm* c, int rc) {
+	if (rc != SMM_HIP_OK && c && c->kind == SMM_COMM_RCCL) commAbort(c);
+	return rc;
+}
+
+static int commUsable(const smm_hip_comm* c) {
+	if (c && c->broken) {
+		setError("comm: the communicator was aborted after an earlier failure");
+		return SMM_HIP_ERR_COMM;
+	}
+	return SMM_HIP_OK;
 }
 
 // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
@@ -200,7 +274,7 @@ static int commAllreduceI64(smm_hip_comm* c, long long* h, int count) {
 	SMM_HIP_TRY(hipMemcpyAsync(c->d_i64, h, count * sizeof(long long), hipMemcpyHostToDevice, c->stream));
 	SMM_RCCL_TRY(rccl()->AllReduce(c->d_i64, c->d_i64, static_cast<size_t>(count), ncclInt64, ncclSum, c->nccl, c->stream));
 	SMM_HIP_TRY(hipMemcpyAsync(h, c->d_i64, count * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-	SMM_HIP_TRY(hipStreamSynchronize(c->stream));
+	SMM_TRY(boundedSync(c, c->stream));
 	return SMM_HIP_OK;
 }
 
@@ -516,12 +590,19 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 // dotMode / w1 / parts as in launchSpmv; with dotMode != 0 parts is a finishing buffer and its totals are complete (locally) when
 // the last launch ends.
 template <typename T>
-static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s) {
+static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s,
+                      const T* jacobiDiag = nullptr) {
 	smm_hip_comm* c = D->comm;
 	const T* own = ext + D->ownOffset;
 	const bool exchange = !D->sends.empty() || !D->recvs.empty();
 	const int finish = dotMode ? SPMV_FINISH : 0;
-	if (D->remEmpty && !exchange) return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
+	// jacobiDiag (op must be SMM_OP_ASSIGN): out = (A x) / diag with the division folded into the launch that completes a row -- the
+	// local block's when nothing is remote, else the remote block's epilogue ("add, then divide"): the loop then has the kernel count
+	// of the unpreconditioned one, and the dot products of the divided vector ride in the same epilogue
+	if (D->remEmpty && !exchange) {
+		if (jacobiDiag) return launchSpmv<T>(D->aLoc, op, jacobiDiag, own, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_DIV_LHS);
+		return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
+	}
 	hipEvent_t landed = nullptr;
 	if (exchange) {
 		hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;  // the callback kind blocks anyway
@@ -537,6 +618,7 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 	// persistent SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
 	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, landed ? SPMV_LEAVE_ROOM : 0));
 	if (landed) SMM_HIP_TRY(hipStreamWaitEvent(s, landed, 0));
+	if (jacobiDiag) return launchSpmv<T>(D->aRem, SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_ADD_DIV, jacobiDiag);
 	return launchSpmv<T>(D->aRem, op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
 }
 
@@ -742,10 +824,9 @@ static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1,
 // iteration on every rank, so a BLOCKING read of it at fixed iteration numbers is consistent; the asynchronous mailbox of the single-GPU
 // loops (whose answer depends on how far the host has run ahead) is not.  One pipeline drain every CHECK_EVERY iterations.
 constexpr int CHECK_EVERY = 16;
-static int readDone(const int* d_done, hipStream_t s, int* done) {
+static int readDone(smm_hip_comm* c, const int* d_done, hipStream_t s, int* done) {
 	SMM_HIP_TRY(hipMemcpyAsync(done, d_done, sizeof(int), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
-	return SMM_HIP_OK;
+	return boundedSync(c, s);
 }
 
 template <typename T>
@@ -797,6 +878,11 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	if (pre && !D->scratch) SMM_TRY(devAlloc(&D->scratch, static_cast<size_t>(std::max(1, n)) * sizeof(T)));
 	T* scratch = static_cast<T*>(D->scratch);
 	hipEvent_t ev = nullptr;
+	// Jacobi: x = rhs / diag is folded into the rows of the SpMV (smm_solvers.hip does the same on one GPU): no apply launch, no dot
+	// launch -- 8 kernels per iteration like the unpreconditioned loop.  (Not with the PATTERN family, which has no divide epilogue.)
+	const T* jacobiDiag = pre && M->kind == SMM_PRECOND_JACOBI && D->aLoc->family != SMM_SPMV_PATTERN && (!D->aRem || D->aRem->family != SMM_SPMV_PATTERN)
+	                          ? static_cast<const T*>(M->d_values)
+	                          : nullptr;
 
 	// r = b - A x (ref:2215) [; r = M^-1 r, ref:2217-2224]
 	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
@@ -817,12 +903,14 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	for (int i = 0; i < planned; ++i) {
 		if (i > 0 && i % CHECK_EVERY == 0) {
 			int seen = 0;
-			SMM_TRY(readDone(doneFlag, s, &seen));
+			SMM_TRY(readDone(D->comm, doneFlag, s, &seen));
 			if (seen) break;
 		}
 		const int par = i & 1;
 		// ap = [M^-1] A p ; ap.r0 (ref:2233-2243)
-		if (pre) {
+		if (jacobiDiag) {
+			SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s, jacobiDiag));
+		} else if (pre) {
 			SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, ap, r0, nullptr, 1, partsA, doneFlag);
@@ -833,7 +921,9 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 		SMM_TRY(join(s, ev));
 		distBicgS<T><<<gridFor(n), TPB, 0, s>>>(n, sc, par, partsA + PARTS_TOTALS, ap, r, sv);
 		// as = [M^-1] A s ; as.as, as.s (ref:2249-2261)
-		if (pre) {
+		if (jacobiDiag) {
+			SMM_TRY(distMatvec<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s, jacobiDiag));
+		} else if (pre) {
 			SMM_TRY(distMatvec<T>(D, sExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, as, as, sv, 2, partsB, doneFlag);
@@ -851,7 +941,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	SMM_HIP_TRY(hipGetLastError());
 	DistScal<T> h;
 	SMM_HIP_TRY(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	SMM_TRY(boundedSync(D->comm, s));
 	if (status) *status = h.iters > maxIterations ? SMM_SOLVER_MAX_ITERATIONS_REACHED : SMM_SOLVER_SUCCESS;  // ref:2279-2282
 	if (iterations) *iterations = h.iters;
 	if (resnorm) *resnorm = h.res;
@@ -886,7 +976,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	for (int i = 0; i < maxIterations; ++i) {
 		if (i % CHECK_EVERY == 0) {  // i == 0: the early exit of ref:2342-2344 costs nothing more than this read
 			int seen = 0;
-			SMM_TRY(readDone(doneFlag, s, &seen));
+			SMM_TRY(readDone(D->comm, doneFlag, s, &seen));
 			if (seen) break;
 		}
 		const int par = i & 1;
@@ -902,7 +992,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	SMM_HIP_TRY(hipGetLastError());
 	DistScal<T> h;
 	SMM_HIP_TRY(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	SMM_TRY(boundedSync(D->comm, s));
 	if (status) *status = h.status;
 	if (iterations) *iterations = h.iters;
 	if (resnorm2) *resnorm2 = h.res;
@@ -968,10 +1058,51 @@ int smm_hip_comm_create_rccl(int rank, int world, const void* id, smm_hip_comm**
 	c->kind = SMM_COMM_RCCL;
 	ncclUniqueId u;
 	memcpy(&u, id, sizeof(u));
-	const ncclResult_t r = api->CommInitRank(&c->nccl, world, u, rank);
-	if (r != ncclSuccess) {
+	// ncclCommInitRank blocks until every rank has arrived.  It runs on a helper thread so that this rank can give up after
+	// SMM_HIP_COMM_TIMEOUT_S seconds (a peer that never starts, a wrong unique id): the helper is then left behind -- it cannot be
+	// cancelled -- and the caller is expected to exit; nothing else is shared with it but the state block below.
+	struct InitState {
+		std::mutex mu;
+		std::condition_variable cv;
+		bool done = false;
+		ncclResult_t result = ncclSuccess;
+		ncclComm_t comm = nullptr;
+	};
+	auto state = std::make_shared<InitState>();
+	int device = 0;
+	SMM_HIP_TRY(hipGetDevice(&device));
+	std::thread([state, api, world, u, rank, device]() {
+		(void)hipSetDevice(device);
+		ncclComm_t comm = nullptr;
+		const ncclResult_t r = api->CommInitRank(&comm, world, u, rank);
+		std::lock_guard<std::mutex> lock(state->mu);
+		state->result = r;
+		state->comm = comm;
+		state->done = true;
+		state->cv.notify_all();
+	}).detach();
+	{
+		std::unique_lock<std::mutex> lock(state->mu);
+		if (!state->cv.wait_for(lock, std::chrono::duration<double>(commTimeoutSeconds()), [&] { return state->done; })) {
+			delete c;
+			setError("comm_create_rccl: rank %d of %d waited %.0f s in ncclCommInitRank (is every rank running, with the same unique id?)", rank, world,
+			         commTimeoutSeconds());
+			return SMM_HIP_ERR_COMM;
+		}
+	}
+	if (state->result != ncclSuccess) {
 		delete c;
-		return rcclFail(r, "ncclCommInitRank");
+		return rcclFail(state->result, "ncclCommInitRank");
+	}
+	c->nccl = state->comm;
+	if (api->CommCount) {  // the size as RCCL itself reports it
+		int count = 0;
+		if (api->CommCount(c->nccl, &count) != ncclSuccess || count != world) {
+			const int st = rcclFail(ncclInternalError, "ncclCommCount (communicator size differs from the requested world)");
+			commAbort(c);
+			delete c;
+			return st;
+		}
 	}
 	return commFinish(c, out);
 }
@@ -1022,14 +1153,37 @@ int smm_hip_comm_info(const smm_hip_comm* c, int* rank, int* world, int* kind) {
 	return SMM_HIP_OK;
 }
 
+int smm_hip_comm_rccl_ranks(const smm_hip_comm* c, int* count) {
+	if (!c || !count) {
+		setError("comm_rccl_ranks: null argument");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*count = 0;
+	if (c->kind != SMM_COMM_RCCL) return SMM_HIP_OK;  // not an RCCL communicator: 0
+	SMM_TRY(commUsable(c));
+	RcclApi* api = rccl();
+	if (!api || !api->CommCount) {
+		setError("comm_rccl_ranks: this librccl has no ncclCommCount");
+		return SMM_HIP_ERR_COMM;
+	}
+	SMM_RCCL_TRY(api->CommCount(c->nccl, count));
+	return SMM_HIP_OK;
+}
+
 // exercises every collective the loops use on this communicator: an all-reduce of (rank + 1) and a ring exchange (with one rank:
 // a send to / receive from itself).  Returns SMM_HIP_ERR_COMM when a result is wrong.
+static int commSelftest(smm_hip_comm* c);
 int smm_hip_comm_selftest(smm_hip_comm* c) {
 	if (!c) {
 		setError("comm_selftest: null communicator");
 		return SMM_HIP_ERR_INVALID;
 	}
 	SMM_TRY(ensureInit());
+	SMM_TRY(commUsable(c));
+	return guardComm(c, commSelftest(c));
+}
+
+static int commSelftest(smm_hip_comm* c) {
 	hipStream_t s = c->stream;
 	DevBuf<double> buf;
 	SMM_TRY(buf.alloc(4));
@@ -1043,7 +1197,7 @@ int smm_hip_comm_selftest(smm_hip_comm* c) {
 	}
 	double g[4];
 	SMM_HIP_TRY(hipMemcpyAsync(g, buf, sizeof(g), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	SMM_TRY(boundedSync(c, s));
 	if (c->kind != SMM_COMM_SELF) {
 		const double want = 0.5 * c->world * (c->world + 1);
 		const int prev = (c->rank + c->world - 1) % c->world;
@@ -1073,11 +1227,13 @@ int smm_hip_partition_rows_by_nnz(const int* start, int rows, int world, int* bo
 
 int smm_hip_dist_csr_create_dev_f32(smm_hip_comm* comm, int n_global, const int* bounds, const int* d_start, const int* d_positions,
                                     const float* d_values, smm_hip_dist_csr** out) {
-	return distCreate<float>(comm, n_global, bounds, d_start, d_positions, d_values, out);
+	SMM_TRY(commUsable(comm));
+	return guardComm(comm, distCreate<float>(comm, n_global, bounds, d_start, d_positions, d_values, out));
 }
 int smm_hip_dist_csr_create_dev_f64(smm_hip_comm* comm, int n_global, const int* bounds, const int* d_start, const int* d_positions,
                                     const double* d_values, smm_hip_dist_csr** out) {
-	return distCreate<double>(comm, n_global, bounds, d_start, d_positions, d_values, out);
+	SMM_TRY(commUsable(comm));
+	return guardComm(comm, distCreate<double>(comm, n_global, bounds, d_start, d_positions, d_values, out));
 }
 
 int smm_hip_dist_csr_destroy(smm_hip_dist_csr* D) {
@@ -1116,28 +1272,34 @@ int smm_hip_dist_csr_local_block(const smm_hip_dist_csr* D, smm_hip_csr** a_loc,
 }
 
 int smm_hip_dist_spmv_dev_f32(smm_hip_dist_csr* D, int op, const float* d_lhs, const float* d_x, float* d_out, smm_hip_stream stream) {
-	return distSpmv<float>(D, op, d_lhs, d_x, d_out, pickStream(stream));
+	SMM_TRY(commUsable(D ? D->comm : nullptr));
+	return guardComm(D ? D->comm : nullptr, distSpmv<float>(D, op, d_lhs, d_x, d_out, pickStream(stream)));
 }
 int smm_hip_dist_spmv_dev_f64(smm_hip_dist_csr* D, int op, const double* d_lhs, const double* d_x, double* d_out, smm_hip_stream stream) {
-	return distSpmv<double>(D, op, d_lhs, d_x, d_out, pickStream(stream));
+	SMM_TRY(commUsable(D ? D->comm : nullptr));
+	return guardComm(D ? D->comm : nullptr, distSpmv<double>(D, op, d_lhs, d_x, d_out, pickStream(stream)));
 }
 
 int smm_hip_dist_bicgstab_dev_f32(smm_hip_dist_csr* D, const float* d_b, float* d_x, int maxIterations, float eps, const smm_hip_precond* M_loc,
                                   smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm) {
-	return distBicgstab<float>(D, d_b, d_x, maxIterations, eps, M_loc, pickStream(stream), solver_status, iterations, resnorm);
+	SMM_TRY(commUsable(D ? D->comm : nullptr));
+	return guardComm(D ? D->comm : nullptr, distBicgstab<float>(D, d_b, d_x, maxIterations, eps, M_loc, pickStream(stream), solver_status, iterations, resnorm));
 }
 int smm_hip_dist_bicgstab_dev_f64(smm_hip_dist_csr* D, const double* d_b, double* d_x, int maxIterations, double eps, const smm_hip_precond* M_loc,
                                   smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm) {
-	return distBicgstab<double>(D, d_b, d_x, maxIterations, eps, M_loc, pickStream(stream), solver_status, iterations, resnorm);
+	SMM_TRY(commUsable(D ? D->comm : nullptr));
+	return guardComm(D ? D->comm : nullptr, distBicgstab<double>(D, d_b, d_x, maxIterations, eps, M_loc, pickStream(stream), solver_status, iterations, resnorm));
 }
 
 int smm_hip_dist_cg_dev_f32(smm_hip_dist_csr* D, const float* d_b, const float* d_x0, float* d_x, int maxIterations, float eps,
                             smm_hip_stream stream, int* solver_status, int* iterations, float* resnorm2) {
-	return distCg<float>(D, d_b, d_x0, d_x, maxIterations, eps, pickStream(stream), solver_status, iterations, resnorm2);
+	SMM_TRY(commUsable(D ? D->comm : nullptr));
+	return guardComm(D ? D->comm : nullptr, distCg<float>(D, d_b, d_x0, d_x, maxIterations, eps, pickStream(stream), solver_status, iterations, resnorm2));
 }
 int smm_hip_dist_cg_dev_f64(smm_hip_dist_csr* D, const double* d_b, const double* d_x0, double* d_x, int maxIterations, double eps,
                             smm_hip_stream stream, int* solver_status, int* iterations, double* resnorm2) {
-	return distCg<double>(D, d_b, d_x0, d_x, maxIterations, eps, pickStream(stream), solver_status, iterations, resnorm2);
+	SMM_TRY(commUsable(D ? D->comm : nullptr));
+	return guardComm(D ? D->comm : nullptr, distCg<double>(D, d_b, d_x0, d_x, maxIterations, eps, pickStream(stream), solver_status, iterations, resnorm2));
 }
 
 }  // extern "C"

@@ -156,7 +156,7 @@ constexpr int NPART = 2048;  // 256 CUs x 8 resident workgroups of 256 lanes
 // the partials (lastBlockSums, smm_device.h) and leaves the totals at partials[PARTS_TOTALS + k]; the ticket counter sits behind them.
 template <typename T>
 int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
-               const int* doneFlag, hipStream_t s, int extraFlags = 0);
+               const int* doneFlag, hipStream_t s, int extraFlags = 0, const T* divisor = nullptr);
 
 // live event timing of SpMV launches (smm_hip_profile_*): begin returns a slot or -1 when profiling is off
 int profBegin(hipStream_t s);
@@ -174,6 +174,10 @@ constexpr int SPMV_LEAVE_ROOM = 0x400;
 // launch-side: out[i] = (A x)[i] / lhs[i] (op must be SMM_OP_ASSIGN).  Reaches the kernels as the internal operation SPMV_OP_DIV.
 constexpr int SPMV_DIV_LHS = 0x800;
 constexpr int SPMV_OP_DIV = 3;
+// launch-side: out[i] = (lhs[i] + (A x)[i]) / divisor[i] (op must be SMM_OP_ADD; `divisor` argument of launchSpmv): the remote block of a
+// row-partitioned SpMV with the Jacobi division folded in ("add, then divide").  Internal operation SPMV_OP_ADD_DIV.
+constexpr int SPMV_ADD_DIV = 0x1000;
+constexpr int SPMV_OP_ADD_DIV = 4;
 constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer
 constexpr int PARTS_LEN = 2 * NPART + 4;   // elements of a finishing buffer: 2 x NPART partials, 2 totals, 8 bytes for the ticket
 template <typename T>

@@ -47,10 +47,13 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #endif
 
 template <typename T>
-__device__ __forceinline__ T applyOp(int op, const T* __restrict__ lhs, int row, T dot) {
+__device__ __forceinline__ T applyOp(int op, const T* __restrict__ lhs, const T* __restrict__ divisor, int row, T dot) {
 	if (op == SMM_OP_ASSIGN) return dot;
+	// internal (SPMV_DIV_LHS / SPMV_ADD_DIV): the Jacobi apply x = rhs / diag (smm_precond.hip) folded into the row -- the same division
+	// on the same operands as SpMV + apply, so the same bits
+	if (op == SPMV_OP_DIV) return dot / divisor[row];
 	const T l = lhs[row];
-	if (op == SPMV_OP_DIV) return dot / l;  // internal (SPMV_DIV_LHS): the Jacobi apply x = rhs / diag (smm_precond.hip) folded into the row
+	if (op == SPMV_OP_ADD_DIV) return (l + dot) / divisor[row];  // the remote block of a row-partitioned SpMV: add to A_loc x, then divide
 	return op == SMM_OP_ADD ? l + dot : l - dot;
 }
 
@@ -59,7 +62,7 @@ __device__ __forceinline__ T applyOp(int op, const T* __restrict__ lhs, int row,
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int L>
 __global__ __launch_bounds__(TPB) void spmvVectorKernel(int rows, const int* __restrict__ start, const int* __restrict__ positions,
-                                                        const T* __restrict__ values, int op, const T* lhs, const T* __restrict__ x, T* out,
+                                                        const T* __restrict__ values, int op, const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out,
                                                         int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
                                                         const int* __restrict__ doneFlag) {
 	__shared__ T red[4];
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(TPB) void spmvVectorKernel(int rows, const int* __r
 		}
 		dot = groupSum<L>(dot);
 		if (row < rows && lane == 0) {
-			const T o = applyOp(op, lhs, static_cast<int>(row), dot);
+			const T o = applyOp(op, lhs, divisor, static_cast<int>(row), dot);
 			out[row] = o;
 			if (dotMode == 1) {
 				acc1 += o * w1[row];
@@ -202,7 +205,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smmDynLds[];
 template <typename T, int L>
 __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int chunkTiles, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
                                                         const int* __restrict__ positions, const T* __restrict__ values, int opFlags, const T* lhs,
-                                                        const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
+                                                        const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
                                                         T* __restrict__ partials, const int* __restrict__ doneFlag) {
 	using Cfg = StreamCfg<T>;
 	constexpr int GATHER = 8;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 					dot = groupSum<WAVE>(dot);
 				}
 				if (lane == 0) {
-					const T o = applyOp(op, lhs, r0, dot);
+					const T o = applyOp(op, lhs, divisor, r0, dot);
 					out[r0] = o;
 					if (dotMode == 2) acc0 += o * o;
 					if (dotMode) acc1 += o * w1[r0];
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 				for (int k = start[row]; k < e; ++k) {
 					dot = smmFma(values[k], x[positions[k]], dot);
 				}
-				const T o = applyOp(op, lhs, row, dot);
+				const T o = applyOp(op, lhs, divisor, row, dot);
 				out[row] = o;
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 			}
 			if (piece == 0 && rl < nrows) {
 				const int row = r0 + rl;
-				const T o = applyOp(op, lhs, row, dot);
+				const T o = applyOp(op, lhs, divisor, row, dot);
 #ifdef SMM_EXP_NOOUT  // ablation builds only: the kernel without its out[] stream
 				if (o == T(123.456)) out[row] = o;
 #else
@@ -476,7 +479,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <typename T, int L, int G>
 __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int chunkTiles, const int2* __restrict__ rowBlocks, const int* __restrict__ start,
                                                       const int* __restrict__ positions, const T* __restrict__ values, int opFlags, const T* lhs,
-                                                      const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
+                                                      const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
                                                       T* __restrict__ partials, const int* __restrict__ doneFlag) {
 	using Cfg = TileCfg<T>;
 	static_assert(L == 1 || L == 2 || L == 4, "pieces per row");
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 					dot = groupSum<WAVE>(dot);
 				}
 				if (lane == 0) {
-					const T o = applyOp(op, lhs, r0, dot);
+					const T o = applyOp(op, lhs, divisor, r0, dot);
 					out[r0] = o;
 					if (dotMode == 2) acc0 += o * o;
 					if (dotMode) acc1 += o * w1[r0];
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 				const int e = start[row + 1];
 				T dot = T(0);
 				for (int k = start[row]; k < e; ++k) dot = smmFma(values[k], x[positions[k]], dot);
-				const T o = applyOp(op, lhs, row, dot);
+				const T o = applyOp(op, lhs, divisor, row, dot);
 				out[row] = o;
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 			}
 			if (piece == 0 && rl < nrows) {
 				const int row = r0 + rl;
-				const T o = applyOp(op, lhs, row, dot);
+				const T o = applyOp(op, lhs, divisor, row, dot);
 				if (ntOut) __builtin_nontemporal_store(o, out + row);
 				else out[row] = o;
 				if (dotMode == 2) acc0 += o * o;
@@ -905,14 +908,14 @@ void chooseSpmvConfig(smm_hip_csr* m) {
 }
 
 template <typename T, int L>
-static void launchVector(const smm_hip_csr* m, int grid, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
+static void launchVector(const smm_hip_csr* m, int grid, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {
-	spmvVectorKernel<T, L><<<grid, TPB, 0, s>>>(m->rows, m->d_start, m->d_positions, static_cast<const T*>(m->d_values), op, lhs, x, out,
+	spmvVectorKernel<T, L><<<grid, TPB, 0, s>>>(m->rows, m->d_start, m->d_positions, static_cast<const T*>(m->d_values), op, lhs, divisor, x, out,
 	                                            dotMode, w1, partials, doneFlag);
 }
 
 template <typename T, int L, int G>
-static void launchTileG(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+static void launchTileG(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                         hipStream_t s) {
 	const int cap = m->stream_nnz_cap + 3;
 	const int rt = tileRows(L);
@@ -931,29 +934,29 @@ static void launchTileG(const smm_hip_csr* m, int op, const T* lhs, const T* x, 
 	const int nGroups = std::min(8, grid);
 	const int chunkTiles = m->stream_chunk_tiles > 0 ? m->stream_chunk_tiles : (m->n_rowblocks + nGroups - 1) / nGroups;
 	spmvTileKernel<T, L, G><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, chunkTiles, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions,
-	                                             static_cast<const T*>(m->d_values), (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1,
+	                                             static_cast<const T*>(m->d_values), (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out, dotMode, w1,
 	                                             partials, doneFlag);
 }
 
 template <typename T, int L>
-static void launchTile(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+static void launchTile(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                        hipStream_t s) {
 #define SMM_TILE_G(GV) \
-	case GV: launchTileG<T, L, GV>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	case GV: launchTileG<T, L, GV>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
 	switch (tileBatch(m, L)) {
 		SMM_TILE_G(4) SMM_TILE_G(5) SMM_TILE_G(6) SMM_TILE_G(7) SMM_TILE_G(8) SMM_TILE_G(9) SMM_TILE_G(10) SMM_TILE_G(11) SMM_TILE_G(12)
 		SMM_TILE_G(13) SMM_TILE_G(14) SMM_TILE_G(15)
-	default: launchTileG<T, L, 16>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	default: launchTileG<T, L, 16>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
 	}
 #undef SMM_TILE_G
 }
 
 template <typename T, int L>
-static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
+static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {
 	if constexpr (L == 1 || L == 2 || L == 4) {
 		if (useTileKernel(L)) {
-			launchTile<T, L>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s);
+			launchTile<T, L>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
 			return;
 		}
 	}
@@ -968,12 +971,12 @@ static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 	const int nGroups = std::min(8, grid);
 	const int chunkTiles = m->stream_chunk_tiles > 0 ? m->stream_chunk_tiles : (m->n_rowblocks + nGroups - 1) / nGroups;
 	spmvStreamKernel<T, L><<<grid, TPB, lds, s>>>(m->n_rowblocks, cap, chunkTiles, reinterpret_cast<const int2*>(m->d_rowblocks), m->d_start, m->d_positions, static_cast<const T*>(m->d_values),
-	                                            (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode, w1, partials, doneFlag);
+	                                            (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
 }
 
 template <typename T>
 int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
-               hipStream_t s, int extraFlags) {
+               hipStream_t s, int extraFlags, const T* divisor) {
 	if (m->dtype != dtypeOf<T>()) {
 		setError("spmv: matrix dtype does not match the _f32/_f64 entry point");
 		return SMM_HIP_ERR_INVALID;
@@ -995,7 +998,8 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		setError("spmv: fused dot needs w1 and partials");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if ((extraFlags & ~(SPMV_FINISH | SPMV_LEAVE_ROOM | SPMV_DIV_LHS)) || ((extraFlags & SPMV_FINISH) && !dotMode)) {
+	if ((extraFlags & ~(SPMV_FINISH | SPMV_LEAVE_ROOM | SPMV_DIV_LHS | SPMV_ADD_DIV)) || ((extraFlags & SPMV_FINISH) && !dotMode) ||
+	    ((extraFlags & SPMV_DIV_LHS) && (extraFlags & SPMV_ADD_DIV))) {
 		setError("spmv: bad extra flags");
 		return SMM_HIP_ERR_INVALID;
 	}
@@ -1005,7 +1009,17 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 			return SMM_HIP_ERR_INVALID;
 		}
 		op = SPMV_OP_DIV;
+		divisor = lhs;
 		extraFlags &= ~SPMV_DIV_LHS;
+	} else if (extraFlags & SPMV_ADD_DIV) {  // out = (lhs + A x) / divisor, row by row
+		if (op != SMM_OP_ADD || (m->rows > 0 && (!lhs || !divisor)) || m->family == SMM_SPMV_PATTERN) {
+			setError("spmv: the add-then-divide form needs SMM_OP_ADD, lhs, a divisor vector and a family other than PATTERN");
+			return SMM_HIP_ERR_INVALID;
+		}
+		op = SPMV_OP_ADD_DIV;
+		extraFlags &= ~SPMV_ADD_DIV;
+	} else {
+		divisor = nullptr;
 	}
 	if (m->rows == 0 && !dotMode) return SMM_HIP_OK;
 	op |= extraFlags;  // the kernels split `op` into the operation (low byte) and flags
@@ -1036,13 +1050,13 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	}
 #define SMM_DISPATCH_L(FN)                                                           \
 	switch (L) {                                                                     \
-	case 1: FN<T, 1>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;   \
-	case 2: FN<T, 2>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;   \
-	case 4: FN<T, 4>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;   \
-	case 8: FN<T, 8>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;   \
-	case 16: FN<T, 16>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break; \
-	case 32: FN<T, 32>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break; \
-	default: FN<T, 64>(m, grid, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break; \
+	case 1: FN<T, 1>(m, grid, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;   \
+	case 2: FN<T, 2>(m, grid, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;   \
+	case 4: FN<T, 4>(m, grid, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;   \
+	case 8: FN<T, 8>(m, grid, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;   \
+	case 16: FN<T, 16>(m, grid, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break; \
+	case 32: FN<T, 32>(m, grid, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break; \
+	default: FN<T, 64>(m, grid, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break; \
 	}
 	const int profSlot = profBegin(s);
 	if (family == SMM_SPMV_STREAM) {
@@ -1056,8 +1070,8 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	return SMM_HIP_OK;
 }
 
-template int launchSpmv<float>(const smm_hip_csr*, int, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t, int);
-template int launchSpmv<double>(const smm_hip_csr*, int, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t, int);
+template int launchSpmv<float>(const smm_hip_csr*, int, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t, int, const float*);
+template int launchSpmv<double>(const smm_hip_csr*, int, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t, int, const double*);
 
 // host-pointer entry: copy in, run, copy out (the reference's calling convention, ref:1110-1126)
 template <typename T>

@@ -492,7 +492,9 @@ class NativeComm:
 
         r, w, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(_lib.load().smm_hip_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)))
-        return {"rank": r.value, "world": w.value, "kind": {0: "self", 1: "rccl", 2: "host"}[k.value]}
+        n = ctypes.c_int()
+        _lib.check(_lib.load().smm_hip_comm_rccl_ranks(self._h, ctypes.byref(n)))  # ncclCommCount: 0 unless this is an RCCL communicator
+        return {"rank": r.value, "world": w.value, "kind": {0: "self", 1: "rccl", 2: "host"}[k.value], "rccl_ranks": n.value}
 
     def selftest(self):
         from . import _lib
@@ -626,7 +628,12 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
             print(f"rank {rank}: native communicator unavailable ({e}); using the Python driver over torch.distributed", file=sys.stderr)
             driver = "python"
     if driver == "native":
-        comm.selftest()
+        # every collective the loop uses, once, with bounded waits (SMM_HIP_COMM_TIMEOUT_S): a rank whose peers never join gets
+        # SMM_HIP_ERR_COMM here instead of hanging, and the process ends with a non-zero status (a fresh exit, never a re-exec)
+        try:
+            comm.selftest()
+        except Exception as e:  # noqa: BLE001
+            raise SystemExit(f"rank {rank}: the communicator's self-test failed: {e}")
         A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, np_dtype)
         del d_pos, d_val
         A.spmv(OP_ASSIGN, None, x_true, b, stream)
@@ -644,7 +651,7 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         solver._matvec(ops.x_ext, ops.own(ops.x_ext), b, OP_ASSIGN, None, 0, None)
         halo, ext_len = solver.halo_elements, ops.x_ext.numel()
         one_launch = getattr(ops, "rem_empty", False) and not solver.sends and not solver.recvs
-        comm_info = {"rank": rank, "world": world, "kind": "torch.distributed/" + dist.get_backend()}
+        comm_info = {"rank": rank, "world": world, "kind": "torch.distributed/" + dist.get_backend(), "rccl_ranks": 0}
 
         def solve(it):
             return solver.solve(b, x, it, 0.0, check_every=1 << 30)
@@ -694,6 +701,7 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         "nnz": nnz_total,
         "resnorm": float(resnorm),
         "max_rel_err_vs_x_true": float(err.item()),
+        "rccl_ranks": comm_info["rccl_ranks"],  # the communicator's size as RCCL reports it (ncclCommCount); 0: not an RCCL communicator
         "distributed": {"driver": driver, "comm": comm_info["kind"], "comm_ranks": comm_info["world"],
                         "kernels_per_iteration": 8 if driver == "native" else 13, "allreduces_per_iteration": 3, "halo_exchanges_per_iteration": 2},
         "per_rank": {"rows": hi - lo, "nnz": nnz_local, "halo_elements": halo,

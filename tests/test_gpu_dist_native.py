@@ -224,7 +224,7 @@ def test_native_rccl_single_rank(smm, oracle):
     h = ctypes.c_void_p()
     _lib.check(lib.smm_hip_comm_create_rccl(0, 1, ident, ctypes.byref(h)))
     comm = NativeComm(h)
-    assert comm.info() == {"rank": 0, "world": 1, "kind": "rccl"}
+    assert comm.info() == {"rank": 0, "world": 1, "kind": "rccl", "rccl_ranks": 1}  # rccl_ranks: ncclCommCount
     comm.selftest()
     dev = torch.device("cuda:0")
     dtype = np.float32
@@ -241,6 +241,33 @@ def test_native_rccl_single_rank(smm, oracle):
     assert float(np.max(np.abs(x.cpu().numpy() - x_ref))) <= 3e-4 * float(np.max(np.abs(x_ref)))
     A.close()
     comm.close()
+
+
+def test_rccl_init_gives_up_when_a_peer_never_arrives():
+    """failure containment: ncclCommInitRank for a world of 2 with only this rank present must not block for ever --
+    after SMM_HIP_COMM_TIMEOUT_S the call returns SMM_HIP_ERR_COMM, and the process can leave with a status of its own (a fresh
+    process here: the helper thread left behind in ncclCommInitRank dies with it)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes, os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import sparse_matrix_math_amd as smm\n"
+        "from sparse_matrix_math_amd import _lib\n"
+        "smm.init(0)\n"
+        "lib = _lib.load()\n"
+        "ident = ctypes.create_string_buffer(128)\n"
+        "_lib.check(lib.smm_hip_comm_unique_id(ident))\n"
+        "h = ctypes.c_void_p()\n"
+        "t0 = time.time()\n"
+        "rc = lib.smm_hip_comm_create_rccl(0, 2, ident, ctypes.byref(h))\n"
+        "print('RC', rc, 'SECONDS', round(time.time() - t0, 1), lib.smm_hip_last_error().decode(), flush=True)\n"
+        "os._exit(7 if rc == -6 else 1)\n" % root)
+    env = dict(os.environ, SMM_HIP_COMM_TIMEOUT_S="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 7, out.stdout + out.stderr[-2000:]
+    assert "RC -6" in out.stdout and "ncclCommInitRank" in out.stdout
+    seconds = float(out.stdout.split("SECONDS")[1].split()[0])
+    assert 3.5 <= seconds <= 30
 
 
 def test_partition_rows_by_nnz_native_matches_python(smm):
@@ -266,7 +293,7 @@ def test_bench_self_launch_rehearsal(ranks):
     env = dict(os.environ, SMM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rows", "600000", "--max-offset", "65536", "--steps", "20",
-           "--warmup", "10", "--iters-per-solve", "10"]
+           "--warmup", "10", "--iters-per-solve", "10", "--cpu-seconds", "2"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -280,3 +307,9 @@ def test_bench_self_launch_rehearsal(ranks):
     assert line["per_rank"]["halo_elements"] > 0
     assert line["max_rel_err_vs_x_true"] < 1e-3
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    # the N > 1 line carries the same objects as the one-GPU line: the per-rank roofline (A_loc + A_rem bytes over
+    # their launch time), the CPU baseline of the WORKLOAD (rank 0 times it on the whole matrix) and the communicator's size as RCCL
+    # reports it (0 here: the rehearsal's communicator is host callbacks over gloo, not RCCL)
+    assert line["roofline"]["algorithmic_bytes_per_launch"] > 0 and line["roofline"]["avg_launch_ms"] > 0 and line["roofline"]["launches"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] in ("port", "reference")
+    assert line["rccl_ranks"] == 0
