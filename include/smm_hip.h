@@ -78,14 +78,17 @@ extern "C" {
 #define SMM_DTYPE_F64 1
 #define SMM_DTYPE_I64 2 /* only as the element type handed to smm_hip_host_allreduce_fn */
 
-/* SpMV kernel families (smm_hip_csr_set_kernel).  AUTO picks from nnz/row. */
+/* SpMV kernel families (smm_hip_csr_set_kernel).  AUTO picks from nnz/row, and for large matrices tries PATTERN (below). */
 #define SMM_SPMV_AUTO 0
 #define SMM_SPMV_VECTOR 1 /* L lanes of a wavefront per row, wave shuffle reduction */
 #define SMM_SPMV_STREAM 2 /* row blocks staged through LDS with 16-byte coalesced loads, row-sequential sums */
-/* OPT-IN, never chosen by AUTO: for matrices whose rows all take their columns from one set of <= 64 offsets relative to the
- * row (stencil and banded matrices).  positions[] is then replaced by one 64-bit mask per row, verified against every
- * entry when the family is selected, and an SpMV streams only values[].  Same result bit for bit as the other families at the
- * same lanes_per_row.  smm_hip_csr_set_kernel returns SMM_HIP_ERR_INVALID when the matrix has no such pattern. */
+/* For matrices whose rows all take their columns from one set of <= 64 offsets relative to the row (stencil and banded matrices).
+ * positions[] is then replaced by one 64-bit mask per row, verified against EVERY entry on the device before the family is used, and an
+ * SpMV streams only values[] (half the bytes for fp32).  Same result bit for bit as the other families at the same lanes_per_row.
+ * Selected explicitly (smm_hip_csr_set_kernel returns SMM_HIP_ERR_INVALID when the matrix has no such pattern) or by AUTO: the first
+ * SpMV of a matrix with >= 2^25 stored entries and rows of <= 64 entries runs the analysis once, on the caller's stream, and switches
+ * the matrix over when it passes (smm_hip_csr_get_kernel then reports SMM_SPMV_PATTERN); a matrix that does not fit stays with STREAM.
+ * Environment: SMM_HIP_AUTO_PATTERN=0 keeps AUTO on STREAM, SMM_HIP_AUTO_PATTERN_MIN_NNZ moves the threshold. */
 #define SMM_SPMV_PATTERN 3
 
 typedef struct smm_hip_csr smm_hip_csr;         /* device-resident CSRMatrix<T> (ref:1243-1259) */

@@ -879,10 +879,8 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	T* scratch = static_cast<T*>(D->scratch);
 	hipEvent_t ev = nullptr;
 	// Jacobi: x = rhs / diag is folded into the rows of the SpMV (smm_solvers.hip does the same on one GPU): no apply launch, no dot
-	// launch -- 8 kernels per iteration like the unpreconditioned loop.  (Not with the PATTERN family, which has no divide epilogue.)
-	const T* jacobiDiag = pre && M->kind == SMM_PRECOND_JACOBI && D->aLoc->family != SMM_SPMV_PATTERN && (!D->aRem || D->aRem->family != SMM_SPMV_PATTERN)
-	                          ? static_cast<const T*>(M->d_values)
-	                          : nullptr;
+	// launch -- 8 kernels per iteration like the unpreconditioned loop
+	const T* jacobiDiag = pre && M->kind == SMM_PRECOND_JACOBI ? static_cast<const T*>(M->d_values) : nullptr;
 
 	// r = b - A x (ref:2215) [; r = M^-1 r, ref:2217-2224]
 	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x, sizeof(T) * n, hipMemcpyDeviceToDevice, s));

@@ -194,9 +194,9 @@ int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows
 // calls that have no stream) the whole device is drained first and the library's own stream is used
 int ensureCsrReady(const smm_hip_csr* m, hipStream_t s, bool streamKnown);
 // PATTERN family: analyse + verify the matrix (idempotent), and the launch behind launchSpmv
-int ensurePattern(smm_hip_csr* m);
+int ensurePattern(smm_hip_csr* m, hipStream_t s = nullptr, bool streamKnown = false, bool quiet = false);
 template <typename T>
-int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials,
+int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                       const int* doneFlag, hipStream_t s);
 void chooseSpmvConfig(smm_hip_csr* m);
 

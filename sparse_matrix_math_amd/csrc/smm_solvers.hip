@@ -655,7 +655,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	}
 	const DevApplier<T> apply{M};
 	SMM_TRY(ensureCsrReady(a, s, true));
-	const T* jacobiDiag = precondition && M->kind == SMM_PRECOND_JACOBI && a->family != SMM_SPMV_PATTERN ? static_cast<const T*>(M->d_values) : nullptr;
+	const T* jacobiDiag = precondition && M->kind == SMM_PRECOND_JACOBI ? static_cast<const T*>(M->d_values) : nullptr;
 	const smm_hip_precond* blockM = precondition && isBlockKind(M->kind) ? M : nullptr;
 	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm, jacobiDiag, blockM)));
 	return precondition ? precondTakeError(M, s) : SMM_HIP_OK;

@@ -891,6 +891,21 @@ static int lanesForAvg(double avg, int family) {
 	return l;
 }
 
+// AUTO considers the PATTERN family for matrices of at least 2^25 stored entries (below that an SpMV is a few tens of microseconds and
+// the one-off analysis -- a pass over positions[] -- would not pay for itself within a short solve) whose rows could fit 64 offsets
+static bool autoPatternWanted(const smm_hip_csr* m) {
+	static const int allowed = [] {
+		const char* env = getenv("SMM_HIP_AUTO_PATTERN");
+		return env ? atoi(env) : 1;
+	}();
+	static const long long minNnz = [] {
+		const char* env = getenv("SMM_HIP_AUTO_PATTERN_MIN_NNZ");
+		return env ? atoll(env) : (1LL << 25);
+	}();
+	if (!allowed || m->rows <= 0) return false;
+	return m->nnz >= minNnz && static_cast<double>(m->nnz) / m->rows <= 64.0;
+}
+
 void chooseSpmvConfig(smm_hip_csr* m) {
 	const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 0.0;
 	int family = SMM_SPMV_STREAM;
@@ -1004,16 +1019,16 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		return SMM_HIP_ERR_INVALID;
 	}
 	if (extraFlags & SPMV_DIV_LHS) {  // out = (A x) / lhs, row by row
-		if (op != SMM_OP_ASSIGN || (m->rows > 0 && !lhs) || m->family == SMM_SPMV_PATTERN) {
-			setError("spmv: the divide-by-lhs form needs SMM_OP_ASSIGN, a divisor vector and a family other than PATTERN");
+		if (op != SMM_OP_ASSIGN || (m->rows > 0 && !lhs)) {
+			setError("spmv: the divide-by-lhs form needs SMM_OP_ASSIGN and a divisor vector");
 			return SMM_HIP_ERR_INVALID;
 		}
 		op = SPMV_OP_DIV;
 		divisor = lhs;
 		extraFlags &= ~SPMV_DIV_LHS;
 	} else if (extraFlags & SPMV_ADD_DIV) {  // out = (lhs + A x) / divisor, row by row
-		if (op != SMM_OP_ADD || (m->rows > 0 && (!lhs || !divisor)) || m->family == SMM_SPMV_PATTERN) {
-			setError("spmv: the add-then-divide form needs SMM_OP_ADD, lhs, a divisor vector and a family other than PATTERN");
+		if (op != SMM_OP_ADD || (m->rows > 0 && (!lhs || !divisor))) {
+			setError("spmv: the add-then-divide form needs SMM_OP_ADD, lhs and a divisor vector");
 			return SMM_HIP_ERR_INVALID;
 		}
 		op = SPMV_OP_ADD_DIV;
@@ -1023,11 +1038,24 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	}
 	if (m->rows == 0 && !dotMode) return SMM_HIP_OK;
 	op |= extraFlags;  // the kernels split `op` into the operation (low byte) and flags
+	// AUTO, large matrices: the first SpMV tries the index-free PATTERN family (smm_spmv_pattern.hip) -- analysis and verification of
+	// every entry on the caller's stream, once; a matrix that passes is served by it from here on (same bits as STREAM at equal lanes,
+	// half the bytes for fp32), one that does not stays where it is
+	if (!m->kernelForced && m->family == SMM_SPMV_STREAM && m->pat_state == 0 && autoPatternWanted(m)) {
+		auto* mm = const_cast<smm_hip_csr*>(m);
+		const int st = ensurePattern(mm, s, true, true);
+		if (st == SMM_HIP_OK) {
+			mm->family = SMM_SPMV_PATTERN;
+			mm->lanes = lanesForAvg(static_cast<double>(m->nnz) / m->rows, SMM_SPMV_PATTERN);
+		} else if (st != SMM_HIP_ERR_INVALID) {
+			return st;  // a HIP failure, not "no pattern"
+		}
+	}
 	int family = m->family;
 	const int L = m->lanes;
 	if (family == SMM_SPMV_PATTERN) {
 		const int profSlot = profBegin(s);
-		const int st = launchSpmvPattern<T>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s);  // `op` carries the flags
+		const int st = launchSpmvPattern<T>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);  // `op` carries the flags
 		profEnd(profSlot, s);
 		return st;
 	}
@@ -1157,6 +1185,10 @@ int smm_hip_csr_set_kernel(smm_hip_csr* m, int family, int lanes_per_row) {
 	}
 	if (family == SMM_SPMV_AUTO) {
 		chooseSpmvConfig(m);
+		if (lanes_per_row == 0 && m->pat_state > 0 && autoPatternWanted(m)) {  // already analysed and verified: AUTO's choice stands
+			m->family = SMM_SPMV_PATTERN;
+			m->lanes = lanesForAvg(m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 0.0, SMM_SPMV_PATTERN);
+		}
 	} else {
 		m->family = family;
 		const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 0.0;

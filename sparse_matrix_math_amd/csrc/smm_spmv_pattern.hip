@@ -7,9 +7,12 @@
 // the device; the kernel then streams only values[] -- for fp32 that halves the bytes of an SpMV.  The result is the same
 // number as the generic kernels bit for bit (same products, same left-to-right order with one lane per row).
 //
-// OPT-IN (smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, lanes)): the library's headline numbers and bench.py's roofline are
-// defined on the reference's layout (values + positions + start), so AUTO never selects this family.
-// smm_hip_csr_set_kernel fails with SMM_HIP_ERR_INVALID when the matrix has no such pattern.
+// Selected explicitly (smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, lanes): fails with SMM_HIP_ERR_INVALID when the matrix has no such
+// pattern) or by AUTO: the first SpMV of a LARGE matrix (>= 2^25 stored entries, rows of <= 64 entries; launchSpmv) runs the analysis
+// below on the caller's stream -- offsets discovered from a sample of rows on the device, then EVERY entry verified -- and switches the
+// matrix to this family when it passes; a matrix that does not fit (i.i.d. columns ...) stays with STREAM.  SMM_HIP_AUTO_PATTERN=0
+// turns the automatic choice off.  bench.py's roofline stays defined on the reference's layout (values + positions + start,
+// SURVEY.md section 8d) and on the STREAM kernel; what this family moves is reported beside it with its true byte count.
 //
 // Kernel structure = spmvStreamKernel (smm_spmv.hip): persistent workgroups walk row tiles, values[] is fetched one tile
 // ahead with 16-byte non-temporal loads into registers, stored to LDS, and lane (row, piece) walks its piece of its row in
@@ -35,9 +38,11 @@ struct PatCfg {
 };
 
 template <typename T>
-__device__ __forceinline__ T patApplyOp(int op, const T* __restrict__ lhs, int row, T dot) {
+__device__ __forceinline__ T patApplyOp(int op, const T* __restrict__ lhs, const T* __restrict__ divisor, int row, T dot) {
 	if (op == SMM_OP_ASSIGN) return dot;
+	if (op == SPMV_OP_DIV) return dot / divisor[row];  // the Jacobi apply folded into the row (smm_spmv.hip, applyOp)
 	const T l = lhs[row];
+	if (op == SPMV_OP_ADD_DIV) return (l + dot) / divisor[row];
 	return op == SMM_OP_ADD ? l + dot : l - dot;
 }
 
@@ -145,8 +150,8 @@ template <typename T, int L>
 __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, int cols, int nOff, const int* __restrict__ offs,
                                                          const int2* __restrict__ rowBlocks, const int* __restrict__ start,
                                                          const unsigned long long* __restrict__ masks, const int* __restrict__ positions,
-                                                         const T* __restrict__ values, int opFlags, const T* lhs, const T* __restrict__ x, T* out,
-                                                         int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
+                                                         const T* __restrict__ values, int opFlags, const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x,
+                                                         T* out, int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
                                                          const int* __restrict__ doneFlag) {
 	using Cfg = PatCfg<T>;
 	constexpr int GATHER = 8;
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 				for (int k = start[row]; k < e; ++k) {
 					dot = smmFma(values[k], x[positions[k]], dot);
 				}
-				const T o = patApplyOp(op, lhs, row, dot);
+				const T o = patApplyOp(op, lhs, divisor, row, dot);
 				out[row] = o;
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 				dot = total;
 			}
 			if (piece == 0 && rl < nrows) {
-				const T o = patApplyOp(op, lhs, row, dot);
+				const T o = patApplyOp(op, lhs, divisor, row, dot);
 				if (ntOut) __builtin_nontemporal_store(o, out + row);
 				else out[row] = o;
 				if (dotMode == 2) acc0 += o * o;
@@ -319,50 +324,91 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 	}
 }
 
-// ---- host side ----------------------------------------------------------------------------------------------------------
-// Find the offset set from a sample of rows, then let the device build the row masks and verify EVERY entry against it.
-int ensurePattern(smm_hip_csr* m) {
-	SMM_TRY(ensureCsrReady(m, nullptr, false));
+// ---- analysis ON THE DEVICE ---------------------------------------------------------------------------------------------------
+// (1) the offset set from a sample of rows: every workgroup collects the distinct (column - row) of its rows in an LDS table (a value is
+// looked up with plain LDS reads first; only a new one is inserted, with an LDS compare-and-swap) and then merges its table into the
+// global one the same way.  More than MAXOFF distinct offsets: `state[1]` is raised.  (2) the host sorts the <= 64 offsets (256 bytes
+// come back), (3) patBuildMasks forms the row masks and VERIFIES every entry of positions[] against the set: a matrix whose unsampled
+// rows use other offsets is refused there.  Nothing of the matrix travels to the host (r02 copied start[] and 512 rows).
+constexpr int PAT_EMPTY = static_cast<int>(0x80000000u);
+
+__device__ __forceinline__ bool patInsert(int* table, int rel) {  // table[MAXOFF], PAT_EMPTY = free; false: the table is full
+	for (int slot = 0; slot < MAXOFF; ++slot) {
+		int cur = __hip_atomic_load(table + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (cur == rel) return true;
+		if (cur == PAT_EMPTY) {
+			cur = atomicCAS(table + slot, PAT_EMPTY, rel);
+			if (cur == PAT_EMPTY || cur == rel) return true;
+		}
+	}
+	return false;
+}
+
+// state: [0 .. MAXOFF) the global table, [MAXOFF] overflow flag, [MAXOFF + 1] longest sampled row
+__global__ __launch_bounds__(TPB) void patSampleOffsets(int rows, int samples, const int* __restrict__ start, const int* __restrict__ positions, int* state) {
+	__shared__ int sTab[MAXOFF];
+	__shared__ int sOver;
+	if (threadIdx.x < MAXOFF) sTab[threadIdx.x] = PAT_EMPTY;
+	if (threadIdx.x == 0) sOver = 0;
+	__syncthreads();
+	int longest = 0;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < samples; i += static_cast<long long>(gridDim.x) * TPB) {
+		const int row = static_cast<int>(i * (rows - 1) / max(1, samples - 1));
+		const int b = start[row], e = start[row + 1];
+		longest = max(longest, e - b);
+		for (int k = b; k < e && k - b <= MAXOFF; ++k) {
+			if (!patInsert(sTab, positions[k] - row)) sOver = 1;
+		}
+	}
+	if (longest) atomicMax(state + MAXOFF + 1, longest);
+	__syncthreads();
+	if (threadIdx.x < MAXOFF && sTab[threadIdx.x] != PAT_EMPTY) {
+		if (!patInsert(state, sTab[threadIdx.x])) sOver = 1;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && sOver) atomicOr(state + MAXOFF, 1);
+}
+
+// streamKnown: `s` is the stream the caller orders its work on (the first SpMV of a matrix): everything is enqueued there and only
+// 264 bytes + one flag come back; otherwise (smm_hip_csr_set_kernel: no stream) the device is drained once and the library's stream used.
+// quiet: the automatic attempt -- a matrix without a pattern is not an error then (no error text, SMM_HIP_ERR_INVALID still returned).
+int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet) {
+	SMM_TRY(ensureCsrReady(m, s, streamKnown));
 	std::lock_guard<std::mutex> lock(m->tileMutex);
-	if (m->pat_state != 0) return m->pat_state > 0 ? SMM_HIP_OK : SMM_HIP_ERR_INVALID;
+	if (m->pat_state != 0) {
+		if (m->pat_state < 0 && !quiet) setError("pattern SpMV: the rows of this matrix do not share a set of <= %d column offsets", MAXOFF);
+		return m->pat_state > 0 ? SMM_HIP_OK : SMM_HIP_ERR_INVALID;
+	}
 	m->pat_state = -1;
-	if (m->rows == 0 || m->nnz == 0) {
-		setError("pattern SpMV: empty matrix");
-		return SMM_HIP_ERR_INVALID;
+	auto refuse = [quiet](const char* why) {
+		if (!quiet) setError("pattern SpMV: %s", why);
+		return static_cast<int>(SMM_HIP_ERR_INVALID);
+	};
+	if (m->rows == 0 || m->nnz == 0) return refuse("empty matrix");
+	if (!streamKnown) {
+		SMM_HIP_TRY(hipDeviceSynchronize());
+		s = libStream();
 	}
-	hipStream_t s = libStream();
-	SMM_HIP_TRY(hipDeviceSynchronize());
-	std::vector<int> hs(static_cast<size_t>(m->rows) + 1);
-	SMM_HIP_TRY(hipMemcpyAsync(hs.data(), m->d_start, hs.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
-	std::vector<int> offs;
-	const int samples = std::min(m->rows, 512);
-	std::vector<int> cols;
-	for (int i = 0; i < samples; ++i) {
-		const int row = static_cast<int>(static_cast<long long>(i) * (m->rows - 1) / std::max(1, samples - 1));
-		const int len = hs[row + 1] - hs[row];
-		if (len <= 0) continue;
-		if (len > MAXOFF) {
-			setError("pattern SpMV: a row holds more than %d entries", MAXOFF);
-			return SMM_HIP_ERR_INVALID;
-		}
-		cols.resize(static_cast<size_t>(len));
-		SMM_HIP_TRY(hipMemcpyAsync(cols.data(), m->d_positions + hs[row], cols.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));
-		for (int c : cols) offs.push_back(c - row);
-		std::sort(offs.begin(), offs.end());
-		offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
-		if (offs.size() > MAXOFF) {
-			setError("pattern SpMV: rows do not share a set of <= %d column offsets", MAXOFF);
-			return SMM_HIP_ERR_INVALID;
-		}
-	}
-	if (offs.empty()) {
-		setError("pattern SpMV: no entries in the sampled rows");
-		return SMM_HIP_ERR_INVALID;
-	}
-	DevBuf<int> d_off, d_flag;  // released on every early return
+	DevBuf<int> d_state, d_off, d_flag;  // released on every early return
 	DevBuf<unsigned long long> d_masks;
+	SMM_TRY(d_state.alloc(MAXOFF + 2));
+	std::vector<int> init(MAXOFF + 2, PAT_EMPTY);
+	init[MAXOFF] = 0;
+	init[MAXOFF + 1] = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(d_state, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));
+	const int samples = std::min(m->rows, 16384);
+	patSampleOffsets<<<(samples + TPB - 1) / TPB, TPB, 0, s>>>(m->rows, samples, m->d_start, m->d_positions, d_state);
+	std::vector<int> got(MAXOFF + 2, 0);
+	SMM_HIP_TRY(hipMemcpyAsync(got.data(), d_state, got.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (got[MAXOFF + 1] > MAXOFF) return refuse("a row holds more than 64 entries");
+	if (got[MAXOFF]) return refuse("the rows do not share a set of <= 64 column offsets");
+	std::vector<int> offs;
+	for (int i = 0; i < MAXOFF; ++i) {
+		if (got[i] != PAT_EMPTY) offs.push_back(got[i]);
+	}
+	if (offs.empty()) return refuse("no entries in the sampled rows");
+	std::sort(offs.begin(), offs.end());
 	SMM_TRY(d_off.alloc(MAXOFF));
 	SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
 	SMM_TRY(d_flag.alloc(1));
@@ -375,10 +421,7 @@ int ensurePattern(smm_hip_csr* m) {
 	int mismatch = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(&mismatch, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	if (mismatch) {
-		setError("pattern SpMV: some entry's column offset is outside the shared offset set");
-		return SMM_HIP_ERR_INVALID;
-	}
+	if (mismatch) return refuse("some entry's column offset is outside the offset set of the sampled rows");
 	m->pat_k = static_cast<int>(offs.size());
 	m->d_pat_off = d_off.detach();
 	m->d_pat_masks = d_masks.detach();
@@ -397,7 +440,7 @@ static int patCap(const smm_hip_csr* m, int lanes) {
 }
 
 template <typename T, int L>
-static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                       hipStream_t s) {
 	constexpr int LW = L > WAVE ? WAVE : L;
 	constexpr int RT = (WAVE / LW) * (TPB / WAVE);
@@ -407,7 +450,7 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* x, T*
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
 	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, numCUs() * perCU), NPART));
 	spmvPatternKernel<T, L><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, m->cols, m->pat_k, m->d_pat_off, reinterpret_cast<const int2*>(m->d_pat_rowblocks),
-	                                             m->d_start, m->d_pat_masks, m->d_positions, static_cast<const T*>(m->d_values), op | spmvOutFlags(m, sizeof(T)), lhs, x, out, dotMode,
+	                                             m->d_start, m->d_pat_masks, m->d_positions, static_cast<const T*>(m->d_values), op | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out, dotMode,
 	                                             w1, partials, doneFlag);
 }
 
@@ -433,10 +476,10 @@ static int buildPatternTiles(smm_hip_csr* m, int capNnz, int maxRows, hipStream_
 }
 
 template <typename T>
-int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
-                      hipStream_t s) {
+int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                      const int* doneFlag, hipStream_t s) {
 	auto* mm = const_cast<smm_hip_csr*>(m);
-	SMM_TRY(ensurePattern(mm));
+	SMM_TRY(ensurePattern(mm, s, true));
 	const int L = std::min(m->lanes, WAVE);
 	const int capNnz = patCap<T>(m, L) - 3;
 	const int maxRows = TPB / L;
@@ -447,16 +490,16 @@ int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* x, T*
 		}
 	}
 	switch (L) {
-	case 1: launchPat<T, 1>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
-	case 2: launchPat<T, 2>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
-	case 4: launchPat<T, 4>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
-	default: launchPat<T, 8>(m, op, lhs, x, out, dotMode, w1, partials, doneFlag, s); break;
+	case 1: launchPat<T, 1>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
+	case 2: launchPat<T, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
+	case 4: launchPat<T, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
+	default: launchPat<T, 8>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
 	}
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
 }
 
-template int launchSpmvPattern<float>(const smm_hip_csr*, int, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
-template int launchSpmvPattern<double>(const smm_hip_csr*, int, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
+template int launchSpmvPattern<float>(const smm_hip_csr*, int, const float*, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
+template int launchSpmvPattern<double>(const smm_hip_csr*, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 
 }  // namespace smm

@@ -139,3 +139,82 @@ def test_pattern_rectangular_and_empty_rows(smm, oracle):
             np.testing.assert_array_equal(out, ref)
         else:
             np.testing.assert_allclose(out, ref, rtol=0, atol=1e-14)
+
+
+def test_auto_selects_pattern_for_a_large_banded_matrix_and_keeps_the_bits(smm, oracle):
+    """AUTO: the first SpMV of a matrix with >= 2^25 stored entries analyses it on the device (offsets from a sample
+    of rows, every entry verified) and switches it to the index-free family; results are those of STREAM at the same lanes bit for bit,
+    and the oracle's within the re-ordering bound"""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n, k, dtype = 700_000, 25, np.float32
+    nnz = smm.host.gen_banded_nnz(n, k, 0x5EED, 1 << 16)
+    assert nnz >= 1 << 25
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    smm.host.gen_banded_dev(n, k, 0x5EED, 1 << 16, d_start, d_pos, d_val, dtype, stream)
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, dtype)
+    assert A.get_kernel() == (STREAM, 2)  # before the first SpMV: the heuristic's choice from nnz / row
+    x = torch.rand(n, dtype=torch.float32, device=dev) - 0.5
+    lhs = torch.rand(n, dtype=torch.float32, device=dev) - 0.5
+    y_auto = torch.empty(n, dtype=torch.float32, device=dev)
+    A.spmv_dev(OP_SUB, lhs, x, y_auto, stream)
+    torch.cuda.synchronize()
+    assert A.get_kernel() == (PATTERN, 2)
+    y_again = torch.empty_like(y_auto)
+    A.spmv_dev(OP_SUB, lhs, x, y_again, stream)
+    A.set_kernel(STREAM, 2)
+    y_stream = torch.empty_like(y_auto)
+    A.spmv_dev(OP_SUB, lhs, x, y_stream, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(y_auto, y_again)
+    body = (d_start[1:] <= nnz - 8200).cpu().numpy()  # (the directly streamed last tiles differ in how a row is cut into lanes)
+    np.testing.assert_array_equal(y_auto.cpu().numpy()[body], y_stream.cpu().numpy()[body])
+    A.set_kernel(smm.SPMV_AUTO, 0)
+    assert A.get_kernel() == (PATTERN, 2)  # analysed and verified already: AUTO's choice stands
+    csr = (d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy())
+    ref = oracle.spmv(csr, OP_SUB, lhs.cpu().numpy(), x.cpu().numpy())
+    mag = np.zeros(n)
+    np.add.at(mag, np.repeat(np.arange(n), np.diff(csr[0])), np.abs(csr[2].astype(np.float64) * x.cpu().numpy()[csr[1]]))
+    assert np.all(np.abs(y_auto.cpu().numpy().astype(np.float64) - ref) <= 64 * np.finfo(dtype).eps * (mag + np.abs(lhs.cpu().numpy())))
+    # the Jacobi fold (divide epilogue) exists in this family too: BiCGStab + Jacobi, 5 passes, against the oracle
+    from oracle.oracle import PRECOND_JACOBI
+
+    M = A.getPreconditioner(smm.SolverPreconditioner.JACOBI)
+    x_true = np.random.default_rng(5).uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, OP_ASSIGN, None, x_true)
+    xs = np.zeros(n, dtype=dtype)
+    info = {}
+    st = smm.BiCGStab(A, b, xs, 5, dtype(1e-30), M, info=info)
+    st_o, x_o, it_o, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 5, dtype(1e-30), PRECOND_JACOBI, oracle.jacobi_setup(csr)[1])
+    assert int(st) == st_o and info["iterations"] == it_o == 5
+    assert np.abs(xs - x_o).max() <= 3e-4 * np.abs(x_o).max()
+
+
+def test_auto_keeps_stream_for_a_large_matrix_without_a_pattern(smm):
+    """i.i.d. columns (SURVEY.md section 8d's secondary matrix): far more than 64 offsets -- AUTO's attempt is refused quietly, the
+    matrix stays with STREAM and the result is right"""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n, width = 700_000, 50
+    g = torch.Generator(device=dev).manual_seed(11)
+    cols = torch.sort(torch.randint(0, n, (n, width), device=dev, generator=g, dtype=torch.int64), dim=1).values
+    d_pos = cols.reshape(-1).to(torch.int32).contiguous()
+    d_start = (torch.arange(n + 1, device=dev, dtype=torch.int64) * width).to(torch.int32)
+    d_val = torch.rand(n * width, dtype=torch.float32, device=dev, generator=g) - 0.5
+    assert n * width >= 1 << 25
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np.float32)
+    x = torch.rand(n, dtype=torch.float32, device=dev, generator=g) - 0.5
+    y = torch.empty(n, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    A.spmv_dev(OP_ASSIGN, None, x, y, stream)
+    torch.cuda.synchronize()
+    assert A.get_kernel()[0] == STREAM
+    want = (d_val.reshape(n, width).double() * x[cols].double()).sum(dim=1)
+    assert float((y.double() - want).abs().max()) <= 64 * np.finfo(np.float32).eps * float((d_val.reshape(n, width).abs() * x[cols].abs()).sum(dim=1).max())
+    with pytest.raises(smm.SmmHipError):
+        A.set_kernel(PATTERN, 0)
