@@ -126,6 +126,7 @@ struct smm_hip_csr {
 	int pat_n_rowblocks = 0;
 	int pat_nnz_cap = 0;
 	int pat_max_rows = 0;
+	int pat_chunk_tiles = 0;
 };
 
 struct smm_hip_precond {

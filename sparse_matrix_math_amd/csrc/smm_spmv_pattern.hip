@@ -18,6 +18,7 @@
 // ahead with 16-byte non-temporal loads into registers, stored to LDS, and lane (row, piece) walks its piece of its row in
 // batches of 8 independent x[] gathers; the column of an entry comes from the next set bit of the row mask.
 #include <algorithm>
+#include <cmath>
 
 #include "smm_device.h"
 #include "smm_internal.h"
@@ -324,6 +325,198 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// TILE form (rows of ~25-128 entries, 2 or 4 pieces per row: the benchmark matrix) -- the structure smm_spmv.hip's spmvTileKernel
+// measured best for the CSR stream, with the column of an entry taken from the row's mask instead of a staged positions[] slice:
+//   * the L pieces of a row live in DIFFERENT waves (wave w: piece w % L of the 64 rows of group w / L), so one gather instruction
+//     reads ONE window of 64 adjacent columns instead of L windows of 64 / L;
+//   * no software pipeline inside the workgroup: a tile's values[] slice is loaded, stored to LDS and summed; with no positions[] in
+//     LDS a tile needs half the space, so five to six workgroups share a CU (three for the CSR kernel) and overlap each other;
+//   * G gathers per batch, fitted to the piece length (26 entries: 2 x 13).
+// Same products in the same order as spmvPatternKernel / the STREAM family at equal L: same bits.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T, int L, int G>
+__global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap, int chunkTiles, int cols, int nOff, const int* __restrict__ offs,
+                                                             const int2* __restrict__ rowBlocks, const int* __restrict__ start,
+                                                             const unsigned long long* __restrict__ masks, const int* __restrict__ positions,
+                                                             const T* __restrict__ values, int opFlags, const T* lhs, const T* __restrict__ divisor,
+                                                             const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
+                                                             T* __restrict__ partials, const int* __restrict__ doneFlag) {
+	using Cfg = PatCfg<T>;
+	static_assert(L == 2 || L == 4, "pieces per row");
+	static_assert(G <= Cfg::PAD, "a batch may read G - 1 slots past its piece");
+	constexpr int NVMAX = Cfg::NVMAX;
+	const int op = opFlags & 0xFF;
+	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;
+	constexpr int GROUPS = TPB / WAVE / L;
+	constexpr int RT = 64 * GROUPS;
+	// LDS: sVal[cap + PAD] | sMask[RT] (8-byte aligned) | sStart[RT + 4] | sOff[MAXOFF] | sPart[(L - 1) * RT] | red[4]
+	T* sVal = reinterpret_cast<T*>(smmPatLds);
+	unsigned long long* sMask = reinterpret_cast<unsigned long long*>(sVal + cap + Cfg::PAD);
+	int* sStart = reinterpret_cast<int*>(sMask + RT);
+	int* sOff = sStart + RT + 4;
+	T* sPart = reinterpret_cast<T*>(sOff + MAXOFF);
+	T* red = sPart + (L - 1) * RT;
+	if (doneFlag && *doneFlag) return;
+
+	const int t = threadIdx.x;
+	const int lane = t & (WAVE - 1);
+	const int wave = t >> 6;
+	const int piece = wave % L;
+	const int rl = (wave / L) * 64 + lane;
+	const int nv = (cap + Cfg::PIECE - 1) / Cfg::PIECE;
+	T acc0 = T(0), acc1 = T(0);
+	for (int i = t; i < cap + Cfg::PAD; i += TPB) sVal[i] = T(0);
+	if (t < MAXOFF) sOff[t] = t < nOff ? offs[t] : 0;
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int xcdGroup = blockIdx.x % nGroups;
+	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;
+	auto tileOf = [&](int j) {
+		const int c = j / chunkTiles;
+		const long long tIdx = (static_cast<long long>(c) * nGroups + xcdGroup) * chunkTiles + (j - c * chunkTiles);
+		return tIdx < nTiles ? static_cast<int>(tIdx) : nTiles;
+	};
+	const int stageLimit = (rowBlocks[nTiles].y & ~3) - (cap + 4);
+	int j = blockIdx.x / nGroups;
+	int tile = tileOf(j);
+	int2 m0 = make_int2(0, 0), m1 = make_int2(0, 0);
+	if (tile < nTiles) {
+		m0 = rowBlocks[tile];
+		m1 = rowBlocks[tile + 1];
+	}
+	__syncthreads();
+	while (tile < nTiles) {
+		const int r0 = m0.x, n0 = m0.y, r1 = m1.x, n1 = m1.y;
+		const int nrows = r1 - r0;
+		const int a0 = n0 & ~3;
+		const bool direct = n1 - n0 > cap - 3 || a0 > stageLimit;
+		if (!direct) {
+			typename Pack16<T>::V rv[NVMAX * (sizeof(T) == 4 ? 1 : 2)];
+#pragma unroll
+			for (int v = 0; v < NVMAX; ++v) {
+				const int i = a0 + 4 * (t + v * TPB);
+				if (v < nv && i < n1) {
+					if constexpr (sizeof(T) == 4) {
+						rv[v] = __builtin_nontemporal_load(reinterpret_cast<const pf32x4*>(values + i));
+					} else {
+						rv[2 * v] = __builtin_nontemporal_load(reinterpret_cast<const pf64x2*>(values + i));
+						rv[2 * v + 1] = __builtin_nontemporal_load(reinterpret_cast<const pf64x2*>(values + i + 2));
+					}
+				}
+			}
+			int ps = 0;
+			unsigned long long pm = 0ULL;
+			if (t < nrows) {
+				ps = start[r0 + t];
+				pm = masks[r0 + t];
+			}
+#pragma unroll
+			for (int v = 0; v < NVMAX; ++v) {
+				const int li = 4 * (t + v * TPB);
+				if (v < nv && a0 + li < n1) {
+					if constexpr (sizeof(T) == 4) {
+						*reinterpret_cast<pf32x4*>(sVal + li) = rv[v];
+					} else {
+						*reinterpret_cast<pf64x2*>(sVal + li) = rv[2 * v];
+						*reinterpret_cast<pf64x2*>(sVal + li + 2) = rv[2 * v + 1];
+					}
+				}
+			}
+			if (t < nrows) {
+				sStart[t] = ps - a0;
+				sMask[t] = pm;
+			}
+			if (t == 0) sStart[nrows] = n1 - a0;
+		}
+		ldsBarrier();
+		j += groupSlots;
+		const int ntile = tileOf(j);
+		int2 m0n = make_int2(0, 0), m1n = make_int2(0, 0);
+		if (ntile < nTiles) {
+			m0n = rowBlocks[ntile];
+			m1n = rowBlocks[ntile + 1];
+		}
+		if (direct) {
+			// over-long rows and the last tiles of the matrix: one lane per row, left to right, straight from HBM (with positions[])
+			for (int rr = t; rr < nrows; rr += TPB) {
+				const int row = r0 + rr;
+				const int e = start[row + 1];
+				T dot = T(0);
+				for (int k = start[row]; k < e; ++k) dot = smmFma(values[k], x[positions[k]], dot);
+				const T o = patApplyOp(op, lhs, divisor, row, dot);
+				out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		} else {
+			T dot = T(0);
+			const int row = r0 + rl;
+			int kb = 0, ke = 0;
+			unsigned long long mm = 0ULL;
+			if (rl < nrows) {
+				const int b = sStart[rl];
+				const int e = sStart[rl + 1];
+				const int piecelen = (e - b + L - 1) / L;
+				kb = b + piece * piecelen;
+				ke = min(e, kb + piecelen);
+				mm = sMask[rl];
+				// this piece starts at the (kb - b)-th entry of the row = the (kb - b)-th set bit of the mask
+				if (piece > 0 && kb < ke) mm &= ~0ULL << selectBit(mm, kb - b);
+			}
+			for (int k = kb; k < ke; k += G) {
+				unsigned off[G];
+				T xv[G], vv[G];
+#pragma unroll
+				for (int u = 0; u < G; ++u) {
+					const int jj = mm ? __builtin_ctzll(mm) : 0;
+					mm &= mm - 1;
+					// entries past the end of the piece get a clamped, valid column; their products are discarded
+					const int col = min(max(row + sOff[jj], 0), cols - 1);
+					off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
+					vv[u] = sVal[k + u];
+				}
+#pragma unroll
+				for (int u = 0; u < G; ++u) xv[u] = patGather<T>(x, off[u]);
+				const int nvalid = ke - k;
+#pragma unroll
+				for (int u = 0; u < G; ++u) {
+					const T next = smmFma(vv[u], xv[u], dot);
+					dot = u < nvalid ? next : dot;
+				}
+			}
+			// pieces of a row meet in LDS and are added left to right: ((p0 + p1) + p2) + p3
+			if (piece > 0 && rl < nrows) sPart[(piece - 1) * RT + rl] = dot;
+			ldsBarrier();
+			if (piece == 0 && rl < nrows) {
+#pragma unroll
+				for (int q = 1; q < L; ++q) dot += sPart[(q - 1) * RT + rl];
+				const T o = patApplyOp(op, lhs, divisor, row, dot);
+				if (ntOut) __builtin_nontemporal_store(o, out + row);
+				else out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		}
+		ldsBarrier();
+		tile = ntile;
+		m0 = m0n;
+		m1 = m1n;
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
+	}
+}
+
 // ---- analysis ON THE DEVICE ---------------------------------------------------------------------------------------------------
 // (1) the offset set from a sample of rows: every workgroup collects the distinct (column - row) of its rows in an LDS table (a value is
 // looked up with plain LDS reads first; only a new one is inserted, with an LDS compare-and-swap) and then merges its table into the
@@ -439,9 +632,66 @@ static int patCap(const smm_hip_csr* m, int lanes) {
 	return nv * PatCfg<T>::PIECE;
 }
 
+// SMM_HIP_PATTERN_VARIANT=0 keeps the pipelined row-per-lane kernel for every L (A/B measurements)
+static bool patUseTile(int lanes) {
+	static const int forced = [] {
+		const char* env = getenv("SMM_HIP_PATTERN_VARIANT");
+		return env ? atoi(env) : -1;
+	}();
+	if (forced == 0) return false;
+	return lanes == 2 || lanes == 4;
+}
+
+// gathers per batch: a piece of p entries is walked in ceil(p / 16) batches of equal size (26 -> 2 x 13), in the three compiled sizes
+static int patBatch(const smm_hip_csr* m, int lanes) {
+	const double len = m->stream_mid_len > 0 ? m->stream_mid_len : (m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0);
+	const int p = std::max(1, static_cast<int>(std::ceil(len / lanes)));
+	const int nb = (p + 15) / 16;
+	int g = (p + nb - 1) / nb;
+	if (const char* env = getenv("SMM_HIP_TILE_BATCH")) g = atoi(env);
+	return g <= 8 ? 8 : g <= 13 ? 13 : 16;
+}
+
+template <typename T, int L, int G>
+static void launchPatTileG(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                           const int* doneFlag, hipStream_t s) {
+	constexpr int RT = 64 * (TPB / WAVE / L);
+	const int cap = m->pat_nnz_cap + 3;
+	const size_t lds = static_cast<size_t>(cap + PatCfg<T>::PAD) * sizeof(T) + RT * 8 + (RT + 4) * 4 + MAXOFF * 4 + static_cast<size_t>(L - 1) * RT * sizeof(T) +
+	                   4 * sizeof(T) + 32;
+	int perCU = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternTileKernel<T, L, G>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
+	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
+	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, cus * perCU), NPART));
+	const int nGroups = std::min(8, grid);
+	const int chunkTiles = m->pat_chunk_tiles > 0 ? m->pat_chunk_tiles : (m->pat_n_rowblocks + nGroups - 1) / nGroups;
+	spmvPatternTileKernel<T, L, G><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, chunkTiles, m->cols, m->pat_k, m->d_pat_off,
+	                                                     reinterpret_cast<const int2*>(m->d_pat_rowblocks), m->d_start, m->d_pat_masks, m->d_positions,
+	                                                     static_cast<const T*>(m->d_values), (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out,
+	                                                     dotMode, w1, partials, doneFlag);
+}
+
+template <typename T, int L>
+static void launchPatTile(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                          const int* doneFlag, hipStream_t s) {
+	switch (patBatch(m, L)) {
+	case 8: launchPatTileG<T, L, 8>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
+	case 13: launchPatTileG<T, L, 13>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
+	default: launchPatTileG<T, L, 16>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s); break;
+	}
+}
+
 template <typename T, int L>
 static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                       hipStream_t s) {
+	if constexpr (L == 2 || L == 4) {
+		if (patUseTile(L)) {
+			launchPatTile<T, L>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
+			return;
+		}
+	}
+	op &= ~SPMV_LEAVE_ROOM;
 	constexpr int LW = L > WAVE ? WAVE : L;
 	constexpr int RT = (WAVE / LW) * (TPB / WAVE);
 	const int cap = m->pat_nnz_cap + 3;
@@ -466,6 +716,7 @@ static int buildPatternTiles(smm_hip_csr* m, int capNnz, int maxRows, hipStream_
 		m->pat_n_rowblocks = m->n_rowblocks;
 		m->pat_nnz_cap = capNnz;
 		m->pat_max_rows = maxRows;
+		m->pat_chunk_tiles = m->stream_chunk_tiles;  // how buildRowBlocks would deal THIS table's tiles to the XCDs
 	}
 	m->d_rowblocks = keepBlocks;
 	m->n_rowblocks = keepN;
