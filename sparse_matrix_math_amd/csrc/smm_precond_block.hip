@@ -162,42 +162,63 @@ __device__ __forceinline__ void blkSweep(const unsigned* __restrict__ rec, long 
 				const bool valid = row != BLK_NOROW;
 				const int lFirst = __builtin_amdgcn_readfirstlane(lvl);
 				const int lLast = __builtin_amdgcn_readlane(lvl, WAVE - 1);
+				const int myLvl = valid ? lvl : -1;  // padding lanes never match a level
 				const T own = valid ? xs[row] : T(0);  // rhs (lower sweep) or y (upper sweep) of the lane's row: no other row writes it
-				for (int lv = lFirst; lv <= lLast; ++lv) {
-					if (valid && lvl == lv) {
-						T xv[KREG];
+				// the step is the dependency chain of the whole sweep (one LDS round trip + the row's arithmetic per level): when every
+				// row of the chunk has exactly KREG entries (the interior of a stencil) it runs without any per-entry predicate
+				const bool allFull = __ballot(valid && n != KREG) == 0ull;
+				unsigned cols[KREG];
+				T vals[KREG];
 #pragma unroll
-						for (int k = 0; k < KREG; ++k) {
-							if (k < n) {
-								const unsigned col = (w[1 + k / 2] >> (16 * (k & 1))) & 0xFFFFu;
-								xv[k] = xs[col];
-							}
-						}
-						T acc = MODE == B_SGS_UP ? T(0) : own;
+				for (int k = 0; k < KREG; ++k) {
+					cols[k] = (w[1 + k / 2] >> (16 * (k & 1))) & 0xFFFFu;
+					vals[k] = fromWords<T>(&w[L::VAL_AT + L::VW * k]);
+				}
+				T diag = T(1);
+				if (HASD) diag = fromWords<T>(&w[L::DIAG_AT]);
+				if (allFull) {
+					for (int lv = lFirst; lv <= lLast; ++lv) {
+						if (myLvl == lv) {
+							T xv[KREG];
 #pragma unroll
-						for (int k = 0; k < KREG; ++k) {
-							if (k < n) {
-								const T val = fromWords<T>(&w[L::VAL_AT + L::VW * k]);
-								acc = MODE == B_SGS_UP ? smmFma(val, xv[k], acc) : smmFma(-val, xv[k], acc);  // ref:1706 / ref:1686
+							for (int k = 0; k < KREG; ++k) xv[k] = xs[cols[k]];
+							T acc = MODE == B_SGS_UP ? T(0) : own;
+#pragma unroll
+							for (int k = 0; k < KREG; ++k) acc = MODE == B_SGS_UP ? smmFma(vals[k], xv[k], acc) : smmFma(-vals[k], xv[k], acc);  // ref:1706 / ref:1686
+							T result;
+							if (MODE == B_ILU_LO) result = acc;
+							else if (MODE == B_SGS_UP) result = own - acc / diag;  // ref:1710
+							else result = acc / diag;                               // ref:1694; ILU: U x = y
+							xs[row] = result;
+						}
+					}
+				} else {
+					for (int lv = lFirst; lv <= lLast; ++lv) {
+						if (myLvl == lv) {
+							T xv[KREG];
+#pragma unroll
+							for (int k = 0; k < KREG; ++k) {
+								if (k < n) xv[k] = xs[cols[k]];
 							}
-						}
-						if (OV && n > KREG) {  // the tail of a long row, straight from memory (slow path)
-							const long long g = recIndex0 + static_cast<long long>(c) * WAVE + lane;
-							for (int e = ovPtr[g]; e < ovPtr[g + 1]; ++e) {
-								const T val = ovVal[e];
-								const T xo = xs[ovCol[e]];
-								acc = MODE == B_SGS_UP ? smmFma(val, xo, acc) : smmFma(-val, xo, acc);
+							T acc = MODE == B_SGS_UP ? T(0) : own;
+#pragma unroll
+							for (int k = 0; k < KREG; ++k) {
+								if (k < n) acc = MODE == B_SGS_UP ? smmFma(vals[k], xv[k], acc) : smmFma(-vals[k], xv[k], acc);
 							}
+							if (OV && n > KREG) {  // the tail of a long row, straight from memory (slow path)
+								const long long g = recIndex0 + static_cast<long long>(c) * WAVE + lane;
+								for (int e = ovPtr[g]; e < ovPtr[g + 1]; ++e) {
+									const T val = ovVal[e];
+									const T xo = xs[ovCol[e]];
+									acc = MODE == B_SGS_UP ? smmFma(val, xo, acc) : smmFma(-val, xo, acc);
+								}
+							}
+							T result;
+							if (MODE == B_ILU_LO) result = acc;
+							else if (MODE == B_SGS_UP) result = own - acc / diag;
+							else result = acc / diag;
+							xs[row] = result;
 						}
-						T result;
-						if (MODE == B_ILU_LO) {
-							result = acc;
-						} else {
-							const T diag = fromWords<T>(&w[L::DIAG_AT]);
-							if (MODE == B_SGS_UP) result = own - acc / diag;  // ref:1710
-							else result = acc / diag;                          // ref:1694; ILU: U x = y
-						}
-						xs[row] = result;
 					}
 				}
 			}
