@@ -27,6 +27,24 @@ def main():
     read_fetch = 2 * vals["FETCH_SIZE"] * 1024
     read_req = 128 * vals.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * vals.get("TCC_EA0_RDREQ_64B_sum", 0) + 32 * vals.get("TCC_EA0_RDREQ_32B_sum", 0)
     write = vals["WRITE_SIZE"] * 1024
+    def family_bytes(name):
+        """the same corrections for another kernel's summary (no stamp: only the roofline's kernel is quoted by bench.py)"""
+        path = os.path.join(src, name)
+        if not os.path.exists(path):
+            return None
+        v, k = {}, None
+        for line in open(path):
+            m = re.match(r"\s+(\S+)\s+n=\s*\d+\s+mean=(\S+)", line)
+            if m:
+                v[m.group(1)] = float(m.group(2))
+            elif line.strip() and k is None:
+                k = line.strip()
+        if "FETCH_SIZE" not in v:
+            return None
+        rq = 128 * v.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * v.get("TCC_EA0_RDREQ_64B_sum", 0) + 32 * v.get("TCC_EA0_RDREQ_32B_sum", 0)
+        return {"kernel": k.replace("void smm::", ""), "read_bytes_per_launch": 2 * v["FETCH_SIZE"] * 1024, "read_bytes_per_launch_from_request_sizes": rq,
+                "write_bytes_per_launch": v.get("WRITE_SIZE", 0) * 1024, "TCC_HIT_sum": v.get("TCC_HIT_sum"), "TCC_MISS_sum": v.get("TCC_MISS_sum")}
+
     out = {
         "rows": 10_000_000, "dtype": "f32", "band_k": 25, "kernel": kernel.replace("void smm::", ""),
         "kernel_source_sha16": bench.spmv_kernel_source_sha(),
@@ -38,6 +56,8 @@ def main():
                       "cross-checked with the size-resolved request counters. WRITE_SIZE is exact.",
         "read_bytes_per_launch": read_fetch, "read_bytes_per_launch_from_request_sizes": read_req, "write_bytes_per_launch": write,
         "hbm_bytes_per_launch": (read_req if read_req else read_fetch) + write,
+        "other_kernels": {"pattern_family_same_matrix": family_bytes("summary_pattern.txt"), "laplacian512_f64_stream": family_bytes("summary_lap_stream.txt"),
+                          "laplacian512_f64_pattern": family_bytes("summary_lap_pattern.txt")},
     }
     path = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     with open(path, "w") as f:
