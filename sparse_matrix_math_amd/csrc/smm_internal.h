@@ -190,7 +190,7 @@ inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s);
 // greedy cut of the rows into runs of <= capNnz stored entries and <= maxRows rows, on the device: tiles[0 .. nTiles] = {first row,
 // start[first row]}, closed by {rows, nnz}; allocated with devAlloc, owned by the caller; synchronises `s`
-int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows, hipStream_t s, int2** tiles, int* nTiles);
+int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows, hipStream_t s, int2** tiles, int* nTiles, int tilesPerChunk = 0);
 // streamKnown: `s` is the stream the caller orders its work on (the `_dev` entry points); otherwise (host-side queries and set-up
 // calls that have no stream) the whole device is drained first and the library's own stream is used
 int ensureCsrReady(const smm_hip_csr* m, hipStream_t s, bool streamKnown);

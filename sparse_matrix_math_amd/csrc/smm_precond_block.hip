@@ -33,6 +33,7 @@ struct smm_precond_block {
 	int kreg = 2;           // in-block entries per row and sweep that live in the records
 	bool overflow = false;  // some row has more than kreg: the rest is in the overflow lists
 	int levelsLo = 0, levelsUp = 0;  // deepest block
+	int maxInBlock = 0;              // most in-block entries of a block
 	long long nChunks = 0;
 	int2* d_bounds = nullptr;  // [nBlocks + 1] {first row, start[first row]}
 	int* d_chunk0 = nullptr;   // [nBlocks + 1] chunks in front of block b
@@ -468,7 +469,7 @@ __device__ __forceinline__ unsigned char* carve(unsigned char*& p, size_t bytes)
 static size_t carveSize(size_t bytes) { return (bytes + 15) & ~static_cast<size_t>(15); }
 
 // info: [0] most lower entries of a row, [1] most upper entries, [2] error bits (1: empty row / missing diagonal, 2: |d| < 1e-5 for
-// SGS), [3] deepest lower sweep, [4] deepest upper sweep (levels)
+// SGS), [3] deepest lower sweep, [4] deepest upper sweep (levels), [5] most in-block entries of a block
 template <typename T>
 __global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
                                                            const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap
 
 	const int bad = stageBlock<T>(st, nullptr, r0, nb, start, positions, vals, scanScratch, checkMagnitude);
 	if (bad) atomicOr(info + 2, bad);
+	if (t == 0) atomicMax(info + 5, st.lptr[nb]);  // the most in-block entries of any block: sizes the LDS of the factor / pack kernel
 	for (int i = t; i < nb; i += BLK_TPB) {
 		lvlLo[i] = BLK_UNKNOWN;
 		lvlUp[i] = BLK_UNKNOWN;
@@ -726,10 +728,13 @@ static size_t packLds(int maxRows, int cap) {
 template <typename T, int KIND, int KREG, bool OV>
 static int packTyped(const smm_hip_csr* a, smm_hip_precond* M, const unsigned* metaLo, const unsigned* metaUp, int* d_info, hipStream_t s) {
 	smm_precond_block* B = M->blk;
-	const size_t lds = packLds<T>(B->blockRows, B->capNnz);
+	// LDS for what the blocks really hold (entries that couple two blocks are not staged): a 7-point stencil keeps 5 of its 7 entries per
+	// row, 70 KB instead of 100 KB per block in fp64 -- two blocks per CU factorise at the same time instead of one
+	const int cap = std::max(64, std::min(B->capNnz, (B->maxInBlock + 63) & ~63));
+	const size_t lds = packLds<T>(B->blockRows, cap);
 	auto kernel = blkPackKernel<T, KIND, KREG, OV>;
 	SMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-	kernel<<<B->nBlocks, BLK_TPB, lds, s>>>(B->blockRows, B->capNnz, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
+	kernel<<<B->nBlocks, BLK_TPB, lds, s>>>(B->blockRows, cap, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
 	                                       metaLo, metaUp, static_cast<T*>(M->d_values), B->d_recLo, B->d_recUp, B->d_ovPtrLo, B->d_ovPtrUp, B->d_ovColLo,
 	                                       B->d_ovColUp, static_cast<T*>(B->d_ovValLo), static_cast<T*>(B->d_ovValUp), d_info);
 	SMM_HIP_TRY(hipGetLastError());
@@ -775,7 +780,8 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_prec
 	B->blockRows = blockRows;
 	B->capNnz = BLK_CAP_NNZ;
 	if (n == 0) return SMM_HIP_OK;
-	SMM_TRY(cutRows(a->d_start, n, a->nnz, B->capNnz, B->blockRows, s, &B->d_bounds, &B->nBlocks));
+	// (seams every 16 blocks instead of every 64: the greedy cut of a super-chunk is a sequential chain of binary searches by one thread)
+	SMM_TRY(cutRows(a->d_start, n, a->nnz, B->capNnz, B->blockRows, s, &B->d_bounds, &B->nBlocks, 16));
 	const int nBlocks = B->nBlocks;
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_chunk0), (static_cast<size_t>(nBlocks) + 1) * sizeof(int)));
 	blkChunkCountKernel<<<(nBlocks + 1 + 255) / 256, 256, 0, s>>>(nBlocks, B->d_bounds, B->d_chunk0);
@@ -816,6 +822,7 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_prec
 	}
 	B->levelsLo = h[3];
 	B->levelsUp = h[4];
+	B->maxInBlock = h[5];
 	const int most = std::max(h[0], h[1]);
 	B->kreg = most <= 2 ? 2 : most <= 4 ? 4 : 8;
 	B->overflow = most > 8;

@@ -767,10 +767,10 @@ __global__ void farColumnKernel(int rows, const int* __restrict__ start, const i
 
 // The cut itself: tiles[0 .. *nTiles] = {first row, start[first row]} with the closing sentinel {rows, nnz}; the table is allocated here
 // (devAlloc) and owned by the caller.  Also used for the row blocks of the block preconditioners (smm_precond_block.hip).
-int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows, hipStream_t s, int2** tiles, int* nTiles) {
+int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows, hipStream_t s, int2** tiles, int* nTiles, int tilesPerChunk) {
 	*tiles = nullptr;
 	*nTiles = 0;
-	const long long chunkNnz = static_cast<long long>(TILES_PER_CHUNK) * capNnz;
+	const long long chunkNnz = static_cast<long long>(tilesPerChunk > 0 ? tilesPerChunk : TILES_PER_CHUNK) * capNnz;
 	const int nChunks = static_cast<int>(nnz / chunkNnz) + 1;
 	DevBuf<int> counts;
 	SMM_TRY(counts.alloc(static_cast<size_t>(nChunks) + 1));
