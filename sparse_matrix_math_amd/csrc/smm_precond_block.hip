@@ -129,26 +129,43 @@ __device__ __forceinline__ void loadRec(unsigned (&w)[DW], const uint2* p) {
 	}
 }
 
-// one sweep of one block: nc chunks of records starting at `rec` (the block's first chunk, lane 0); xs = the block's vector in LDS
+// The record stream of one sweep of one block is what the apply waits for: a wavefront has only the bytes it keeps IN FLIGHT to cover
+// the memory latency with (measured, r03: deps read from an LDS region that is never written -- no LDS write -> read dependency at
+// all -- give the same 47 us; 26 -> 17 instructions per level the same; so neither the level chain nor issue bounds it: D = 4 chunks =
+// 8 KB in flight per wavefront / ~3 us = 2.7 GB/s for the 72 KB of a block's apply does).  So: D chunks ahead, as many as the register
+// file allows at two wavefronts per SIMD, and the first D chunks of BOTH sweeps are requested before anything else is waited for.
+//
+// Register sets: chunk c lives in set c % (2 D) and is loaded D chunks before its use into the set chunk c - D has just left -- so a
+// set is never reloaded while it is read, no register is copied at the loop's back edge, and the wait in front of a chunk's first use
+// counts only the younger loads (the D chunks behind it stay in flight).  Every load is issued unconditionally (past the end: the last
+// chunk again), so that the number of loads in flight is the same on every path and the compiler can wait with a count instead of
+// draining the queue.
+template <typename T, int MODE, int KREG, int D>
+struct SweepRing {
+	static constexpr int DW = RecLayout<T, MODE != B_ILU_LO, KREG>::DW;
+	static constexpr int U = 2 * D;
+	unsigned r[U][DW];
+	const uint2* base;
+	__device__ __forceinline__ void prologue(const unsigned* __restrict__ rec, int nc) {
+		base = reinterpret_cast<const uint2*>(rec) + static_cast<size_t>(threadIdx.x) * (DW / 2);
+#pragma unroll
+		for (int d = 0; d < D; ++d) loadRec<DW>(r[d], base + static_cast<size_t>(min(d, nc - 1)) * (static_cast<size_t>(WAVE) * (DW / 2)));
+	}
+};
+
+// one sweep of one block: nc chunks of records (the ring's prologue has been issued); xs = the block's vector in LDS
 template <typename T, int MODE, int KREG, bool OV, int D>
-__device__ __forceinline__ void blkSweep(const unsigned* __restrict__ rec, long long recIndex0, int nc, T* xs, const int* __restrict__ ovPtr,
+__device__ __forceinline__ void blkSweep(SweepRing<T, MODE, KREG, D>& sr, long long recIndex0, int nc, T* xs, const int* __restrict__ ovPtr,
                                          const unsigned short* __restrict__ ovCol, const T* __restrict__ ovVal) {
 	constexpr bool LOWER = MODE == B_ILU_LO || MODE == B_SGS_LO;
 	constexpr bool HASD = MODE != B_ILU_LO;
 	using L = RecLayout<T, HASD, KREG>;
 	constexpr int DW = L::DW;
 	const int lane = threadIdx.x;
-	const uint2* base = reinterpret_cast<const uint2*>(rec) + static_cast<size_t>(lane) * (DW / 2);
+	const uint2* base = sr.base;
 	constexpr size_t CHUNK_STRIDE = static_cast<size_t>(WAVE) * (DW / 2);  // in uint2
-	// Register sets: chunk c lives in set c % (2 D) and is loaded D chunks before its use into the set chunk c - D has just left --
-	// so a set is never reloaded while it is read, no register is copied at the loop's back edge, and the wait in front of a
-	// chunk's first use counts only the younger loads (the D chunks behind it stay in flight).
 	constexpr int U = 2 * D;
-	unsigned ring[U][DW];
-	// Every load is issued unconditionally (past the end: the last chunk again), so that the number of loads in flight is the same
-	// on every path and the compiler can wait with a count instead of draining the queue.
-#pragma unroll
-	for (int d = 0; d < D; ++d) loadRec<DW>(ring[d], base + static_cast<size_t>(min(d, nc - 1)) * CHUNK_STRIDE);
+	unsigned (&ring)[U][DW] = sr.r;
 	for (int c0 = 0; c0 < nc; c0 += U) {
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
@@ -244,9 +261,13 @@ __global__ __launch_bounds__(WAVE) void blkApplyKernel(const BlkApplyArgs<T> a) 
 		const int nb = a.bounds[b + 1].x - r0;
 		const int nc = (nb + WAVE - 1) / WAVE;
 		const long long rec0 = static_cast<long long>(a.chunk0[b]) * WAVE;
+		SweepRing<T, LO, KREG, D> ringLo;
+		SweepRing<T, UP, KREG, D> ringUp;
+		ringLo.prologue(a.recLo + rec0 * LL::DW, nc);
+		ringUp.prologue(a.recUp + rec0 * LU::DW, nc);  // (in flight across the whole lower sweep)
 		for (int i = lane; i < nb; i += WAVE) xs[i] = a.rhs[r0 + i];
-		blkSweep<T, LO, KREG, OV, D>(a.recLo + rec0 * LL::DW, rec0, nc, xs, a.ovPtrLo, a.ovColLo, a.ovValLo);
-		blkSweep<T, UP, KREG, OV, D>(a.recUp + rec0 * LU::DW, rec0, nc, xs, a.ovPtrUp, a.ovColUp, a.ovValUp);
+		blkSweep<T, LO, KREG, OV, D>(ringLo, rec0, nc, xs, a.ovPtrLo, a.ovColLo, a.ovValLo);
+		blkSweep<T, UP, KREG, OV, D>(ringUp, rec0, nc, xs, a.ovPtrUp, a.ovColUp, a.ovValUp);
 		if (a.dotMode == 0) {
 			for (int i = lane; i < nb; i += WAVE) a.x[r0 + i] = xs[i];
 		} else {
@@ -894,7 +915,8 @@ template int blockCreateTyped<double>(const smm_hip_csr*, int, int, smm_hip_prec
 template <typename T, int KIND, int KREG, bool OV>
 static int launchBlkApply(const smm_hip_precond* M, const BlkApplyArgs<T>& args, hipStream_t s) {
 	const smm_precond_block* B = M->blk;
-	constexpr int D = KREG <= 2 ? 4 : 2;
+	// chunks in flight per sweep: what fits 256 registers (two wavefronts per SIMD) beside the other sweep's first D chunks
+	constexpr int D = KREG <= 2 ? 8 : KREG <= 4 ? 4 : 2;
 	const int grid = std::min(B->nBlocks, NPART);
 	const size_t lds = static_cast<size_t>(B->blockRows) * sizeof(T);
 	blkApplyKernel<T, KIND, KREG, OV, D><<<grid, WAVE, lds, s>>>(args);
