@@ -11,7 +11,7 @@
 //   * for ILU0 the factorisation of the block (IKJ on the block's pattern, one lane per row, level by level, out of LDS);
 //   * one fixed-size RECORD per (chunk, lane) and sweep: {row, level, count | columns (16-bit, local) | diagonal | values} of that
 //     row's first KREG in-block entries in the order the sequential sweep visits them; rows with more entries continue in an
-//     overflow list.  Records of a chunk are adjacent, so a wavefront streams them with 8-byte loads, D chunks ahead of their use.
+//     overflow list.  Records of a chunk are adjacent, so a wavefront streams them with 8-byte loads, D = 2 chunks ahead of their use.
 // Apply (blkApplyKernel): a wavefront loads its block's slice of rhs into LDS, walks the lower chunks and then the upper ones, and
 // inside a chunk the levels one after the other: the lanes whose row is in that level read the x[] they need from LDS, run the
 // row's multiply-adds in the sequential order and store the row's result -- the LDS pipeline of a wavefront is in order, so a later
@@ -129,11 +129,12 @@ __device__ __forceinline__ void loadRec(unsigned (&w)[DW], const uint2* p) {
 	}
 }
 
-// The record stream of one sweep of one block is what the apply waits for: a wavefront has only the bytes it keeps IN FLIGHT to cover
-// the memory latency with (measured, r03: deps read from an LDS region that is never written -- no LDS write -> read dependency at
-// all -- give the same 47 us; 26 -> 17 instructions per level the same; so neither the level chain nor issue bounds it: D = 4 chunks =
-// 8 KB in flight per wavefront / ~3 us = 2.7 GB/s for the 72 KB of a block's apply does).  So: D chunks ahead, as many as the register
-// file allows at two wavefronts per SIMD, and the first D chunks of BOTH sweeps are requested before anything else is waited for.
+// What bounds a sweep (measured on the 108^3 problem, r03, tools/block_apply_only.py): NOT the record stream -- 1, 2, 4 or 8 chunks
+// requested ahead give 47.6 / 48.5 / 51.1 / 51.2 us per apply (SMM_HIP_BLOCK_DEPTH; the deeper rings only add code) --, not the number of
+// instructions of a level (26 -> 17 by dropping the per-entry predicates: 48 -> 48 us), but the dependent chain of a level itself:
+// ds_write of the previous level -> ds_read behind it in the wavefront's in-order LDS queue -> the row's fp64 multiply-adds -> ds_write,
+// ~120 ns, plus ~400 ns per chunk of unpacking: 264 levels = 47 us.  So the ring is shallow (D = 2), and the first chunks of BOTH
+// sweeps are requested before anything is waited for.
 //
 // Register sets: chunk c lives in set c % (2 D) and is loaded D chunks before its use into the set chunk c - D has just left -- so a
 // set is never reloaded while it is read, no register is copied at the loop's back edge, and the wait in front of a chunk's first use
@@ -915,11 +916,24 @@ template int blockCreateTyped<double>(const smm_hip_csr*, int, int, smm_hip_prec
 template <typename T, int KIND, int KREG, bool OV>
 static int launchBlkApply(const smm_hip_precond* M, const BlkApplyArgs<T>& args, hipStream_t s) {
 	const smm_precond_block* B = M->blk;
-	// chunks in flight per sweep: what fits 256 registers (two wavefronts per SIMD) beside the other sweep's first D chunks
-	constexpr int D = KREG <= 2 ? 8 : KREG <= 4 ? 4 : 2;
+	// chunks in flight per sweep (SMM_HIP_BLOCK_DEPTH = 1 / 2 / 4 / 8 overrides where compiled: measurements)
+	static const int depth = [] {
+		const char* env = getenv("SMM_HIP_BLOCK_DEPTH");
+		return env ? atoi(env) : 0;
+	}();
 	const int grid = std::min(B->nBlocks, NPART);
 	const size_t lds = static_cast<size_t>(B->blockRows) * sizeof(T);
-	blkApplyKernel<T, KIND, KREG, OV, D><<<grid, WAVE, lds, s>>>(args);
+	if constexpr (KREG <= 2) {
+		switch (depth) {
+		case 1: blkApplyKernel<T, KIND, KREG, OV, 1><<<grid, WAVE, lds, s>>>(args); break;
+		case 2: blkApplyKernel<T, KIND, KREG, OV, 2><<<grid, WAVE, lds, s>>>(args); break;
+		case 8: blkApplyKernel<T, KIND, KREG, OV, 8><<<grid, WAVE, lds, s>>>(args); break;
+		case 4: blkApplyKernel<T, KIND, KREG, OV, 4><<<grid, WAVE, lds, s>>>(args); break;
+		default: blkApplyKernel<T, KIND, KREG, OV, 2><<<grid, WAVE, lds, s>>>(args); break;
+		}
+	} else {
+		blkApplyKernel<T, KIND, KREG, OV, 2><<<grid, WAVE, lds, s>>>(args);
+	}
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
 }
