@@ -525,6 +525,13 @@ class _BlockView:
 
         _lib.check(_lib.load().smm_hip_csr_set_kernel(self._h, int(family), int(lanes_per_row)))
 
+    def get_kernel(self):
+        from . import _lib
+
+        fam, lanes = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().smm_hip_csr_get_kernel(self._h, ctypes.byref(fam), ctypes.byref(lanes)))
+        return fam.value, lanes.value
+
 
 class NativeDistMatrix:
     """smm_hip_dist_csr: this rank's rows of a row-partitioned matrix + the native solvers on it.  Collective."""
@@ -689,13 +696,30 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     s_bytes = np.dtype(np_dtype).itemsize
     # one matvec = the A_loc launch + the A_rem launch; algorithmic bytes of this rank's slice (SURVEY.md section 8d formula)
     b_local = nnz_local * (s_bytes + 4) + (hi - lo + 1) * 4 + ext_len * s_bytes + (hi - lo) * s_bytes
+    # which family served the two local blocks: AUTO may have moved a large block to the index-free PATTERN family (its first SpMV
+    # verifies every entry); the roofline object is priced with CSR bytes only when the CSR kernels ran -- otherwise the bytes really
+    # moved (no positions[], 8 bytes of mask per row) are reported beside it and `frac` uses THEM
+    families, b_true = None, b_local
+    if driver == "native":
+        blk_loc, blk_rem = A.local_blocks()
+        families = {"A_loc": blk_loc.get_kernel(), "A_rem": blk_rem.get_kernel()}
+        b_true = ext_len * s_bytes + (hi - lo) * s_bytes
+        for name, nnz_blk in (("A_loc", A.nnz_loc), ("A_rem", A.nnz_rem)):
+            if families[name][0] == 3:
+                b_true += nnz_blk * s_bytes + (hi - lo) * 8 + (hi - lo + 1) * 4
+            else:
+                b_true += nnz_blk * (s_bytes + 4) + (hi - lo + 1) * 4
     per_matvec = 1 if one_launch else 2
     matvec_s = spmv_ms * 1e-3 / max(spmv_launches // per_matvec, 1)
-    achieved = b_local / matvec_s / 1e9
+    achieved = b_true / matvec_s / 1e9
+    pattern_used = families is not None and any(f[0] == 3 for f in families.values())
     return {
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "kernel": "spmvStreamKernel (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")"),
-                     "algorithmic_bytes_per_launch": b_local, "avg_launch_ms": matvec_s * 1e3, "launches": spmv_launches // per_matvec},
+                     "kernel": ("spmvPatternTileKernel / spmvTileKernel" if pattern_used else "spmvTileKernel") +
+                               " (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")"),
+                     "algorithmic_bytes_per_launch": b_true, "csr_bytes_per_launch": b_local, "avg_launch_ms": matvec_s * 1e3,
+                     "launches": spmv_launches // per_matvec, "families": families,
+                     "note": "bytes = what the kernels that ran really move per matvec of rank 0 (a block AUTO moved to the PATTERN family has no positions[]); csr_bytes_per_launch is the SURVEY 8d formula"},
         "elapsed": elapsed,
         "iters": iters,
         "nnz": nnz_total,
