@@ -25,6 +25,8 @@ def main():
     args = ap.parse_args()
     smm.init(0)
     dev = torch.device("cuda:0")
+    side = torch.cuda.Stream()  # not the null stream: a hipGraph capture (SMM_HIP_SOLVER_GRAPH) needs a created stream
+    torch.cuda.set_stream(side)
     stream = torch.cuda.current_stream().cuda_stream
     P = smm.SolverPreconditioner
     mats = []
