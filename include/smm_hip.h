@@ -224,6 +224,14 @@ int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out
  * stored entries, cut greedily from row 0; smm_hip_precond_create uses the default.  The cut is a property of the handle:
  * smm_hip_precond_block_bounds returns the nblocks + 1 row numbers (bounds[0] = 0, bounds[nblocks] = rows). */
 int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows, smm_hip_precond** out);
+/* ... and a chosen LEVEL CUT.  Inside a block the forward sweep gives every row a level (0 when it keeps no entry left of the
+ * diagonal, else 1 + the deepest level of the rows its kept entries point to), the backward sweep likewise; entries that point to
+ * a row of level level_cap - 1 are dropped from M (like the entries that couple two blocks), so no sweep of any block runs deeper
+ * than level_cap dependent levels.  level_cap: -1 = the default (16), 0 = no cut (M = the block-diagonal part of A exactly), else
+ * 2 .. 4095.  The rule is a recurrence in the sweep's own row order; the tests' CPU checker states it sequentially
+ * (block_level_cut) and the device result is compared with it bit for bit.  smm_hip_precond_create / _create_block use the default. */
+int smm_hip_precond_create_block_capped(const smm_hip_csr* a, int kind, int block_rows, int level_cap, smm_hip_precond** out);
+int smm_hip_precond_block_level_cap(const smm_hip_precond* M, int* level_cap);
 int smm_hip_precond_block_count(const smm_hip_precond* M, int* nblocks);
 int smm_hip_precond_block_bounds(const smm_hip_precond* M, int* bounds, size_t count);
 int smm_hip_precond_destroy(smm_hip_precond* M);

@@ -204,6 +204,15 @@ class Oracle:
         err = fn(c_int(len(start) - 1), _p(start), _p(pos), _p(val), c_int(len(bounds) - 1), _p(bounds), _p(rhs), _p(x))
         return err, x
 
+    def block_level_cut(self, csr, bounds, cap):
+        """(mask of the stored entries the level-capped block preconditioners keep, deepest level + 1); cap <= 0: no cap"""
+        start, pos, _ = csr
+        bounds = _c(bounds, np.int32)
+        keep = np.zeros(len(pos), dtype=np.uint8)
+        self.lib.smm_oracle_block_level_cut.restype = c_int
+        deepest = self.lib.smm_oracle_block_level_cut(c_int(len(start) - 1), _p(start), _p(pos), c_int(len(bounds) - 1), _p(bounds), c_int(int(cap)), _p(keep))
+        return keep.astype(bool), deepest
+
     def bicgstab_block(self, csr, b, x0, maxit, eps, precond, bounds, precond_values=None):
         start, pos, val = csr
         bounds = _c(bounds, np.int32)
@@ -215,6 +224,31 @@ class Oracle:
         st = fn(c_int(len(start) - 1), _p(start), _p(pos), _p(val), _p(bb), _p(x), c_int(maxit), ct(eps), c_int(precond), _p(precond_values),
                 c_int(len(bounds) - 1), _p(bounds), ctypes.byref(it), ctypes.byref(res))
         return st, x, it.value, res.value
+
+    def bicgstab_block_of(self, csr, mcsr, b, x0, maxit, eps, precond, bounds, precond_values=None):
+        """bicgstab_block with the preconditioner built from another matrix (mcsr; precond_values on ITS pattern)"""
+        start, pos, val = csr
+        ms, mp, mv = mcsr
+        bounds = _c(bounds, np.int32)
+        x = x0.copy()
+        bb = b.copy()
+        it = c_int()
+        fn, ct = self._f("bicgstab_block_of", val.dtype)
+        res = ct()
+        st = fn(c_int(len(start) - 1), _p(start), _p(pos), _p(val), _p(ms), _p(mp), _p(mv), _p(bb), _p(x), c_int(maxit), ct(eps), c_int(precond),
+                _p(precond_values), c_int(len(bounds) - 1), _p(bounds), ctypes.byref(it), ctypes.byref(res))
+        return st, x, it.value, res.value
+
+    def level_cut_matrix(self, csr, bounds, cap):
+        """(the matrix the level-cut block preconditioners are built from: A's in-block entries that the cut keeps; mask of those
+        entries over A's pattern; deepest level + 1).  cap 0 = the block-diagonal part."""
+        start, pos, val = csr
+        keep, deepest = self.block_level_cut(csr, bounds, cap)
+        n = len(start) - 1
+        rowof = np.repeat(np.arange(n), np.diff(start))
+        s2 = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(rowof[keep], minlength=n), out=s2[1:])
+        return (s2, pos[keep].copy(), val[keep].copy()), keep, deepest
 
     def omp_threads(self):
         return self.lib.smm_oracle_omp_max_threads()

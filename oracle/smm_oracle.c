@@ -46,6 +46,53 @@ int smm_oracle_uses_std_fma(void) {
 #endif
 }
 
+/* Level cut of the block preconditioners (an addition; no counterpart in the reference).  Inside block b (rows bounds[b] ..
+ * bounds[b+1]) the forward sweep of a triangular solve gives row i the level  lo(i) = 0 when it keeps no in-block entry left of
+ * the diagonal, else 1 + the largest lo(j) over the entries (i, j), j < i, it keeps; the backward sweep defines up(i) the same
+ * way over the entries right of the diagonal, rows descending.  With a cap C > 0 an entry (i, j), j < i, is KEPT only while
+ * lo(j) < C - 1, and an entry (i, j), j > i, only while up(j) < C - 1: no row of either sweep then sits deeper than level C - 1,
+ * whatever the matrix.  Rows are visited in the sweep's own order (ascending for lo, descending for up), so the rule is a plain
+ * recurrence.  keep[k] = 1 for every stored entry that takes part in M (the diagonal, and the in-block entries the rule keeps),
+ * 0 for entries that couple two blocks or that the cap drops; M is then the block preconditioner of the matrix made of the kept
+ * entries.  cap <= 0: no cap (keep = the block-diagonal part).  Returns the deepest level + 1 over both sweeps and all blocks. */
+int smm_oracle_block_level_cut(int rows, const int* start, const int* positions, int nblocks, const int* bounds, int cap,
+                               unsigned char* keep) {
+	int deepest = 0;
+	int* lvl = (int*)malloc(sizeof(int) * (size_t)(rows > 0 ? rows : 1));
+	if (!lvl) return -1;
+	for (int k = 0; k < start[rows]; ++k) keep[k] = 0;
+	for (int b = 0; b < nblocks; ++b) {
+		const int r0 = bounds[b], r1 = bounds[b + 1];
+		for (int i = r0; i < r1; ++i) { /* forward sweep */
+			int lv = 0;
+			for (int k = start[i]; k < start[i + 1]; ++k) {
+				const int j = positions[k];
+				if (j < r0 || j >= i) continue;
+				if (cap > 0 && lvl[j] >= cap - 1) continue;
+				keep[k] = 1;
+				if (lvl[j] + 1 > lv) lv = lvl[j] + 1;
+			}
+			lvl[i] = lv;
+			if (lv + 1 > deepest) deepest = lv + 1;
+		}
+		for (int i = r1 - 1; i >= r0; --i) { /* backward sweep */
+			int lv = 0;
+			for (int k = start[i]; k < start[i + 1]; ++k) {
+				const int j = positions[k];
+				if (j == i) keep[k] = 1;
+				if (j <= i || j >= r1) continue;
+				if (cap > 0 && lvl[j] >= cap - 1) continue;
+				keep[k] = 1;
+				if (lvl[j] + 1 > lv) lv = lvl[j] + 1;
+			}
+			lvl[i] = lv;
+			if (lv + 1 > deepest) deepest = lv + 1;
+		}
+	}
+	free(lvl);
+	return deepest;
+}
+
 #define T float
 #define FN(name) name##_f32
 #define SQRT sqrtf

@@ -75,6 +75,10 @@ enum {
 	int smm_oracle_bicgstab_block_##S(int rows, const int* start, const int* positions, const T* values, T* b,    \
 	                                  T* x, int maxIterations, T eps, int precond, const T* precond_values,        \
 	                                  int nblocks, const int* bounds, int* iterations, T* resnorm);                \
+	int smm_oracle_bicgstab_block_of_##S(int rows, const int* start, const int* positions, const T* values,       \
+	                                     const int* mstart, const int* mpositions, const T* mvalues, T* b, T* x,   \
+	                                     int maxIterations, T eps, int precond, const T* precond_values,           \
+	                                     int nblocks, const int* bounds, int* iterations, T* resnorm);             \
 	int smm_oracle_ic0_factorize_##S(int rows, const int* start, const int* positions, const T* values,           \
 	                                 T* ic0val);                                                                   \
 	int smm_oracle_ic0_apply_##S(int rows, const int* start, const int* positions, const T* ic0val,               \
@@ -100,6 +104,9 @@ int smm_oracle_omp_max_threads(void);
 void smm_oracle_omp_set_threads(int n);
 /* 1 when built with SMM_WITH_STD_FMA (fused multiply-add), else 0 */
 int smm_oracle_uses_std_fma(void);
+/* which stored entries the level-capped block preconditioners keep (smm_oracle.c); returns the deepest level + 1 */
+int smm_oracle_block_level_cut(int rows, const int* start, const int* positions, int nblocks, const int* bounds, int cap,
+                               unsigned char* keep);
 
 #ifdef __cplusplus
 }

@@ -297,12 +297,13 @@ int precondTakeError(const smm_hip_precond* M, hipStream_t s);
 // block preconditioners (smm_precond_block.hip)
 inline bool isBlockKind(int kind) { return kind == SMM_PRECOND_BLOCK_ILU0 || kind == SMM_PRECOND_BLOCK_SGS; }
 template <typename T>
-int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_precond* M);
+int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap, smm_hip_precond* M);
 // x = M^-1 rhs; dotMode / w1 / partials: dot products of x fused into the epilogue, as in launchSpmv (partials: 2 * NPART elements)
 template <typename T>
 int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s);
 void blockDestroy(struct smm_precond_block* B);
 void blockLevels(const struct smm_precond_block* B, int* lo, int* up);
 int blockDefaultRows();
+int blockDefaultLevelCap();
 
 }  // namespace smm

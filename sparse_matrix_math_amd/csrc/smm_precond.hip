@@ -1033,7 +1033,7 @@ using namespace smm;
 
 extern "C" {
 
-static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, smm_hip_precond** out) {
+static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, int levelCap, smm_hip_precond** out) {
 	if (!a || !out) {
 		setError("precond_create: null argument");
 		return SMM_HIP_ERR_INVALID;
@@ -1051,7 +1051,7 @@ static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, smm_hip_
 	M->a = a;
 	int st = SMM_HIP_OK;
 	if (isBlockKind(kind)) {
-		st = a->dtype == SMM_DTYPE_F32 ? blockCreateTyped<float>(a, kind, blockRows, M) : blockCreateTyped<double>(a, kind, blockRows, M);
+		st = a->dtype == SMM_DTYPE_F32 ? blockCreateTyped<float>(a, kind, blockRows, levelCap, M) : blockCreateTyped<double>(a, kind, blockRows, levelCap, M);
 	} else if (kind != SMM_PRECOND_NONE) {
 		st = a->dtype == SMM_DTYPE_F32 ? createTyped<float>(a, kind, M) : createTyped<double>(a, kind, M);
 	}
@@ -1063,7 +1063,7 @@ static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, smm_hip_
 	return SMM_HIP_OK;
 }
 
-int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out) { return precondCreate(a, kind, blockDefaultRows(), out); }
+int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out) { return precondCreate(a, kind, blockDefaultRows(), blockDefaultLevelCap(), out); }
 
 int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows, smm_hip_precond** out) {
 	if (!isBlockKind(kind)) {
@@ -1074,7 +1074,23 @@ int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows,
 		setError("precond_create_block: block_rows must be 0 (default) or 64 .. 2048");
 		return SMM_HIP_ERR_INVALID;
 	}
-	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), out);
+	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), blockDefaultLevelCap(), out);
+}
+
+int smm_hip_precond_create_block_capped(const smm_hip_csr* a, int kind, int block_rows, int level_cap, smm_hip_precond** out) {
+	if (!isBlockKind(kind)) {
+		setError("precond_create_block_capped: kind %d is not a block preconditioner", kind);
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (block_rows != 0 && (block_rows < 64 || block_rows > 2048)) {
+		setError("precond_create_block_capped: block_rows must be 0 (default) or 64 .. 2048");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (level_cap < -1 || level_cap == 1 || level_cap > 4095) {
+		setError("precond_create_block_capped: level_cap must be -1 (default), 0 (no cut) or 2 .. 4095");
+		return SMM_HIP_ERR_INVALID;
+	}
+	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), level_cap < 0 ? blockDefaultLevelCap() : level_cap, out);
 }
 
 int smm_hip_precond_destroy(smm_hip_precond* M) {

@@ -29,6 +29,7 @@
 struct smm_precond_block {
 	int nBlocks = 0;
 	int blockRows = 0;      // the cut: at most this many rows ...
+	int levelCap = 0;       // the level cut: no sweep of a block deeper than this many levels (0 = no cut)
 	int capNnz = 0;         // ... and this many stored entries per block
 	int kreg = 2;           // in-block entries per row and sweep that live in the records
 	bool overflow = false;  // some row has more than kreg: the rest is in the overflow lists
@@ -55,6 +56,7 @@ constexpr int BLK_TPB = 256;            // set-up kernels: one workgroup per blo
 constexpr int BLK_DEFAULT_ROWS = 1024;
 constexpr int BLK_MIN_ROWS = 64;
 constexpr int BLK_MAX_ROWS = 2048;
+constexpr int BLK_DEFAULT_LEVEL_CAP = 16;  // deepest sweep of a block, in dependent levels (the level cut below)
 constexpr int BLK_CAP_NNZ = 8192;
 constexpr unsigned BLK_NOROW = 0xFFFu;  // row field of a padding lane
 constexpr unsigned short BLK_UNKNOWN = 0xFFFFu;
@@ -345,27 +347,48 @@ struct BlkStage {
 	int* ibG;              // [maxRows]   global index of the first in-block entry of the row
 	unsigned short* nlow;  // [maxRows]   in-block entries left of the diagonal
 	unsigned short* lcol;  // [cap]
+	unsigned short* nall = nullptr;  // [maxRows] (optional) stored in-block entries of the row, the ones the level cut drops included
 };
 
-// returns bit 0: some row of this thread has no diagonal entry (or is empty), bit 1 (checkMagnitude): |d| < 1e-5; fills st.lptr / ibG / nlow / lcol (and lval when LVAL is not null)
+// The LEVEL CUT (r03): a block's forward sweep gives every row a level (0: no kept entry left of the diagonal; else 1 + the deepest
+// level among the rows its kept entries point to), the backward sweep likewise.  With a cap C, entries that point to a row of level
+// C - 1 (`top`) are dropped from M -- exactly like the entries that couple two blocks -- so neither sweep of any block is deeper than
+// C levels, whatever the matrix: a 1024-row block of a 108^3 grid has 116 dependent levels, 16 after the cut, for 2 % more BiCGStab
+// iterations (profiles/r03/level_cap.txt).  The rule is a recurrence in the sweep's own row order; the tests' CPU checker
+// states it sequentially (its block_level_cut).  top = C - 1, 0 = no cut.
+__device__ __forceinline__ bool blkKeeps(int i, int c, const unsigned short* lvlLo, const unsigned short* lvlUp, int top) {
+	if (top <= 0 || c == i) return true;
+	return static_cast<int>(c < i ? lvlLo[c] : lvlUp[c]) < top;
+}
+
+// returns bit 0: some row of this thread has no diagonal entry (or is empty), bit 1 (checkMagnitude): |d| < 1e-5; fills st.lptr / ibG / nlow / lcol (and lval when LVAL is not null).
+// top > 0: the entries the level cut drops (levels of both sweeps in lvlLo / lvlUp) are not staged.
 template <typename T>
 __device__ int stageBlock(const BlkStage& st, T* lval, int r0, int nb, const int* __restrict__ start, const int* __restrict__ positions,
-                          const T* __restrict__ vals, int* scanScratch, int checkMagnitude = 0) {
+                          const T* __restrict__ vals, int* scanScratch, int checkMagnitude = 0, const unsigned short* lvlLo = nullptr,
+                          const unsigned short* lvlUp = nullptr, int top = 0) {
 	constexpr int RPT = BLK_MAX_ROWS / BLK_TPB;  // 8 consecutive rows per thread
 	const int t = threadIdx.x;
-	int cnt[RPT], ib[RPT];
+	int cnt[RPT], all[RPT], ib[RPT];
 	int mine = 0;
 #pragma unroll
 	for (int j = 0; j < RPT; ++j) {
 		const int i = t * RPT + j;
 		cnt[j] = 0;
+		all[j] = 0;
 		ib[j] = 0;
 		if (i < nb) {
 			const int b = start[r0 + i], e = start[r0 + i + 1];
 			const int lo = lowerBoundCol(positions, b, e, r0);
 			const int hi = lowerBoundCol(positions, lo, e, r0 + nb);
 			ib[j] = lo;
+			all[j] = hi - lo;
 			cnt[j] = hi - lo;
+			if (top > 0) {
+				int kept = 0;
+				for (int k = lo; k < hi; ++k) kept += blkKeeps(i, positions[k] - r0, lvlLo, lvlUp, top) ? 1 : 0;
+				cnt[j] = kept;
+			}
 		}
 		mine += cnt[j];
 	}
@@ -378,12 +401,15 @@ __device__ int stageBlock(const BlkStage& st, T* lval, int r0, int nb, const int
 		if (i < nb) {
 			st.lptr[i] = at;
 			st.ibG[i] = ib[j];
-			int low = 0;
+			if (st.nall) st.nall[i] = static_cast<unsigned short>(all[j]);
+			int low = 0, q = 0;
 			bool diag = false;
-			for (int e = 0; e < cnt[j]; ++e) {
+			for (int e = 0; e < all[j]; ++e) {
 				const int c = positions[ib[j] + e] - r0;
-				st.lcol[at + e] = static_cast<unsigned short>(c);
-				if (lval) lval[at + e] = vals[ib[j] + e];
+				if (!blkKeeps(i, c, lvlLo, lvlUp, top)) continue;
+				st.lcol[at + q] = static_cast<unsigned short>(c);
+				if (lval) lval[at + q] = vals[ib[j] + e];
+				++q;
 				low += c < i ? 1 : 0;
 				if (c == i) {
 					diag = true;
@@ -408,9 +434,9 @@ __device__ int stageBlock(const BlkStage& st, T* lval, int r0, int nb, const int
 // wavefront sees it (LDS is in order for a wavefront).  The first unfinished lane always finishes within a pass: <= 64 passes per
 // chunk.  Returns the largest level (>= 2^20: the pass bound tripped).
 template <bool LOWER>
-__device__ int blkLevels(const BlkStage& st, int nb, unsigned short* lvl) {
+__device__ int blkLevels(const BlkStage& st, int nb, unsigned short* lvl, int top) {
 	const int lane = threadIdx.x & (WAVE - 1);
-	int top = 0;
+	int deepest = 0;
 	for (int c = 0; c * WAVE < nb; ++c) {
 		const int q = c * WAVE + lane;
 		bool pending = q < nb;
@@ -430,7 +456,7 @@ __device__ int blkLevels(const BlkStage& st, int nb, unsigned short* lvl) {
 				while (LOWER ? k < kEnd : k > kEnd) {
 					const unsigned short d = lvl[st.lcol[k]];
 					if (d == BLK_UNKNOWN) break;
-					lv = max(lv, static_cast<int>(d) + 1);
+					if (top <= 0 || static_cast<int>(d) < top) lv = max(lv, static_cast<int>(d) + 1);  // (else: the level cut drops this entry)
 					k += LOWER ? 1 : -1;
 				}
 				if (LOWER ? k >= kEnd : k <= kEnd) {
@@ -441,13 +467,13 @@ __device__ int blkLevels(const BlkStage& st, int nb, unsigned short* lvl) {
 		}
 		if (pending) {  // cannot happen (see above); never leave a row without a level
 			lvl[i] = static_cast<unsigned short>(lv);
-			top = 1 << 20;
+			deepest = 1 << 20;
 		}
-		top = max(top, lv);
+		deepest = max(deepest, lv);
 	}
 #pragma unroll
-	for (int o = WAVE / 2; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o, WAVE));
-	return top;
+	for (int o = WAVE / 2; o > 0; o >>= 1) deepest = max(deepest, __shfl_xor(deepest, o, WAVE));
+	return deepest;
 }
 
 // rows sorted by level (all 256 threads): hist[] is scratch of maxRows + 1 ints; ord[q] = row at sorted position q
@@ -493,7 +519,7 @@ static size_t carveSize(size_t bytes) { return (bytes + 15) & ~static_cast<size_
 // info: [0] most lower entries of a row, [1] most upper entries, [2] error bits (1: empty row / missing diagonal, 2: |d| < 1e-5 for
 // SGS), [3] deepest lower sweep, [4] deepest upper sweep (levels), [5] most in-block entries of a block
 template <typename T>
-__global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
+__global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap, int top, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
                                                            const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
                                                            int checkMagnitude, unsigned* __restrict__ metaLo, unsigned* __restrict__ metaUp,
                                                            unsigned short* __restrict__ nEntLo, unsigned short* __restrict__ nEntUp, int* info) {
@@ -528,11 +554,11 @@ __global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap
 	// a missing diagonal makes nlow / the upper part meaningless: the create call fails anyway, skip the analysis
 	if (__syncthreads_or(bad & 1) != 0) return;
 	if (t < WAVE) {  // two wavefronts, one sweep each, at the same time
-		const int top = blkLevels<true>(st, nb, lvlLo);
-		if (t == 0) tops[0] = top;
+		const int deepest = blkLevels<true>(st, nb, lvlLo, top);
+		if (t == 0) tops[0] = deepest;
 	} else if (t < 2 * WAVE) {
-		const int top = blkLevels<false>(st, nb, lvlUp);
-		if (t == WAVE) tops[1] = top;
+		const int deepest = blkLevels<false>(st, nb, lvlUp, top);
+		if (t == WAVE) tops[1] = deepest;
 	}
 	__syncthreads();
 	if (t == 0) {
@@ -549,6 +575,10 @@ __global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap
 		if (q < nb) {
 			const int row = ord[q];
 			n = st.nlow[row];
+			if (top > 0) {  // the entries the level cut keeps
+				n = 0;
+				for (int k = st.lptr[row]; k < st.lptr[row] + st.nlow[row]; ++k) n += static_cast<int>(lvlLo[st.lcol[k]]) < top ? 1 : 0;
+			}
 			meta = static_cast<unsigned>(row) | (static_cast<unsigned>(lvlLo[row]) << 12) | (static_cast<unsigned>(min(n, 255)) << 24);
 		} else {
 			meta = BLK_NOROW | (static_cast<unsigned>(lvlLo[ord[nb - 1]]) << 12);
@@ -565,6 +595,10 @@ __global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap
 		if (q < nb) {
 			const int row = ord[q];
 			n = st.lptr[row + 1] - st.lptr[row] - st.nlow[row] - 1;
+			if (top > 0) {
+				n = 0;
+				for (int k = st.lptr[row] + st.nlow[row] + 1; k < st.lptr[row + 1]; ++k) n += static_cast<int>(lvlUp[st.lcol[k]]) < top ? 1 : 0;
+			}
 			meta = static_cast<unsigned>(row) | (static_cast<unsigned>(lvlUp[row]) << 12) | (static_cast<unsigned>(min(n, 255)) << 24);
 		} else {
 			meta = BLK_NOROW | (static_cast<unsigned>(lvlUp[ord[nb - 1]]) << 12);
@@ -617,7 +651,7 @@ __device__ __forceinline__ bool blkIluRow(const BlkStage& st, T* lval, T* pinv, 
 
 // factorise (ILU0) and write the records of both sweeps.  err: bit 2 = zero / tiny pivot.
 template <typename T, int KIND, int KREG, bool OV>
-__global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
+__global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, int top, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
                                                         const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
                                                         const unsigned* __restrict__ metaLo, const unsigned* __restrict__ metaUp, T* __restrict__ lu,
                                                         unsigned* __restrict__ recLo, unsigned* __restrict__ recUp, const int* __restrict__ ovPtrLo,
@@ -633,6 +667,9 @@ __global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, c
 	T* lval = reinterpret_cast<T*>(carve(p, cap * sizeof(T)));
 	T* pinv = reinterpret_cast<T*>(carve(p, maxRows * sizeof(T)));
 	int* scanScratch = reinterpret_cast<int*>(carve(p, 8 * sizeof(int)));
+	st.nall = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
+	unsigned short* lvlLo = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
+	unsigned short* lvlUp = reinterpret_cast<unsigned short*>(carve(p, maxRows * sizeof(unsigned short)));
 
 	constexpr bool ILU = KIND == SMM_PRECOND_BLOCK_ILU0;
 	const int b = blockIdx.x;
@@ -642,7 +679,15 @@ __global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, c
 	const long long rec0 = static_cast<long long>(chunk0[b]) * WAVE;
 	const int t = threadIdx.x;
 
-	stageBlock<T>(st, lval, r0, nb, start, positions, vals, scanScratch);  // (the analysis kernel has already vetted the structure)
+	if (top > 0) {  // the levels the analysis kernel found, back by row: the level cut needs them to know what to stage
+		for (int q = t; q < nc * WAVE; q += BLK_TPB) {
+			const unsigned mlo = metaLo[rec0 + q], mup = metaUp[rec0 + q];
+			if ((mlo & 0xFFFu) != BLK_NOROW) lvlLo[mlo & 0xFFFu] = static_cast<unsigned short>((mlo >> 12) & 0xFFFu);
+			if ((mup & 0xFFFu) != BLK_NOROW) lvlUp[mup & 0xFFFu] = static_cast<unsigned short>((mup >> 12) & 0xFFFu);
+		}
+		__syncthreads();
+	}
+	stageBlock<T>(st, lval, r0, nb, start, positions, vals, scanScratch, 0, lvlLo, lvlUp, top);  // (the analysis kernel has already vetted the structure)
 	if (ILU) {
 		if (t < WAVE) {
 			bool allOk = true;
@@ -661,9 +706,13 @@ __global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, c
 		}
 		__syncthreads();
 		// the factor on A's pattern (smm_hip_precond_values): in-block entries only, the rest keeps A's value
+		// (entries the level cut dropped keep A's value too)
 		for (int i = t; i < nb; i += BLK_TPB) {
-			const int g = st.ibG[i], l = st.lptr[i], cnt = st.lptr[i + 1] - l;
-			for (int e = 0; e < cnt; ++e) lu[g + e] = lval[l + e];
+			const int g = st.ibG[i], l = st.lptr[i], all = st.nall[i];
+			int q = 0;
+			for (int e = 0; e < all; ++e) {
+				if (blkKeeps(i, positions[g + e] - r0, lvlLo, lvlUp, top)) lu[g + e] = lval[l + q++];
+			}
 		}
 	}
 	using LL = RecLayout<T, !ILU, KREG>;
@@ -744,7 +793,7 @@ static size_t analyzeLds(int maxRows, int cap) {
 template <typename T>
 static size_t packLds(int maxRows, int cap) {
 	return carveSize((maxRows + 1) * sizeof(int)) + carveSize(maxRows * sizeof(int)) + carveSize(maxRows * 2) + carveSize(static_cast<size_t>(cap) * 2) +
-	       carveSize(static_cast<size_t>(cap) * sizeof(T)) + carveSize(maxRows * sizeof(T)) + carveSize(8 * sizeof(int));
+	       carveSize(static_cast<size_t>(cap) * sizeof(T)) + carveSize(maxRows * sizeof(T)) + carveSize(8 * sizeof(int)) + 3 * carveSize(maxRows * 2);
 }
 
 template <typename T, int KIND, int KREG, bool OV>
@@ -756,7 +805,7 @@ static int packTyped(const smm_hip_csr* a, smm_hip_precond* M, const unsigned* m
 	const size_t lds = packLds<T>(B->blockRows, cap);
 	auto kernel = blkPackKernel<T, KIND, KREG, OV>;
 	SMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-	kernel<<<B->nBlocks, BLK_TPB, lds, s>>>(B->blockRows, cap, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
+	kernel<<<B->nBlocks, BLK_TPB, lds, s>>>(B->blockRows, cap, B->levelCap > 0 ? B->levelCap - 1 : 0, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
 	                                       metaLo, metaUp, static_cast<T*>(M->d_values), B->d_recLo, B->d_recUp, B->d_ovPtrLo, B->d_ovPtrUp, B->d_ovColLo,
 	                                       B->d_ovColUp, static_cast<T*>(B->d_ovValLo), static_cast<T*>(B->d_ovValUp), d_info);
 	SMM_HIP_TRY(hipGetLastError());
@@ -785,7 +834,7 @@ static int exclusiveScanInPlace(int* d, size_t n, hipStream_t s) {
 }
 
 template <typename T>
-int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_precond* M) {
+int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap, smm_hip_precond* M) {
 	hipStream_t s = libStream();
 	SMM_HIP_TRY(hipDeviceSynchronize());  // the matrix may still be being written on a caller's stream
 	const int n = a->rows;
@@ -800,6 +849,7 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_prec
 	auto* B = new smm_precond_block();
 	M->blk = B;  // (smm_hip_precond_destroy releases whatever the steps below have allocated so far)
 	B->blockRows = blockRows;
+	B->levelCap = levelCap < 2 ? 0 : std::min(levelCap, 4095);  // (a cap of 1 would drop every coupling: 0 / 1 mean no cut)
 	B->capNnz = BLK_CAP_NNZ;
 	if (n == 0) return SMM_HIP_OK;
 	// (seams every 16 blocks instead of every 64: the greedy cut of a super-chunk is a sequential chain of binary searches by one thread)
@@ -827,7 +877,7 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_prec
 		const size_t lds = analyzeLds(B->blockRows, B->capNnz);
 		auto kernel = blkAnalyzeKernel<T>;
 		SMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-		kernel<<<nBlocks, BLK_TPB, lds, s>>>(B->blockRows, B->capNnz, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
+		kernel<<<nBlocks, BLK_TPB, lds, s>>>(B->blockRows, B->capNnz, B->levelCap > 0 ? B->levelCap - 1 : 0, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
 		                                    kind == SMM_PRECOND_BLOCK_SGS ? 1 : 0, metaLo, metaUp, nEntLo, nEntUp, info);
 		SMM_HIP_TRY(hipGetLastError());
 	}
@@ -910,8 +960,8 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, smm_hip_prec
 	return SMM_HIP_OK;
 }
 
-template int blockCreateTyped<float>(const smm_hip_csr*, int, int, smm_hip_precond*);
-template int blockCreateTyped<double>(const smm_hip_csr*, int, int, smm_hip_precond*);
+template int blockCreateTyped<float>(const smm_hip_csr*, int, int, int, smm_hip_precond*);
+template int blockCreateTyped<double>(const smm_hip_csr*, int, int, int, smm_hip_precond*);
 
 template <typename T, int KIND, int KREG, bool OV>
 static int launchBlkApply(const smm_hip_precond* M, const BlkApplyArgs<T>& args, hipStream_t s) {
@@ -1003,6 +1053,13 @@ void blockLevels(const smm_precond_block* B, int* lo, int* up) {
 	if (up) *up = B ? B->levelsUp : 0;
 }
 
+// SMM_HIP_BLOCK_LEVEL_CAP: the default level cut of a block preconditioner (0 = none)
+int blockDefaultLevelCap() {
+	int cap = BLK_DEFAULT_LEVEL_CAP;
+	if (const char* env = getenv("SMM_HIP_BLOCK_LEVEL_CAP")) cap = atoi(env);
+	return cap < 2 ? 0 : std::min(cap, 4095);
+}
+
 int blockDefaultRows() {
 	int rows = BLK_DEFAULT_ROWS;
 	if (const char* env = getenv("SMM_HIP_BLOCK_ROWS")) rows = atoi(env);
@@ -1021,6 +1078,15 @@ int smm_hip_precond_block_count(const smm_hip_precond* M, int* nblocks) {
 		return SMM_HIP_ERR_INVALID;
 	}
 	*nblocks = M->blk->nBlocks;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_block_level_cap(const smm_hip_precond* M, int* level_cap) {
+	if (!M || !M->blk || !level_cap) {
+		setError("precond_block_level_cap: not a block preconditioner");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*level_cap = M->blk->levelCap;
 	return SMM_HIP_OK;
 }
 

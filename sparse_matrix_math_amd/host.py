@@ -120,14 +120,22 @@ def profile_read(reset=True):
 class Preconditioner:
     """`int apply(const T* rhs, T* x) const` (ref:1173-1235).  Created by CSRMatrix.getPreconditioner."""
 
-    def __init__(self, matrix, kind, block_rows=None):
+    def __init__(self, matrix, kind, block_rows=None, level_cap=None):
         self.matrix = matrix  # keeps the matrix alive (the reference holds a const CSRMatrix&)
         self.kind = SolverPreconditioner(kind)
         self._h = ctypes.c_void_p()
-        if block_rows is None:
+        if block_rows is None and level_cap is None:
             check(_lib.load().smm_hip_precond_create(matrix._h, int(kind), ctypes.byref(self._h)))
-        else:  # BLOCK_ILU0 / BLOCK_SGS with a chosen block size
+        elif level_cap is None:  # BLOCK_ILU0 / BLOCK_SGS with a chosen block size
             check(_lib.load().smm_hip_precond_create_block(matrix._h, int(kind), int(block_rows), ctypes.byref(self._h)))
+        else:  # ... and a chosen level cut (0 = none: M is the block-diagonal part of A exactly)
+            check(_lib.load().smm_hip_precond_create_block_capped(matrix._h, int(kind), int(block_rows or 0), int(level_cap), ctypes.byref(self._h)))
+
+    def level_cap(self):
+        """BLOCK_ kinds: the level cut this handle was built with (0 = none)"""
+        c = ctypes.c_int()
+        check(_lib.load().smm_hip_precond_block_level_cap(self._h, ctypes.byref(c)))
+        return c.value
 
     def block_bounds(self):
         """BLOCK_ kinds: the nblocks + 1 row numbers at which the rows were cut"""
@@ -267,8 +275,8 @@ class CSRMatrix:
         name = "smm_hip_spmv_fused_finish_dev" if finish else "smm_hip_spmv_fused_dev"
         check(_fn(name, self._suf)(self._h, int(op), _dptr(d_lhs), _dptr(d_x), _dptr(d_out), int(dot_mode), _dptr(d_w1), _dptr(d_partials), _dptr(stream)))
 
-    def getPreconditioner(self, kind, block_rows=None):  # ref:1643-1651; block_rows: BLOCK_ kinds only (None = default)
-        return Preconditioner(self, kind, block_rows)
+    def getPreconditioner(self, kind, block_rows=None, level_cap=None):  # ref:1643-1651; block_rows / level_cap: BLOCK_ kinds only (None = default)
+        return Preconditioner(self, kind, block_rows, level_cap)
 
     def close(self):
         if self._h:

@@ -58,6 +58,74 @@ def test_block_sgs_is_reference_sgs_of_block_diagonal(oracle, reference, dtype):
             np.testing.assert_array_equal(xs, xs_ref)
 
 
+def slow_level_cut(csr, bounds, cap):
+    """the rule of smm_oracle_block_level_cut written once more, with sets: which (row, column) pairs M keeps, the level of every row"""
+    start, pos, _ = csr
+    kept, lo, up = set(), {}, {}
+    for b0, b1 in zip(bounds[:-1], bounds[1:]):
+        for i in range(b0, b1):  # forward sweep, rows ascending
+            deps = [j for j in pos[start[i]:start[i + 1]] if b0 <= j < i and (cap <= 0 or lo[j] < cap - 1)]
+            kept.update((i, j) for j in deps)
+            lo[i] = 1 + max(lo[j] for j in deps) if deps else 0
+        for i in range(b1 - 1, b0 - 1, -1):  # backward sweep, rows descending
+            deps = [j for j in pos[start[i]:start[i + 1]] if i < j < b1 and (cap <= 0 or up[j] < cap - 1)]
+            kept.update((i, j) for j in deps)
+            up[i] = 1 + max(up[j] for j in deps) if deps else 0
+            kept.add((i, i))
+    return kept, lo, up
+
+
+def test_level_cut_rule(oracle):
+    """smm_oracle_block_level_cut against the restatement above; no cap = the block-diagonal part; every kept entry points to a row
+    above the deepest level, every dropped in-block entry to a row ON it; and the levels of the cut matrix really stop at the cap"""
+    for csr, bounds in (
+        (gen.convdiff3d(9, 0.3, dtype=np.float64), np.array([0, 3, 4, 400, 729], dtype=np.int32)),
+        (gen.poisson2d(20, dtype=np.float64), np.array([0, 400], dtype=np.int32)),
+        (gen.banded_random_spd(600, k=6, seed=4, max_offset=30, dtype=np.float64), np.append(np.arange(0, 600, 128), 600).astype(np.int32)),
+        (gen.random_rows(300, 300, 2, 12, seed=9, dtype=np.float64, diag_dominant=True), np.array([0, 150, 300], dtype=np.int32)),
+    ):
+        start, pos, _ = csr
+        rows = len(start) - 1
+        rowof = np.repeat(np.arange(rows), np.diff(start))
+        keep0, deepest0 = oracle.block_level_cut(csr, bounds, 0)
+        np.testing.assert_array_equal(keep0, block_diagonal_part(csr, bounds)[1])
+        for cap in (2, 3, 5, 9, deepest0, deepest0 + 7):
+            keep, deepest = oracle.block_level_cut(csr, bounds, cap)
+            want, lo, up = slow_level_cut(csr, bounds, cap)
+            assert set(zip(rowof[keep].tolist(), pos[keep].tolist())) == want
+            assert deepest == 1 + max(max(lo.values()), max(up.values())) <= cap
+            assert not (keep & ~keep0).any()
+            dropped = keep0 & ~keep
+            assert all((lo if j < i else up)[j] == cap - 1 for i, j in zip(rowof[dropped].tolist(), pos[dropped].tolist()))
+            if cap >= deepest0:
+                np.testing.assert_array_equal(keep, keep0)  # a cap the blocks never reach drops nothing
+            # the cut matrix has the levels the rule promised: cutting it again with no cap changes nothing and reports the same depth
+            mcsr = oracle.level_cut_matrix(csr, bounds, cap)[0]
+            again, deepest2 = oracle.block_level_cut(mcsr, bounds, 0)
+            assert again.all() and deepest2 == deepest
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_level_cut_block_sgs_is_reference_sgs_of_the_cut_matrix(oracle, reference, dtype):
+    """live, in the build container: block SGS with a level cut = the real reference's SGS of the matrix the cut leaves, apply and
+    inside the reference's BiCGStab template"""
+    csr = gen.convdiff3d(9, 0.3, dtype=dtype)
+    rows = len(csr[0]) - 1
+    rhs = rhs_of(rows, dtype)
+    b = gen.row_sums(csr[0], csr[2])
+    bounds = np.append(np.arange(0, rows, 200), rows).astype(np.int32)
+    for cap in (2, 4, 16):
+        mcsr = oracle.level_cut_matrix(csr, bounds, cap)[0]
+        with reference.csr(csr) as a, reference.csr(mcsr) as m:
+            err, x_ref = reference.sgs_apply(m, rhs)
+            assert err == 0
+            np.testing.assert_array_equal(oracle.block_sgs_apply(mcsr, bounds, rhs)[1], x_ref)
+            st_ref, xs_ref = reference.bicgstab_sgs_of(a, m, b, np.zeros(rows, dtype=dtype), 7, dtype(1e-30))
+            st, xs, it, _ = oracle.bicgstab_block_of(csr, mcsr, b, np.zeros(rows, dtype=dtype), 7, dtype(1e-30), PRECOND_BLOCK_SGS, bounds)
+            assert st == st_ref
+            np.testing.assert_array_equal(xs, xs_ref)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_block_forms_are_the_global_forms_on_the_block_diagonal(oracle, dtype):
     for mname, csr in matrices(dtype).items():

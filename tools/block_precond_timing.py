@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--block-rows", default="0")
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--skip-global", action="store_true")
+    ap.add_argument("--level-caps", default="-1", help="level cuts of the block kinds to time: -1 = the default, 0 = none, 2 .. 4095")
     ap.add_argument("--poisson2d", type=int, default=0, help="also: 2-D Poisson N x N")
     args = ap.parse_args()
     smm.init(0)
@@ -50,13 +51,16 @@ def main():
         kinds = [("none", None, None)]
         if not args.skip_global:
             kinds += [("jacobi", P.JACOBI, None), ("ilu0", P.ILU0, None), ("sgs", P.SYMMETRIC_GAUS_SEIDEL, None)]
+        kinds = [k + (None,) for k in kinds]
         for br in [int(v) for v in args.block_rows.split(",")]:
-            kinds += [(f"block_ilu0[{br or 'default'}]", P.BLOCK_ILU0, br), (f"block_sgs[{br or 'default'}]", P.BLOCK_SGS, br)]
-        for label, kind, br in kinds:
+            for cap in [int(v) for v in args.level_caps.split(",")]:
+                tag = f"{br or 'default'}, cap {'default' if cap < 0 else cap}"
+                kinds += [(f"block_ilu0[{tag}]", P.BLOCK_ILU0, br, cap), (f"block_sgs[{tag}]", P.BLOCK_SGS, br, cap)]
+        for label, kind, br, cap in kinds:
             for attempt in range(2):  # the second create shows the steady state (allocations cached)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                M = A.getPreconditioner(kind, br if br else None) if kind is not None else None
+                M = A.getPreconditioner(kind, br if br else None, cap) if kind is not None else None
                 torch.cuda.synchronize()
                 tc = time.perf_counter() - t0
                 if attempt == 0 and M is not None:
