@@ -326,14 +326,16 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         P = smm.SolverPreconditioner
         bytes_apply = 2 * (nnz * 12 + (n + 1) * 4) + 5 * n * 8  # two triangular sweeps over A's pattern ~ 2 x SpMV bytes
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for name, kind in (("none", None), ("jacobi", P.JACOBI), ("ilu0", P.ILU0), ("block_ilu0", P.BLOCK_ILU0), ("block_sgs", P.BLOCK_SGS)):
+        # block_*: the default level cut (16); *_uncut: the same blocks without it (M = the block-diagonal part of A exactly)
+        for name, kind, cap in (("none", None, None), ("jacobi", P.JACOBI, None), ("ilu0", P.ILU0, None), ("block_ilu0", P.BLOCK_ILU0, None),
+                                ("block_sgs", P.BLOCK_SGS, None), ("block_ilu0_uncut", P.BLOCK_ILU0, 0)):
             M, tc = None, 0.0
             for _ in range(2 if kind is not None else 0):  # the second create is the steady state (device allocations cached)
                 if M is not None:
                     M.close()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                M = A.getPreconditioner(kind)
+                M = A.getPreconditioner(kind, None, cap)
                 torch.cuda.synchronize()
                 tc = time.perf_counter() - t0
             for _ in range(2):
@@ -359,6 +361,7 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
                     leg[name].update(apply_us=ms_apply * 1e3, apply_gbps=bytes_apply / ms_apply / 1e6, levels=list(M.levels()))
                     if kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
                         leg[name]["blocks"] = len(M.block_bounds()) - 1
+                        leg[name]["level_cap"] = M.level_cap()
                 M.close()
         out["bicgstab_convdiff108_f64"] = leg
         A.close()
