@@ -14,7 +14,7 @@ timeout -k 10 500 python bench.py > $OUT/bench_stdout.json 2> $OUT/bench_stderr.
 cp $(ls $OUT/rocprof/*/*_kernel_stats.csv | head -1) $OUT/bench_kernel_stats.csv
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_block -- python3 $ROOT/tools/block_precond_timing.py --skip-global --block-rows 0 > $OUT/block_under_rocprof.txt 2> /dev/null ) || { echo "rocprofv3 block run failed"; exit 1; }
 cp $(ls $OUT/rocprof_block/*/*_kernel_stats.csv | head -1) $OUT/block_kernel_stats.csv
-timeout -k 10 300 python tools/block_precond_timing.py --block-rows 0,512,768 --poisson2d 1000 2>&1 | grep -v amdgpu.ids > $OUT/block_precond_timing.txt || { echo "block timing failed"; exit 1; }
+timeout -k 10 300 python tools/block_precond_timing.py --block-rows 0,512,768 --level-caps=-1,0 --poisson2d 1000 2>&1 | grep -v amdgpu.ids > $OUT/block_precond_timing.txt || { echo "block timing failed"; exit 1; }
 timeout -k 10 400 python tools/configs_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/configs_timing.txt || { echo "configs_timing failed"; exit 1; }
 timeout -k 10 100 python tools/cg_c2.py 2>&1 | grep -v amdgpu.ids > $OUT/cg_config2.txt || { echo "cg_c2 failed"; exit 1; }
 timeout -k 10 300 python tools/spmv_sweep.py --configs 2:1,2:2,2:4,3:1,3:2,3:4 2>&1 | grep -E "matrix|family" > $OUT/spmv_sweep_c3.txt
