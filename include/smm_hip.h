@@ -82,14 +82,22 @@ extern "C" {
 #define SMM_SPMV_AUTO 0
 #define SMM_SPMV_VECTOR 1 /* L lanes of a wavefront per row, wave shuffle reduction */
 #define SMM_SPMV_STREAM 2 /* row blocks staged through LDS with 16-byte coalesced loads, row-sequential sums */
-/* For matrices whose rows all take their columns from one set of <= 64 offsets relative to the row (stencil and banded matrices).
- * positions[] is then replaced by one 64-bit mask per row, verified against EVERY entry on the device before the family is used, and an
- * SpMV streams only values[] (half the bytes for fp32).  Same result bit for bit as the other families at the same lanes_per_row.
- * Selected explicitly (smm_hip_csr_set_kernel returns SMM_HIP_ERR_INVALID when the matrix has no such pattern) or by AUTO: the first
- * SpMV of a matrix with >= 2^25 stored entries and rows of <= 64 entries runs the analysis once, on the caller's stream, and switches
- * the matrix over when it passes (smm_hip_csr_get_kernel then reports SMM_SPMV_PATTERN); a matrix that does not fit stays with STREAM.
- * Environment: SMM_HIP_AUTO_PATTERN=0 keeps AUTO on STREAM, SMM_HIP_AUTO_PATTERN_MIN_NNZ moves the threshold. */
+/* For matrices whose entries take their columns from a limited set of offsets relative to the row (stencil, banded and band-numbered
+ * mesh matrices).  positions[] (4 bytes per entry) is replaced, in one of two encodings (smm_hip_csr_pattern_info tells which):
+ *   MASKS  <= 64 distinct offsets and rows of <= 64 entries: one 64-bit mask per ROW, verified against EVERY entry on the device before
+ *          the family is used; an SpMV streams only values[] (half the bytes for fp32);
+ *   CODES  <= 65536 distinct offsets: one 16-bit index into the matrix's sorted offset dictionary per ENTRY (6 instead of 8 bytes per
+ *          fp32 entry), built on the device from all entries.
+ * Same result bit for bit as the other families at the same lanes_per_row.  Selected explicitly (smm_hip_csr_set_kernel returns
+ * SMM_HIP_ERR_INVALID when the matrix fits neither encoding) or by AUTO: the first SpMV of a matrix with >= 2^25 stored entries and
+ * <= 64 entries per row on average runs the analysis once, on the caller's stream, and switches the matrix over when it passes
+ * (smm_hip_csr_get_kernel then reports SMM_SPMV_PATTERN); a matrix that does not fit stays with STREAM.
+ * Environment: SMM_HIP_AUTO_PATTERN=0 keeps AUTO on STREAM, SMM_HIP_AUTO_PATTERN_MIN_NNZ moves the threshold, SMM_HIP_AUTO_DICT=0 keeps
+ * AUTO from using the CODES encoding. */
 #define SMM_SPMV_PATTERN 3
+#define SMM_PATTERN_NONE 0  /* smm_hip_csr_pattern_info: not analysed, or the matrix fits neither encoding */
+#define SMM_PATTERN_MASKS 1
+#define SMM_PATTERN_CODES 2
 
 typedef struct smm_hip_csr smm_hip_csr;         /* device-resident CSRMatrix<T> (ref:1243-1259) */
 typedef struct smm_hip_precond smm_hip_precond; /* device-resident preconditioner */
@@ -132,6 +140,9 @@ int smm_hip_csr_get_kernel(const smm_hip_csr* m, int* family, int* lanes_per_row
  * tiles, the nonzeros / rows a tile was cut for, and whether the launches go to spmvTileKernel (1: the pieces of a row in different
  * waves -- 2 or 4 lanes per row, the benchmark matrix) or to the pipelined spmvStreamKernel (0).  Diagnostics for tests and benches. */
 int smm_hip_csr_tile_info(const smm_hip_csr* m, int* tiles, int* tile_nnz_cap, int* tile_max_rows, int* tile_kernel);
+/* The PATTERN family's encoding of this matrix (SMM_PATTERN_*) and the number of distinct offsets it found; NONE / 0 before the
+ * analysis has run (the first SpMV of a large matrix, or smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, ...)). */
+int smm_hip_csr_pattern_info(const smm_hip_csr* m, int* encoding, int* offsets);
 /* Times the candidate SpMV configurations on this matrix and keeps the fastest. */
 int smm_hip_csr_autotune(smm_hip_csr* m);
 

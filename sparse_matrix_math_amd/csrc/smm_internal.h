@@ -118,7 +118,9 @@ struct smm_hip_csr {
 	int max_row_len = -1;        // longest row, found on first demand (smm_resident.hip)
 	std::mutex tileMutex;  // the tile table is built lazily by the first SpMV; concurrent solves on one matrix are allowed
 	// PATTERN family (opt-in, smm_spmv_pattern.hip): shared column offsets + one 64-bit mask per row, its own tile table
-	int pat_state = 0;  // 0 not analysed, 1 usable, -1 the matrix has no such pattern
+	int pat_state = 0;  // 0 not analysed, 1 usable, -1 the matrix has no such pattern, -2 no masks and the dictionary not tried (ensurePattern)
+	int pat_encoding = 0;  // 0: one 64-bit mask per row (<= 64 offsets); 1: one 16-bit code per entry (<= 65536 offsets)
+	unsigned short* d_pat_codes = nullptr;
 	int pat_k = 0;
 	int* d_pat_off = nullptr;
 	unsigned long long* d_pat_masks = nullptr;

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "smm_device.h"
 #include "smm_internal.h"
 
@@ -606,26 +608,311 @@ __global__ __launch_bounds__(TPB) void patSampleOffsets(int rows, int samples, c
 	if (threadIdx.x == 0 && sOver) atomicOr(state + MAXOFF, 1);
 }
 
-// streamKnown: `s` is the stream the caller orders its work on (the first SpMV of a matrix): everything is enqueued there and only
-// 264 bytes + one flag come back; otherwise (smm_hip_csr_set_kernel: no stream) the device is drained once and the library's stream used.
-// quiet: the automatic attempt -- a matrix without a pattern is not an error then (no error text, SMM_HIP_ERR_INVALID still returned).
-int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet) {
-	SMM_TRY(ensureCsrReady(m, s, streamKnown));
-	std::lock_guard<std::mutex> lock(m->tileMutex);
-	if (m->pat_state != 0) {
-		if (m->pat_state < 0 && !quiet) setError("pattern SpMV: the rows of this matrix do not share a set of <= %d column offsets", MAXOFF);
-		return m->pat_state > 0 ? SMM_HIP_OK : SMM_HIP_ERR_INVALID;
+// ---------------------------------------------------------------------------------------------------------------------------------
+// DICTIONARY encoding of the same family (r03): matrices whose entries use MORE than 64 distinct offsets
+// column - row, or hold rows of more than 64 entries, but no more than 65 536 distinct offsets in all -- banded matrices with hundreds
+// of diagonals, meshes numbered along a band.  positions[] (4 bytes per entry) is replaced by a 16-bit CODE per entry, the index of
+// the entry's offset in the matrix's sorted dictionary: 6 instead of 8 bytes per fp32 entry.  (For <= 64 offsets the masks above cost
+// 8 bytes per ROW and win.)  Built on the device from ALL entries -- there is nothing to sample and nothing to verify afterwards: an
+// entry's code is found by searching the dictionary for its own offset.  The kernel is spmvPatternKernel with a staged slice of codes
+// in place of the row masks: same lanes, same products, same order, same bits as the STREAM family at equal lanes.
+constexpr int DICT_MAX = 65536;
+constexpr int DICT_HCAP = 1 << 18;    // open-addressing table of the offsets seen (<= 25 % full)
+constexpr int DICT_LDS_MAX = 4096;    // dictionaries up to this size are copied to LDS by every workgroup, larger ones stay in L2
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct DictCfg {
+	static constexpr int NCMAX = (PatCfg<T>::NVMAX * PatCfg<T>::PIECE + 8 + 8 * TPB - 1) / (8 * TPB);  // 16-byte loads of 8 codes per lane
+};
+
+// Walks the entries of 64 consecutive rows with one wavefront, coalesced (the scheme of patBuildMasks): f(entry index, row, column).
+template <typename F>
+__device__ __forceinline__ void forEntriesOf64Rows(int rows, long long group, const int* __restrict__ start, const int* __restrict__ positions,
+                                                   int* sRow, F f) {
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int r0 = static_cast<int>(group * WAVE);
+	const int nr = min(WAVE, rows - r0);
+	sRow[lane] = start[r0 + min(lane, nr)];
+	if (lane == 0) sRow[WAVE] = start[r0 + nr];
+	const int eBegin = __builtin_amdgcn_readfirstlane(sRow[0]);
+	const int eEnd = start[r0 + nr];
+	for (int e0 = eBegin; e0 < eEnd; e0 += WAVE) {
+		const int e = e0 + lane;
+		if (e < eEnd) {
+			int lo = 0, hi = nr;  // the last row i in [0, nr) with sRow[i] <= e
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (sRow[mid] <= e) lo = mid; else hi = mid;
+			}
+			f(e, r0 + lo, positions[e]);
+		}
 	}
-	m->pat_state = -1;
-	auto refuse = [quiet](const char* why) {
-		if (!quiet) setError("pattern SpMV: %s", why);
-		return static_cast<int>(SMM_HIP_ERR_INVALID);
+}
+
+__global__ void fillIntKernel(int* p, int n, int v) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ unsigned dictHash(int off) { return (static_cast<unsigned>(off) * 0x9E3779B1u) >> (32 - 18); }
+
+// state: [0] distinct offsets so far, [1] raised when there are more than DICT_MAX (every wavefront then stops at its next group)
+__global__ __launch_bounds__(TPB) void dictCollectKernel(int rows, const int* __restrict__ start, const int* __restrict__ positions, int* table, int* state) {
+	__shared__ int sRow[TPB / WAVE][WAVE + 1];
+	__shared__ int sSeen[1024];  // offsets this workgroup has already handed to the global table (direct-mapped; a lost race only repeats a lookup)
+	for (int i = threadIdx.x; i < 1024; i += TPB) sSeen[i] = PAT_EMPTY;
+	__syncthreads();
+	const int w = threadIdx.x >> 6;
+	const long long groups = (static_cast<long long>(rows) + WAVE - 1) / WAVE;
+	for (long long g = static_cast<long long>(blockIdx.x) * (TPB / WAVE) + w; g < groups; g += static_cast<long long>(gridDim.x) * (TPB / WAVE)) {
+		if (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+		forEntriesOf64Rows(rows, g, start, positions, sRow[w], [&](int, int row, int col) {
+			const int off = col - row;
+			const unsigned h = dictHash(off);
+			if (sSeen[h & 1023u] == off) return;
+			sSeen[h & 1023u] = off;
+			for (unsigned probe = 0; probe < static_cast<unsigned>(DICT_HCAP); ++probe) {
+				int* slot = table + ((h + probe) & (DICT_HCAP - 1));
+				int cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (cur == off) return;
+				if (cur == PAT_EMPTY) {
+					cur = atomicCAS(slot, PAT_EMPTY, off);
+					if (cur == PAT_EMPTY) {
+						if (atomicAdd(state, 1) + 1 > DICT_MAX) atomicOr(state + 1, 1);
+						return;
+					}
+					if (cur == off) return;
+				}
+				if (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (the table fills up only past the limit)
+			}
+		});
+	}
+}
+
+// codes[e] = index of (column - row) of entry e in the sorted dictionary; an offset that is not there (impossible: the dictionary was
+// collected from these very entries) raises the flag
+__global__ __launch_bounds__(TPB) void dictEncodeKernel(int rows, int k, const int* __restrict__ dict, const int* __restrict__ start,
+                                                        const int* __restrict__ positions, unsigned short* __restrict__ codes, int* mismatch) {
+	__shared__ int sRow[TPB / WAVE][WAVE + 1];
+	const int w = threadIdx.x >> 6;
+	const long long groups = (static_cast<long long>(rows) + WAVE - 1) / WAVE;
+	bool bad = false;
+	for (long long g = static_cast<long long>(blockIdx.x) * (TPB / WAVE) + w; g < groups; g += static_cast<long long>(gridDim.x) * (TPB / WAVE)) {
+		forEntriesOf64Rows(rows, g, start, positions, sRow[w], [&](int e, int row, int col) {
+			const int off = col - row;
+			int a = 0, b = k;
+			while (a < b) {
+				const int mid = (a + b) >> 1;
+				if (dict[mid] < off) a = mid + 1; else b = mid;
+			}
+			if (a >= k || dict[a] != off) {
+				bad = true;
+				a = 0;
+			}
+			codes[e] = static_cast<unsigned short>(a);
+		});
+	}
+	if (bad) atomicOr(mismatch, 1);
+}
+
+template <typename T, int L, bool DLDS>
+__global__ __launch_bounds__(TPB) void spmvDictKernel(int nTiles, int cap, int cols, int nOff, const int* __restrict__ dict,
+                                                      const int2* __restrict__ rowBlocks, const int* __restrict__ start,
+                                                      const unsigned short* __restrict__ codes, const int* __restrict__ positions,
+                                                      const T* __restrict__ values, int opFlags, const T* lhs, const T* __restrict__ divisor,
+                                                      const T* __restrict__ x, T* out, int dotMode, const T* __restrict__ w1,
+                                                      T* __restrict__ partials, const int* __restrict__ doneFlag) {
+	using Cfg = PatCfg<T>;
+	constexpr int GATHER = 8;
+	constexpr int NCMAX = DictCfg<T>::NCMAX;
+	const int op = opFlags & 0xFF;
+	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;
+	constexpr int LW = L > WAVE ? WAVE : L;
+	constexpr int RW = WAVE / LW;
+	constexpr int RT = RW * (TPB / WAVE);
+	// LDS: sVal[cap + PAD] | sStart[RT + 4] | sCode[cap + PAD + 8, 16-bit] | sDict[nOff, when it fits] | red[4]
+	T* sVal = reinterpret_cast<T*>(smmPatLds);
+	int* sStart = reinterpret_cast<int*>(sVal + cap + Cfg::PAD);
+	unsigned short* sCode = reinterpret_cast<unsigned short*>(sStart + RT + 4);
+	const int codeSlots = (cap + Cfg::PAD + 8 + 7) & ~7;
+	int* sDict = reinterpret_cast<int*>(sCode + codeSlots);
+	T* red = reinterpret_cast<T*>(sDict + (DLDS ? ((nOff + 1) & ~1) : 0));
+	if (doneFlag && *doneFlag) return;
+
+	const int t = threadIdx.x;
+	const int lane = t & (WAVE - 1);
+	const int rowInWave = lane % RW;
+	const int piece = lane / RW;
+	const int rl = (t >> 6) * RW + rowInWave;
+	const int nv = cap / Cfg::PIECE;
+	T acc0 = T(0), acc1 = T(0);
+	for (int i = t; i < cap + Cfg::PAD; i += TPB) sVal[i] = T(0);
+	for (int i = t; i < codeSlots; i += TPB) sCode[i] = 0;  // whatever a lane reads past its piece is a valid code (the products are discarded)
+	if (DLDS) {
+		for (int i = t; i < nOff; i += TPB) sDict[i] = dict[i];
+	}
+
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int xcdGroup = blockIdx.x % nGroups;
+	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;
+	const int perGroup = (nTiles + nGroups - 1) / nGroups;
+	const int tileEnd = min(nTiles, (xcdGroup + 1) * perGroup);
+	const int stageLimit = (rowBlocks[nTiles].y & ~3) - cap;
+	int tile = xcdGroup * perGroup + blockIdx.x / nGroups;
+
+	PatStaged<T> regs;
+	pu32x4 rc[NCMAX];
+	int ps = 0;
+	// codes of the entries [c0, n1), c0 = the tile's first entry rounded down to 8: 16-byte loads; the array is padded, so a load that starts
+	// inside it may run past the last entry
+	auto loadCodes = [&](int c0, int n1) {
+#pragma unroll
+		for (int v = 0; v < NCMAX; ++v) {
+			const int i = c0 + 8 * (t + v * TPB);
+			if (i < n1) rc[v] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4*>(codes + i));
+		}
 	};
-	if (m->rows == 0 || m->nnz == 0) return refuse("empty matrix");
-	if (!streamKnown) {
-		SMM_HIP_TRY(hipDeviceSynchronize());
-		s = libStream();
+	auto storeCodes = [&](int c0, int n1) {
+#pragma unroll
+		for (int v = 0; v < NCMAX; ++v) {
+			const int li = 8 * (t + v * TPB);
+			if (c0 + li < n1) *reinterpret_cast<pu32x4*>(sCode + li) = rc[v];
+		}
+	};
+	int2 m0 = make_int2(0, 0), m1 = make_int2(0, 0), nm0 = make_int2(0, 0), nm1 = make_int2(0, 0);
+	if (tile < tileEnd) {
+		m0 = rowBlocks[tile];
+		m1 = rowBlocks[tile + 1];
+		if (tile + groupSlots < tileEnd) {
+			nm0 = rowBlocks[tile + groupSlots];
+			nm1 = rowBlocks[tile + groupSlots + 1];
+		}
+		if (m1.y - m0.y <= cap - 3 && (m0.y & ~3) <= stageLimit) {
+			patStageLoad<T>(regs, t, nv, m0.y & ~3, m1.y, values);
+			loadCodes(m0.y & ~7, m1.y);
+			if (t < m1.x - m0.x) ps = start[m0.x + t];
+		}
 	}
+	__syncthreads();
+	while (tile < tileEnd) {
+		const int r0 = m0.x, n0 = m0.y, r1 = m1.x, n1 = m1.y;
+		const int nrows = r1 - r0;
+		const int a0 = n0 & ~3;
+		const int delta = a0 - (n0 & ~7);  // sCode[i] is entry (n0 & ~7) + i, sVal[i] is entry a0 + i
+		const bool direct = n1 - n0 > cap - 3 || a0 > stageLimit;
+		if (!direct) {
+			patStageStore<T>(regs, t, nv, a0, n1, sVal);
+			storeCodes(n0 & ~7, n1);
+			if (t < nrows) sStart[t] = ps - a0;
+			if (t == 0) sStart[nrows] = n1 - a0;
+		}
+		ldsBarrier();
+		const int ntile = tile + groupSlots;
+		const int2 m0n = nm0, m1n = nm1;
+		if (ntile < tileEnd) {
+			if (m1n.y - m0n.y <= cap - 3 && (m0n.y & ~3) <= stageLimit) {
+				patStageLoad<T>(regs, t, nv, m0n.y & ~3, m1n.y, values);
+				loadCodes(m0n.y & ~7, m1n.y);
+				if (t < m1n.x - m0n.x) ps = start[m0n.x + t];
+			}
+			if (ntile + groupSlots < tileEnd) {
+				nm0 = rowBlocks[ntile + groupSlots];
+				nm1 = rowBlocks[ntile + groupSlots + 1];
+			}
+		}
+		if (direct) {
+			// over-long rows and the last tiles of the matrix: one lane per row, left to right, straight from HBM (with positions[])
+			for (int rr = t; rr < nrows; rr += TPB) {
+				const int row = r0 + rr;
+				const int e = start[row + 1];
+				T dot = T(0);
+				for (int k = start[row]; k < e; ++k) dot = smmFma(values[k], x[positions[k]], dot);
+				const T o = patApplyOp(op, lhs, divisor, row, dot);
+				out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		} else {
+			T dot = T(0);
+			const int row = r0 + rl;
+			if (rl < nrows) {
+				const int b = sStart[rl];
+				const int e = sStart[rl + 1];
+				int kb = b, ke = e;
+				if (LW > 1) {
+					const int piecelen = (e - b + LW - 1) / LW;
+					kb = b + piece * piecelen;
+					ke = min(e, kb + piecelen);
+				}
+				for (int k = kb; k < ke; k += GATHER) {
+					const int nvalid = ke - k;
+					unsigned off[GATHER];
+					T xv[GATHER], vv[GATHER];
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						const int code = sCode[k + u + delta];
+						const int rel = DLDS ? sDict[code] : dict[code];
+						// entries past the end of the piece get a clamped, valid column; their products are discarded
+						const int col = min(max(row + rel, 0), cols - 1);
+						off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
+						vv[u] = sVal[k + u];
+					}
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) xv[u] = patGather<T>(x, off[u]);
+#pragma unroll
+					for (int u = 0; u < GATHER; ++u) {
+						const T next = smmFma(vv[u], xv[u], dot);
+						dot = u < nvalid ? next : dot;
+					}
+				}
+			}
+			if (LW > 1) {
+				T total = dot;
+#pragma unroll
+				for (int q = 1; q < LW; ++q) total += __shfl(dot, rowInWave + q * RW, WAVE);
+				dot = total;
+			}
+			if (piece == 0 && rl < nrows) {
+				const T o = patApplyOp(op, lhs, divisor, row, dot);
+				if (ntOut) __builtin_nontemporal_store(o, out + row);
+				else out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		}
+		ldsBarrier();
+		tile = ntile;
+		m0 = m0n;
+		m1 = m1n;
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
+	}
+}
+
+// SMM_HIP_AUTO_DICT=0: the automatic attempt (first SpMV of a large matrix) stops at the masks; the dictionary encoding then needs an
+// explicit smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, lanes)
+static bool autoDictAllowed() {
+	static const bool on = [] {
+		const char* env = getenv("SMM_HIP_AUTO_DICT");
+		return env ? atoi(env) != 0 : true;
+	}();
+	return on;
+}
+
+// the mask encoding: SMM_HIP_OK, SMM_HIP_ERR_INVALID (no such pattern: *why says which test failed) or a HIP failure
+static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	DevBuf<int> d_state, d_off, d_flag;  // released on every early return
 	DevBuf<unsigned long long> d_masks;
 	SMM_TRY(d_state.alloc(MAXOFF + 2));
@@ -638,13 +925,17 @@ int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet) {
 	std::vector<int> got(MAXOFF + 2, 0);
 	SMM_HIP_TRY(hipMemcpyAsync(got.data(), d_state, got.size() * sizeof(int), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	if (got[MAXOFF + 1] > MAXOFF) return refuse("a row holds more than 64 entries");
-	if (got[MAXOFF]) return refuse("the rows do not share a set of <= 64 column offsets");
+	auto no = [why](const char* text) {
+		*why = text;
+		return static_cast<int>(SMM_HIP_ERR_INVALID);
+	};
+	if (got[MAXOFF + 1] > MAXOFF) return no("a row holds more than 64 entries");
+	if (got[MAXOFF]) return no("the rows do not share a set of <= 64 column offsets");
 	std::vector<int> offs;
 	for (int i = 0; i < MAXOFF; ++i) {
 		if (got[i] != PAT_EMPTY) offs.push_back(got[i]);
 	}
-	if (offs.empty()) return refuse("no entries in the sampled rows");
+	if (offs.empty()) return no("no entries in the sampled rows");
 	std::sort(offs.begin(), offs.end());
 	SMM_TRY(d_off.alloc(MAXOFF));
 	SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
@@ -658,10 +949,95 @@ int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet) {
 	int mismatch = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(&mismatch, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	if (mismatch) return refuse("some entry's column offset is outside the offset set of the sampled rows");
+	if (mismatch) return no("some entry's column offset is outside the offset set of the sampled rows");
 	m->pat_k = static_cast<int>(offs.size());
+	m->pat_encoding = 0;
 	m->d_pat_off = d_off.detach();
 	m->d_pat_masks = d_masks.detach();
+	return SMM_HIP_OK;
+}
+
+// the dictionary encoding: every entry's offset into a device hash set, the set sorted (rocPRIM radix sort), every entry encoded
+static int tryDict(smm_hip_csr* m, hipStream_t s, const char** why) {
+	auto no = [why](const char* text) {
+		*why = text;
+		return static_cast<int>(SMM_HIP_ERR_INVALID);
+	};
+	DevBuf<int> d_table, d_sorted, d_state, d_dict;
+	DevBuf<unsigned short> d_codes;
+	DevBuf<char> temp;
+	SMM_TRY(d_table.alloc(DICT_HCAP));
+	SMM_TRY(d_sorted.alloc(DICT_HCAP));
+	SMM_TRY(d_state.alloc(4));
+	SMM_HIP_TRY(hipMemsetAsync(d_state, 0, 4 * sizeof(int), s));
+	fillIntKernel<<<DICT_HCAP / TPB, TPB, 0, s>>>(d_table, DICT_HCAP, PAT_EMPTY);
+	const long long groups = (static_cast<long long>(m->rows) + WAVE - 1) / WAVE;
+	const int grid = static_cast<int>(std::max<long long>(1, std::min<long long>((groups + TPB / WAVE - 1) / (TPB / WAVE), numCUs() * 8LL)));
+	dictCollectKernel<<<grid, TPB, 0, s>>>(m->rows, m->d_start, m->d_positions, d_table, d_state);
+	int st[4] = {0, 0, 0, 0};
+	SMM_HIP_TRY(hipMemcpyAsync(st, d_state, sizeof(st), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	if (st[1] || st[0] > DICT_MAX) return no("the entries use more than 65536 distinct column offsets");
+	const int k = st[0];
+	if (k <= 0) return no("no entries");
+	// PAT_EMPTY is INT_MIN: after an ascending sort of the whole table the dictionary is its last k entries
+	size_t tempBytes = 0;
+	SMM_HIP_TRY(rocprim::radix_sort_keys(nullptr, tempBytes, d_table.p, d_sorted.p, static_cast<size_t>(DICT_HCAP), 0, 32, s));
+	SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
+	SMM_HIP_TRY(rocprim::radix_sort_keys(temp.p, tempBytes, d_table.p, d_sorted.p, static_cast<size_t>(DICT_HCAP), 0, 32, s));
+	SMM_TRY(d_dict.alloc(static_cast<size_t>(k)));
+	SMM_HIP_TRY(hipMemcpyAsync(d_dict, d_sorted.p + (DICT_HCAP - k), static_cast<size_t>(k) * sizeof(int), hipMemcpyDeviceToDevice, s));
+	// 16 codes of padding: the kernel's 16-byte loads may start at the last entry
+	const size_t nCodes = static_cast<size_t>(m->nnz) + 16;
+	SMM_TRY(d_codes.alloc(nCodes));
+	SMM_HIP_TRY(hipMemsetAsync(d_codes.p + m->nnz, 0, 16 * sizeof(unsigned short), s));
+	dictEncodeKernel<<<grid, TPB, 0, s>>>(m->rows, k, d_dict, m->d_start, m->d_positions, d_codes, d_state.p + 2);
+	SMM_HIP_TRY(hipMemcpyAsync(st, d_state, sizeof(st), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // also: the scratch buffers go back to the allocator when this scope ends
+	if (st[2]) return no("an entry's offset is missing from the dictionary built from the entries");
+	m->pat_k = k;
+	m->pat_encoding = 1;
+	m->d_pat_off = d_dict.detach();
+	m->d_pat_codes = d_codes.detach();
+	return SMM_HIP_OK;
+}
+
+// streamKnown: `s` is the stream the caller orders its work on (the first SpMV of a matrix): everything is enqueued there and only
+// a few hundred bytes come back; otherwise (smm_hip_csr_set_kernel: no stream) the device is drained once and the library's stream used.
+// quiet: the automatic attempt -- a matrix without a pattern is not an error then (no error text, SMM_HIP_ERR_INVALID still returned).
+// pat_state: 0 not analysed, 1 usable, -1 refused by both encodings, -2 refused by the masks with the dictionary not tried yet (an
+// automatic attempt with SMM_HIP_AUTO_DICT=0): an explicit request tries it then.
+int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet) {
+	SMM_TRY(ensureCsrReady(m, s, streamKnown));
+	std::lock_guard<std::mutex> lock(m->tileMutex);
+	const bool dictWanted = !quiet || autoDictAllowed();
+	if (m->pat_state > 0) return SMM_HIP_OK;
+	if (m->pat_state == -1 || (m->pat_state == -2 && !dictWanted)) {
+		if (!quiet) setError("pattern SpMV: the entries of this matrix use more than %d distinct column offsets", DICT_MAX);
+		return SMM_HIP_ERR_INVALID;
+	}
+	const bool masksTried = m->pat_state == -2;
+	m->pat_state = -1;
+	auto refuse = [quiet](const char* why) {
+		if (!quiet) setError("pattern SpMV: %s", why);
+		return static_cast<int>(SMM_HIP_ERR_INVALID);
+	};
+	if (m->rows == 0 || m->nnz == 0) return refuse("empty matrix");
+	if (!streamKnown) {
+		SMM_HIP_TRY(hipDeviceSynchronize());
+		s = libStream();
+	}
+	const char* why = "";
+	int st = masksTried ? static_cast<int>(SMM_HIP_ERR_INVALID) : tryMasks(m, s, &why);
+	if (st == SMM_HIP_ERR_INVALID) {
+		if (!dictWanted) {
+			m->pat_state = -2;
+			return refuse(why);
+		}
+		st = tryDict(m, s, &why);
+	}
+	if (st == SMM_HIP_ERR_INVALID) return refuse(why);
+	SMM_TRY(st);
 	m->pat_state = 1;
 	return SMM_HIP_OK;
 }
@@ -727,8 +1103,37 @@ static void launchPatTile(const smm_hip_csr* m, int op, const T* lhs, const T* d
 }
 
 template <typename T, int L>
+static void launchDict(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+                       hipStream_t s) {
+	op &= ~SPMV_LEAVE_ROOM;
+	constexpr int LW = L > WAVE ? WAVE : L;
+	constexpr int RT = (WAVE / LW) * (TPB / WAVE);
+	const int cap = m->pat_nnz_cap + 3;
+	const bool dlds = m->pat_k <= DICT_LDS_MAX;
+	const size_t lds = static_cast<size_t>(cap + PatCfg<T>::PAD) * sizeof(T) + (RT + 4) * 4 + static_cast<size_t>((cap + PatCfg<T>::PAD + 8 + 7) & ~7) * 2 +
+	                   (dlds ? static_cast<size_t>((m->pat_k + 1) & ~1) * 4 : 0) + 4 * sizeof(T) + 32;
+	int perCU = 0;
+	const void* fn = dlds ? reinterpret_cast<const void*>(spmvDictKernel<T, L, true>) : reinterpret_cast<const void*>(spmvDictKernel<T, L, false>);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
+	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, numCUs() * perCU), NPART));
+	const int flags = op | spmvOutFlags(m, sizeof(T));
+	const int2* tiles = reinterpret_cast<const int2*>(m->d_pat_rowblocks);
+	if (dlds) {
+		spmvDictKernel<T, L, true><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, m->cols, m->pat_k, m->d_pat_off, tiles, m->d_start, m->d_pat_codes, m->d_positions,
+		                                                 static_cast<const T*>(m->d_values), flags, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+	} else {
+		spmvDictKernel<T, L, false><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, m->cols, m->pat_k, m->d_pat_off, tiles, m->d_start, m->d_pat_codes, m->d_positions,
+		                                                  static_cast<const T*>(m->d_values), flags, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+	}
+}
+
+template <typename T, int L>
 static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                       hipStream_t s) {
+	if (m->pat_encoding == 1) {  // the dictionary encoding: one kernel form for every L
+		launchDict<T, L>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
+		return;
+	}
 	if constexpr (L == 2 || L == 4) {
 		if (patUseTile(L)) {
 			launchPatTile<T, L>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
@@ -798,3 +1203,13 @@ template int launchSpmvPattern<float>(const smm_hip_csr*, int, const float*, con
 template int launchSpmvPattern<double>(const smm_hip_csr*, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 
 }  // namespace smm
+
+extern "C" int smm_hip_csr_pattern_info(const smm_hip_csr* m, int* encoding, int* offsets) {
+	if (!m) {
+		smm::setError("csr_pattern_info: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (encoding) *encoding = m->pat_state > 0 ? (m->pat_encoding == 1 ? SMM_PATTERN_CODES : SMM_PATTERN_MASKS) : SMM_PATTERN_NONE;
+	if (offsets) *offsets = m->pat_state > 0 ? m->pat_k : 0;
+	return SMM_HIP_OK;
+}

@@ -268,6 +268,12 @@ class CSRMatrix:
         check(_lib.load().smm_hip_csr_tile_info(self._h, *[ctypes.byref(c) for c in v]))
         return tuple(c.value for c in v)
 
+    def pattern_info(self):
+        """(encoding, distinct offsets) of the PATTERN family for this matrix: encoding 0 none / not analysed, 1 row masks, 2 entry codes"""
+        enc, k = ctypes.c_int(), ctypes.c_int()
+        check(_lib.load().smm_hip_csr_pattern_info(self._h, ctypes.byref(enc), ctypes.byref(k)))
+        return enc.value, k.value
+
     def spmv_fused_dev(self, op, d_lhs, d_x, d_out, dot_mode, d_w1, d_partials, stream=None, finish=False):
         """SpMV with the dot products of the fresh out[] in its epilogue (dot_mode 1: out.w1; 2: out.out and out.w1).  finish=False:
         d_partials receives 2 x partials_count() per-workgroup sums; finish=True: d_partials is a finishing buffer of finish_len()

@@ -85,33 +85,143 @@ def test_pattern_solver(smm, oracle):
     np.testing.assert_allclose(res[STREAM][5], res[PATTERN][5], rtol=0, atol=1e-5)
 
 
+MASKS, CODES = 1, 2
+
+
 def test_pattern_refuses_matrices_without_one(smm):
-    # random columns: far more than 64 distinct offsets
-    csr = gen.random_rows(500, 500, 1, 9, seed=4)
-    A = smm.CSRMatrix(500, 500, *csr)
+    # more than 65536 distinct offsets (two random columns per row): neither encoding fits
+    rng = np.random.default_rng(4)
+    n = 200_000
+    pos = np.sort(rng.integers(0, n, size=(n, 2)), axis=1)
+    pos[:, 1] = np.where(pos[:, 1] == pos[:, 0], (pos[:, 0] + 1) % n, pos[:, 1])
+    pos = np.sort(pos, axis=1).astype(np.int32).ravel()
+    start = (2 * np.arange(n + 1)).astype(np.int32)
+    A = smm.CSRMatrix(n, n, start, pos, rng.uniform(-1, 1, 2 * n))
     before = A.get_kernel()
     with pytest.raises(smm.SmmHipError):
         A.set_kernel(PATTERN, 0)
-    assert A.get_kernel() == before
-    # a stencil with ONE entry moved off the pattern in a row the sampling does not look at: the full verification finds it
+    assert A.get_kernel() == before and A.pattern_info() == (0, 0)
+    with pytest.raises(smm.SmmHipError):  # (the refusal is remembered)
+        A.set_kernel(PATTERN, 1)
+    # empty matrix
+    E = smm.CSRMatrix(5, 5, np.zeros(6, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
+    with pytest.raises(smm.SmmHipError):
+        E.set_kernel(PATTERN, 1)
+
+
+def test_masks_give_way_to_codes(smm, oracle):
+    """what the row masks cannot describe goes to the dictionary encoding, same bits"""
+    rng = np.random.default_rng(12)
+    # a stencil with ONE entry moved off the pattern in a row the sampling does not look at: the full verification of the masks finds it
     start, pos, val = gen.poisson2d(300)
     pos = pos.copy()
     row = 44_444
     e = start[row]  # first entry of the row (column row - 300): move it one to the left, still ascending
     assert pos[e] == row - 300
     pos[e] -= 1
-    B = smm.CSRMatrix(90_000, 90_000, start, pos, val)
-    with pytest.raises(smm.SmmHipError):
-        B.set_kernel(PATTERN, 1)
-    # rows longer than 64 entries
-    dense = gen.random_rows(100, 4000, 80, 90, seed=2)
-    C = smm.CSRMatrix(100, 4000, *dense)
-    with pytest.raises(smm.SmmHipError):
-        C.set_kernel(PATTERN, 1)
-    # empty matrix
-    E = smm.CSRMatrix(5, 5, np.zeros(6, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
-    with pytest.raises(smm.SmmHipError):
-        E.set_kernel(PATTERN, 1)
+    cases = {
+        "stencil_with_a_stray_entry": ((start, pos, val), 90_000, 6),
+        "random_columns": (gen.random_rows(500, 500, 1, 9, seed=4), 500, None),   # hundreds of offsets
+        "rows_of_80_to_90_entries": (gen.random_rows(100, 4000, 80, 90, seed=2), 4000, None),
+    }
+    for name, (csr, cols, k) in cases.items():
+        rows = len(csr[0]) - 1
+        A = smm.CSRMatrix(rows, cols, *csr)
+        A.set_kernel(PATTERN, 1)
+        enc, found = A.pattern_info()
+        assert enc == CODES and (k is None or found == k), name
+        rowof = np.repeat(np.arange(rows), np.diff(csr[0]))
+        assert found == len(np.unique(csr[1].astype(np.int64) - rowof))
+        x = rng.uniform(-1, 1, cols)
+        out = np.zeros(rows)
+        A.rMult(x, out)
+        np.testing.assert_array_equal(out, oracle.spmv(csr, OP_ASSIGN, None, x), err_msg=name)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_codes_match_oracle_and_stream(smm, oracle, dtype):
+    """the dictionary encoding (> 64 offsets): every lane count and operation against STREAM bit for bit, one lane per row against the
+    oracle bit for bit (ref:1484-1499); dictionaries that live in LDS (<= 4096 offsets) and in global memory"""
+    rng = np.random.default_rng(8)
+    big = gen.random_rows(6000, 6000, 3, 40, seed=21, dtype=dtype)
+    cases = {
+        "banded_65_diagonals": (gen.banded_random_spd(6000, 32, 0x5EED, 2500, dtype=dtype), 6000),
+        "banded_33_diagonals_wide": (gen.banded_random_spd(20_000, 16, 3, 9000, dtype=dtype), 20_000),  # <= 64 offsets: the masks take it
+        "random_6000": (big, 6000),                                               # ~ 11 000 offsets: dictionary in global memory
+        "ragged_with_empty_rows": (gen.random_rows(3000, 2500, 0, 130, seed=5, dtype=dtype, empty_every=7), 2500),
+        "70_entries_in_the_only_row": (gen.random_rows(1, 400, 70, 70, seed=1, dtype=dtype), 400),
+    }
+    for name, (csr, cols) in cases.items():
+        rows = len(csr[0]) - 1
+        csr = (csr[0].astype(np.int32), csr[1], csr[2])
+        A = smm.CSRMatrix(rows, cols, *csr)
+        x = rng.uniform(-1, 1, cols).astype(dtype)
+        lhs = rng.uniform(-1, 1, rows).astype(dtype)
+        A.set_kernel(PATTERN, 1)
+        enc, k = A.pattern_info()
+        if name == "banded_33_diagonals_wide":
+            assert enc == MASKS and k == 33
+            continue
+        assert enc == CODES, name
+        if name == "random_6000":
+            assert k > 4096
+        for op in (OP_ASSIGN, OP_ADD, OP_SUB):
+            ref = oracle.spmv(csr, op, lhs, x)
+            for lanes in (1, 2, 4, 8):
+                A.set_kernel(STREAM, lanes)
+                want = run(A, op, lhs, x, rows, dtype)
+                A.set_kernel(PATTERN, lanes)
+                got = run(A, op, lhs, x, rows, dtype)
+                body = csr[0][1:] <= csr[0][-1] - 8200 if lanes > 1 else np.ones(rows, dtype=bool)
+                np.testing.assert_array_equal(got[body], want[body], err_msg=f"{name} op {op} lanes {lanes}")
+                mag = np.zeros(rows)
+                np.add.at(mag, np.repeat(np.arange(rows), np.diff(csr[0])), np.abs(csr[2].astype(np.float64) * x[csr[1]]))
+                assert np.all(np.abs(got.astype(np.float64) - want) <= 64 * np.finfo(dtype).eps * (mag + np.abs(lhs))), (name, op, lanes)
+                if lanes == 1:
+                    np.testing.assert_array_equal(got, ref, err_msg=f"{name} op {op}")
+
+
+def test_auto_uses_codes_for_a_large_matrix_with_many_diagonals(smm, oracle):
+    """65 diagonals, 2^25 entries: AUTO's attempt fails the masks and takes the dictionary; bits of STREAM at the same lanes; BiCGStab +
+    Jacobi (the divide epilogue) against the oracle"""
+    import torch
+    from oracle.oracle import PRECOND_JACOBI
+
+    dev = torch.device("cuda:0")
+    n, k, dtype = 600_000, 32, np.float32  # (the generator draws at most 32 offsets per side: 65 diagonals)
+    nnz = smm.host.gen_banded_nnz(n, k, 0x5EED, 1 << 16)
+    assert nnz >= 1 << 25
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    smm.host.gen_banded_dev(n, k, 0x5EED, 1 << 16, d_start, d_pos, d_val, dtype, stream)
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, dtype)
+    x = torch.rand(n, dtype=torch.float32, device=dev) - 0.5
+    lhs = torch.rand(n, dtype=torch.float32, device=dev) - 0.5
+    y_auto = torch.empty(n, dtype=torch.float32, device=dev)
+    A.spmv_dev(OP_SUB, lhs, x, y_auto, stream)
+    torch.cuda.synchronize()
+    fam, lanes = A.get_kernel()
+    assert fam == PATTERN and A.pattern_info() == (CODES, 2 * k + 1)
+    A.set_kernel(STREAM, lanes)
+    y_stream = torch.empty_like(y_auto)
+    A.spmv_dev(OP_SUB, lhs, x, y_stream, stream)
+    torch.cuda.synchronize()
+    body = (d_start[1:] <= nnz - 8200).cpu().numpy()
+    np.testing.assert_array_equal(y_auto.cpu().numpy()[body], y_stream.cpu().numpy()[body])
+    A.set_kernel(smm.SPMV_AUTO, 0)
+    assert A.get_kernel()[0] == PATTERN
+    csr = (d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy())
+    M = A.getPreconditioner(smm.SolverPreconditioner.JACOBI)
+    x_true = np.random.default_rng(5).uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, OP_ASSIGN, None, x_true)
+    xs = np.zeros(n, dtype=dtype)
+    info = {}
+    st = smm.BiCGStab(A, b, xs, 5, dtype(1e-30), M, info=info)
+    st_o, x_o, it_o, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 5, dtype(1e-30), PRECOND_JACOBI, oracle.jacobi_setup(csr)[1])
+    assert int(st) == st_o and info["iterations"] == it_o == 5
+    assert np.abs(xs - x_o).max() <= 3e-4 * np.abs(x_o).max()
 
 
 def test_pattern_rectangular_and_empty_rows(smm, oracle):
