@@ -14,6 +14,9 @@
 // turns the automatic choice off.  bench.py's roofline stays defined on the reference's layout (values + positions + start,
 // SURVEY.md section 8d) and on the STREAM kernel; what this family moves is reported beside it with its true byte count.
 //
+// Matrices the masks cannot describe (more than 64 offsets, rows of more than 64 entries) but whose entries use <= 65 536 distinct
+// offsets get the CODES encoding instead: a 16-bit dictionary index per entry (further down: "DICTIONARY encoding").
+//
 // Kernel structure = spmvStreamKernel (smm_spmv.hip): persistent workgroups walk row tiles, values[] is fetched one tile
 // ahead with 16-byte non-temporal loads into registers, stored to LDS, and lane (row, piece) walks its piece of its row in
 // batches of 8 independent x[] gathers; the column of an entry comes from the next set bit of the row mask.
