@@ -870,6 +870,9 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	}
 	maxIterations = std::min(maxIterations, D->nGlobal);  // ref:2200
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2201-2203
+	// many SpMVs ahead: both local blocks may take the index-free family (each rank decides for its own blocks; no collective involved)
+	if (D->aLoc) SMM_TRY(adoptPatternForSolver(D->aLoc, maxIterations, s));
+	if (D->aRem) SMM_TRY(adoptPatternForSolver(D->aRem, maxIterations, s));
 	T *r = static_cast<T*>(D->r), *r0 = static_cast<T*>(D->r0), *ap = static_cast<T*>(D->ap), *as = static_cast<T*>(D->as);
 	T *pExt = static_cast<T*>(D->pExt), *sExt = static_cast<T*>(D->sExt), *xExt = static_cast<T*>(D->xExt);
 	T *p = pExt + D->ownOffset, *sv = sExt + D->ownOffset;
@@ -957,6 +960,8 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		return SMM_HIP_ERR_INVALID;
 	}
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2345-2347 (no clamp otherwise)
+	if (D->aLoc) SMM_TRY(adoptPatternForSolver(D->aLoc, maxIterations, s));
+	if (D->aRem) SMM_TRY(adoptPatternForSolver(D->aRem, maxIterations, s));
 	T *r = static_cast<T*>(D->r), *ap = static_cast<T*>(D->ap);
 	T *pExt = static_cast<T*>(D->pExt), *xExt = static_cast<T*>(D->xExt);
 	T* p = pExt + D->ownOffset;

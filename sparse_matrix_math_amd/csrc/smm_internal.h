@@ -198,6 +198,8 @@ int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows
 int ensureCsrReady(const smm_hip_csr* m, hipStream_t s, bool streamKnown);
 // PATTERN family: analyse + verify the matrix (idempotent), and the launch behind launchSpmv
 int ensurePattern(smm_hip_csr* m, hipStream_t s = nullptr, bool streamKnown = false, bool quiet = false);
+// before a solver's loop: lets a mid-size matrix (>= 2^20 entries) take the PATTERN family when it fits (smm_spmv_pattern.hip)
+int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream_t s);
 template <typename T>
 int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                       const int* doneFlag, hipStream_t s);

@@ -439,6 +439,8 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 		SMM_TRY(cgResidentTry<T>(a, b, x0, x, maxIterations, eps, s, status, iterations, resnorm2, &handled));
 		if (handled) return SMM_HIP_OK;
 	}
+	SMM_TRY(ensureCsrReady(a, s, true));
+	SMM_TRY(adoptPatternForSolver(a, maxIterations, s));  // many SpMVs ahead: a mid-size banded / stencil matrix takes the index-free family
 	DevBuf<T> r, p, Ap, z, parts, parts2;
 	DevBuf<Scal<T>> sc;
 	SMM_TRY(r.alloc(n));
@@ -655,6 +657,7 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	}
 	const DevApplier<T> apply{M};
 	SMM_TRY(ensureCsrReady(a, s, true));
+	SMM_TRY(adoptPatternForSolver(a, maxIterations, s));
 	const T* jacobiDiag = precondition && M->kind == SMM_PRECOND_JACOBI ? static_cast<const T*>(M->d_values) : nullptr;
 	const smm_hip_precond* blockM = precondition && isBlockKind(M->kind) ? M : nullptr;
 	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm, jacobiDiag, blockM)));
@@ -712,6 +715,8 @@ int bicgsymmetricDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, 
 	const int n = a->rows;
 	maxIterations = std::min(maxIterations, n);  // ref:2030-2033
 	if (maxIterations == -1) maxIterations = n;
+	SMM_TRY(ensureCsrReady(a, s, true));
+	SMM_TRY(adoptPatternForSolver(a, maxIterations, s));
 	DevBuf<T> r, p, ap, parts;
 	DevBuf<Scal<T>> sc;
 	SMM_TRY(r.alloc(n));

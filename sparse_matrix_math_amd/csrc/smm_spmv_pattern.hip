@@ -1045,6 +1045,33 @@ int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet) {
 	return SMM_HIP_OK;
 }
 
+// A SOLVER is about to run many SpMVs with this matrix: matrices far below AUTO's single-SpMV threshold are worth the one-off analysis
+// then (convection-diffusion 108^3, 8.7 M entries: the analysis costs a few hundred microseconds, BiCGStab's 660 SpMVs gain 3 ms of
+// 37.7; profiles/r03/solver_pattern_small.txt).  Same rules as the AUTO step of launchSpmv otherwise: never against a forced kernel,
+// never twice, SMM_HIP_AUTO_PATTERN=0 turns it off; SMM_HIP_SOLVER_PATTERN_MIN_NNZ moves the threshold (default 2^20).
+int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream_t s) {
+	static const int allowed = [] {
+		const char* env = getenv("SMM_HIP_AUTO_PATTERN");
+		return env ? atoi(env) : 1;
+	}();
+	static const long long minNnz = [] {
+		const char* env = getenv("SMM_HIP_SOLVER_PATTERN_MIN_NNZ");
+		return env ? atoll(env) : (1LL << 20);
+	}();
+	if (!allowed || !m || m->rows <= 0 || m->kernelForced || m->family != SMM_SPMV_STREAM || m->pat_state != 0) return SMM_HIP_OK;
+	if (plannedIterations >= 0 && plannedIterations < 32) return SMM_HIP_OK;
+	const double avg = static_cast<double>(m->nnz) / m->rows;
+	if (m->nnz < minNnz || avg > 64.0) return SMM_HIP_OK;
+	auto* mm = const_cast<smm_hip_csr*>(m);
+	const int st = ensurePattern(mm, s, true, true);
+	if (st == SMM_HIP_OK) {
+		mm->family = SMM_SPMV_PATTERN;
+		mm->lanes = avg <= 24 ? 1 : avg <= 64 ? 2 : avg <= 128 ? 4 : 8;  // (the PATTERN rule of smm_spmv.hip's lanesForAvg)
+		return SMM_HIP_OK;
+	}
+	return st == SMM_HIP_ERR_INVALID ? static_cast<int>(SMM_HIP_OK) : st;  // "no pattern" is not a failure
+}
+
 template <typename T>
 static int patCap(const smm_hip_csr* m, int lanes) {
 	const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 1.0;
