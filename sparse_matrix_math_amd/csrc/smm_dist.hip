@@ -865,7 +865,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	// communication; with one rank it is the single-GPU preconditioner, with more a weaker one (iteration counts differ)
 	const bool pre = M != nullptr && M->kind != SMM_PRECOND_NONE;
 	if (pre && (M->a != D->aLoc || M->kind == SMM_PRECOND_IC0)) {
-		setError("dist_bicgstab: preconditioner must be JACOBI / ILU0 / SGS of the local diagonal block (smm_hip_dist_csr_local_block)");
+		setError("dist_bicgstab: preconditioner must be JACOBI / ILU0 / SGS / BLOCK_ILU0 / BLOCK_SGS of the local diagonal block (smm_hip_dist_csr_local_block)");
 		return SMM_HIP_ERR_INVALID;
 	}
 	maxIterations = std::min(maxIterations, D->nGlobal);  // ref:2200

@@ -184,7 +184,7 @@ def test_native_cg_matches_oracle(smm, oracle, world):
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_native_preconditioned(smm, oracle, world):
     """block-Jacobi by rank: one rank = the single-GPU preconditioned solver; Jacobi is the same preconditioner for any number of
-    ranks; SGS / ILU0 on several ranks are weaker preconditioners that must still converge and still help"""
+    ranks; SGS / ILU0 and their block forms on several ranks are weaker preconditioners that must still converge and still help"""
     P = smm.SolverPreconditioner
     dtype = np.float64
     csr = gen.convdiff3d(16, 0.3, dtype=dtype)
@@ -194,7 +194,7 @@ def test_native_preconditioned(smm, oracle, world):
     A = smm.CSRMatrix(n, n, *csr)
     eps = 1e-9
     (_, it_none, _), _, _, _ = _solve(smm, csr, b, world, dtype, -1, eps)
-    for kind in (P.JACOBI, P.ILU0, P.SYMMETRIC_GAUS_SEIDEL):
+    for kind in (P.JACOBI, P.ILU0, P.SYMMETRIC_GAUS_SEIDEL, P.BLOCK_ILU0, P.BLOCK_SGS):
         (status, iters, res), x, _, _ = _solve(smm, csr, b, world, dtype, -1, eps, precond=kind)
         assert status == 0 and res <= eps, (kind, world)
         np.testing.assert_allclose(x, x_true, rtol=1e-6, err_msg=f"{kind} world {world}")
