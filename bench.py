@@ -264,10 +264,20 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         # what AUTO does with it: the PATTERN family, with the bytes it really moves (values + 8 bytes per row + vectors + start[])
         try:
             A.set_kernel(3, 0)
+            A.pattern_allow_const(False)  # first the MASKS kernel: values[] still read
             ms_p = time_spmv(A, n, torch.float64, 5)
             p_bytes = nnz * 8 + n * 8 + (n + 1) * 4 + 2 * n * 8
             out["spmv_laplacian512_f64"]["pattern_family"] = {"avg_launch_ms": ms_p, "true_bytes_per_launch": p_bytes, "gbps": p_bytes / ms_p / 1e6,
                                                               "frac": p_bytes / ms_p / 1e6 / HBM_PEAK_GBPS}
+            # ... and what AUTO really runs for a Laplacian: every diagonal holds one value (verified against every entry), so values[]
+            # is not read either: the row's mask, x, y
+            A.pattern_allow_const(True)
+            if A.pattern_info()[0] == 3:
+                ms_c = time_spmv(A, n, torch.float64, 5)
+                c_bytes = n * 8 + 2 * n * 8
+                out["spmv_laplacian512_f64"]["const_diagonals"] = {"avg_launch_ms": ms_c, "true_bytes_per_launch": c_bytes, "gbps": c_bytes / ms_c / 1e6,
+                                                                   "frac": c_bytes / ms_c / 1e6 / HBM_PEAK_GBPS,
+                                                                   "note": "PATTERN family, constant-diagonal encoding: what AUTO runs for this matrix"}
         except smm.SmmHipError as e:
             out["spmv_laplacian512_f64"]["pattern_family"] = {"skipped": str(e)[:200]}
         A.close()
@@ -327,8 +337,12 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         bytes_apply = 2 * (nnz * 12 + (n + 1) * 4) + 5 * n * 8  # two triangular sweeps over A's pattern ~ 2 x SpMV bytes
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # block_*: the default level cut (16); *_uncut: the same blocks without it (M = the block-diagonal part of A exactly)
+        # *_values_read: the same legs with the constant-diagonal SpMV encoding turned off -- this stand-in has constant coefficients, so
+        # the solvers' SpMV reads no values[] (PATTERN / CONST); a general matrix such as atmosmodd would run the kernel that does
         for name, kind, cap in (("none", None, None), ("jacobi", P.JACOBI, None), ("ilu0", P.ILU0, None), ("block_ilu0", P.BLOCK_ILU0, None),
-                                ("block_sgs", P.BLOCK_SGS, None), ("block_ilu0_uncut", P.BLOCK_ILU0, 0)):
+                                ("block_sgs", P.BLOCK_SGS, None), ("block_ilu0_uncut", P.BLOCK_ILU0, 0),
+                                ("none_values_read", None, None), ("block_ilu0_values_read", P.BLOCK_ILU0, None)):
+            A.pattern_allow_const(not name.endswith("_values_read"))
             M, tc = None, 0.0
             for _ in range(2 if kind is not None else 0):  # the second create is the steady state (device allocations cached)
                 if M is not None:
@@ -363,6 +377,9 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
                         leg[name]["blocks"] = len(M.block_bounds()) - 1
                         leg[name]["level_cap"] = M.level_cap()
                 M.close()
+        A.pattern_allow_const(True)
+        leg["spmv"] = {"family_lanes": list(A.get_kernel()), "pattern_encoding": A.pattern_info()[0],
+                       "note": "encoding 3 = row masks + constant diagonals (no values[] read), 1 = row masks + values[]"}
         out["bicgstab_convdiff108_f64"] = leg
         A.close()
         del A, d_start, d_pos, d_val

@@ -86,6 +86,8 @@ extern "C" {
  * mesh matrices).  positions[] (4 bytes per entry) is replaced, in one of two encodings (smm_hip_csr_pattern_info tells which):
  *   MASKS  <= 64 distinct offsets and rows of <= 64 entries: one 64-bit mask per ROW, verified against EVERY entry on the device before
  *          the family is used; an SpMV streams only values[] (half the bytes for fp32);
+ *          When in addition every entry of a diagonal holds the same value (constant-coefficient stencils: the Laplacians) -- CONST --
+ *          values[] is not read either: 24 bytes per fp64 row instead of 104;
  *   CODES  <= 65536 distinct offsets: one 16-bit index into the matrix's sorted offset dictionary per ENTRY (6 instead of 8 bytes per
  *          fp32 entry), built on the device from all entries.
  * Same result bit for bit as the other families at the same lanes_per_row.  Selected explicitly (smm_hip_csr_set_kernel returns
@@ -93,11 +95,13 @@ extern "C" {
  * <= 64 entries per row on average runs the analysis once, on the caller's stream, and switches the matrix over when it passes
  * (smm_hip_csr_get_kernel then reports SMM_SPMV_PATTERN); a matrix that does not fit stays with STREAM.
  * Environment: SMM_HIP_AUTO_PATTERN=0 keeps AUTO on STREAM, SMM_HIP_AUTO_PATTERN_MIN_NNZ moves the threshold, SMM_HIP_AUTO_DICT=0 keeps
- * AUTO from using the CODES encoding. */
+ * AUTO from using the CODES encoding, SMM_HIP_PATTERN_CONST=0 turns the constant-diagonal form off. */
 #define SMM_SPMV_PATTERN 3
 #define SMM_PATTERN_NONE 0  /* smm_hip_csr_pattern_info: not analysed, or the matrix fits neither encoding */
 #define SMM_PATTERN_MASKS 1
 #define SMM_PATTERN_CODES 2
+#define SMM_PATTERN_CONST 3 /* MASKS, and every diagonal holds one value (verified bit for bit against every entry): with one lane per
+                             * row an SpMV reads the row's mask, x and <= 32 numbers -- no positions[], no values[] (the Laplacians) */
 
 typedef struct smm_hip_csr smm_hip_csr;         /* device-resident CSRMatrix<T> (ref:1243-1259) */
 typedef struct smm_hip_precond smm_hip_precond; /* device-resident preconditioner */
@@ -143,6 +147,9 @@ int smm_hip_csr_tile_info(const smm_hip_csr* m, int* tiles, int* tile_nnz_cap, i
 /* The PATTERN family's encoding of this matrix (SMM_PATTERN_*) and the number of distinct offsets it found; NONE / 0 before the
  * analysis has run (the first SpMV of a large matrix, or smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, ...)). */
 int smm_hip_csr_pattern_info(const smm_hip_csr* m, int* encoding, int* offsets);
+/* allow = 0: a matrix with constant diagonals keeps reading values[] (the MASKS kernels); 1 (default): CONST where it applies.  For
+ * measurements of one against the other; the results are the same bits either way. */
+int smm_hip_csr_pattern_allow_const(smm_hip_csr* m, int allow);
 /* Times the candidate SpMV configurations on this matrix and keeps the fastest. */
 int smm_hip_csr_autotune(smm_hip_csr* m);
 

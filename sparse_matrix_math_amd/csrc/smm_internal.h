@@ -121,6 +121,10 @@ struct smm_hip_csr {
 	int pat_state = 0;  // 0 not analysed, 1 usable, -1 the matrix has no such pattern, -2 no masks and the dictionary not tried (ensurePattern)
 	int pat_encoding = 0;  // 0: one 64-bit mask per row (<= 64 offsets); 1: one 16-bit code per entry (<= 65536 offsets)
 	unsigned short* d_pat_codes = nullptr;
+	bool pat_const = false;  // masks + every diagonal holds one value (d_pat_cval[j], raw bits): the CONST kernel needs no values[]
+	unsigned long long* d_pat_cval = nullptr;
+	bool pat_const_off = false;  // smm_hip_csr_pattern_allow_const(m, 0): keep reading values[] (A/B measurements)
+	int pat_max_off = 0;  // largest |column - row| of the offset list
 	int pat_k = 0;
 	int* d_pat_off = nullptr;
 	unsigned long long* d_pat_masks = nullptr;

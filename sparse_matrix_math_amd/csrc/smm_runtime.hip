@@ -494,6 +494,7 @@ int smm_hip_csr_destroy(smm_hip_csr* m) {
 	devFree(m->d_pat_off);
 	devFree(m->d_pat_masks);
 	devFree(m->d_pat_codes);
+	devFree(m->d_pat_cval);
 	devFree(m->d_pat_rowblocks);
 	delete m;
 	return SMM_HIP_OK;

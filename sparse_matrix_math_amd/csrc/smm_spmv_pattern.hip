@@ -85,10 +85,18 @@ __device__ __forceinline__ int selectBit(unsigned long long m, int k) {
 // row by a binary search over the 65 row starts of the group (LDS), its offset index by a binary search over the offset list (LDS), and
 // sets its bit in the row's mask with an LDS atomic.  Verified on the way: the offset is in the list; columns ascend strictly inside a
 // row (ref:1247-1249: the kernels pair the n-th value of a row with the n-th set bit); no two entries of a row share a bit.
+// Constant diagonals (values != nullptr and the sample has not already said no -- flags[1]): every entry's value is compared, bit for
+// bit, with the one value its offset was given (cvalBits, from the sampled rows); any difference raises flags[1].
 __global__ __launch_bounds__(TPB) void patBuildMasks(int rows, int k, const int* __restrict__ offs, const int* __restrict__ start,
                                                      const int* __restrict__ positions, unsigned long long* __restrict__ masks,
-                                                     int* __restrict__ mismatch) {
+                                                     int* __restrict__ flags, const void* __restrict__ values, int elemBytes,
+                                                     const unsigned long long* __restrict__ cvalBits) {
+	int* mismatch = flags;
 	__shared__ int sOff[MAXOFF];
+	__shared__ unsigned long long sCval[MAXOFF];
+	const bool checkConst = values != nullptr && flags[1] == 0;
+	if (checkConst && threadIdx.x < k) sCval[threadIdx.x] = cvalBits[threadIdx.x];
+	bool varies = false;
 	__shared__ int sRow[TPB / WAVE][WAVE + 1];
 	__shared__ unsigned sLo[TPB / WAVE][WAVE], sHi[TPB / WAVE][WAVE];
 	if (threadIdx.x < k) sOff[threadIdx.x] = offs[threadIdx.x];
@@ -131,6 +139,11 @@ __global__ __launch_bounds__(TPB) void patBuildMasks(int rows, int k, const int*
 					const unsigned bit = 1u << (a & 31);
 					const unsigned before = a < 32 ? atomicOr(&sLo[w][i], bit) : atomicOr(&sHi[w][i], bit);
 					if (before & bit) bad = true;  // two entries of a row on one diagonal
+					if (checkConst) {
+						const unsigned long long bits = elemBytes == 4 ? static_cast<unsigned long long>(static_cast<const unsigned*>(values)[e])
+						                                               : static_cast<const unsigned long long*>(values)[e];
+						if (bits != sCval[a]) varies = true;
+					}
 				}
 			}
 			int prevCol = __shfl_up(col, 1, WAVE), prevRow = __shfl_up(i, 1, WAVE);
@@ -149,6 +162,35 @@ __global__ __launch_bounds__(TPB) void patBuildMasks(int rows, int k, const int*
 		}
 	}
 	if (bad) atomicOr(mismatch, 1);
+	if (varies) atomicOr(flags + 1, 1);
+}
+
+// One value per offset from the sampled rows (mode 0: plain stores -- any of them will do, the full check follows), then (mode 1) the same
+// rows compared with it: a matrix whose diagonals vary inside the sample is told apart here, and patBuildMasks never reads values[].
+__global__ __launch_bounds__(TPB) void patConstSample(int rows, int samples, int k, const int* __restrict__ offs, const int* __restrict__ start,
+                                                      const int* __restrict__ positions, const void* __restrict__ values, int elemBytes,
+                                                      unsigned long long* cvalBits, int* flags, int mode) {
+	__shared__ int sOff[MAXOFF];
+	if (threadIdx.x < k) sOff[threadIdx.x] = offs[threadIdx.x];
+	__syncthreads();
+	bool varies = false;
+	for (long long i = static_cast<long long>(blockIdx.x) * TPB + threadIdx.x; i < samples; i += static_cast<long long>(gridDim.x) * TPB) {
+		const int row = static_cast<int>(i * (rows - 1) / max(1, samples - 1));
+		for (int e = start[row]; e < start[row + 1]; ++e) {
+			const int rel = positions[e] - row;
+			int a = 0, b = k;
+			while (a < b) {
+				const int mid = (a + b) >> 1;
+				if (sOff[mid] < rel) a = mid + 1; else b = mid;
+			}
+			if (a >= k || sOff[a] != rel) continue;  // (patBuildMasks refuses such a matrix)
+			const unsigned long long bits = elemBytes == 4 ? static_cast<unsigned long long>(static_cast<const unsigned*>(values)[e])
+			                                               : static_cast<const unsigned long long*>(values)[e];
+			if (mode == 0) cvalBits[a] = bits;
+			else if (cvalBits[a] != bits) varies = true;
+		}
+	}
+	if (varies) atomicOr(flags + 1, 1);
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smmPatLds[];
@@ -612,6 +654,116 @@ __global__ __launch_bounds__(TPB) void patSampleOffsets(int rows, int samples, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// CONSTANT DIAGONALS (r03): when, on top of the row masks, every entry of a diagonal holds the SAME value -- the Laplacians of BASELINE
+// configs 1, 2 and 4, every constant-coefficient stencil -- values[] is redundant as well: an SpMV needs the row's mask, x and one value
+// per offset (<= 64 numbers, LDS).  For the 512^3 fp64 Laplacian that is 24 bytes per row instead of 84 (PATTERN) or 104 (CSR).  The
+// property is verified bit for bit against EVERY entry on the device (patConstSample, patBuildMasks) before the encoding is used, so the
+// products are the reference's products: c_j == values[k] as bit patterns, multiplied with the same x[] in the same left-to-right order
+// (the mask's bit order is the ascending column order of the row, ref:1484-1499).  One lane per row only (the stencils' choice anyway);
+// a request for more lanes per row is served by the mask kernels above, so "same bits as STREAM at equal lanes" holds.
+// Rows are dealt in tiles of TPB rows; chunkTiles as in the tile kernels (0: one contiguous eighth per XCD).
+template <typename T>
+__global__ __launch_bounds__(TPB) void spmvPatternConstKernel(int rows, int cols, int nOff, const int* __restrict__ offs,
+                                                              const unsigned long long* __restrict__ cvalBits,
+                                                              const unsigned long long* __restrict__ masks, int chunkTiles, int opFlags,
+                                                              const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode,
+                                                              const T* __restrict__ w1, T* __restrict__ partials, const int* __restrict__ doneFlag) {
+	constexpr int GATHER = 8;
+	__shared__ int sOff[MAXOFF];
+	__shared__ T sC[MAXOFF];
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	const int op = opFlags & 0xFF;
+	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;
+	const int t = threadIdx.x;
+	if (t < MAXOFF) {
+		sOff[t] = t < nOff ? offs[t] : 0;
+		T c = T(0);
+		if (t < nOff) {
+			const unsigned long long bits = cvalBits[t];
+			if (sizeof(T) == 4) {
+				const unsigned lo = static_cast<unsigned>(bits);
+				__builtin_memcpy(&c, &lo, 4);
+			} else {
+				__builtin_memcpy(&c, &bits, sizeof(T));
+			}
+		}
+		sC[t] = c;
+	}
+	__syncthreads();
+	const int nTiles = (rows + TPB - 1) / TPB;
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int xcdGroup = blockIdx.x % nGroups;
+	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;
+	const int perGroup = (nTiles + nGroups - 1) / nGroups;
+	auto tileOf = [&](int j) {  // the j-th tile of this XCD group
+		if (chunkTiles <= 0) {
+			const int tl = xcdGroup * perGroup + j;
+			return j < perGroup && tl < nTiles ? tl : nTiles;
+		}
+		const int c = j / chunkTiles;
+		const long long tIdx = (static_cast<long long>(c) * nGroups + xcdGroup) * chunkTiles + (j - c * chunkTiles);
+		return tIdx < nTiles ? static_cast<int>(tIdx) : nTiles;
+	};
+	T acc0 = T(0), acc1 = T(0);
+	int j = blockIdx.x / nGroups;
+	int tile = tileOf(j);
+	unsigned long long nextMask = 0ULL;
+	if (tile < nTiles && tile * TPB + t < rows) nextMask = masks[static_cast<size_t>(tile) * TPB + t];
+	while (tile < nTiles) {
+		const int row = tile * TPB + t;
+		unsigned long long mm = nextMask;
+		j += groupSlots;
+		const int ntile = tileOf(j);
+		nextMask = 0ULL;
+		if (ntile < nTiles && ntile * TPB + t < rows) nextMask = masks[static_cast<size_t>(ntile) * TPB + t];
+		if (row < rows) {
+			T dot = T(0);
+			do {  // (an empty row runs one batch of discarded products)
+				unsigned off[GATHER];
+				T cv[GATHER], xv[GATHER];
+				bool live[GATHER];
+#pragma unroll
+				for (int u = 0; u < GATHER; ++u) {
+					live[u] = mm != 0ULL;
+					const int jj = mm ? __builtin_ctzll(mm) : 0;
+					mm &= mm - 1;
+					const int col = min(max(row + sOff[jj], 0), cols - 1);  // (dead slots: a clamped, valid column)
+					off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
+					cv[u] = sC[jj];
+				}
+#pragma unroll
+				for (int u = 0; u < GATHER; ++u) xv[u] = patGather<T>(x, off[u]);
+#pragma unroll
+				for (int u = 0; u < GATHER; ++u) {
+					const T next = smmFma(cv[u], xv[u], dot);
+					dot = live[u] ? next : dot;
+				}
+			} while (mm != 0ULL);
+			const T o = patApplyOp(op, lhs, divisor, row, dot);
+			if (ntOut) __builtin_nontemporal_store(o, out + row);
+			else out[row] = o;
+			if (dotMode == 2) acc0 += o * o;
+			if (dotMode) acc1 += o * w1[row];
+		}
+		tile = ntile;
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // DICTIONARY encoding of the same family (r03): matrices whose entries use MORE than 64 distinct offsets
 // column - row, or hold rows of more than 64 entries, but no more than 65 536 distinct offsets in all -- banded matrices with hundreds
 // of diagonals, meshes numbered along a band.  positions[] (4 bytes per entry) is replaced by a 16-bit CODE per entry, the index of
@@ -942,21 +1094,40 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	std::sort(offs.begin(), offs.end());
 	SMM_TRY(d_off.alloc(MAXOFF));
 	SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
-	SMM_TRY(d_flag.alloc(1));
+	SMM_TRY(d_flag.alloc(2));  // [0] an entry off the offset set / out of order, [1] some diagonal holds more than one value
+	DevBuf<unsigned long long> d_cval;
+	SMM_TRY(d_cval.alloc(MAXOFF));
 	std::vector<int> padded(MAXOFF, 0);
 	std::copy(offs.begin(), offs.end(), padded.begin());
 	SMM_HIP_TRY(hipMemcpyAsync(d_off, padded.data(), MAXOFF * sizeof(int), hipMemcpyHostToDevice, s));
-	SMM_HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+	SMM_HIP_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), s));
+	SMM_HIP_TRY(hipMemsetAsync(d_cval, 0, MAXOFF * sizeof(unsigned long long), s));
+	const int k = static_cast<int>(offs.size());
+	const int elemBytes = m->dtype == SMM_DTYPE_F32 ? 4 : 8;
+	// constant diagonals are looked for in matrices of stencil shape only (<= 32 offsets); SMM_HIP_PATTERN_CONST=0 turns the encoding off
+	static const bool constAllowed = [] {
+		const char* env = getenv("SMM_HIP_PATTERN_CONST");
+		return env ? atoi(env) != 0 : true;
+	}();
+	const bool tryConst = constAllowed && k <= 32;
+	if (tryConst) {
+		const int sgrid = (samples + TPB - 1) / TPB;
+		patConstSample<<<sgrid, TPB, 0, s>>>(m->rows, samples, k, d_off, m->d_start, m->d_positions, m->d_values, elemBytes, d_cval, d_flag, 0);
+		patConstSample<<<sgrid, TPB, 0, s>>>(m->rows, samples, k, d_off, m->d_start, m->d_positions, m->d_values, elemBytes, d_cval, d_flag, 1);
+	}
 	const int grid = static_cast<int>(std::min<long long>((m->rows + TPB - 1LL) / TPB, numCUs() * 8LL));
-	patBuildMasks<<<grid, TPB, 0, s>>>(m->rows, static_cast<int>(offs.size()), d_off, m->d_start, m->d_positions, d_masks, d_flag);
-	int mismatch = 0;
-	SMM_HIP_TRY(hipMemcpyAsync(&mismatch, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+	patBuildMasks<<<grid, TPB, 0, s>>>(m->rows, k, d_off, m->d_start, m->d_positions, d_masks, d_flag, tryConst ? m->d_values : nullptr, elemBytes, d_cval);
+	int flags[2] = {0, 0};
+	SMM_HIP_TRY(hipMemcpyAsync(flags, d_flag, sizeof(flags), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
-	if (mismatch) return no("some entry's column offset is outside the offset set of the sampled rows");
-	m->pat_k = static_cast<int>(offs.size());
+	if (flags[0]) return no("some entry's column offset is outside the offset set of the sampled rows");
+	m->pat_k = k;
 	m->pat_encoding = 0;
+	m->pat_max_off = std::max(std::abs(offs.front()), std::abs(offs.back()));
 	m->d_pat_off = d_off.detach();
 	m->d_pat_masks = d_masks.detach();
+	m->pat_const = tryConst && flags[1] == 0;
+	if (m->pat_const) m->d_pat_cval = d_cval.detach();
 	return SMM_HIP_OK;
 }
 
@@ -1132,6 +1303,26 @@ static void launchPatTile(const smm_hip_csr* m, int op, const T* lhs, const T* d
 	}
 }
 
+template <typename T>
+static void launchPatConst(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                           const int* doneFlag, hipStream_t s) {
+	op &= ~SPMV_LEAVE_ROOM;
+	const int nTiles = (m->rows + TPB - 1) / TPB;
+	static const int perCU = [] {
+		const char* env = getenv("SMM_HIP_CONST_WGS_PER_CU");
+		return env ? std::max(1, atoi(env)) : 8;
+	}();
+	const int grid = std::max(1, std::min(std::min(nTiles, numCUs() * perCU), NPART));
+	// the tiles' deal to the XCDs: one span of the farthest diagonal (a grid plane) per XCD in turn when that is many tiles but a small
+	// part of the matrix -- the rule of buildRowBlocks (smm_spmv.hip) -- else one contiguous eighth each
+	int chunkTiles = 0;
+	const long long farTiles = m->pat_max_off / TPB;
+	if (farTiles >= 256 && farTiles * 32 <= nTiles) chunkTiles = static_cast<int>(farTiles);
+	if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) chunkTiles = std::max(0, atoi(env));
+	spmvPatternConstKernel<T><<<grid, TPB, 0, s>>>(m->rows, m->cols, m->pat_k, m->d_pat_off, m->d_pat_cval, m->d_pat_masks, chunkTiles, op | spmvOutFlags(m, sizeof(T)),
+	                                              lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+}
+
 template <typename T, int L>
 static void launchDict(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                        hipStream_t s) {
@@ -1160,6 +1351,12 @@ static void launchDict(const smm_hip_csr* m, int op, const T* lhs, const T* divi
 template <typename T, int L>
 static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                       hipStream_t s) {
+	if constexpr (L == 1) {
+		if (m->pat_encoding == 0 && m->pat_const && !m->pat_const_off) {  // constant diagonals: no values[] either (one lane per row only)
+			launchPatConst<T>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
+			return;
+		}
+	}
 	if (m->pat_encoding == 1) {  // the dictionary encoding: one kernel form for every L
 		launchDict<T, L>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
 		return;
@@ -1234,12 +1431,21 @@ template int launchSpmvPattern<double>(const smm_hip_csr*, int, const double*, c
 
 }  // namespace smm
 
+extern "C" int smm_hip_csr_pattern_allow_const(smm_hip_csr* m, int allow) {
+	if (!m) {
+		smm::setError("csr_pattern_allow_const: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	m->pat_const_off = allow == 0;
+	return SMM_HIP_OK;
+}
+
 extern "C" int smm_hip_csr_pattern_info(const smm_hip_csr* m, int* encoding, int* offsets) {
 	if (!m) {
 		smm::setError("csr_pattern_info: null matrix");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if (encoding) *encoding = m->pat_state > 0 ? (m->pat_encoding == 1 ? SMM_PATTERN_CODES : SMM_PATTERN_MASKS) : SMM_PATTERN_NONE;
+	if (encoding) *encoding = m->pat_state > 0 ? (m->pat_encoding == 1 ? SMM_PATTERN_CODES : m->pat_const && !m->pat_const_off ? SMM_PATTERN_CONST : SMM_PATTERN_MASKS) : SMM_PATTERN_NONE;
 	if (offsets) *offsets = m->pat_state > 0 ? m->pat_k : 0;
 	return SMM_HIP_OK;
 }

@@ -532,6 +532,13 @@ class _BlockView:
         _lib.check(_lib.load().smm_hip_csr_get_kernel(self._h, ctypes.byref(fam), ctypes.byref(lanes)))
         return fam.value, lanes.value
 
+    def pattern_info(self):
+        from . import _lib
+
+        enc, k = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().smm_hip_csr_pattern_info(self._h, ctypes.byref(enc), ctypes.byref(k)))
+        return enc.value, k.value
+
 
 class NativeDistMatrix:
     """smm_hip_dist_csr: this rank's rows of a row-partitioned matrix + the native solvers on it.  Collective."""
@@ -702,10 +709,15 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     families, b_true = None, b_local
     if driver == "native":
         blk_loc, blk_rem = A.local_blocks()
-        families = {"A_loc": blk_loc.get_kernel(), "A_rem": blk_rem.get_kernel()}
+        families = {"A_loc": blk_loc.get_kernel() + blk_loc.pattern_info()[:1], "A_rem": blk_rem.get_kernel() + blk_rem.pattern_info()[:1]}
         b_true = ext_len * s_bytes + (hi - lo) * s_bytes
         for name, nnz_blk in (("A_loc", A.nnz_loc), ("A_rem", A.nnz_rem)):
-            if families[name][0] == 3:
+            fam, lanes, enc = families[name]
+            if fam == 3 and enc == 3 and lanes == 1:  # constant diagonals: the row masks only
+                b_true += (hi - lo) * 8
+            elif fam == 3 and enc == 2:  # a 16-bit code per entry
+                b_true += nnz_blk * (s_bytes + 2) + (hi - lo + 1) * 4
+            elif fam == 3:  # row masks + values
                 b_true += nnz_blk * s_bytes + (hi - lo) * 8 + (hi - lo + 1) * 4
             else:
                 b_true += nnz_blk * (s_bytes + 4) + (hi - lo + 1) * 4
@@ -718,7 +730,7 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
                      "kernel": ("spmvPatternTileKernel / spmvTileKernel" if pattern_used else "spmvTileKernel") +
                                " (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")"),
                      "algorithmic_bytes_per_launch": b_true, "csr_bytes_per_launch": b_local, "avg_launch_ms": matvec_s * 1e3,
-                     "launches": spmv_launches // per_matvec, "families": families,
+                     "launches": spmv_launches // per_matvec, "families": families,  # (family, lanes per row, PATTERN encoding) of each block
                      "note": "bytes = what the kernels that ran really move per matvec of rank 0 (a block AUTO moved to the PATTERN family has no positions[]); csr_bytes_per_launch is the SURVEY 8d formula"},
         "elapsed": elapsed,
         "iters": iters,

@@ -269,10 +269,15 @@ class CSRMatrix:
         return tuple(c.value for c in v)
 
     def pattern_info(self):
-        """(encoding, distinct offsets) of the PATTERN family for this matrix: encoding 0 none / not analysed, 1 row masks, 2 entry codes"""
+        """(encoding, distinct offsets) of the PATTERN family for this matrix: encoding 0 none / not analysed, 1 row masks, 2 entry
+        codes, 3 row masks + constant diagonals (no values[] read)"""
         enc, k = ctypes.c_int(), ctypes.c_int()
         check(_lib.load().smm_hip_csr_pattern_info(self._h, ctypes.byref(enc), ctypes.byref(k)))
         return enc.value, k.value
+
+    def pattern_allow_const(self, allow):
+        """False: a matrix with constant diagonals keeps reading values[] (measurements); same bits either way"""
+        check(_lib.load().smm_hip_csr_pattern_allow_const(self._h, 1 if allow else 0))
 
     def spmv_fused_dev(self, op, d_lhs, d_x, d_out, dot_mode, d_w1, d_partials, stream=None, finish=False):
         """SpMV with the dot products of the fresh out[] in its epilogue (dot_mode 1: out.w1; 2: out.out and out.w1).  finish=False:

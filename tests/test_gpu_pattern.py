@@ -304,6 +304,103 @@ def test_auto_selects_pattern_for_a_large_banded_matrix_and_keeps_the_bits(smm, 
     assert np.abs(xs - x_o).max() <= 3e-4 * np.abs(x_o).max()
 
 
+CONST = 3
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_constant_diagonals(smm, oracle, dtype):
+    """every diagonal holds one value (the Laplacians, constant-coefficient convection-diffusion): the CONST encoding reads no values[];
+    bit for bit the oracle's numbers with one lane per row (ref:1484-1499), STREAM's at more lanes (served by the mask kernels); a single
+    deviating value in a row the sampling does not look at sends the matrix back to the masks"""
+    rng = np.random.default_rng(31)
+    start, pos, val = gen.poisson2d(300, dtype=dtype)
+    odd = val.copy()
+    row = 44_441
+    odd[start[row] + 1] = dtype(-1.0000001) if dtype == np.float32 else -1.0000000000001  # one entry of one diagonal, one ulp-ish off
+    cases = {
+        "poisson2d_200": (gen.poisson2d(200, dtype=dtype), CONST),
+        "poisson2d_37x23": (gen.poisson2d(37, 23, dtype=dtype), CONST),
+        "stencil3d_40x9x21": (gen.stencil3d(40, 9, 21, 6.0, -1.25, -0.75, dtype=dtype), CONST),
+        "convdiff3d_17": (gen.convdiff3d(17, 0.3, dtype=dtype), CONST),
+        "banded_random_values": (gen.banded_random_spd(20_000, 12, 0x5EED, 4096, dtype=dtype), MASKS),
+        "poisson2d_300_one_value_off": ((start, pos, odd), MASKS),
+    }
+    for name, (csr, want_enc) in cases.items():
+        rows = len(csr[0]) - 1
+        A = smm.CSRMatrix(rows, rows, *csr)
+        x = rng.uniform(-1, 1, rows).astype(dtype)
+        lhs = rng.uniform(-1, 1, rows).astype(dtype)
+        A.set_kernel(PATTERN, 1)
+        assert A.pattern_info()[0] == want_enc, name
+        for op in (OP_ASSIGN, OP_ADD, OP_SUB):
+            ref = oracle.spmv(csr, op, lhs, x)
+            np.testing.assert_array_equal(run(A, op, lhs, x, rows, dtype), ref, err_msg=f"{name} op {op}")
+        if want_enc != CONST:
+            continue
+        # the same matrix on the mask kernel (values[] read): the same bits
+        A.pattern_allow_const(False)
+        assert A.pattern_info()[0] == MASKS
+        np.testing.assert_array_equal(run(A, OP_SUB, lhs, x, rows, dtype), oracle.spmv(csr, OP_SUB, lhs, x))
+        A.pattern_allow_const(True)
+        # two lanes per row: STREAM's bits (before both families' directly streamed tails)
+        A.set_kernel(STREAM, 2)
+        want = run(A, OP_ADD, lhs, x, rows, dtype)
+        A.set_kernel(PATTERN, 2)
+        got = run(A, OP_ADD, lhs, x, rows, dtype)
+        body = csr[0][1:] <= csr[0][-1] - 8200
+        np.testing.assert_array_equal(got[body], want[body], err_msg=name)
+    # inside the solvers (Jacobi folded into the rows: the divide epilogue; CG: the fused dots) against the oracle
+    from oracle.oracle import PRECOND_JACOBI
+
+    csr = gen.convdiff3d(17, 0.3, dtype=dtype)
+    rows = len(csr[0]) - 1
+    A = smm.CSRMatrix(rows, rows, *csr)
+    A.set_kernel(PATTERN, 1)
+    assert A.pattern_info()[0] == CONST
+    b = oracle.spmv(csr, OP_ASSIGN, None, rng.uniform(0.5, 1.5, rows).astype(dtype))
+    xs = np.zeros(rows, dtype=dtype)
+    info = {}
+    st = smm.BiCGStab(A, b, xs, 4, dtype(1e-30), A.getPreconditioner(smm.SolverPreconditioner.JACOBI), info=info)
+    st_o, x_o, it_o, _ = oracle.bicgstab(csr, b, np.zeros(rows, dtype=dtype), 4, dtype(1e-30), PRECOND_JACOBI, oracle.jacobi_setup(csr)[1])
+    assert int(st) == st_o and info["iterations"] == it_o == 4
+    assert np.abs(xs - x_o).max() <= (3e-4 if dtype == np.float32 else 1e-10) * np.abs(x_o).max()
+
+
+def test_constant_diagonals_at_scale(smm, oracle):
+    """4.8 M rows of a 3-D stencil (512 x 256 x 37; AUTO: >= 2^25 entries): CONST chosen on the first SpMV, the reference's bits, the
+    fused dot products finished inside the launch"""
+    import torch
+
+    dev = torch.device("cuda:0")
+    nx, ny, nz, dtype = 512, 256, 37, np.float64
+    n = nx * ny * nz
+    nnz = smm.host.gen_stencil3d_nnz(nx, ny, nz)
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    smm.host.gen_stencil3d_dev(nx, ny, nz, 6.0, -1.25, -0.75, d_start, d_pos, d_val, dtype, stream)
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, dtype)
+    x = torch.rand(n, dtype=torch.float64, device=dev) - 0.5
+    lhs = torch.rand(n, dtype=torch.float64, device=dev) - 0.5
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    A.spmv_dev(OP_SUB, lhs, x, y, stream)
+    torch.cuda.synchronize()
+    assert A.get_kernel() == (PATTERN, 1) and A.pattern_info() == (CONST, 7)
+    csr = (d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy())
+    np.testing.assert_array_equal(y.cpu().numpy(), oracle.spmv(csr, OP_SUB, lhs.cpu().numpy(), x.cpu().numpy()))
+    fin = torch.zeros(smm.host.finish_len(), dtype=torch.float64, device=dev)
+    A.spmv_fused_dev(OP_ASSIGN, None, x, y, 2, x, fin, stream, finish=True)
+    torch.cuda.synchronize()
+    ref = oracle.spmv(csr, OP_ASSIGN, None, x.cpu().numpy())
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    off = smm.host.finish_totals_offset()
+    totals = fin.cpu().numpy()
+    xs = x.cpu().numpy()
+    assert abs(totals[off] - float(ref @ ref)) <= 1e-10 * float(ref @ ref)
+    assert abs(totals[off + 1] - float(ref @ xs)) <= 1e-10 * float(np.abs(ref * xs).sum())
+
+
 def test_auto_keeps_stream_for_a_large_matrix_without_a_pattern(smm):
     """i.i.d. columns (SURVEY.md section 8d's secondary matrix): far more than 64 offsets -- AUTO's attempt is refused quietly, the
     matrix stays with STREAM and the result is right"""

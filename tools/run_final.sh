@@ -18,6 +18,6 @@ import json,os
 d=json.load(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/final_bench.json"))
 print("value",d["value"],"roofline",d["roofline"]["frac"],d["roofline"]["traffic"],"stream",d.get("stream_family",{}).get("value"),"auto frac",d.get("auto_family",{}).get("frac"))
 e=d["extras"]["bicgstab_convdiff108_f64"]
-print({k:(round(v["create_plus_solve_ms"],2),v["iterations"],round(v.get("apply_us",0),1)) for k,v in e.items() if isinstance(v,dict)})
+print({k:(round(v["create_plus_solve_ms"],2),v["iterations"],round(v.get("apply_us",0),1)) for k,v in e.items() if isinstance(v,dict) and "iterations" in v})
 print(d["extras"]["spmv_laplacian512_f64"])
 PY
