@@ -14,6 +14,8 @@
 // turns the automatic choice off.  bench.py's roofline stays defined on the reference's layout (values + positions + start,
 // SURVEY.md section 8d) and on the STREAM kernel; what this family moves is reported beside it with its true byte count.
 //
+// When every diagonal of such a matrix holds ONE value (constant-coefficient stencils: the Laplacians) values[] is redundant too: the
+// CONST encoding further down reads the row's mask, x and <= 32 numbers.
 // Matrices the masks cannot describe (more than 64 offsets, rows of more than 64 entries) but whose entries use <= 65 536 distinct
 // offsets get the CODES encoding instead: a 16-bit dictionary index per entry (further down: "DICTIONARY encoding").
 //
