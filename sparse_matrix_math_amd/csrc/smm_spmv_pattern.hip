@@ -1240,6 +1240,7 @@ int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream
 	if (st == SMM_HIP_OK) {
 		mm->family = SMM_SPMV_PATTERN;
 		mm->lanes = avg <= 24 ? 1 : avg <= 64 ? 2 : avg <= 128 ? 4 : 8;  // (the PATTERN rule of smm_spmv.hip's lanesForAvg)
+		if (mm->pat_encoding == 0 && mm->pat_const) mm->lanes = 1;  // constant diagonals (<= 32 entries per row): the kernel without values[] is the one-lane one
 		return SMM_HIP_OK;
 	}
 	return st == SMM_HIP_ERR_INVALID ? static_cast<int>(SMM_HIP_OK) : st;  // "no pattern" is not a failure
