@@ -1309,13 +1309,14 @@ static void launchPatTile(const smm_hip_csr* m, int op, const T* lhs, const T* d
 template <typename T>
 static void launchPatConst(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                            const int* doneFlag, hipStream_t s) {
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();  // room for the RCCL kernel beside A_loc (smm_dist.hip)
 	op &= ~SPMV_LEAVE_ROOM;
 	const int nTiles = (m->rows + TPB - 1) / TPB;
 	static const int perCU = [] {
 		const char* env = getenv("SMM_HIP_CONST_WGS_PER_CU");
 		return env ? std::max(1, atoi(env)) : 8;
 	}();
-	const int grid = std::max(1, std::min(std::min(nTiles, numCUs() * perCU), NPART));
+	const int grid = std::max(1, std::min(std::min(nTiles, cus * perCU), NPART));
 	// the tiles' deal to the XCDs: one span of the farthest diagonal (a grid plane) per XCD in turn when that is many tiles but a small
 	// part of the matrix -- the rule of buildRowBlocks (smm_spmv.hip) -- else one contiguous eighth each
 	int chunkTiles = 0;
@@ -1329,6 +1330,7 @@ static void launchPatConst(const smm_hip_csr* m, int op, const T* lhs, const T* 
 template <typename T, int L>
 static void launchDict(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
                        hipStream_t s) {
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 	op &= ~SPMV_LEAVE_ROOM;
 	constexpr int LW = L > WAVE ? WAVE : L;
 	constexpr int RT = (WAVE / LW) * (TPB / WAVE);
@@ -1339,7 +1341,7 @@ static void launchDict(const smm_hip_csr* m, int op, const T* lhs, const T* divi
 	int perCU = 0;
 	const void* fn = dlds ? reinterpret_cast<const void*>(spmvDictKernel<T, L, true>) : reinterpret_cast<const void*>(spmvDictKernel<T, L, false>);
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
-	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, numCUs() * perCU), NPART));
+	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, cus * perCU), NPART));
 	const int flags = op | spmvOutFlags(m, sizeof(T));
 	const int2* tiles = reinterpret_cast<const int2*>(m->d_pat_rowblocks);
 	if (dlds) {
@@ -1370,6 +1372,7 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 			return;
 		}
 	}
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 	op &= ~SPMV_LEAVE_ROOM;
 	constexpr int LW = L > WAVE ? WAVE : L;
 	constexpr int RT = (WAVE / LW) * (TPB / WAVE);
@@ -1377,7 +1380,7 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 	const size_t lds = static_cast<size_t>(cap + PatCfg<T>::PAD) * sizeof(T) + RT * 8 + (RT + 4) * 4 + MAXOFF * 4 + 4 * sizeof(T) + 32;
 	int perCU = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
-	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, numCUs() * perCU), NPART));
+	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, cus * perCU), NPART));
 	spmvPatternKernel<T, L><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, m->cols, m->pat_k, m->d_pat_off, reinterpret_cast<const int2*>(m->d_pat_rowblocks),
 	                                             m->d_start, m->d_pat_masks, m->d_positions, static_cast<const T*>(m->d_values), op | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out, dotMode,
 	                                             w1, partials, doneFlag);
