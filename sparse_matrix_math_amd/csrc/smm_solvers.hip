@@ -150,34 +150,44 @@ __device__ __forceinline__ T sumPartsAll(const T* __restrict__ partials, T* red5
 	return v;
 }
 
-// alpha = rr / (Ap.p) ; x = alpha p + xcur ; r = -alpha Ap + r ; partial ||r||^2   (ref:2354-2375)
+// The two update kernels of a CG iteration (ref:2354-2394), split so that every vector is passed as few times as the data flow
+// allows: the first needs only Ap and r (r = -alpha Ap + r and ||r||^2 -- the next reduction point), the second reads p once for
+// BOTH of its uses (x = alpha p + xcur, the reference's :2362-2366, and p = beta p + r): 8 vector passes per iteration instead of
+// the 9 of "x and r, then p" (r03; config 4's iteration is two thirds vector updates since its SpMV reads no values[]).  Same
+// expressions on the same operands: same bits.
+// alpha = rr / (Ap.p) ; r = -alpha Ap + r ; partial ||r||^2.  sc->pad = the done flag as this iteration found it: the second kernel
+// decides by it (its own workgroup 0 raises `done` while other workgroups of the same launch may not have started yet).
 // (the vector loops of the fused kernels go through streamMap, smm_device.h: 16-byte accesses, 4 packs per lane in flight)
 template <typename T, bool NT>
-__global__ __launch_bounds__(TPB) void cgFusedXR(int n, const Scal<T>* __restrict__ sc, int par, const T* __restrict__ partsA, const T* p,
-                                                 const T* Ap, const T* xcur, T* x, T* r, T* __restrict__ partsC) {
+__global__ __launch_bounds__(TPB) void cgFusedR(int n, Scal<T>* sc, int par, const T* __restrict__ partsA, const T* Ap, T* r,
+                                                T* __restrict__ partsC) {
 	__shared__ T red[5];
-	if (sc->done) return;
+	const int done = sc->done;
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->pad = done;
+	if (done) return;
 	const T alpha = sc->rrPing[par] / sumPartsAll(partsA, red);
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
 	T acc = T(0);
-	const T* const in[4] = {p, xcur, Ap, r};
-	T* const out[2] = {x, r};
-	streamMap<T, NT, 4, 2>(n, in, out, [&](const T(&v)[4], T(&o)[2]) {
-		o[0] = smmFma(alpha, v[0], v[1]);
-		const T ri = smmFma(-alpha, v[2], v[3]);
-		o[1] = ri;
+	const T* const in[2] = {Ap, r};
+	T* const out[1] = {r};
+	streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) {
+		const T ri = smmFma(-alpha, v[0], v[1]);
+		o[0] = ri;
 		acc += ri * ri;
 	});
 	const T s = blockSum256(acc, red);
 	if (threadIdx.x == 0) partsC[blockIdx.x] = s;
 }
 
-// convergence test, beta, p = beta p + r   (ref:2377-2394)
+// x = alpha p + xcur ; convergence test ; beta ; p = beta p + r   (ref:2362-2394: x is updated before the test, p only when the loop goes on)
 template <typename T, bool NT>
-__global__ __launch_bounds__(TPB) void cgFusedP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, T* p, const T* r) {
+__global__ __launch_bounds__(TPB) void cgFusedXP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, T* p, const T* r, const T* xcur,
+                                                 T* x) {
 	__shared__ T red[5];
-	if (sc->done) return;
+	if (sc->pad) return;
 	const T rrNew = sumPartsAll(partsC, red);
 	const T rrOld = sc->rrPing[par];
+	const T alpha = sc->alpha;
 	const bool converged = eps * eps > rrNew;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		sc->iters += 1;
@@ -189,11 +199,19 @@ __global__ __launch_bounds__(TPB) void cgFusedP(int n, Scal<T>* sc, int par, con
 			sc->rrPing[par ^ 1] = rrNew;
 		}
 	}
-	if (converged) return;
+	if (converged) {
+		const T* const in[2] = {p, xcur};
+		T* const out[1] = {x};
+		streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(alpha, v[0], v[1]); });
+		return;
+	}
 	const T beta = rrNew / rrOld;
-	const T* const in[2] = {p, r};
-	T* const out[1] = {p};
-	streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
+	const T* const in[3] = {p, xcur, r};
+	T* const out[2] = {x, p};
+	streamMap<T, NT, 3, 2>(n, in, out, [&](const T(&v)[3], T(&o)[2]) {
+		o[0] = smmFma(alpha, v[0], v[1]);
+		o[1] = smmFma(beta, v[0], v[2]);
+	});
 }
 
 // alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247)
@@ -490,8 +508,8 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			cgUpdateP<T><<<g, TPB, 0, s>>>(n, sc, p, z);
 		} else {
 			// alpha and beta are formed inside the two update kernels (no scalar launches)
-			SMM_LAUNCH_UPDATE(cgFusedXR, updateNT(n, sizeof(T), 6), NPART, s, n, sc, i & 1, parts, p, Ap, xcur, x, r, parts2);
-			SMM_LAUNCH_UPDATE(cgFusedP, updateNT(n, sizeof(T), 3), g, s, n, sc, i & 1, parts2, eps, p, r);
+			SMM_LAUNCH_UPDATE(cgFusedR, updateNT(n, sizeof(T), 3), NPART, s, n, sc, i & 1, parts, Ap, r, parts2);
+			SMM_LAUNCH_UPDATE(cgFusedXP, updateNT(n, sizeof(T), 5), g, s, n, sc, i & 1, parts2, eps, p, r, xcur, x);
 		}
 	}
 	SMM_HIP_TRY(hipGetLastError());
