@@ -775,7 +775,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstKernel(int rows, int cols
 // in place of the row masks: same lanes, same products, same order, same bits as the STREAM family at equal lanes.
 constexpr int DICT_MAX = 65536;
 constexpr int DICT_HCAP = 1 << 18;    // open-addressing table of the offsets seen (<= 25 % full)
-constexpr int DICT_LDS_MAX = 4096;    // dictionaries up to this size are copied to LDS by every workgroup, larger ones stay in L2
+constexpr int DICT_LDS_MAX = 2048;    // dictionaries up to this size are copied to LDS by every workgroup (the kernel stays below 64 KB of LDS), larger ones stay in L2
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T>

@@ -141,7 +141,7 @@ def test_masks_give_way_to_codes(smm, oracle):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_codes_match_oracle_and_stream(smm, oracle, dtype):
     """the dictionary encoding (> 64 offsets): every lane count and operation against STREAM bit for bit, one lane per row against the
-    oracle bit for bit (ref:1484-1499); dictionaries that live in LDS (<= 4096 offsets) and in global memory"""
+    oracle bit for bit (ref:1484-1499); dictionaries that live in LDS (<= 2048 offsets) and in global memory"""
     rng = np.random.default_rng(8)
     big = gen.random_rows(6000, 6000, 3, 40, seed=21, dtype=dtype)
     cases = {
@@ -150,6 +150,8 @@ def test_codes_match_oracle_and_stream(smm, oracle, dtype):
         "random_6000": (big, 6000),                                               # ~ 11 000 offsets: dictionary in global memory
         "ragged_with_empty_rows": (gen.random_rows(3000, 2500, 0, 130, seed=5, dtype=dtype, empty_every=7), 2500),
         "70_entries_in_the_only_row": (gen.random_rows(1, 400, 70, 70, seed=1, dtype=dtype), 400),
+        # ~ 1900 offsets (a dictionary in LDS close to its limit) with rows of 60-64 entries (the largest tiles): the kernel's LDS budget
+        "long_rows_large_lds_dictionary": (gen.random_rows(4000, 1000, 60, 64, seed=17, dtype=dtype), 1000),
     }
     for name, (csr, cols) in cases.items():
         rows = len(csr[0]) - 1
@@ -164,7 +166,7 @@ def test_codes_match_oracle_and_stream(smm, oracle, dtype):
             continue
         assert enc == CODES, name
         if name == "random_6000":
-            assert k > 4096
+            assert k > 2048
         for op in (OP_ASSIGN, OP_ADD, OP_SUB):
             ref = oracle.spmv(csr, op, lhs, x)
             for lanes in (1, 2, 4, 8):
