@@ -151,7 +151,7 @@ def test_codes_match_oracle_and_stream(smm, oracle, dtype):
         "ragged_with_empty_rows": (gen.random_rows(3000, 2500, 0, 130, seed=5, dtype=dtype, empty_every=7), 2500),
         "70_entries_in_the_only_row": (gen.random_rows(1, 400, 70, 70, seed=1, dtype=dtype), 400),
         # ~ 1900 offsets (a dictionary in LDS close to its limit) with rows of 60-64 entries (the largest tiles): the kernel's LDS budget
-        "long_rows_large_lds_dictionary": (gen.random_rows(4000, 1000, 60, 64, seed=17, dtype=dtype), 1000),
+        "long_rows_large_lds_dictionary": (gen.random_rows(1000, 1000, 60, 64, seed=17, dtype=dtype), 1000),
     }
     for name, (csr, cols) in cases.items():
         rows = len(csr[0]) - 1
