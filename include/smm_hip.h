@@ -249,6 +249,18 @@ int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows,
  * 2 .. 4095.  The rule is a recurrence in the sweep's own row order; the tests' CPU checker states it sequentially
  * (block_level_cut) and the device result is compared with it bit for bit.  smm_hip_precond_create / _create_block use the default. */
 int smm_hip_precond_create_block_capped(const smm_hip_csr* a, int kind, int block_rows, int level_cap, smm_hip_precond** out);
+/* ... and a chosen PARTITION.  CONTIGUOUS: blocks are runs of consecutive rows (cut greedily from row 0).  BRICKS: for a matrix that is
+ * a 2-D / 3-D grid stencil in natural order -- its entries use the offsets {0, +-1, +-nx[, +-nx ny]}, found and verified by the PATTERN
+ * analysis -- the blocks are bricks of the grid (16 x 8 x 8 points for 1024 rows; squares in 2-D), so that M keeps the couplings of all
+ * grid directions inside a block; the rows of a block keep their natural order.  Any other matrix: SMM_HIP_ERR_INVALID.  AUTO (what
+ * every other create call uses): bricks where they apply, contiguous otherwise (SMM_HIP_BLOCK_BRICKS=0: always contiguous).
+ * smm_hip_precond_block_rows returns the rows block by block (order[bounds[b] .. bounds[b+1]) are block b's rows; the identity for
+ * contiguous blocks) and the brick's extent along the grid axes ({0, 0, 0} for contiguous blocks); either pointer may be NULL. */
+#define SMM_BLOCKS_AUTO 0
+#define SMM_BLOCKS_CONTIGUOUS 1
+#define SMM_BLOCKS_BRICKS 2
+int smm_hip_precond_create_block_ex(const smm_hip_csr* a, int kind, int block_rows, int level_cap, int partition, smm_hip_precond** out);
+int smm_hip_precond_block_rows(const smm_hip_precond* M, int* order, size_t count, int* brick);
 int smm_hip_precond_block_level_cap(const smm_hip_precond* M, int* level_cap);
 int smm_hip_precond_block_count(const smm_hip_precond* M, int* nblocks);
 int smm_hip_precond_block_bounds(const smm_hip_precond* M, int* bounds, size_t count);

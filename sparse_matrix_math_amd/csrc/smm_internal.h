@@ -125,6 +125,7 @@ struct smm_hip_csr {
 	unsigned long long* d_pat_cval = nullptr;
 	bool pat_const_off = false;  // smm_hip_csr_pattern_allow_const(m, 0): keep reading values[] (A/B measurements)
 	int pat_max_off = 0;  // largest |column - row| of the offset list
+	std::vector<int> pat_offs_host;  // MASKS: the sorted offsets (host copy: the brick partition of the block preconditioners reads the grid from them)
 	int pat_k = 0;
 	int* d_pat_off = nullptr;
 	unsigned long long* d_pat_masks = nullptr;
@@ -305,7 +306,7 @@ int precondTakeError(const smm_hip_precond* M, hipStream_t s);
 // block preconditioners (smm_precond_block.hip)
 inline bool isBlockKind(int kind) { return kind == SMM_PRECOND_BLOCK_ILU0 || kind == SMM_PRECOND_BLOCK_SGS; }
 template <typename T>
-int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap, smm_hip_precond* M);
+int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap, int partition, smm_hip_precond* M);
 // x = M^-1 rhs; dotMode / w1 / partials: dot products of x fused into the epilogue, as in launchSpmv (partials: 2 * NPART elements)
 template <typename T>
 int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s);

@@ -1033,7 +1033,7 @@ using namespace smm;
 
 extern "C" {
 
-static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, int levelCap, smm_hip_precond** out) {
+static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, int levelCap, int partition, smm_hip_precond** out) {
 	if (!a || !out) {
 		setError("precond_create: null argument");
 		return SMM_HIP_ERR_INVALID;
@@ -1051,7 +1051,7 @@ static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, int leve
 	M->a = a;
 	int st = SMM_HIP_OK;
 	if (isBlockKind(kind)) {
-		st = a->dtype == SMM_DTYPE_F32 ? blockCreateTyped<float>(a, kind, blockRows, levelCap, M) : blockCreateTyped<double>(a, kind, blockRows, levelCap, M);
+		st = a->dtype == SMM_DTYPE_F32 ? blockCreateTyped<float>(a, kind, blockRows, levelCap, partition, M) : blockCreateTyped<double>(a, kind, blockRows, levelCap, partition, M);
 	} else if (kind != SMM_PRECOND_NONE) {
 		st = a->dtype == SMM_DTYPE_F32 ? createTyped<float>(a, kind, M) : createTyped<double>(a, kind, M);
 	}
@@ -1063,7 +1063,7 @@ static int precondCreate(const smm_hip_csr* a, int kind, int blockRows, int leve
 	return SMM_HIP_OK;
 }
 
-int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out) { return precondCreate(a, kind, blockDefaultRows(), blockDefaultLevelCap(), out); }
+int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out) { return precondCreate(a, kind, blockDefaultRows(), blockDefaultLevelCap(), SMM_BLOCKS_AUTO, out); }
 
 int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows, smm_hip_precond** out) {
 	if (!isBlockKind(kind)) {
@@ -1074,23 +1074,35 @@ int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows,
 		setError("precond_create_block: block_rows must be 0 (default) or 64 .. 2048");
 		return SMM_HIP_ERR_INVALID;
 	}
-	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), blockDefaultLevelCap(), out);
+	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), blockDefaultLevelCap(), SMM_BLOCKS_AUTO, out);
 }
 
-int smm_hip_precond_create_block_capped(const smm_hip_csr* a, int kind, int block_rows, int level_cap, smm_hip_precond** out) {
+static int createBlockChecked(const char* who, const smm_hip_csr* a, int kind, int block_rows, int level_cap, int partition, smm_hip_precond** out) {
 	if (!isBlockKind(kind)) {
-		setError("precond_create_block_capped: kind %d is not a block preconditioner", kind);
+		setError("%s: kind %d is not a block preconditioner", who, kind);
 		return SMM_HIP_ERR_INVALID;
 	}
 	if (block_rows != 0 && (block_rows < 64 || block_rows > 2048)) {
-		setError("precond_create_block_capped: block_rows must be 0 (default) or 64 .. 2048");
+		setError("%s: block_rows must be 0 (default) or 64 .. 2048", who);
 		return SMM_HIP_ERR_INVALID;
 	}
 	if (level_cap < -1 || level_cap == 1 || level_cap > 4095) {
-		setError("precond_create_block_capped: level_cap must be -1 (default), 0 (no cut) or 2 .. 4095");
+		setError("%s: level_cap must be -1 (default), 0 (no cut) or 2 .. 4095", who);
 		return SMM_HIP_ERR_INVALID;
 	}
-	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), level_cap < 0 ? blockDefaultLevelCap() : level_cap, out);
+	if (partition < SMM_BLOCKS_AUTO || partition > SMM_BLOCKS_BRICKS) {
+		setError("%s: partition must be SMM_BLOCKS_AUTO, _CONTIGUOUS or _BRICKS", who);
+		return SMM_HIP_ERR_INVALID;
+	}
+	return precondCreate(a, kind, block_rows ? block_rows : blockDefaultRows(), level_cap < 0 ? blockDefaultLevelCap() : level_cap, partition, out);
+}
+
+int smm_hip_precond_create_block_capped(const smm_hip_csr* a, int kind, int block_rows, int level_cap, smm_hip_precond** out) {
+	return createBlockChecked("precond_create_block_capped", a, kind, block_rows, level_cap, SMM_BLOCKS_AUTO, out);
+}
+
+int smm_hip_precond_create_block_ex(const smm_hip_csr* a, int kind, int block_rows, int level_cap, int partition, smm_hip_precond** out) {
+	return createBlockChecked("precond_create_block_ex", a, kind, block_rows, level_cap, partition, out);
 }
 
 int smm_hip_precond_destroy(smm_hip_precond* M) {

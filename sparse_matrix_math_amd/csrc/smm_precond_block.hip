@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "smm_device.h"
@@ -36,7 +37,10 @@ struct smm_precond_block {
 	int levelsLo = 0, levelsUp = 0;  // deepest block
 	int maxInBlock = 0;              // most in-block entries of a block
 	long long nChunks = 0;
-	int2* d_bounds = nullptr;  // [nBlocks + 1] {first row, start[first row]}
+	int2* d_bounds = nullptr;  // [nBlocks + 1] {first row (contiguous) / first position in d_rowOrder (bricks), unused}
+	int* d_rowOrder = nullptr; // bricks: the rows block by block, ascending inside a block; nullptr = contiguous blocks
+	int* d_invOrder = nullptr; // bricks: row -> position in d_rowOrder
+	int brick[3] = {0, 0, 0};  // bricks: rows of a brick along each grid axis
 	int* d_chunk0 = nullptr;   // [nBlocks + 1] chunks in front of block b
 	unsigned* d_recLo = nullptr;
 	unsigned* d_recUp = nullptr;
@@ -104,6 +108,7 @@ template <typename T>
 struct BlkApplyArgs {
 	int nBlocks;
 	const int2* bounds;
+	const int* rowOrder;  // nullptr: block b = rows [bounds[b], bounds[b+1]); else rows rowOrder[bounds[b] .. bounds[b+1])
 	const int* chunk0;
 	const unsigned* recLo;
 	const unsigned* recUp;
@@ -268,16 +273,17 @@ __global__ __launch_bounds__(WAVE) void blkApplyKernel(const BlkApplyArgs<T> a) 
 		SweepRing<T, UP, KREG, D> ringUp;
 		ringLo.prologue(a.recLo + rec0 * LL::DW, nc);
 		ringUp.prologue(a.recUp + rec0 * LU::DW, nc);  // (in flight across the whole lower sweep)
-		for (int i = lane; i < nb; i += WAVE) xs[i] = a.rhs[r0 + i];
+		for (int i = lane; i < nb; i += WAVE) xs[i] = a.rhs[a.rowOrder ? a.rowOrder[r0 + i] : r0 + i];
 		blkSweep<T, LO, KREG, OV, D>(ringLo, rec0, nc, xs, a.ovPtrLo, a.ovColLo, a.ovValLo);
 		blkSweep<T, UP, KREG, OV, D>(ringUp, rec0, nc, xs, a.ovPtrUp, a.ovColUp, a.ovValUp);
 		if (a.dotMode == 0) {
-			for (int i = lane; i < nb; i += WAVE) a.x[r0 + i] = xs[i];
+			for (int i = lane; i < nb; i += WAVE) a.x[a.rowOrder ? a.rowOrder[r0 + i] : r0 + i] = xs[i];
 		} else {
 			for (int i = lane; i < nb; i += WAVE) {
 				const T v = xs[i];
-				a.x[r0 + i] = v;
-				const T w = a.w1[r0 + i];
+				const int g = a.rowOrder ? a.rowOrder[r0 + i] : r0 + i;
+				a.x[g] = v;
+				const T w = a.w1[g];
 				if (a.dotMode == 2) {
 					acc0 += v * v;
 					acc1 += v * w;
@@ -361,10 +367,22 @@ __device__ __forceinline__ bool blkKeeps(int i, int c, const unsigned short* lvl
 	return static_cast<int>(c < i ? lvlLo[c] : lvlUp[c]) < top;
 }
 
+// Which rows form a block.  CONTIGUOUS (rowOrder == nullptr): block b = rows [p0, p0 + nb).  PERMUTED (bricks of a grid, r03): block b =
+// rows rowOrder[p0 .. p0 + nb) -- ascending inside a block, so a block's rows keep their natural order -- and invOrder[] is the inverse
+// map (row -> position).  Local index of row / column g: its position - p0; it belongs to the block when that lies in [0, nb).
+struct BlkRows {
+	const int* rowOrder;
+	const int* invOrder;
+	__device__ __forceinline__ int rowAt(int p) const { return rowOrder ? rowOrder[p] : p; }
+	__device__ __forceinline__ int posOf(int g) const { return invOrder ? invOrder[g] : g; }
+};
+
 // returns bit 0: some row of this thread has no diagonal entry (or is empty), bit 1 (checkMagnitude): |d| < 1e-5; fills st.lptr / ibG / nlow / lcol (and lval when LVAL is not null).
-// top > 0: the entries the level cut drops (levels of both sweeps in lvlLo / lvlUp) are not staged.
+// Staged: the entries of the block's rows whose column belongs to the block, columns local, in the row's own (ascending) order; top > 0:
+// minus the entries the level cut drops (levels of both sweeps in lvlLo / lvlUp).  st.ibG[i] = first stored entry of local row i,
+// st.nall[i] = its stored entries (all of them: the factor write-back walks the row again with the same tests).
 template <typename T>
-__device__ int stageBlock(const BlkStage& st, T* lval, int r0, int nb, const int* __restrict__ start, const int* __restrict__ positions,
+__device__ int stageBlock(const BlkStage& st, T* lval, const BlkRows& br, int p0, int nb, const int* __restrict__ start, const int* __restrict__ positions,
                           const T* __restrict__ vals, int* scanScratch, int checkMagnitude = 0, const unsigned short* lvlLo = nullptr,
                           const unsigned short* lvlUp = nullptr, int top = 0) {
 	constexpr int RPT = BLK_MAX_ROWS / BLK_TPB;  // 8 consecutive rows per thread
@@ -378,17 +396,16 @@ __device__ int stageBlock(const BlkStage& st, T* lval, int r0, int nb, const int
 		all[j] = 0;
 		ib[j] = 0;
 		if (i < nb) {
-			const int b = start[r0 + i], e = start[r0 + i + 1];
-			const int lo = lowerBoundCol(positions, b, e, r0);
-			const int hi = lowerBoundCol(positions, lo, e, r0 + nb);
-			ib[j] = lo;
-			all[j] = hi - lo;
-			cnt[j] = hi - lo;
-			if (top > 0) {
-				int kept = 0;
-				for (int k = lo; k < hi; ++k) kept += blkKeeps(i, positions[k] - r0, lvlLo, lvlUp, top) ? 1 : 0;
-				cnt[j] = kept;
+			const int g = br.rowAt(p0 + i);
+			const int b = start[g], e = start[g + 1];
+			ib[j] = b;
+			all[j] = e - b;
+			int kept = 0;
+			for (int k = b; k < e; ++k) {
+				const int c = br.posOf(positions[k]) - p0;
+				kept += (static_cast<unsigned>(c) < static_cast<unsigned>(nb) && blkKeeps(i, c, lvlLo, lvlUp, top)) ? 1 : 0;
 			}
+			cnt[j] = kept;
 		}
 		mine += cnt[j];
 	}
@@ -401,12 +418,12 @@ __device__ int stageBlock(const BlkStage& st, T* lval, int r0, int nb, const int
 		if (i < nb) {
 			st.lptr[i] = at;
 			st.ibG[i] = ib[j];
-			if (st.nall) st.nall[i] = static_cast<unsigned short>(all[j]);
+			if (st.nall) st.nall[i] = static_cast<unsigned short>(min(all[j], 0xFFFF));
 			int low = 0, q = 0;
 			bool diag = false;
 			for (int e = 0; e < all[j]; ++e) {
-				const int c = positions[ib[j] + e] - r0;
-				if (!blkKeeps(i, c, lvlLo, lvlUp, top)) continue;
+				const int c = br.posOf(positions[ib[j] + e]) - p0;
+				if (static_cast<unsigned>(c) >= static_cast<unsigned>(nb) || !blkKeeps(i, c, lvlLo, lvlUp, top)) continue;
 				st.lcol[at + q] = static_cast<unsigned short>(c);
 				if (lval) lval[at + q] = vals[ib[j] + e];
 				++q;
@@ -519,7 +536,7 @@ static size_t carveSize(size_t bytes) { return (bytes + 15) & ~static_cast<size_
 // info: [0] most lower entries of a row, [1] most upper entries, [2] error bits (1: empty row / missing diagonal, 2: |d| < 1e-5 for
 // SGS), [3] deepest lower sweep, [4] deepest upper sweep (levels), [5] most in-block entries of a block
 template <typename T>
-__global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap, int top, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
+__global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap, int top, const int2* __restrict__ bounds, BlkRows br, const int* __restrict__ chunk0,
                                                            const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
                                                            int checkMagnitude, unsigned* __restrict__ metaLo, unsigned* __restrict__ metaUp,
                                                            unsigned short* __restrict__ nEntLo, unsigned short* __restrict__ nEntUp, int* info) {
@@ -544,7 +561,7 @@ __global__ __launch_bounds__(BLK_TPB) void blkAnalyzeKernel(int maxRows, int cap
 	const long long rec0 = static_cast<long long>(chunk0[b]) * WAVE;
 	const int t = threadIdx.x;
 
-	const int bad = stageBlock<T>(st, nullptr, r0, nb, start, positions, vals, scanScratch, checkMagnitude);
+	const int bad = stageBlock<T>(st, nullptr, br, r0, nb, start, positions, vals, scanScratch, checkMagnitude);
 	if (bad) atomicOr(info + 2, bad);
 	if (t == 0) atomicMax(info + 5, st.lptr[nb]);  // the most in-block entries of any block: sizes the LDS of the factor / pack kernel
 	for (int i = t; i < nb; i += BLK_TPB) {
@@ -651,7 +668,7 @@ __device__ __forceinline__ bool blkIluRow(const BlkStage& st, T* lval, T* pinv, 
 
 // factorise (ILU0) and write the records of both sweeps.  err: bit 2 = zero / tiny pivot.
 template <typename T, int KIND, int KREG, bool OV>
-__global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, int top, const int2* __restrict__ bounds, const int* __restrict__ chunk0,
+__global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, int top, const int2* __restrict__ bounds, BlkRows br, const int* __restrict__ chunk0,
                                                         const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ vals,
                                                         const unsigned* __restrict__ metaLo, const unsigned* __restrict__ metaUp, T* __restrict__ lu,
                                                         unsigned* __restrict__ recLo, unsigned* __restrict__ recUp, const int* __restrict__ ovPtrLo,
@@ -687,7 +704,7 @@ __global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, i
 		}
 		__syncthreads();
 	}
-	stageBlock<T>(st, lval, r0, nb, start, positions, vals, scanScratch, 0, lvlLo, lvlUp, top);  // (the analysis kernel has already vetted the structure)
+	stageBlock<T>(st, lval, br, r0, nb, start, positions, vals, scanScratch, 0, lvlLo, lvlUp, top);  // (the analysis kernel has already vetted the structure)
 	if (ILU) {
 		if (t < WAVE) {
 			bool allOk = true;
@@ -706,12 +723,13 @@ __global__ __launch_bounds__(BLK_TPB) void blkPackKernel(int maxRows, int cap, i
 		}
 		__syncthreads();
 		// the factor on A's pattern (smm_hip_precond_values): in-block entries only, the rest keeps A's value
-		// (entries the level cut dropped keep A's value too)
+		// (entries of other blocks and entries the level cut dropped keep A's value)
 		for (int i = t; i < nb; i += BLK_TPB) {
 			const int g = st.ibG[i], l = st.lptr[i], all = st.nall[i];
 			int q = 0;
 			for (int e = 0; e < all; ++e) {
-				if (blkKeeps(i, positions[g + e] - r0, lvlLo, lvlUp, top)) lu[g + e] = lval[l + q++];
+				const int c = br.posOf(positions[g + e]) - r0;
+				if (static_cast<unsigned>(c) < static_cast<unsigned>(nb) && blkKeeps(i, c, lvlLo, lvlUp, top)) lu[g + e] = lval[l + q++];
 			}
 		}
 	}
@@ -805,7 +823,7 @@ static int packTyped(const smm_hip_csr* a, smm_hip_precond* M, const unsigned* m
 	const size_t lds = packLds<T>(B->blockRows, cap);
 	auto kernel = blkPackKernel<T, KIND, KREG, OV>;
 	SMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-	kernel<<<B->nBlocks, BLK_TPB, lds, s>>>(B->blockRows, cap, B->levelCap > 0 ? B->levelCap - 1 : 0, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
+	kernel<<<B->nBlocks, BLK_TPB, lds, s>>>(B->blockRows, cap, B->levelCap > 0 ? B->levelCap - 1 : 0, B->d_bounds, BlkRows{B->d_rowOrder, B->d_invOrder}, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
 	                                       metaLo, metaUp, static_cast<T*>(M->d_values), B->d_recLo, B->d_recUp, B->d_ovPtrLo, B->d_ovPtrUp, B->d_ovColLo,
 	                                       B->d_ovColUp, static_cast<T*>(B->d_ovValLo), static_cast<T*>(B->d_ovValUp), d_info);
 	SMM_HIP_TRY(hipGetLastError());
@@ -833,8 +851,122 @@ static int exclusiveScanInPlace(int* d, size_t n, hipStream_t s) {
 	return SMM_HIP_OK;
 }
 
+// ---- the BRICK partition (r03) ----------------------------------------------------------------------------------------------
+// Contiguous row blocks of a 3-D grid in natural order are a few grid LINES of one plane: every coupling to the planes above and below
+// is dropped from M and BiCGStab needs 150 iterations on the 108^3 problem where the exact ILU0 needs 67.  When the matrix is a grid
+// stencil -- its PATTERN analysis (smm_spmv_pattern.hip) found the offsets {0, +-1, +-nx[, +-nx ny]} -- the blocks are BRICKS of the grid
+// instead (16 x 8 x 8 points by default): M keeps 87-92 % of A's entries instead of 65-68 %, the sweeps of a brick are 30 levels deep
+// before the level cut, and the same solve takes 95-105 iterations (profiles/r03/brick_blocks.txt).  A brick's rows are not contiguous:
+// the handle keeps the row order block by block (ascending inside a block, so the sweeps inside a block follow the natural order) and
+// its inverse; the kernels address rows through them.  Matrices of any other shape keep the contiguous cut.
+__global__ void brickKeyKernel(int n, int nx, int ny, int bx, int by, int bz, int nbx, int nby, unsigned* __restrict__ keys, int* __restrict__ rows) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
+	keys[i] = static_cast<unsigned>(((iz / bz) * nby + iy / by) * nbx + ix / bx);
+	rows[i] = i;
+}
+__global__ void brickHeadKernel(int n, const unsigned* __restrict__ keys, const int* __restrict__ order, int* __restrict__ inv, int* __restrict__ head) {
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p > n) return;
+	if (p == n) {
+		head[p] = 0;
+		return;
+	}
+	inv[order[p]] = p;
+	head[p] = (p == 0 || keys[p] != keys[p - 1]) ? 1 : 0;
+}
+__global__ void brickBoundsKernel(int n, const int* __restrict__ headScan, int2* __restrict__ bounds) {
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p > n) return;
+	if (p == n) bounds[headScan[n]] = make_int2(n, 0);  // closing entry
+	else if (headScan[p + 1] != headScan[p]) bounds[headScan[p]] = make_int2(p, 0);  // p starts block headScan[p]
+}
+
+// the grid a stencil matrix lives on, from the offsets of its PATTERN analysis: {0, +-1, +-nx} or {0, +-1, +-nx, +-nx ny}
+static bool brickGrid(const smm_hip_csr* a, int* nx, int* ny) {
+	if (a->pat_state <= 0 || a->pat_encoding != 0 || a->pat_offs_host.empty()) return false;
+	std::vector<int> u;
+	for (int o : a->pat_offs_host) {
+		const int v = std::abs(o);
+		if (v != 0 && std::find(u.begin(), u.end(), v) == u.end()) u.push_back(v);
+	}
+	std::sort(u.begin(), u.end());
+	if (u.size() < 2 || u.size() > 3 || u[0] != 1 || u[1] < 4) return false;
+	*nx = u[1];
+	*ny = 0;  // 2-D
+	if (u.size() == 3) {
+		if (u[2] % u[1] != 0 || u[2] / u[1] < 2) return false;
+		*ny = u[2] / u[1];
+	}
+	return true;
+}
+
+// SMM_HIP_BLOCK_BRICKS=0: always the contiguous cut
+static bool bricksAllowed() {
+	static const bool on = [] {
+		const char* env = getenv("SMM_HIP_BLOCK_BRICKS");
+		return env ? atoi(env) != 0 : true;
+	}();
+	return on;
+}
+
+// fills B->d_rowOrder / d_invOrder / d_bounds / nBlocks / brick[]; returns SMM_HIP_OK with B->d_rowOrder == nullptr when the matrix is
+// not a grid stencil (the caller then cuts contiguous blocks)
+static int brickPartition(const smm_hip_csr* a, smm_precond_block* B, hipStream_t s) {
+	int nx = 0, ny = 0;
+	if (!brickGrid(a, &nx, &ny)) return SMM_HIP_OK;
+	const int n = a->rows;
+	const int rowsMax = std::min(B->blockRows, B->capNnz / std::max(1, a->pat_k));  // a row holds at most pat_k entries (verified)
+	int bx, by, bz;
+	if (ny == 0) {  // 2-D: squares
+		by = bx = std::max(2, static_cast<int>(std::sqrt(static_cast<double>(rowsMax))));
+		bx = std::min(bx, nx);
+		bz = 1;
+		ny = (n + nx - 1) / nx;  // (one "plane": iz = 0 for every row)
+		by = std::min(by, ny);
+	} else {  // 3-D: rowsMax / 64 x 8 x 8 (16 x 8 x 8 for 1024 rows)
+		by = std::min(8, ny);
+		bz = 8;
+		bx = std::min(nx, std::max(4, rowsMax / (by * bz)));
+		while (bx * by * bz > rowsMax && bz > 1) bz /= 2;
+		while (bx * by * bz > rowsMax && bx > 1) bx /= 2;
+	}
+	if (bx * by * bz < 64) return SMM_HIP_OK;  // (degenerate grids: not worth a permutation)
+	const int nbx = (nx + bx - 1) / bx, nby = (ny + by - 1) / by;
+	DevBuf<unsigned> keys, keysSorted;
+	DevBuf<int> rows, head;
+	DevBuf<char> temp;
+	SMM_TRY(keys.alloc(static_cast<size_t>(n)));
+	SMM_TRY(keysSorted.alloc(static_cast<size_t>(n)));
+	SMM_TRY(rows.alloc(static_cast<size_t>(n)));
+	SMM_TRY(head.alloc(static_cast<size_t>(n) + 1));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_rowOrder), static_cast<size_t>(n) * sizeof(int)));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_invOrder), static_cast<size_t>(n) * sizeof(int)));
+	const int grid = (n + 1 + 255) / 256;
+	brickKeyKernel<<<grid, 256, 0, s>>>(n, nx, ny, bx, by, bz, nbx, nby, keys, rows);
+	size_t tempBytes = 0;  // (LSD radix sort: stable, so the rows of a block stay in ascending order)
+	SMM_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tempBytes, keys.p, keysSorted.p, rows.p, B->d_rowOrder, static_cast<size_t>(n), 0, 32, s));
+	SMM_TRY(temp.alloc(tempBytes ? tempBytes : 1));
+	SMM_HIP_TRY(rocprim::radix_sort_pairs(temp.p, tempBytes, keys.p, keysSorted.p, rows.p, B->d_rowOrder, static_cast<size_t>(n), 0, 32, s));
+	brickHeadKernel<<<grid, 256, 0, s>>>(n, keysSorted, B->d_rowOrder, B->d_invOrder, head);
+	SMM_TRY(exclusiveScanInPlace(head, static_cast<size_t>(n) + 1, s));  // head[p] = blocks that start before position p; drains s
+	int nBlocks = 0;
+	SMM_HIP_TRY(hipMemcpyAsync(&nBlocks, head.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_bounds), (static_cast<size_t>(nBlocks) + 1) * sizeof(int2)));
+	brickBoundsKernel<<<grid, 256, 0, s>>>(n, head, B->d_bounds);
+	SMM_HIP_TRY(hipGetLastError());
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // the scratch buffers go back to the allocator when this scope ends
+	B->nBlocks = nBlocks;
+	B->brick[0] = bx;
+	B->brick[1] = by;
+	B->brick[2] = bz;
+	return SMM_HIP_OK;
+}
+
 template <typename T>
-int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap, smm_hip_precond* M) {
+int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap, int partition, smm_hip_precond* M) {
 	hipStream_t s = libStream();
 	SMM_HIP_TRY(hipDeviceSynchronize());  // the matrix may still be being written on a caller's stream
 	const int n = a->rows;
@@ -852,8 +984,20 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap
 	B->levelCap = levelCap < 2 ? 0 : std::min(levelCap, 4095);  // (a cap of 1 would drop every coupling: 0 / 1 mean no cut)
 	B->capNnz = BLK_CAP_NNZ;
 	if (n == 0) return SMM_HIP_OK;
-	// (seams every 16 blocks instead of every 64: the greedy cut of a super-chunk is a sequential chain of binary searches by one thread)
-	SMM_TRY(cutRows(a->d_start, n, a->nnz, B->capNnz, B->blockRows, s, &B->d_bounds, &B->nBlocks, 16));
+	if (partition != SMM_BLOCKS_CONTIGUOUS && (partition == SMM_BLOCKS_BRICKS || bricksAllowed())) {
+		// the grid is read from the matrix's PATTERN analysis (run here, quietly, when no SpMV has asked for it yet)
+		const int st = ensurePattern(const_cast<smm_hip_csr*>(a), s, true, true);
+		if (st != SMM_HIP_OK && st != SMM_HIP_ERR_INVALID) return st;
+		SMM_TRY(brickPartition(a, B, s));
+	}
+	if (!B->d_rowOrder) {
+		if (partition == SMM_BLOCKS_BRICKS) {
+			setError("block preconditioner: bricks were asked for, but the matrix is not a 2-D / 3-D grid stencil with offsets {0, +-1, +-nx[, +-nx ny]}");
+			return SMM_HIP_ERR_INVALID;
+		}
+		// (seams every 16 blocks instead of every 64: the greedy cut of a super-chunk is a sequential chain of binary searches by one thread)
+		SMM_TRY(cutRows(a->d_start, n, a->nnz, B->capNnz, B->blockRows, s, &B->d_bounds, &B->nBlocks, 16));
+	}
 	const int nBlocks = B->nBlocks;
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(&B->d_chunk0), (static_cast<size_t>(nBlocks) + 1) * sizeof(int)));
 	blkChunkCountKernel<<<(nBlocks + 1 + 255) / 256, 256, 0, s>>>(nBlocks, B->d_bounds, B->d_chunk0);
@@ -877,7 +1021,7 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap
 		const size_t lds = analyzeLds(B->blockRows, B->capNnz);
 		auto kernel = blkAnalyzeKernel<T>;
 		SMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-		kernel<<<nBlocks, BLK_TPB, lds, s>>>(B->blockRows, B->capNnz, B->levelCap > 0 ? B->levelCap - 1 : 0, B->d_bounds, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
+		kernel<<<nBlocks, BLK_TPB, lds, s>>>(B->blockRows, B->capNnz, B->levelCap > 0 ? B->levelCap - 1 : 0, B->d_bounds, BlkRows{B->d_rowOrder, B->d_invOrder}, B->d_chunk0, a->d_start, a->d_positions, static_cast<const T*>(a->d_values),
 		                                    kind == SMM_PRECOND_BLOCK_SGS ? 1 : 0, metaLo, metaUp, nEntLo, nEntUp, info);
 		SMM_HIP_TRY(hipGetLastError());
 	}
@@ -960,8 +1104,8 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap
 	return SMM_HIP_OK;
 }
 
-template int blockCreateTyped<float>(const smm_hip_csr*, int, int, int, smm_hip_precond*);
-template int blockCreateTyped<double>(const smm_hip_csr*, int, int, int, smm_hip_precond*);
+template int blockCreateTyped<float>(const smm_hip_csr*, int, int, int, int, smm_hip_precond*);
+template int blockCreateTyped<double>(const smm_hip_csr*, int, int, int, int, smm_hip_precond*);
 
 template <typename T, int KIND, int KREG, bool OV>
 static int launchBlkApply(const smm_hip_precond* M, const BlkApplyArgs<T>& args, hipStream_t s) {
@@ -1011,6 +1155,7 @@ int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, con
 	BlkApplyArgs<T> args;
 	args.nBlocks = B->nBlocks;
 	args.bounds = B->d_bounds;
+	args.rowOrder = B->d_rowOrder;
 	args.chunk0 = B->d_chunk0;
 	args.recLo = B->d_recLo;
 	args.recUp = B->d_recUp;
@@ -1036,6 +1181,8 @@ template int blockApplyDev<double>(const smm_hip_precond*, const double*, double
 void blockDestroy(smm_precond_block* B) {
 	if (!B) return;
 	devFree(B->d_bounds);
+	devFree(B->d_rowOrder);
+	devFree(B->d_invOrder);
 	devFree(B->d_chunk0);
 	devFree(B->d_recLo);
 	devFree(B->d_recUp);
@@ -1078,6 +1225,34 @@ int smm_hip_precond_block_count(const smm_hip_precond* M, int* nblocks) {
 		return SMM_HIP_ERR_INVALID;
 	}
 	*nblocks = M->blk->nBlocks;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_precond_block_rows(const smm_hip_precond* M, int* order, size_t count, int* brick) {
+	if (!M || !M->blk) {
+		setError("precond_block_rows: not a block preconditioner");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const smm_precond_block* B = M->blk;
+	const size_t n = M->a ? static_cast<size_t>(M->a->rows) : 0;
+	if (brick) {
+		brick[0] = B->brick[0];
+		brick[1] = B->brick[1];
+		brick[2] = B->brick[2];
+	}
+	if (!order) return SMM_HIP_OK;
+	if (count != n) {
+		setError("precond_block_rows: the matrix has %zu rows", n);
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (!B->d_rowOrder) {
+		for (size_t i = 0; i < n; ++i) order[i] = static_cast<int>(i);
+		return SMM_HIP_OK;
+	}
+	SMM_TRY(ensureInit());
+	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipMemcpyAsync(order, B->d_rowOrder, n * sizeof(int), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipStreamSynchronize(s));
 	return SMM_HIP_OK;
 }
 

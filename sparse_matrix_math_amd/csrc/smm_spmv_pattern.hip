@@ -1124,6 +1124,7 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	SMM_HIP_TRY(hipStreamSynchronize(s));
 	if (flags[0]) return no("some entry's column offset is outside the offset set of the sampled rows");
 	m->pat_k = k;
+	m->pat_offs_host = offs;
 	m->pat_encoding = 0;
 	m->pat_max_off = std::max(std::abs(offs.front()), std::abs(offs.back()));
 	m->d_pat_off = d_off.detach();

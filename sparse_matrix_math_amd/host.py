@@ -120,16 +120,26 @@ def profile_read(reset=True):
 class Preconditioner:
     """`int apply(const T* rhs, T* x) const` (ref:1173-1235).  Created by CSRMatrix.getPreconditioner."""
 
-    def __init__(self, matrix, kind, block_rows=None, level_cap=None):
+    def __init__(self, matrix, kind, block_rows=None, level_cap=None, partition=None):
         self.matrix = matrix  # keeps the matrix alive (the reference holds a const CSRMatrix&)
         self.kind = SolverPreconditioner(kind)
         self._h = ctypes.c_void_p()
-        if block_rows is None and level_cap is None:
+        if block_rows is None and level_cap is None and partition is None:
             check(_lib.load().smm_hip_precond_create(matrix._h, int(kind), ctypes.byref(self._h)))
-        elif level_cap is None:  # BLOCK_ILU0 / BLOCK_SGS with a chosen block size
+        elif level_cap is None and partition is None:  # BLOCK_ILU0 / BLOCK_SGS with a chosen block size
             check(_lib.load().smm_hip_precond_create_block(matrix._h, int(kind), int(block_rows), ctypes.byref(self._h)))
-        else:  # ... and a chosen level cut (0 = none: M is the block-diagonal part of A exactly)
-            check(_lib.load().smm_hip_precond_create_block_capped(matrix._h, int(kind), int(block_rows or 0), int(level_cap), ctypes.byref(self._h)))
+        else:  # ... a chosen level cut (0 = none; None / -1 = the default) and partition (None / 0 = auto, 1 = contiguous rows, 2 = grid bricks)
+            check(_lib.load().smm_hip_precond_create_block_ex(matrix._h, int(kind), int(block_rows or 0), -1 if level_cap is None else int(level_cap),
+                                                               int(partition or 0), ctypes.byref(self._h)))
+
+    def block_rows(self):
+        """BLOCK_ kinds: (the rows block by block -- order[bounds[b] : bounds[b+1]] are block b's rows, the identity for contiguous
+        blocks --, the brick's extent along the grid axes or (0, 0, 0))"""
+        n = self.matrix.rows
+        order = np.zeros(n, dtype=np.int32)
+        brick = (ctypes.c_int * 3)()
+        check(_lib.load().smm_hip_precond_block_rows(self._h, order.ctypes.data_as(ctypes.c_void_p), n, ctypes.cast(brick, ctypes.c_void_p)))
+        return order, tuple(brick)
 
     def level_cap(self):
         """BLOCK_ kinds: the level cut this handle was built with (0 = none)"""
@@ -286,8 +296,8 @@ class CSRMatrix:
         name = "smm_hip_spmv_fused_finish_dev" if finish else "smm_hip_spmv_fused_dev"
         check(_fn(name, self._suf)(self._h, int(op), _dptr(d_lhs), _dptr(d_x), _dptr(d_out), int(dot_mode), _dptr(d_w1), _dptr(d_partials), _dptr(stream)))
 
-    def getPreconditioner(self, kind, block_rows=None, level_cap=None):  # ref:1643-1651; block_rows / level_cap: BLOCK_ kinds only (None = default)
-        return Preconditioner(self, kind, block_rows, level_cap)
+    def getPreconditioner(self, kind, block_rows=None, level_cap=None, partition=None):  # ref:1643-1651; the keyword arguments: BLOCK_ kinds only (None = default)
+        return Preconditioner(self, kind, block_rows, level_cap, partition)
 
     def close(self):
         if self._h:
