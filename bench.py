@@ -336,11 +336,12 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         P = smm.SolverPreconditioner
         bytes_apply = 2 * (nnz * 12 + (n + 1) * 4) + 5 * n * 8  # two triangular sweeps over A's pattern ~ 2 x SpMV bytes
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # block_*: the default level cut (16); *_uncut: the same blocks without it (M = the block-diagonal part of A exactly)
+        # block_*: the defaults -- bricks of the grid as blocks, level cut 16; *_uncut: the same blocks without the cut (M = the
+        # block-diagonal part of A exactly); *_contiguous: runs of consecutive rows as blocks (what a matrix that is no grid stencil gets)
         # *_values_read: the same legs with the constant-diagonal SpMV encoding turned off -- this stand-in has constant coefficients, so
         # the solvers' SpMV reads no values[] (PATTERN / CONST); a general matrix such as atmosmodd would run the kernel that does
         for name, kind, cap in (("none", None, None), ("jacobi", P.JACOBI, None), ("ilu0", P.ILU0, None), ("block_ilu0", P.BLOCK_ILU0, None),
-                                ("block_sgs", P.BLOCK_SGS, None), ("block_ilu0_uncut", P.BLOCK_ILU0, 0),
+                                ("block_sgs", P.BLOCK_SGS, None), ("block_ilu0_uncut", P.BLOCK_ILU0, 0), ("block_ilu0_contiguous", P.BLOCK_ILU0, None),
                                 ("none_values_read", None, None), ("block_ilu0_values_read", P.BLOCK_ILU0, None)):
             A.pattern_allow_const(not name.endswith("_values_read"))
             M, tc = None, 0.0
@@ -349,7 +350,7 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
                     M.close()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                M = A.getPreconditioner(kind, None, cap)
+                M = A.getPreconditioner(kind, None, cap, 1 if name.endswith("_contiguous") else None)
                 torch.cuda.synchronize()
                 tc = time.perf_counter() - t0
             for _ in range(2):
@@ -376,6 +377,7 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
                     if kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
                         leg[name]["blocks"] = len(M.block_bounds()) - 1
                         leg[name]["level_cap"] = M.level_cap()
+                        leg[name]["brick"] = list(M.block_rows()[1])  # blocks = bricks of the grid of this many points per axis ([0, 0, 0]: runs of consecutive rows)
                 M.close()
         A.pattern_allow_const(True)
         leg["spmv"] = {"family_lanes": list(A.get_kernel()), "pattern_encoding": A.pattern_info()[0],

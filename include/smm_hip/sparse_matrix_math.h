@@ -292,8 +292,9 @@ public:
 		IC0Preconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_IC0) {}
 		IC0Preconditioner(IC0Preconditioner&&) noexcept = default;
 	};
-	// additions: ILU0 / SGS of the block-diagonal part of A (blocks of <= 1024 rows, every block's sweeps cut to <= 16 dependent
-	// levels; smm_hip.h, SMM_PRECOND_BLOCK_*, smm_hip_precond_create_block_capped for other sizes / cuts)
+	// additions: ILU0 / SGS of the block-diagonal part of A (blocks of <= 1024 rows -- bricks of the grid when the matrix is a grid
+	// stencil, runs of consecutive rows otherwise --, every block's sweeps cut to <= 16 dependent levels; smm_hip.h,
+	// SMM_PRECOND_BLOCK_*, smm_hip_precond_create_block_ex for other sizes / cuts / partitions)
 	class BlockILU0Preconditioner : public PreconditionerBase {
 	public:
 		BlockILU0Preconditioner(const CSRMatrix& m) noexcept : PreconditionerBase(m, SMM_PRECOND_BLOCK_ILU0) {}

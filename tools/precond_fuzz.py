@@ -9,6 +9,7 @@ import sparse_matrix_math_amd as smm
 from sparse_matrix_math_amd import generators as gen
 from oracle.oracle import Oracle
 import test_gpu_resident as T
+from test_gpu_precond_block import permuted
 
 smm.init(0)
 oracle = Oracle()
@@ -73,15 +74,18 @@ for trial in range(60):
     try:
         I = A.getPreconditioner(P.BLOCK_ILU0, block_rows, cap)
         bounds = I.block_bounds()
-        mcsr, keep, deepest = oracle.level_cut_matrix(csr, bounds, I.level_cap())
+        order, brick = I.block_rows()  # (grid stencils get bricks: the oracle works on P A P^T, where the blocks are contiguous)
+        pcsr, src = permuted(csr, order)
+        mcsr, keep, deepest = oracle.level_cut_matrix(pcsr, bounds, I.level_cap())
         e, lu = oracle.block_ilu0_factorize(mcsr, bounds)
         ok = e == 0 and max(I.levels()) == deepest
-        ok = ok and np.array_equal(I.values()[keep], lu) and np.array_equal(I.values()[~keep], csr[2][~keep])
+        dev_lu = I.values()[src]
+        ok = ok and np.array_equal(dev_lu[keep], lu) and np.array_equal(dev_lu[~keep], pcsr[2][~keep])
         x = np.zeros(n, dtype=dtype); I.apply(rhs, x)
-        ok = ok and np.array_equal(x, oracle.block_ilu0_apply(mcsr, bounds, lu, rhs)[1])
+        ok = ok and np.array_equal(x[order], oracle.block_ilu0_apply(mcsr, bounds, lu, rhs[order])[1])
         S = A.getPreconditioner(P.BLOCK_SGS, block_rows, cap); S.apply(rhs, x)
-        ok = ok and np.array_equal(x, oracle.block_sgs_apply(mcsr, bounds, rhs)[1])
-        note = f"blocks {len(bounds) - 1} levels {I.levels()} kept {int(keep.sum())}/{len(keep)}"
+        ok = ok and np.array_equal(x[order], oracle.block_sgs_apply(mcsr, bounds, rhs[order])[1])
+        note = f"blocks {len(bounds) - 1} brick {brick} levels {I.levels()} kept {int(keep.sum())}/{len(keep)}"
     except smm.SmmHipError as err:
         ok, note = False, f"refused: {str(err)[:60]}"  # (diagonally dominant matrices: nothing to refuse)
     bad += not ok
