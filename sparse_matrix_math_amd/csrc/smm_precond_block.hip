@@ -836,6 +836,7 @@ static int packKind(const smm_hip_csr* a, smm_hip_precond* M, const unsigned* me
 	if (B->overflow) return packTyped<T, KIND, 8, true>(a, M, metaLo, metaUp, d_info, s);
 	switch (B->kreg) {
 	case 2: return packTyped<T, KIND, 2, false>(a, M, metaLo, metaUp, d_info, s);
+	case 3: return packTyped<T, KIND, 3, false>(a, M, metaLo, metaUp, d_info, s);
 	case 4: return packTyped<T, KIND, 4, false>(a, M, metaLo, metaUp, d_info, s);
 	default: return packTyped<T, KIND, 8, false>(a, M, metaLo, metaUp, d_info, s);
 	}
@@ -1040,11 +1041,11 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap
 	B->levelsUp = h[4];
 	B->maxInBlock = h[5];
 	const int most = std::max(h[0], h[1]);
-	B->kreg = most <= 2 ? 2 : most <= 4 ? 4 : 8;
+	B->kreg = most <= 2 ? 2 : most <= 3 ? 3 : most <= 4 ? 4 : 8;  // (3: the rows of a 7-point stencil inside a brick)
 	B->overflow = most > 8;
 	if (const char* env = getenv("SMM_HIP_BLOCK_KREG")) {  // testing: force the overflow path on matrices with short rows
 		const int k = atoi(env);
-		if (k == 2 || k == 4 || k == 8) {
+		if (k == 2 || k == 3 || k == 4 || k == 8) {
 			B->kreg = std::max(B->kreg, k);
 		} else if (k == -8) {
 			B->kreg = 8;
@@ -1074,6 +1075,10 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap
 	case 2:
 		dwLo = ilu ? RecLayout<T, false, 2>::DW : RecLayout<T, true, 2>::DW;
 		dwUp = RecLayout<T, true, 2>::DW;
+		break;
+	case 3:
+		dwLo = ilu ? RecLayout<T, false, 3>::DW : RecLayout<T, true, 3>::DW;
+		dwUp = RecLayout<T, true, 3>::DW;
 		break;
 	case 4:
 		dwLo = ilu ? RecLayout<T, false, 4>::DW : RecLayout<T, true, 4>::DW;
@@ -1138,6 +1143,7 @@ static int launchBlkApplyKind(const smm_hip_precond* M, const BlkApplyArgs<T>& a
 	if (B->overflow) return launchBlkApply<T, KIND, 8, true>(M, args, s);
 	switch (B->kreg) {
 	case 2: return launchBlkApply<T, KIND, 2, false>(M, args, s);
+	case 3: return launchBlkApply<T, KIND, 3, false>(M, args, s);
 	case 4: return launchBlkApply<T, KIND, 4, false>(M, args, s);
 	default: return launchBlkApply<T, KIND, 8, false>(M, args, s);
 	}
