@@ -239,8 +239,10 @@ int smm_hip_bicgsymmetric_f64(const smm_hip_csr* a, double* b, double* x, int ma
  * (missing or |d|<1e-5 diagonal, empty row, non-SPD IC0 pivot) return SMM_HIP_ERR_PRECOND. */
 int smm_hip_precond_create(const smm_hip_csr* a, int kind, smm_hip_precond** out);
 /* The block kinds with a chosen block size: blocks of at most block_rows rows (64 .. 2048; 0 = the default, 1024) and at most 8192
- * stored entries, cut greedily from row 0; smm_hip_precond_create uses the default.  The cut is a property of the handle:
- * smm_hip_precond_block_bounds returns the nblocks + 1 row numbers (bounds[0] = 0, bounds[nblocks] = rows). */
+ * stored entries; smm_hip_precond_create uses the default.  The partition is a property of the handle:
+ * smm_hip_precond_block_bounds returns nblocks + 1 numbers (bounds[0] = 0, bounds[nblocks] = rows) -- row numbers when the blocks are
+ * runs of consecutive rows, positions in the row order of smm_hip_precond_block_rows when they are bricks of a grid (see
+ * smm_hip_precond_create_block_ex: grid stencils get bricks by default). */
 int smm_hip_precond_create_block(const smm_hip_csr* a, int kind, int block_rows, smm_hip_precond** out);
 /* ... and a chosen LEVEL CUT.  Inside a block the forward sweep gives every row a level (0 when it keeps no entry left of the
  * diagonal, else 1 + the deepest level of the rows its kept entries point to), the backward sweep likewise; entries that point to
