@@ -202,7 +202,7 @@ int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows
 // calls that have no stream) the whole device is drained first and the library's own stream is used
 int ensureCsrReady(const smm_hip_csr* m, hipStream_t s, bool streamKnown);
 // PATTERN family: analyse + verify the matrix (idempotent), and the launch behind launchSpmv
-int ensurePattern(smm_hip_csr* m, hipStream_t s = nullptr, bool streamKnown = false, bool quiet = false);
+int ensurePattern(smm_hip_csr* m, hipStream_t s = nullptr, bool streamKnown = false, bool quiet = false, bool masksOnly = false);
 // before a solver's loop: lets a mid-size matrix (>= 2^20 entries) take the PATTERN family when it fits (smm_spmv_pattern.hip)
 int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream_t s);
 template <typename T>

@@ -987,9 +987,12 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap
 	if (n == 0) return SMM_HIP_OK;
 	if (partition != SMM_BLOCKS_CONTIGUOUS && (partition == SMM_BLOCKS_BRICKS || bricksAllowed())) {
 		// the grid is read from the matrix's PATTERN analysis (run here, quietly, when no SpMV has asked for it yet)
-		const int st = ensurePattern(const_cast<smm_hip_csr*>(a), s, true, true);
+		const int st = ensurePattern(const_cast<smm_hip_csr*>(a), s, true, true, true);
 		if (st != SMM_HIP_OK && st != SMM_HIP_ERR_INVALID) return st;
 		SMM_TRY(brickPartition(a, B, s));
+		// a preconditioner is built for a solver: let the matrix take the compressed SpMV family now (the analysis above has already
+		// run; the solvers' own request would find nothing left to analyse)
+		SMM_TRY(adoptPatternForSolver(a, -1, s));
 	}
 	if (!B->d_rowOrder) {
 		if (partition == SMM_BLOCKS_BRICKS) {

@@ -1184,10 +1184,12 @@ static int tryDict(smm_hip_csr* m, hipStream_t s, const char** why) {
 // quiet: the automatic attempt -- a matrix without a pattern is not an error then (no error text, SMM_HIP_ERR_INVALID still returned).
 // pat_state: 0 not analysed, 1 usable, -1 refused by both encodings, -2 refused by the masks with the dictionary not tried yet (an
 // automatic attempt with SMM_HIP_AUTO_DICT=0): an explicit request tries it then.
-int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet) {
+int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet, bool masksOnly) {
 	SMM_TRY(ensureCsrReady(m, s, streamKnown));
 	std::lock_guard<std::mutex> lock(m->tileMutex);
-	const bool dictWanted = !quiet || autoDictAllowed();
+	// masksOnly: a caller that can only use the row masks (the brick partition of the block preconditioners reads the grid from their
+	// offsets) does not pay for the dictionary; an explicit request later still tries it (state -2)
+	const bool dictWanted = !masksOnly && (!quiet || autoDictAllowed());
 	if (m->pat_state > 0) return SMM_HIP_OK;
 	if (m->pat_state == -1 || (m->pat_state == -2 && !dictWanted)) {
 		if (!quiet) setError("pattern SpMV: the entries of this matrix use more than %d distinct column offsets", DICT_MAX);
@@ -1232,12 +1234,13 @@ int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream
 		const char* env = getenv("SMM_HIP_SOLVER_PATTERN_MIN_NNZ");
 		return env ? atoll(env) : (1LL << 20);
 	}();
-	if (!allowed || !m || m->rows <= 0 || m->kernelForced || m->family != SMM_SPMV_STREAM || m->pat_state != 0) return SMM_HIP_OK;
+	if (!allowed || !m || m->rows <= 0 || m->kernelForced || m->family != SMM_SPMV_STREAM || m->pat_state == -1) return SMM_HIP_OK;
 	if (plannedIterations >= 0 && plannedIterations < 32) return SMM_HIP_OK;
 	const double avg = static_cast<double>(m->nnz) / m->rows;
 	if (m->nnz < minNnz || avg > 64.0) return SMM_HIP_OK;
 	auto* mm = const_cast<smm_hip_csr*>(m);
-	const int st = ensurePattern(mm, s, true, true);
+	// (pat_state > 0: already analysed -- e.g. by a block preconditioner that read the grid from the offsets -- and only not adopted yet)
+	const int st = m->pat_state > 0 ? static_cast<int>(SMM_HIP_OK) : ensurePattern(mm, s, true, true);
 	if (st == SMM_HIP_OK) {
 		mm->family = SMM_SPMV_PATTERN;
 		mm->lanes = avg <= 24 ? 1 : avg <= 64 ? 2 : avg <= 128 ? 4 : 8;  // (the PATTERN rule of smm_spmv.hip's lanesForAvg)

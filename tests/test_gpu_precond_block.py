@@ -282,6 +282,23 @@ def test_block_preconditioners_at_config_sizes(smm, oracle, n, dtype):
     np.testing.assert_allclose(x, np.ones(rows), atol=1e-6)
 
 
+def test_creating_the_preconditioner_first_still_gives_the_solver_its_spmv_family(smm):
+    """the brick partition analyses the matrix's offsets at create time; a solver that comes later finds the analysis done and must
+    still move the matrix to the PATTERN family (>= 2^20 entries)"""
+    P = smm.SolverPreconditioner
+    csr = gen.convdiff3d(60, 0.3, dtype=np.float64)  # 1.5 M entries
+    rows = len(csr[0]) - 1
+    A = make(smm, csr)
+    assert A.get_kernel()[0] == 2 and A.pattern_info()[0] == 0  # STREAM, not analysed
+    M = A.getPreconditioner(P.BLOCK_ILU0)
+    assert M.block_rows()[1] == (16, 8, 8)
+    assert A.get_kernel() == (3, 1) and A.pattern_info() == (3, 7)  # PATTERN, one lane per row, constant diagonals, 7 offsets
+    b = gen.row_sums(csr[0], csr[2])
+    x = np.zeros(rows)
+    assert int(smm.BiCGStab(A, b, x, -1, 1e-9, M)) == 0
+    np.testing.assert_allclose(x, np.ones(rows), atol=1e-6)
+
+
 def test_block_apply_is_repeatable_and_asynchronous(smm):
     """device-pointer apply on the caller's stream, twice: same bits; and the fused-dot epilogue leaves x unchanged"""
     torch = pytest.importorskip("torch")
