@@ -1235,7 +1235,7 @@ int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream
 		return env ? atoll(env) : (1LL << 20);
 	}();
 	if (!allowed || !m || m->rows <= 0 || m->kernelForced || m->family != SMM_SPMV_STREAM || m->pat_state == -1) return SMM_HIP_OK;
-	if (plannedIterations >= 0 && plannedIterations < 32) return SMM_HIP_OK;
+	if (plannedIterations >= 0 && plannedIterations < 16) return SMM_HIP_OK;  // (a few passes do not pay for a pass over positions[])
 	const double avg = static_cast<double>(m->nnz) / m->rows;
 	if (m->nnz < minNnz || avg > 64.0) return SMM_HIP_OK;
 	auto* mm = const_cast<smm_hip_csr*>(m);
