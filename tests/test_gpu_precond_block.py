@@ -341,3 +341,11 @@ def test_block_preconditioner_structural_failures(smm):
         A.getPreconditioner(P.BLOCK_ILU0, 32)  # block_rows out of range
     with pytest.raises(Exception):
         A.getPreconditioner(P.JACOBI, 64)  # not a block kind
+    start, pos, val = gen.poisson2d(12, dtype=np.float64)
+    good = smm.CSRMatrix(rows, rows, start, pos, val)
+    with pytest.raises(Exception):
+        good.getPreconditioner(P.BLOCK_ILU0, 64, None, 3)  # unknown partition
+    with pytest.raises(Exception):
+        good.getPreconditioner(P.BLOCK_ILU0, 64, -2)  # level cut out of range
+    M = good.getPreconditioner(P.BLOCK_SGS, 64, 0, 2)  # bricks asked for, on a 12 x 12 grid: 8 x 8 squares
+    assert M.block_rows()[1] == (8, 8, 1) and M.level_cap() == 0 and len(M.block_bounds()) == 5
