@@ -377,6 +377,9 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
                     if kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
                         leg[name]["blocks"] = len(M.block_bounds()) - 1
                         leg[name]["level_cap"] = M.level_cap()
+                        rec = M.block_record_bytes()  # what the apply really moves: both sweeps' records, rhs, x (the fused dot's w1 is not read here)
+                        true_b = n * (sum(rec) + 2 * 8)
+                        leg[name].update(apply_true_bytes=true_b, apply_true_gbps=true_b / ms_apply / 1e6, apply_true_frac=true_b / ms_apply / 1e6 / HBM_PEAK_GBPS)
                         leg[name]["brick"] = list(M.block_rows()[1])  # blocks = bricks of the grid of this many points per axis ([0, 0, 0]: runs of consecutive rows)
                 M.close()
         A.pattern_allow_const(True)

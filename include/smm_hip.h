@@ -263,6 +263,9 @@ int smm_hip_precond_create_block_capped(const smm_hip_csr* a, int kind, int bloc
 #define SMM_BLOCKS_BRICKS 2
 int smm_hip_precond_create_block_ex(const smm_hip_csr* a, int kind, int block_rows, int level_cap, int partition, smm_hip_precond** out);
 int smm_hip_precond_block_rows(const smm_hip_precond* M, int* order, size_t count, int* brick);
+/* Bytes one apply reads per row besides rhs / x (/ w1): the fixed-size record of the lower and of the upper sweep, and the row-order
+ * entries of a brick partition.  (Rows with more in-block entries than a record holds continue in overflow lists, not counted.) */
+int smm_hip_precond_block_record_bytes(const smm_hip_precond* M, int* lower, int* upper, int* order);
 int smm_hip_precond_block_level_cap(const smm_hip_precond* M, int* level_cap);
 int smm_hip_precond_block_count(const smm_hip_precond* M, int* nblocks);
 int smm_hip_precond_block_bounds(const smm_hip_precond* M, int* bounds, size_t count);

@@ -97,6 +97,7 @@ _PLAIN = {
     "smm_hip_precond_block_level_cap": (c_int, [_P, POINTER(c_int)]),
     "smm_hip_precond_create_block_ex": (c_int, [_P, c_int, c_int, c_int, c_int, POINTER(_P)]),
     "smm_hip_precond_block_rows": (c_int, [_P, _P, c_size_t, _P]),
+    "smm_hip_precond_block_record_bytes": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "smm_hip_precond_block_count": (c_int, [_P, POINTER(c_int)]),
     "smm_hip_precond_block_bounds": (c_int, [_P, _P, c_size_t]),
     "smm_hip_precond_destroy": (c_int, [_P]),

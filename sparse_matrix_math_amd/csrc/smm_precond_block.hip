@@ -1265,6 +1265,26 @@ int smm_hip_precond_block_rows(const smm_hip_precond* M, int* order, size_t coun
 	return SMM_HIP_OK;
 }
 
+// bytes one apply moves per row, apart from the vectors: the record of the lower and of the upper sweep, the row-order entries (bricks)
+int smm_hip_precond_block_record_bytes(const smm_hip_precond* M, int* lower, int* upper, int* order) {
+	if (!M || !M->blk) {
+		setError("precond_block_record_bytes: not a block preconditioner");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const smm_precond_block* B = M->blk;
+	const bool f32 = M->dtype == SMM_DTYPE_F32;
+	const bool ilu = M->kind == SMM_PRECOND_BLOCK_ILU0;
+	auto dw = [&](bool hasDiag) {  // RecLayout<T, hasDiag, kreg>::DW
+		const int vw = f32 ? 1 : 2;
+		const int raw = 1 + (B->kreg + 1) / 2 + (hasDiag ? vw : 0) + vw * B->kreg;
+		return (raw + 1) & ~1;
+	};
+	if (lower) *lower = 4 * dw(!ilu);
+	if (upper) *upper = 4 * dw(true);
+	if (order) *order = B->d_rowOrder ? 8 : 0;  // read once for rhs, once for x
+	return SMM_HIP_OK;
+}
+
 int smm_hip_precond_block_level_cap(const smm_hip_precond* M, int* level_cap) {
 	if (!M || !M->blk || !level_cap) {
 		setError("precond_block_level_cap: not a block preconditioner");

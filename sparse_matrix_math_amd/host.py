@@ -132,6 +132,12 @@ class Preconditioner:
             check(_lib.load().smm_hip_precond_create_block_ex(matrix._h, int(kind), int(block_rows or 0), -1 if level_cap is None else int(level_cap),
                                                                int(partition or 0), ctypes.byref(self._h)))
 
+    def block_record_bytes(self):
+        """BLOCK_ kinds: bytes one apply reads per row besides the vectors: (lower-sweep record, upper-sweep record, row-order entries)"""
+        v = [ctypes.c_int() for _ in range(3)]
+        check(_lib.load().smm_hip_precond_block_record_bytes(self._h, *[ctypes.byref(c) for c in v]))
+        return tuple(c.value for c in v)
+
     def block_rows(self):
         """BLOCK_ kinds: (the rows block by block -- order[bounds[b] : bounds[b+1]] are block b's rows, the identity for contiguous
         blocks --, the brick's extent along the grid axes or (0, 0, 0))"""
