@@ -766,6 +766,133 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstKernel(int rows, int cols
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// MASKS, short rows (<= KMAX entries: the 5- and 7-point stencils with varying coefficients), one lane per row, WITHOUT workgroup tiles
+// (r03): every WAVEFRONT owns 64 consecutive rows; their values[] are one contiguous run, fetched with coalesced loads one group
+// ahead into registers, passed through a wave-private LDS slice (a wavefront's LDS operations are in order: no barrier anywhere) and
+// read back by the row's lane.  Same products in the same order as spmvPatternKernel<T, 1> / the reference; the tile kernel's two
+// workgroup barriers per 256 rows and its tile table are what this form drops.
+template <typename T, int KMAX>
+__global__ __launch_bounds__(TPB) void spmvPatternWaveKernel(int rows, int cols, int nOff, const int* __restrict__ offs, const int* __restrict__ start,
+                                                             const T* __restrict__ values, const unsigned long long* __restrict__ masks, int chunkTiles,
+                                                             int opFlags, const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out,
+                                                             int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
+                                                             const int* __restrict__ doneFlag) {
+	constexpr int GATHER = 8;
+	__shared__ int sOff[MAXOFF];
+	__shared__ T sVal[TPB / WAVE][WAVE * KMAX + GATHER];
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	const int op = opFlags & 0xFF;
+	const bool ntOut = (opFlags & SPMV_NT_OUT) != 0;
+	const int t = threadIdx.x;
+	const int lane = t & (WAVE - 1);
+	const int wv = t >> 6;
+	if (t < MAXOFF) sOff[t] = t < nOff ? offs[t] : 0;
+	for (int i = lane; i < WAVE * KMAX + GATHER; i += WAVE) sVal[wv][i] = T(0);
+	__syncthreads();
+	const int nTiles = (rows + TPB - 1) / TPB;
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int xcdGroup = blockIdx.x % nGroups;
+	const int groupSlots = (static_cast<int>(gridDim.x) - xcdGroup + nGroups - 1) / nGroups;
+	const int perGroup = (nTiles + nGroups - 1) / nGroups;
+	auto tileOf = [&](int j) {  // the j-th tile of this XCD group
+		if (chunkTiles <= 0) {
+			const int tl = xcdGroup * perGroup + j;
+			return j < perGroup && tl < nTiles ? tl : nTiles;
+		}
+		const int c = j / chunkTiles;
+		const long long tIdx = (static_cast<long long>(c) * nGroups + xcdGroup) * chunkTiles + (j - c * chunkTiles);
+		return tIdx < nTiles ? static_cast<int>(tIdx) : nTiles;
+	};
+	// what a wavefront fetches for its 64 rows of a tile: mask and row start per lane, and the rows' values[] run in KMAX coalesced loads
+	struct Fetched {
+		unsigned long long mask;
+		int b, eBeg, eEnd;
+		T v[KMAX];
+	};
+	auto fetch = [&](int tile, Fetched& f) {
+		f.mask = 0ULL;
+		f.b = 0;
+		f.eBeg = 0;
+		f.eEnd = 0;
+		if (tile >= nTiles) return;
+		const int r0 = tile * TPB + wv * WAVE;
+		if (r0 >= rows) return;
+		const int nr = min(WAVE, rows - r0);
+		const int row = r0 + min(lane, nr - 1);
+		f.b = start[row];
+		if (lane < nr) f.mask = masks[row];
+		f.eBeg = __builtin_amdgcn_readfirstlane(f.b);
+		f.eEnd = start[r0 + nr];
+#pragma unroll
+		for (int k = 0; k < KMAX; ++k) {
+			const int idx = f.eBeg + k * WAVE + lane;
+			f.v[k] = idx < f.eEnd ? __builtin_nontemporal_load(values + idx) : T(0);
+		}
+	};
+	T acc0 = T(0), acc1 = T(0);
+	int j = blockIdx.x / nGroups;
+	int tile = tileOf(j);
+	Fetched cur, nxt;
+	fetch(tile, cur);
+	while (tile < nTiles) {
+		const int row = tile * TPB + t;
+		j += groupSlots;
+		const int ntile = tileOf(j);
+		fetch(ntile, nxt);  // in flight while this group is summed
+#pragma unroll
+		for (int k = 0; k < KMAX; ++k) sVal[wv][k * WAVE + lane] = cur.v[k];
+		if (row < rows) {
+			unsigned long long mm = cur.mask;
+			int at = cur.b - cur.eBeg;  // the row's next value in the wavefront's slice
+			T dot = T(0);
+			do {  // (an empty row runs one batch of discarded products)
+				unsigned off[GATHER];
+				T cv[GATHER], xv[GATHER];
+				bool live[GATHER];
+#pragma unroll
+				for (int u = 0; u < GATHER; ++u) {
+					live[u] = mm != 0ULL;
+					const int jj = mm ? __builtin_ctzll(mm) : 0;
+					mm &= mm - 1;
+					const int col = min(max(row + sOff[jj], 0), cols - 1);  // (dead slots: a clamped, valid column)
+					off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
+					cv[u] = sVal[wv][at + u];  // (dead slots read past the row: the slice is padded by GATHER)
+				}
+				at += GATHER;
+#pragma unroll
+				for (int u = 0; u < GATHER; ++u) xv[u] = patGather<T>(x, off[u]);
+#pragma unroll
+				for (int u = 0; u < GATHER; ++u) {
+					const T next = smmFma(cv[u], xv[u], dot);
+					dot = live[u] ? next : dot;
+				}
+			} while (mm != 0ULL);
+			const T o = patApplyOp(op, lhs, divisor, row, dot);
+			if (ntOut) __builtin_nontemporal_store(o, out + row);
+			else out[row] = o;
+			if (dotMode == 2) acc0 += o * o;
+			if (dotMode) acc1 += o * w1[row];
+		}
+		tile = ntile;
+		cur = nxt;
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // DICTIONARY encoding of the same family (r03): matrices whose entries use MORE than 64 distinct offsets
 // column - row, or hold rows of more than 64 entries, but no more than 65 536 distinct offsets in all -- banded matrices with hundreds
 // of diagonals, meshes numbered along a band.  positions[] (4 bytes per entry) is replaced by a 16-bit CODE per entry, the index of
@@ -1363,6 +1490,27 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 	if constexpr (L == 1) {
 		if (m->pat_encoding == 0 && m->pat_const && !m->pat_const_off) {  // constant diagonals: no values[] either (one lane per row only)
 			launchPatConst<T>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
+			return;
+		}
+	}
+	if constexpr (L == 1) {
+		// workgroups per CU of the wave-private form (0 = off: the tile kernel below); measured best on the 512^3 Laplacian: 4 for fp64
+		// (2.29 ms against 2.38 at 8 and 2.99 for the tile kernel), 8 for fp32 (1.40 against 1.55 at 4 and 1.50)
+		static const int waveEnv = [] {
+			const char* env = getenv("SMM_HIP_PATTERN_WAVE");
+			return env ? atoi(env) : -1;
+		}();
+		const int waveForm = waveEnv >= 0 ? waveEnv : (sizeof(T) == 8 ? 4 : 8);
+		if (waveForm && m->pat_encoding == 0 && m->pat_k <= 8) {
+			const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
+			const int nTiles = (m->rows + TPB - 1) / TPB;
+			const int grid = std::max(1, std::min(std::min(nTiles, cus * waveForm), NPART));
+			int chunkTiles = 0;
+			const long long farTiles = m->pat_max_off / TPB;
+			if (farTiles >= 256 && farTiles * 32 <= nTiles) chunkTiles = static_cast<int>(farTiles);
+			if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) chunkTiles = std::max(0, atoi(env));
+			spmvPatternWaveKernel<T, 8><<<grid, TPB, 0, s>>>(m->rows, m->cols, m->pat_k, m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks, chunkTiles,
+			                                                (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
 			return;
 		}
 	}
