@@ -1501,7 +1501,7 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 			return env ? atoi(env) : -1;
 		}();
 		const int waveForm = waveEnv >= 0 ? waveEnv : (sizeof(T) == 8 ? 4 : 8);
-		if (waveForm && m->pat_encoding == 0 && m->pat_k <= 8) {
+		if (waveForm && m->pat_encoding == 0 && m->pat_k <= 16) {
 			const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 			const int nTiles = (m->rows + TPB - 1) / TPB;
 			const int grid = std::max(1, std::min(std::min(nTiles, cus * waveForm), NPART));
@@ -1509,8 +1509,14 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 			const long long farTiles = m->pat_max_off / TPB;
 			if (farTiles >= 256 && farTiles * 32 <= nTiles) chunkTiles = static_cast<int>(farTiles);
 			if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) chunkTiles = std::max(0, atoi(env));
-			spmvPatternWaveKernel<T, 8><<<grid, TPB, 0, s>>>(m->rows, m->cols, m->pat_k, m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks, chunkTiles,
-			                                                (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+			const int flags = (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T));
+			if (m->pat_k <= 8) {
+				spmvPatternWaveKernel<T, 8><<<grid, TPB, 0, s>>>(m->rows, m->cols, m->pat_k, m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks, chunkTiles,
+				                                                flags, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+			} else {  // 9 .. 16 entries per row: the same kernel with a slice of 16 values per row
+				spmvPatternWaveKernel<T, 16><<<grid, TPB, 0, s>>>(m->rows, m->cols, m->pat_k, m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks, chunkTiles,
+				                                                 flags, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+			}
 			return;
 		}
 	}
