@@ -401,6 +401,18 @@ def test_constant_diagonals_at_scale(smm, oracle):
     xs = x.cpu().numpy()
     assert abs(totals[off] - float(ref @ ref)) <= 1e-10 * float(ref @ ref)
     assert abs(totals[off + 1] - float(ref @ xs)) <= 1e-10 * float(np.abs(ref * xs).sum())
+    # the same matrix with values[] read (what a stencil with varying coefficients gets): the wave-private MASKS kernel, same bits
+    A.pattern_allow_const(False)
+    assert A.pattern_info() == (MASKS, 7)
+    A.spmv_dev(OP_SUB, lhs, x, y, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y.cpu().numpy(), oracle.spmv(csr, OP_SUB, lhs.cpu().numpy(), x.cpu().numpy()))
+    fin.zero_()
+    A.spmv_fused_dev(OP_ASSIGN, None, x, y, 2, x, fin, stream, finish=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    totals = fin.cpu().numpy()
+    assert abs(totals[off] - float(ref @ ref)) <= 1e-10 * float(ref @ ref)
 
 
 def test_auto_keeps_stream_for_a_large_matrix_without_a_pattern(smm):
