@@ -60,14 +60,14 @@ def spmv_bytes(rows, cols, nnz, s):
     return nnz * (s + 4) + (rows + 1) * 4 + cols * s + rows * s
 
 
-def spmv_kernel_source_sha():
-    """sha256 over the CODE the SpMV kernel is compiled from (comments and white space stripped, so that a reworded comment does not
-    orphan a measurement): a traffic measurement is only quoted for the kernel it was taken on"""
+def _source_sha(names):
+    """sha256 over the CODE the named kernel sources are compiled from (comments and white space stripped, so that a reworded comment
+    does not orphan a measurement): a traffic measurement is only quoted for the kernel it was taken on"""
     import hashlib
     import re
 
     h = hashlib.sha256()
-    for name in ("smm_spmv.hip", "smm_device.h"):  # (not smm_internal.h: it changes with every unrelated entry point)
+    for name in names:  # (not smm_internal.h: it changes with every unrelated entry point)
         with open(os.path.join(ROOT, "sparse_matrix_math_amd", "csrc", name), encoding="utf-8") as f:
             text = f.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # block comments
@@ -76,18 +76,33 @@ def spmv_kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def load_traffic(args):
-    """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/spmv_traffic.json; tools/pmc_traffic.sh +
-    tools/traffic_json.py write it, one rocprofv3 pass per counter group) -- quoted ONLY when it was measured on this workload AND on
-    the kernel source this tree builds (sha stamped at measurement time); otherwise null rather than a stale number."""
+def spmv_kernel_source_sha():
+    """the CSR kernels (spmvTileKernel / spmvStreamKernel)"""
+    return _source_sha(("smm_spmv.hip", "smm_device.h"))
+
+
+def pattern_kernel_source_sha():
+    """the PATTERN family's kernels"""
+    return _source_sha(("smm_spmv_pattern.hip", "smm_device.h"))
+
+
+def load_traffic(args, kernel):
+    """Fabric-side bytes per launch of `kernel` on the bench matrix from the committed rocprofv3 PMC passes (profiles/spmv_traffic.json;
+    tools/pmc_traffic.sh + tools/traffic_json.py write it, one rocprofv3 pass per counter group) -- quoted ONLY when it was measured on
+    this workload, on a kernel of this name AND on the kernel source this tree builds (sha stamped at measurement time); otherwise
+    null rather than a stale number."""
     path = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if (t.get("rows") == args.rows and t.get("dtype") == args.dtype and t.get("band_k") == args.band_k
-                and t.get("kernel_source_sha16") == spmv_kernel_source_sha()):
+        if not (t.get("rows") == args.rows and t.get("dtype") == args.dtype and t.get("band_k") == args.band_k):
+            return None
+        if t.get("kernel", "").startswith(kernel + "<") and t.get("kernel_source_sha16") == spmv_kernel_source_sha():
             return t.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
+        o = (t.get("other_kernels") or {}).get("pattern_family_same_matrix") or {}
+        if o.get("kernel", "").startswith(kernel + "<") and o.get("kernel_source_sha16") == pattern_kernel_source_sha():
+            return (o.get("read_bytes_per_launch_from_request_sizes") or o.get("read_bytes_per_launch")) + o.get("write_bytes_per_launch", 0)
+    except (OSError, ValueError, TypeError):
         pass
     return None
 
@@ -130,6 +145,10 @@ def cpu_model():
 
 
 def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
+    """The bounded CPU sample: the GPU leg's own unit of work -- solves of --iters-per-solve BiCGStab iterations from x0 = 0, set-up
+    included -- on the same matrix.  Every figure is taken AFTER a warm-up solve of the same thread count (first touch of the
+    temporaries, page cache, OpenMP team start-up) and the all-core figure is the median of three samples with their spread printed:
+    the GPU boxes' hosts are shared, and single samples of this leg moved by 30 % between rounds."""
     import numpy as np
 
     from oracle.oracle import Oracle
@@ -138,48 +157,56 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
     cores, share = host_cores()
     csr = (start, positions, values)
     x0 = np.zeros(len(b), dtype=np_dtype)
+    per_solve = max(1, args.iters_per_solve)
 
-    def timed(threads, budget):
+    def solve_rate(fn, iters):
+        t0 = time.perf_counter()
+        it = fn(iters)
+        return it / (time.perf_counter() - t0)
+
+    def port(iters):
+        return oracle.bicgstab(csr, b, x0, iters, 0.0, omp=True)[2]
+
+    def samples(threads, n, iters, floor=2):
         oracle.set_threads(threads)
         t0 = time.perf_counter()
-        oracle.bicgstab(csr, b, x0, 1, 0.0, omp=True)  # also warms the page cache / first touch
-        one = time.perf_counter() - t0
-        iters = int(max(2, min(200, budget / max(one, 1e-3))))
-        t0 = time.perf_counter()
-        _, _, it, _ = oracle.bicgstab(csr, b, x0, iters, 0.0, omp=True)
-        return it, time.perf_counter() - t0
+        port(1)  # warm-up, untimed (one iteration = 3 SpMVs with the set-up)
+        per_it = (time.perf_counter() - t0) * 2 / 3
+        iters = int(max(floor, min(iters, budget_s * 0.2 / max(per_it, 1e-3))))  # a sample stays within ~20 % of the budget
+        return sorted(solve_rate(port, iters) for _ in range(n)), iters
 
-    it, dt = timed(cores, budget_s * 0.6)
+    rates, iters = samples(cores, 3, per_solve)
     out = {
-        "value": it / dt,
+        "value": rates[1],
         "unit": "iterations/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{it} BiCGStab iterations of the same {len(b)}-row matrix (OpenMP port of the reference loop, {dt:.1f} s, all {cores} physical cores)",
+        "sample": f"median of 3 solves of {iters} BiCGStab iterations (set-up SpMV included, like the GPU leg's solves of {per_solve}) of the same {len(b)}-row "
+                  f"matrix after a warm-up solve: OpenMP port of the reference loop on all {cores} physical cores",
+        "spread": [rates[0], rates[-1]],
         "cpu_model": cpu_model(),
     }
     if share != cores:  # the 16-core share of one GPU of the box
-        it16, dt16 = timed(share, budget_s * 0.3)
-        out["value_16_cores"] = it16 / dt16
-    # the same loop on one core (what the reference's default, non-TBB build does): two iterations are enough to time it
-    oracle.set_threads(1)
-    t0 = time.perf_counter()
-    _, _, it1, _ = oracle.bicgstab(csr, b, x0, 2, 0.0, omp=True)
-    dt1 = time.perf_counter() - t0
+        r16, _ = samples(share, 3, per_solve)
+        out["value_16_cores"] = r16[1]
+    # one core: the port, and the real reference (oracle/_ref/libsmm_ref.so: built from /root/reference in the build container and
+    # DELIBERATELY carried to the GPU box as a binary) -- its own SMM::BiCGStab, single-threaded as its default
+    # build is; both after a warm-up call, the same number of iterations (>= 5) each
+    one_core_iters = int(max(5, min(10, per_solve)))
+    r1, it1 = samples(1, 1, one_core_iters, floor=5)
     oracle.set_threads(cores)
-    out["value_1_core"] = it1 / dt1
-    # the real reference (oracle/_ref/libsmm_ref.so: built from /root/reference in the build container and DELIBERATELY carried to the
-    # GPU box as a binary): its own SMM::BiCGStab on the same matrix, single-threaded as its default build is
+    out["value_1_core"] = r1[0]
+    out["one_core_sample"] = f"{it1} iterations after a warm-up solve"
     try:
         from oracle.oracle import Reference
 
         if Reference.available():
             ref = Reference()
             with ref.csr(csr) as m:
+                ref.bicgstab(m, b, x0, 1, 0.0)  # warm-up
                 t0 = time.perf_counter()
-                ref.bicgstab(m, b, x0, 2, 0.0)
-                dtr = time.perf_counter() - t0
-            out["reference_1_core"] = 2 / dtr
+                ref.bicgstab(m, b, x0, it1, 0.0)
+                out["reference_1_core"] = it1 / (time.perf_counter() - t0)
     except Exception as e:  # noqa: BLE001 -- the reference leg is optional; the port above is the baseline
         out["reference_error"] = str(e)[:200]
     return out
@@ -546,51 +573,47 @@ def main():
             host.profile_enable(False)
             return iters, elapsed, spmv_ms, spmv_launches, resnorm
 
-        KERNEL_NAMES = {2: "spmvStreamKernel", 3: "spmvPatternKernel"}
-        iters, elapsed, spmv_ms, spmv_launches, resnorm = timed_leg()  # THE timed region: the library as a user gets it (AUTO)
+        def roofline_of(kernel, nbytes, spmv_ms, spmv_launches, where):
+            """the roofline object of one timed leg: the bytes ONE launch of `kernel` moves by its own layout (smm_hip_csr_kernel_desc) over
+            the average launch time measured live with HIP events on the launch stream inside that leg"""
+            avg_s = spmv_ms * 1e-3 / max(spmv_launches, 1)
+            achieved = nbytes / avg_s / 1e9
+            r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                 "traffic": load_traffic(args, kernel), "kernel": kernel, "algorithmic_bytes_per_launch": nbytes,
+                 "avg_launch_ms": avg_s * 1e3, "launches": spmv_launches, "measured_in": where}
+            if r["traffic"]:
+                # measured fabric-side bytes (PMC, profiles/spmv_traffic.json) over the live launch time: how hard the memory system is
+                # actually driven -- the gap to `achieved` is x[] cache lines re-fetched from beyond L2
+                r["traffic_gbps"] = r["traffic"] / avg_s / 1e9
+            return r
+
+        # THE timed region: the library as a user gets it (AUTO).  value, ms_per_step and roofline all describe THIS leg: roofline is its
+        # dominant kernel priced with the bytes that kernel's own data layout moves -- never with another layout's
+        kernel, kernel_bytes = A.kernel_desc()
+        iters, elapsed, spmv_ms, spmv_launches, resnorm = timed_leg()
         err = float(((x - x_true).abs() / x_true).max())
         b_spmv = spmv_bytes(n, n, nnz, s_bytes)
+        chosen_by = "autotune" if args.autotune else "forced" if (args.spmv_family or args.spmv_lanes) else "auto"
         result = {"elapsed": elapsed, "iters": iters, "nnz": nnz, "resnorm": float(resnorm), "max_rel_err_vs_x_true": err,
-                  "spmv_kernel": {"family": family, "lanes_per_row": lanes, "chosen_by": "autotune" if args.autotune else "forced" if (args.spmv_family or args.spmv_lanes) else "auto",
-                                  "first_spmv_ms": first_spmv_ms}}
-        stream_leg = None
+                  "spmv_kernel": {"family": family, "lanes_per_row": lanes, "kernel": kernel, "chosen_by": chosen_by, "first_spmv_ms": first_spmv_ms,
+                                  "pattern_encoding": A.pattern_info()[0]}}
+        result["roofline"] = roofline_of(kernel, kernel_bytes, spmv_ms, spmv_launches, "the timed region")
         if family == 3:
-            # The roofline object is defined on the reference's CSR layout and on the kernel that streams it: it is
-            # measured in a leg of its own with the STREAM family forced -- same matrix, same K iterations.  What the AUTO-selected family
-            # moves (values + one 8-byte mask per row, no positions[]) is reported beside it with its TRUE byte count.
-            p_bytes = nnz * s_bytes + n * 8 + (n + 1) * 4 + 2 * n * s_bytes
-            p_avg_s = spmv_ms * 1e-3 / max(spmv_launches, 1)
-            result["auto_family"] = {
-                "family": "PATTERN", "kernel": "spmvPatternKernel", "lanes_per_row": lanes, "value": iters / elapsed, "unit": "iterations/s",
-                "spmv_avg_launch_ms": p_avg_s * 1e3, "true_bytes_per_launch": p_bytes, "gbps": p_bytes / p_avg_s / 1e9,
-                "frac": p_bytes / p_avg_s / 1e9 / HBM_PEAK_GBPS, "setup_first_spmv_ms": first_spmv_ms,
-                "note": "positions[] replaced by one verified 64-bit mask per row; bit-identical to STREAM at equal lanes; chosen by AUTO on the first SpMV"}
+            result["roofline"]["note"] = ("PATTERN family chosen by AUTO on the first SpMV: positions[] replaced by one verified 64-bit mask per row "
+                                          "(bit-identical to STREAM at equal lanes); bytes = values + masks + start + x + out, NOT the CSR formula")
+            # The metric names "CSR SpMV GB/s (% HBM peak)": that contract -- the reference's CSR layout on the kernel that streams it
+            # (SURVEY.md section 8d) -- is measured in a leg of its own with the STREAM family forced: same matrix, same K iterations
             A.set_kernel(2, 0)
-            s_family, s_lanes = A.get_kernel()
-            s_iters, s_elapsed, spmv_ms, spmv_launches, s_res = timed_leg()
-            stream_leg = {"value": s_iters / s_elapsed, "unit": "iterations/s", "ms_per_step": s_elapsed / s_iters * 1e3, "lanes_per_row": s_lanes,
-                          "max_rel_err_vs_x_true": float(((x - x_true).abs() / x_true).max())}
+            s_kernel, s_bytes_launch = A.kernel_desc()
+            s_iters, s_elapsed, s_ms, s_launches, _s_res = timed_leg()
+            csr = roofline_of(s_kernel, s_bytes_launch, s_ms, s_launches, "a leg of its own with the STREAM family forced (same matrix, same K iterations)")
+            csr.update(value=s_iters / s_elapsed, value_unit="iterations/s", ms_per_step=s_elapsed / s_iters * 1e3, lanes_per_row=A.get_kernel()[1],
+                       max_rel_err_vs_x_true=float(((x - x_true).abs() / x_true).max()))
             A.set_kernel(0, 0)  # back to AUTO's choice
-            r_family, r_lanes = s_family, s_lanes
+            result["roofline_csr"] = csr
         else:
-            r_family, r_lanes = family, lanes
-        spmv_avg_s = spmv_ms * 1e-3 / max(spmv_launches, 1)
-        achieved = b_spmv / spmv_avg_s / 1e9
-        result["roofline"] = {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": load_traffic(args),
-            "kernel": ("spmvTileKernel" if r_family == 2 and r_lanes in (2, 4) else KERNEL_NAMES.get(r_family, "spmvVectorKernel")),
-            "algorithmic_bytes_per_launch": b_spmv,
-            "avg_launch_ms": spmv_avg_s * 1e3,
-            "launches": spmv_launches,
-            "measured_in": "a leg of its own with the STREAM family forced (the timed region runs AUTO's PATTERN family)" if stream_leg else "the timed region",
-        }
-        if stream_leg:
-            result["stream_family"] = stream_leg
+            result["roofline_csr"] = dict(result["roofline"], value=iters / elapsed, value_unit="iterations/s", ms_per_step=elapsed / iters * 1e3)
+        assert result["roofline_csr"]["algorithmic_bytes_per_launch"] == b_spmv or result["roofline_csr"]["kernel"] == "spmvVectorKernel"
         if not args.no_extras:
             result.setdefault("extras", {}).update(extra_spmv_legs(args, smm, host, torch, np, dev, stream))
         mtx = args.mtx or (os.path.join(ROOT, "atmosmodd.mtx") if os.path.exists(os.path.join(ROOT, "atmosmodd.mtx")) else None)
@@ -636,13 +659,9 @@ def main():
         line.update(result)
         if backend != "nccl":
             line["rehearsal_backend"] = backend  # ranks share GPUs and halos go through the host: not a measurement
-        if "roofline" in line:
-            line["spmv_gbps"] = line["roofline"]["achieved"]
-            line["spmv_pct_hbm_peak"] = 100.0 * line["roofline"]["frac"]
-            if line["roofline"].get("traffic"):
-                # measured HBM-side bytes (PMC, profiles/spmv_traffic.json) over the live launch time: how hard the memory system
-                # is actually driven -- the gap to `achieved` is x[] cache lines re-fetched from beyond L2
-                line["roofline"]["traffic_gbps"] = line["roofline"]["traffic"] / (line["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+        if "roofline_csr" in line:  # the metric's first half: CSR SpMV GB/s and % of HBM peak -- always the CSR layout's figure
+            line["spmv_gbps"] = line["roofline_csr"]["achieved"]
+            line["spmv_pct_hbm_peak"] = 100.0 * line["roofline_csr"]["frac"]
         print(json.dumps(line))
     if use_dist:
         dist.barrier()

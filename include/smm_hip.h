@@ -147,6 +147,13 @@ int smm_hip_csr_tile_info(const smm_hip_csr* m, int* tiles, int* tile_nnz_cap, i
 /* The PATTERN family's encoding of this matrix (SMM_PATTERN_*) and the number of distinct offsets it found; NONE / 0 before the
  * analysis has run (the first SpMV of a large matrix, or smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, ...)). */
 int smm_hip_csr_pattern_info(const smm_hip_csr* m, int* encoding, int* offsets);
+/* Which kernel the next SpMV of this matrix launches and what one launch of it has to move: `name` receives the kernel's template name
+ * as a profiler prints it, without the template arguments ("spmvTileKernel", "spmvPatternTileKernel", "spmvPatternConstKernel" ...;
+ * name_cap bytes, always terminated); *bytes_per_launch the bytes of the layout THAT kernel reads and writes once -- for the CSR
+ * kernels SURVEY section 8d's B_spmv = nnz (s + 4) + (rows + 1) 4 + cols s + rows s, for the PATTERN encodings what they store instead of
+ * positions[] (8 bytes per row of mask; 2 bytes per entry of code; no values[] for CONST) + start[] where the kernel reads it + x +
+ * out.  Benchmarks price a kernel's launch time with THIS number, never with another layout's.  Diagnostics, like tile_info. */
+int smm_hip_csr_kernel_desc(const smm_hip_csr* m, char* name, int name_cap, long long* bytes_per_launch);
 /* allow = 0: a matrix with constant diagonals keeps reading values[] (the MASKS kernels); 1 (default): CONST where it applies.  For
  * measurements of one against the other; the results are the same bits either way. */
 int smm_hip_csr_pattern_allow_const(smm_hip_csr* m, int allow);

@@ -5,6 +5,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -105,9 +107,14 @@ struct smm_hip_csr {
 	int* d_positions = nullptr;
 	void* d_values = nullptr;
 	bool owns = false;
-	// resolved SpMV configuration
-	int family = SMM_SPMV_VECTOR;
-	int lanes = 4;
+	// resolved SpMV configuration: family (low byte) and lanes per row, published TOGETHER as one word -- concurrent solves on one const
+	// matrix are allowed (ref:2316-2324 take `const CSRMatrix<T>&`), and the automatic switch to the PATTERN family
+	// happens inside such a solve: a launch reads the word once and never sees one family with the other's lanes
+	std::atomic<int> kernelWord{SMM_SPMV_VECTOR | (4 << 8)};
+	int family() const { return kernelWord.load(std::memory_order_acquire) & 0xFF; }
+	int lanes() const { return kernelWord.load(std::memory_order_acquire) >> 8; }
+	void setKernel(int family, int lanes) { kernelWord.store((family & 0xFF) | (lanes << 8), std::memory_order_release); }
+	std::mutex adoptMutex;  // the automatic STREAM -> PATTERN switch (analysis + publication of the word) is done by one thread at a time
 	// STREAM family: row blocks (first row of every block; n_rowblocks+1 entries) staged through LDS
 	int* d_rowblocks = nullptr;
 	int n_rowblocks = 0;
@@ -118,13 +125,19 @@ struct smm_hip_csr {
 	int max_row_len = -1;        // longest row, found on first demand (smm_resident.hip)
 	std::mutex tileMutex;  // the tile table is built lazily by the first SpMV; concurrent solves on one matrix are allowed
 	// PATTERN family (opt-in, smm_spmv_pattern.hip): shared column offsets + one 64-bit mask per row, its own tile table
-	int pat_state = 0;  // 0 not analysed, 1 usable, -1 the matrix has no such pattern, -2 no masks and the dictionary not tried (ensurePattern)
+	// 0 not analysed, 1 usable, -1 the matrix has no such pattern, -2 no masks and the dictionary not tried, -3 an automatic attempt failed
+	// for lack of resources (an explicit request tries again; automatic ones do not) -- ensurePattern.  Every pat_* field below is written
+	// under tileMutex BEFORE the state turns 1 (release) and read only after it was seen as 1 (acquire)
+	std::atomic<int> pat_state{0};
 	int pat_encoding = 0;  // 0: one 64-bit mask per row (<= 64 offsets); 1: one 16-bit code per entry (<= 65536 offsets)
 	unsigned short* d_pat_codes = nullptr;
 	bool pat_const = false;  // masks + every diagonal holds one value (d_pat_cval[j], raw bits): the CONST kernel needs no values[]
 	unsigned long long* d_pat_cval = nullptr;
 	bool pat_const_off = false;  // smm_hip_csr_pattern_allow_const(m, 0): keep reading values[] (A/B measurements)
 	int pat_max_off = 0;  // largest |column - row| of the offset list
+	// CONST on grid-shaped matrices: the plan of the 2.5-D kernel (smm_spmv_march.hip), made once at the end of the CONST analysis
+	bool march_ok = false;
+	int march_P = 0, march_H = 0, march_lo = 0, march_hi = 0;  // rows per plane, halo (elements), whether -P / +P are offsets
 	std::vector<int> pat_offs_host;  // MASKS: the sorted offsets (host copy: the brick partition of the block preconditioners reads the grid from them)
 	int pat_k = 0;
 	int* d_pat_off = nullptr;
@@ -191,10 +204,18 @@ constexpr int PARTS_LEN = 2 * NPART + 4;   // elements of a finishing buffer: 2 
 template <typename T>
 __host__ __device__ inline unsigned* partsTicket(T* partials) { return reinterpret_cast<unsigned*>(partials + PARTS_TOTALS + 2); }
 inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
+	static const int forced = [] {  // SMM_HIP_NT_OUT=0 / 1: A/B measurements of the store policy
+		const char* env = getenv("SMM_HIP_NT_OUT");
+		return env ? atoi(env) : -1;
+	}();
+	if (forced >= 0) return forced ? SPMV_NT_OUT : 0;
 	return static_cast<double>(m->rows) * static_cast<double>(elemBytes) > 64.0 * 1024 * 1024 ? SPMV_NT_OUT : 0;
 }
 
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s);
+// the cut behind buildRowBlocks without touching the handle (the PATTERN family keeps a table of its own): *blocks is allocated with
+// devAlloc and owned by the caller; *chunkTiles = how the tiles are dealt to the XCDs (0: one contiguous eighth each)
+int buildTileTable(const smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s, int** blocks, int* nBlocks, int* chunkTiles);
 // greedy cut of the rows into runs of <= capNnz stored entries and <= maxRows rows, on the device: tiles[0 .. nTiles] = {first row,
 // start[first row]}, closed by {rows, nnz}; allocated with devAlloc, owned by the caller; synchronises `s`
 int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows, hipStream_t s, int2** tiles, int* nTiles, int tilesPerChunk = 0);
@@ -205,8 +226,17 @@ int ensureCsrReady(const smm_hip_csr* m, hipStream_t s, bool streamKnown);
 int ensurePattern(smm_hip_csr* m, hipStream_t s = nullptr, bool streamKnown = false, bool quiet = false, bool masksOnly = false);
 // before a solver's loop: lets a mid-size matrix (>= 2^20 entries) take the PATTERN family when it fits (smm_spmv_pattern.hip)
 int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream_t s);
+// the automatic attempt of a single SpMV (launchSpmv): never fails -- a matrix the analysis refuses, or cannot find memory for, stays with STREAM
+void adoptPatternQuietly(const smm_hip_csr* m, hipStream_t s);
+int patternLanesFor(const smm_hip_csr* m);
+// the PATTERN kernel launchPat picks for `lanes` and the bytes one launch moves (smm_hip_csr_kernel_desc)
+const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes);
+void planConstMarch(smm_hip_csr* m);
 template <typename T>
-int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                         const int* doneFlag, hipStream_t s);
+template <typename T>
+int launchSpmvPattern(const smm_hip_csr* m, int lanes, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                       const int* doneFlag, hipStream_t s);
 void chooseSpmvConfig(smm_hip_csr* m);
 

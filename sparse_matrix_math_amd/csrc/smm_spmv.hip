@@ -793,14 +793,11 @@ int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows
 	return SMM_HIP_OK;
 }
 
-int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
+int buildTileTable(const smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s, int** blocks, int* nBlocks, int* chunkTiles) {
 	const int rows = m->rows;
-	devFree(m->d_rowblocks);
-	m->d_rowblocks = nullptr;
-	m->n_rowblocks = 0;
-	m->stream_nnz_cap = capNnz;
-	m->stream_max_rows = maxRows;
-	m->stream_chunk_tiles = 0;
+	*blocks = nullptr;
+	*nBlocks = 0;
+	*chunkTiles = 0;
 	DevBuf<int> info;
 	SMM_TRY(info.alloc(2));
 	SMM_HIP_TRY(hipMemsetAsync(info, 0, 2 * sizeof(int), s));
@@ -810,8 +807,8 @@ int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 	int2* tiles = nullptr;
 	int nTiles = 0;
 	SMM_TRY(cutRows(m->d_start, rows, m->nnz, capNnz, maxRows, s, &tiles, &nTiles));  // synchronises s: `far` has arrived
-	m->d_rowblocks = reinterpret_cast<int*>(tiles);
-	m->n_rowblocks = nTiles;
+	*blocks = reinterpret_cast<int*>(tiles);
+	*nBlocks = nTiles;
 	// How the tiles are dealt to the 8 XCDs.  The farthest column a middle row touches tells how far apart (in rows) two uses of
 	// the same x[] line are.  When that distance is many tiles but a small fraction of the matrix (3-D stencils: one grid plane),
 	// the tiles are dealt one such span per XCD, round-robin, so the 8 XCDs sweep 8 adjacent planes together instead of 8 regions
@@ -820,9 +817,24 @@ int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 	if (rows > 0 && nTiles > 0) {
 		const double rowsPerTile = static_cast<double>(rows) / nTiles;
 		const long long farTiles = static_cast<long long>(far / rowsPerTile);
-		if (farTiles >= 256 && farTiles * 32 <= nTiles) m->stream_chunk_tiles = static_cast<int>(farTiles);
+		if (farTiles >= 256 && farTiles * 32 <= nTiles) *chunkTiles = static_cast<int>(farTiles);
 	}
-	if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) m->stream_chunk_tiles = std::max(0, atoi(env));  // tuning override
+	if (const char* env = getenv("SMM_HIP_XCD_CHUNK_TILES")) *chunkTiles = std::max(0, atoi(env));  // tuning override
+	return SMM_HIP_OK;
+}
+
+// the STREAM family's table (caller holds tileMutex).  The old table goes back to the allocator's quarantine: launches already
+// enqueued with it stay valid
+int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
+	int* blocks = nullptr;
+	int n = 0, chunk = 0;
+	SMM_TRY(buildTileTable(m, capNnz, maxRows, s, &blocks, &n, &chunk));
+	devFree(m->d_rowblocks);
+	m->d_rowblocks = blocks;
+	m->n_rowblocks = n;
+	m->stream_nnz_cap = capNnz;
+	m->stream_max_rows = maxRows;
+	m->stream_chunk_tiles = chunk;
 	return SMM_HIP_OK;
 }
 
@@ -914,12 +926,12 @@ void chooseSpmvConfig(smm_hip_csr* m) {
 		if (f == SMM_SPMV_VECTOR || f == SMM_SPMV_STREAM) family = f;
 	}
 	if (m->rows == 0 || m->nnz == 0) family = SMM_SPMV_VECTOR;
-	m->family = family;
-	m->lanes = lanesForAvg(avg, family);
+	int lanes = lanesForAvg(avg, family);
 	if (const char* env = getenv("SMM_HIP_SPMV_LANES")) {
 		const int l = atoi(env);
-		if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) m->lanes = l;
+		if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) lanes = l;
 	}
+	m->setKernel(family, lanes);
 }
 
 template <typename T, int L>
@@ -1040,22 +1052,17 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 	op |= extraFlags;  // the kernels split `op` into the operation (low byte) and flags
 	// AUTO, large matrices: the first SpMV tries the index-free PATTERN family (smm_spmv_pattern.hip) -- analysis and verification of
 	// every entry on the caller's stream, once; a matrix that passes is served by it from here on (same bits as STREAM at equal lanes,
-	// half the bytes for fp32), one that does not stays where it is
-	if (!m->kernelForced && m->family == SMM_SPMV_STREAM && m->pat_state == 0 && autoPatternWanted(m)) {
-		auto* mm = const_cast<smm_hip_csr*>(m);
-		const int st = ensurePattern(mm, s, true, true);
-		if (st == SMM_HIP_OK) {
-			mm->family = SMM_SPMV_PATTERN;
-			mm->lanes = lanesForAvg(static_cast<double>(m->nnz) / m->rows, SMM_SPMV_PATTERN);
-		} else if (st != SMM_HIP_ERR_INVALID) {
-			return st;  // a HIP failure, not "no pattern"
-		}
+	// half the bytes for fp32), one that does not -- or whose analysis could not get its memory -- stays where it is: the attempt is an
+	// optimisation and never fails the caller's SpMV.  One thread at a time (adoptMutex); the others wait and then read the word.
+	if (!m->kernelForced && m->family() == SMM_SPMV_STREAM && m->pat_state.load(std::memory_order_acquire) == 0 && autoPatternWanted(m)) {
+		adoptPatternQuietly(m, s);
 	}
-	int family = m->family;
-	const int L = m->lanes;
+	const int kernelWord = m->kernelWord.load(std::memory_order_acquire);  // family and lanes of THIS launch, read once
+	const int family = kernelWord & 0xFF;
+	const int L = kernelWord >> 8;
 	if (family == SMM_SPMV_PATTERN) {
 		const int profSlot = profBegin(s);
-		const int st = launchSpmvPattern<T>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);  // `op` carries the flags
+		const int st = launchSpmvPattern<T>(m, L, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);  // `op` carries the flags
 		profEnd(profSlot, s);
 		return st;
 	}
@@ -1186,15 +1193,13 @@ int smm_hip_csr_set_kernel(smm_hip_csr* m, int family, int lanes_per_row) {
 	if (family == SMM_SPMV_AUTO) {
 		chooseSpmvConfig(m);
 		if (lanes_per_row == 0 && m->pat_state > 0 && autoPatternWanted(m)) {  // already analysed and verified: AUTO's choice stands
-			m->family = SMM_SPMV_PATTERN;
-			m->lanes = lanesForAvg(m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 0.0, SMM_SPMV_PATTERN);
+			m->setKernel(SMM_SPMV_PATTERN, patternLanesFor(m));
 		}
 	} else {
-		m->family = family;
 		const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 0.0;
-		m->lanes = lanesForAvg(avg, family);
+		m->setKernel(family, lanesForAvg(avg, family));
 	}
-	if (lanes_per_row) m->lanes = lanes_per_row;
+	if (lanes_per_row) m->setKernel(m->family(), lanes_per_row);
 	m->kernelForced = family != SMM_SPMV_AUTO || lanes_per_row != 0;
 	return SMM_HIP_OK;
 }
@@ -1206,8 +1211,9 @@ int smm_hip_csr_get_kernel(const smm_hip_csr* m, int* family, int* lanes_per_row
 	}
 	SMM_TRY(ensureInit());
 	SMM_TRY(ensureCsrReady(m, nullptr, false));
-	if (family) *family = m->family;
-	if (lanes_per_row) *lanes_per_row = m->lanes;
+	const int word = m->kernelWord.load(std::memory_order_acquire);
+	if (family) *family = word & 0xFF;
+	if (lanes_per_row) *lanes_per_row = word >> 8;
 	return SMM_HIP_OK;
 }
 
@@ -1222,7 +1228,33 @@ int smm_hip_csr_tile_info(const smm_hip_csr* m, int* tiles, int* tile_nnz_cap, i
 	if (tiles) *tiles = m->d_rowblocks ? m->n_rowblocks : 0;
 	if (tile_nnz_cap) *tile_nnz_cap = m->d_rowblocks ? m->stream_nnz_cap : 0;
 	if (tile_max_rows) *tile_max_rows = m->d_rowblocks ? m->stream_max_rows : 0;
-	if (tile_kernel) *tile_kernel = m->family == SMM_SPMV_STREAM && useTileKernel(m->lanes) ? 1 : 0;
+	if (tile_kernel) *tile_kernel = m->family() == SMM_SPMV_STREAM && useTileKernel(m->lanes()) ? 1 : 0;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_csr_kernel_desc(const smm_hip_csr* m, char* name, int name_cap, long long* bytes_per_launch) {
+	if (!m) {
+		setError("csr_kernel_desc: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	SMM_TRY(ensureCsrReady(m, nullptr, false));
+	const int word = m->kernelWord.load(std::memory_order_acquire);
+	const int family = word & 0xFF, lanes = word >> 8;
+	const long long s = m->dtype == SMM_DTYPE_F32 ? 4 : 8;
+	long long bytes = static_cast<long long>(m->nnz) * (s + 4) + (static_cast<long long>(m->rows) + 1) * 4 + static_cast<long long>(m->cols) * s +
+	                  static_cast<long long>(m->rows) * s;  // B_spmv of the CSR layout
+	const char* kernel = "spmvVectorKernel";
+	if (family == SMM_SPMV_PATTERN && m->pat_state.load(std::memory_order_acquire) > 0) {
+		kernel = patternKernelDesc(m, lanes, &bytes);
+	} else if (family == SMM_SPMV_STREAM || family == SMM_SPMV_PATTERN) {
+		kernel = (lanes == 1 || lanes == 2 || lanes == 4) && useTileKernel(lanes) ? "spmvTileKernel" : "spmvStreamKernel";
+	}
+	if (name && name_cap > 0) {
+		std::strncpy(name, kernel, static_cast<size_t>(name_cap));
+		name[name_cap - 1] = 0;
+	}
+	if (bytes_per_launch) *bytes_per_launch = bytes;
 	return SMM_HIP_OK;
 }
 
@@ -1246,13 +1278,12 @@ int smm_hip_csr_autotune(smm_hip_csr* m) {
 	SMM_HIP_TRY(hipEventCreate(&e1));
 	const double avg = static_cast<double>(m->nnz) / m->rows;
 	float best = 1e30f;
-	int bestFamily = m->family, bestLanes = m->lanes;
+	int bestFamily = m->family(), bestLanes = m->lanes();
 	int status = SMM_HIP_OK;
 	for (int family = SMM_SPMV_VECTOR; family <= SMM_SPMV_STREAM && status == SMM_HIP_OK; ++family) {
 		const int center = lanesForAvg(avg, family);
 		for (int lanes = std::max(1, center / 2); lanes <= std::min(64, center * 2) && status == SMM_HIP_OK; lanes *= 2) {
-			m->family = family;
-			m->lanes = lanes;
+			m->setKernel(family, lanes);
 			for (int rep = 0; rep < 3 && status == SMM_HIP_OK; ++rep) {
 				hipEventRecord(e0, s);
 				if (m->dtype == SMM_DTYPE_F32) {
@@ -1272,8 +1303,7 @@ int smm_hip_csr_autotune(smm_hip_csr* m) {
 			}
 		}
 	}
-	m->family = bestFamily;
-	m->lanes = bestLanes;
+	m->setKernel(bestFamily, bestLanes);
 	m->kernelForced = true;
 	hipEventDestroy(e0);
 	hipEventDestroy(e1);

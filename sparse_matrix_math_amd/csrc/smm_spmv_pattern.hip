@@ -707,18 +707,23 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstKernel(int rows, int cols
 		const long long tIdx = (static_cast<long long>(c) * nGroups + xcdGroup) * chunkTiles + (j - c * chunkTiles);
 		return tIdx < nTiles ? static_cast<int>(tIdx) : nTiles;
 	};
+#if defined(SMM_EXP_CONST) && (SMM_EXP_CONST & 4)  // ablation builds only: no mask stream (every row takes the first row's mask)
+#define SMM_CONST_MASK_AT(i) masks[((i) & 0) + static_cast<size_t>(rows) / 2 + rows / 1024 + 37]  // (an interior row of a cubic grid)
+#else
+#define SMM_CONST_MASK_AT(i) masks[i]
+#endif
 	T acc0 = T(0), acc1 = T(0);
 	int j = blockIdx.x / nGroups;
 	int tile = tileOf(j);
 	unsigned long long nextMask = 0ULL;
-	if (tile < nTiles && tile * TPB + t < rows) nextMask = masks[static_cast<size_t>(tile) * TPB + t];
+	if (tile < nTiles && tile * TPB + t < rows) nextMask = SMM_CONST_MASK_AT(static_cast<size_t>(tile) * TPB + t);
 	while (tile < nTiles) {
 		const int row = tile * TPB + t;
 		unsigned long long mm = nextMask;
 		j += groupSlots;
 		const int ntile = tileOf(j);
 		nextMask = 0ULL;
-		if (ntile < nTiles && ntile * TPB + t < rows) nextMask = masks[static_cast<size_t>(ntile) * TPB + t];
+		if (ntile < nTiles && ntile * TPB + t < rows) nextMask = SMM_CONST_MASK_AT(static_cast<size_t>(ntile) * TPB + t);
 		if (row < rows) {
 			T dot = T(0);
 			do {  // (an empty row runs one batch of discarded products)
@@ -730,7 +735,13 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstKernel(int rows, int cols
 					live[u] = mm != 0ULL;
 					const int jj = mm ? __builtin_ctzll(mm) : 0;
 					mm &= mm - 1;
-					const int col = min(max(row + sOff[jj], 0), cols - 1);  // (dead slots: a clamped, valid column)
+	#if defined(SMM_EXP_CONST) && (SMM_EXP_CONST & 2)  // ablation builds only (tools/run_const_ablate.sh): every gather reads x[row]
+				const int col = row;
+#elif defined(SMM_EXP_CONST) && (SMM_EXP_CONST & 8)  // ... only the far (plane) gathers are redirected to x[row]
+				const int col = (sOff[jj] > 4096 || sOff[jj] < -4096) ? row : min(max(row + sOff[jj], 0), cols - 1);
+#else
+				const int col = min(max(row + sOff[jj], 0), cols - 1);  // (dead slots: a clamped, valid column)
+#endif
 					off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
 					cv[u] = sC[jj];
 				}
@@ -743,8 +754,12 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstKernel(int rows, int cols
 				}
 			} while (mm != 0ULL);
 			const T o = patApplyOp(op, lhs, divisor, row, dot);
+#if defined(SMM_EXP_CONST) && (SMM_EXP_CONST & 1)  // ablation builds only: the kernel without its out[] stream
+			if (o == T(-1.2345e30)) out[row] = o;
+#else
 			if (ntOut) __builtin_nontemporal_store(o, out + row);
 			else out[row] = o;
+#endif
 			if (dotMode == 2) acc0 += o * o;
 			if (dotMode) acc1 += o * w1[row];
 		}
@@ -1258,6 +1273,7 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	m->d_pat_masks = d_masks.detach();
 	m->pat_const = tryConst && flags[1] == 0;
 	if (m->pat_const) m->d_pat_cval = d_cval.detach();
+	planConstMarch(m);
 	return SMM_HIP_OK;
 }
 
@@ -1317,18 +1333,21 @@ int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet, b
 	// masksOnly: a caller that can only use the row masks (the brick partition of the block preconditioners reads the grid from their
 	// offsets) does not pay for the dictionary; an explicit request later still tries it (state -2)
 	const bool dictWanted = !masksOnly && (!quiet || autoDictAllowed());
-	if (m->pat_state > 0) return SMM_HIP_OK;
-	if (m->pat_state == -1 || (m->pat_state == -2 && !dictWanted)) {
+	const int state = m->pat_state.load(std::memory_order_acquire);
+	if (state > 0) return SMM_HIP_OK;
+	if (state == -1 || (state == -2 && !dictWanted)) {
 		if (!quiet) setError("pattern SpMV: the entries of this matrix use more than %d distinct column offsets", DICT_MAX);
 		return SMM_HIP_ERR_INVALID;
 	}
-	const bool masksTried = m->pat_state == -2;
-	m->pat_state = -1;
-	auto refuse = [quiet](const char* why) {
+	if (state == -3 && quiet) return SMM_HIP_ERR_INVALID;  // an automatic attempt ran out of resources before: only an explicit request tries again
+	const bool masksTried = state == -2;
+	// (the state turns -1 only when the matrix was really refused -- not before the allocations, whose failure says nothing about it)
+	auto refuse = [quiet, m](const char* why, int newState) {
+		m->pat_state.store(newState, std::memory_order_release);
 		if (!quiet) setError("pattern SpMV: %s", why);
 		return static_cast<int>(SMM_HIP_ERR_INVALID);
 	};
-	if (m->rows == 0 || m->nnz == 0) return refuse("empty matrix");
+	if (m->rows == 0 || m->nnz == 0) return refuse("empty matrix", -1);
 	if (!streamKnown) {
 		SMM_HIP_TRY(hipDeviceSynchronize());
 		s = libStream();
@@ -1336,16 +1355,45 @@ int ensurePattern(smm_hip_csr* m, hipStream_t s, bool streamKnown, bool quiet, b
 	const char* why = "";
 	int st = masksTried ? static_cast<int>(SMM_HIP_ERR_INVALID) : tryMasks(m, s, &why);
 	if (st == SMM_HIP_ERR_INVALID) {
-		if (!dictWanted) {
-			m->pat_state = -2;
-			return refuse(why);
-		}
+		if (!dictWanted) return refuse(why, -2);
 		st = tryDict(m, s, &why);
 	}
-	if (st == SMM_HIP_ERR_INVALID) return refuse(why);
-	SMM_TRY(st);
-	m->pat_state = 1;
+	if (st == SMM_HIP_ERR_INVALID) return refuse(why, -1);
+	if (st != SMM_HIP_OK) {  // a HIP failure (no memory for the masks / codes / sort scratch ...): nothing was learnt about the matrix
+		if (quiet) m->pat_state.store(-3, std::memory_order_release);
+		return st;
+	}
+	m->pat_state.store(1, std::memory_order_release);
 	return SMM_HIP_OK;
+}
+
+// lanes per row the PATTERN family runs this (analysed) matrix with: the rule of smm_spmv.hip's lanesForAvg; constant diagonals
+// (<= 32 entries per row): the kernel without values[] is the one-lane one
+int patternLanesFor(const smm_hip_csr* m) {
+	const double avg = m->rows > 0 ? static_cast<double>(m->nnz) / m->rows : 0.0;
+	if (m->pat_state.load(std::memory_order_acquire) > 0 && m->pat_encoding == 0 && m->pat_const) return 1;
+	return avg <= 24 ? 1 : avg <= 64 ? 2 : avg <= 128 ? 4 : 8;
+}
+
+// The automatic STREAM -> PATTERN switch, shared by launchSpmv's first-SpMV rule and the solvers' rule below.  Concurrent solves on one
+// const matrix may arrive here together: one thread analyses (adoptMutex), the others wait and find the word already published.  The
+// attempt is an optimisation: whatever goes wrong inside it (the matrix has no pattern; no memory for 8 bytes per row or 2 per entry or
+// the sort's scratch) leaves the matrix on STREAM, clears HIP's sticky "last error" and is NOT reported -- the caller's SpMV or solve
+// would have run fine without it.
+void adoptPatternQuietly(const smm_hip_csr* cm, hipStream_t s) {
+	auto* m = const_cast<smm_hip_csr*>(cm);
+	std::lock_guard<std::mutex> lock(m->adoptMutex);
+	if (m->kernelForced || m->family() != SMM_SPMV_STREAM) return;  // another thread switched it while this one waited
+	int state = m->pat_state.load(std::memory_order_acquire);
+	if (state < 0 && state != -2) return;
+	// (state > 0: already analysed -- e.g. by a block preconditioner that read the grid from the offsets -- and only not adopted yet)
+	const int st = state > 0 ? static_cast<int>(SMM_HIP_OK) : ensurePattern(m, s, true, true);
+	if (st == SMM_HIP_OK) {
+		m->setKernel(SMM_SPMV_PATTERN, patternLanesFor(m));
+	} else if (st != SMM_HIP_ERR_INVALID) {
+		(void)hipGetLastError();
+		setError("");
+	}
 }
 
 // A SOLVER is about to run many SpMVs with this matrix: matrices far below AUTO's single-SpMV threshold are worth the one-off analysis
@@ -1361,20 +1409,14 @@ int adoptPatternForSolver(const smm_hip_csr* m, int plannedIterations, hipStream
 		const char* env = getenv("SMM_HIP_SOLVER_PATTERN_MIN_NNZ");
 		return env ? atoll(env) : (1LL << 20);
 	}();
-	if (!allowed || !m || m->rows <= 0 || m->kernelForced || m->family != SMM_SPMV_STREAM || m->pat_state == -1) return SMM_HIP_OK;
+	if (!allowed || !m || m->rows <= 0 || m->kernelForced || m->family() != SMM_SPMV_STREAM) return SMM_HIP_OK;
+	const int state = m->pat_state.load(std::memory_order_acquire);
+	if (state == -1 || state == -3) return SMM_HIP_OK;
 	if (plannedIterations >= 0 && plannedIterations < 16) return SMM_HIP_OK;  // (a few passes do not pay for a pass over positions[])
 	const double avg = static_cast<double>(m->nnz) / m->rows;
 	if (m->nnz < minNnz || avg > 64.0) return SMM_HIP_OK;
-	auto* mm = const_cast<smm_hip_csr*>(m);
-	// (pat_state > 0: already analysed -- e.g. by a block preconditioner that read the grid from the offsets -- and only not adopted yet)
-	const int st = m->pat_state > 0 ? static_cast<int>(SMM_HIP_OK) : ensurePattern(mm, s, true, true);
-	if (st == SMM_HIP_OK) {
-		mm->family = SMM_SPMV_PATTERN;
-		mm->lanes = avg <= 24 ? 1 : avg <= 64 ? 2 : avg <= 128 ? 4 : 8;  // (the PATTERN rule of smm_spmv.hip's lanesForAvg)
-		if (mm->pat_encoding == 0 && mm->pat_const) mm->lanes = 1;  // constant diagonals (<= 32 entries per row): the kernel without values[] is the one-lane one
-		return SMM_HIP_OK;
-	}
-	return st == SMM_HIP_ERR_INVALID ? static_cast<int>(SMM_HIP_OK) : st;  // "no pattern" is not a failure
+	adoptPatternQuietly(m, s);
+	return SMM_HIP_OK;  // "no pattern" / "no memory for the analysis" are not failures of the solve
 }
 
 template <typename T>
@@ -1440,6 +1482,7 @@ static void launchPatTile(const smm_hip_csr* m, int op, const T* lhs, const T* d
 template <typename T>
 static void launchPatConst(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                            const int* doneFlag, hipStream_t s) {
+	if (launchPatConstMarch<T>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)) return;  // grid-shaped: the 2.5-D form
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();  // room for the RCCL kernel beside A_loc (smm_dist.hip)
 	op &= ~SPMV_LEAVE_ROOM;
 	const int nTiles = (m->rows + TPB - 1) / TPB;
@@ -1544,34 +1587,56 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 	                                             w1, partials, doneFlag);
 }
 
+// mirrors launchPat's choice (keep the two together)
+const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes) {
+	const long long s = m->dtype == SMM_DTYPE_F32 ? 4 : 8;
+	const long long rows = m->rows, cols = m->cols, nnz = m->nnz;
+	const long long vectors = cols * s + rows * s, startBytes = (rows + 1) * 4;
+	const int L = std::min(lanes, WAVE);
+	if (m->pat_encoding == 1) {
+		*bytes = nnz * (s + 2) + startBytes + vectors;
+		return "spmvDictKernel";
+	}
+	if (L == 1 && m->pat_const && !m->pat_const_off) {
+		*bytes = rows * 8 + vectors;  // the row's mask, x, out: neither values[] nor start[]
+		static const bool marchOn = [] {
+			const char* env = getenv("SMM_HIP_CONST_MARCH");
+			return env ? atoi(env) != 0 : true;
+		}();
+		return m->march_ok && marchOn ? "spmvPatternConstMarchKernel" : "spmvPatternConstKernel";
+	}
+	*bytes = nnz * s + rows * 8 + startBytes + vectors;
+	if (L == 1) {
+		static const int waveEnv = [] {
+			const char* env = getenv("SMM_HIP_PATTERN_WAVE");
+			return env ? atoi(env) : -1;
+		}();
+		if (waveEnv != 0 && m->pat_k <= 16) return "spmvPatternWaveKernel";
+	}
+	if ((L == 2 || L == 4) && patUseTile(L)) return "spmvPatternTileKernel";
+	return "spmvPatternKernel";
+}
+
 // tiles for this family are cut for its own LDS capacity (values only): kept beside the STREAM family's table
 static int buildPatternTiles(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
-	int* keepBlocks = m->d_rowblocks;
-	const int keepN = m->n_rowblocks, keepCap = m->stream_nnz_cap, keepRows = m->stream_max_rows, keepChunk = m->stream_chunk_tiles;
-	m->d_rowblocks = nullptr;
-	const int st = buildRowBlocks(m, capNnz, maxRows, s);
-	if (st == SMM_HIP_OK) {
-		devFree(m->d_pat_rowblocks);
-		m->d_pat_rowblocks = m->d_rowblocks;
-		m->pat_n_rowblocks = m->n_rowblocks;
-		m->pat_nnz_cap = capNnz;
-		m->pat_max_rows = maxRows;
-		m->pat_chunk_tiles = m->stream_chunk_tiles;  // how buildRowBlocks would deal THIS table's tiles to the XCDs
-	}
-	m->d_rowblocks = keepBlocks;
-	m->n_rowblocks = keepN;
-	m->stream_nnz_cap = keepCap;
-	m->stream_max_rows = keepRows;
-	m->stream_chunk_tiles = keepChunk;
-	return st;
+	int* blocks = nullptr;
+	int n = 0, chunk = 0;
+	SMM_TRY(buildTileTable(m, capNnz, maxRows, s, &blocks, &n, &chunk));  // (never through the STREAM family's fields: a launch of another thread may be reading them)
+	devFree(m->d_pat_rowblocks);
+	m->d_pat_rowblocks = blocks;
+	m->pat_n_rowblocks = n;
+	m->pat_nnz_cap = capNnz;
+	m->pat_max_rows = maxRows;
+	m->pat_chunk_tiles = chunk;
+	return SMM_HIP_OK;
 }
 
 template <typename T>
-int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+int launchSpmvPattern(const smm_hip_csr* m, int lanes, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                       const int* doneFlag, hipStream_t s) {
 	auto* mm = const_cast<smm_hip_csr*>(m);
 	SMM_TRY(ensurePattern(mm, s, true));
-	const int L = std::min(m->lanes, WAVE);
+	const int L = std::min(lanes, WAVE);
 	const int capNnz = patCap<T>(m, L) - 3;
 	const int maxRows = TPB / L;
 	{
@@ -1590,8 +1655,8 @@ int launchSpmvPattern(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 	return SMM_HIP_OK;
 }
 
-template int launchSpmvPattern<float>(const smm_hip_csr*, int, const float*, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
-template int launchSpmvPattern<double>(const smm_hip_csr*, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
+template int launchSpmvPattern<float>(const smm_hip_csr*, int, int, const float*, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
+template int launchSpmvPattern<double>(const smm_hip_csr*, int, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 
 }  // namespace smm
 

@@ -706,10 +706,11 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     # which family served the two local blocks: AUTO may have moved a large block to the index-free PATTERN family (its first SpMV
     # verifies every entry); the roofline object is priced with CSR bytes only when the CSR kernels ran -- otherwise the bytes really
     # moved (no positions[], 8 bytes of mask per row) are reported beside it and `frac` uses THEM
-    families, b_true = None, b_local
+    families, b_true, kernels = None, b_local, ["spmvTileKernel"]
     if driver == "native":
         blk_loc, blk_rem = A.local_blocks()
         families = {"A_loc": blk_loc.get_kernel() + blk_loc.pattern_info()[:1], "A_rem": blk_rem.get_kernel() + blk_rem.pattern_info()[:1]}
+        kernels = [blk_loc.kernel_desc()[0]] + ([] if one_launch else [blk_rem.kernel_desc()[0]])  # the library's own answer (smm_hip_csr_kernel_desc)
         b_true = ext_len * s_bytes + (hi - lo) * s_bytes
         for name, nnz_blk in (("A_loc", A.nnz_loc), ("A_rem", A.nnz_rem)):
             fam, lanes, enc = families[name]
@@ -724,14 +725,14 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     per_matvec = 1 if one_launch else 2
     matvec_s = spmv_ms * 1e-3 / max(spmv_launches // per_matvec, 1)
     achieved = b_true / matvec_s / 1e9
-    pattern_used = families is not None and any(f[0] == 3 for f in families.values())
     return {
+        # the same definition as the one-GPU line's `roofline`: the kernels the timed region runs, priced with the bytes THEIR layouts move
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "kernel": ("spmvPatternTileKernel / spmvTileKernel" if pattern_used else "spmvTileKernel") +
-                               " (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")"),
+                     "kernel": " + ".join(kernels) + " (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")"),
                      "algorithmic_bytes_per_launch": b_true, "csr_bytes_per_launch": b_local, "avg_launch_ms": matvec_s * 1e3,
                      "launches": spmv_launches // per_matvec, "families": families,  # (family, lanes per row, PATTERN encoding) of each block
-                     "note": "bytes = what the kernels that ran really move per matvec of rank 0 (a block AUTO moved to the PATTERN family has no positions[]); csr_bytes_per_launch is the SURVEY 8d formula"},
+                     "note": "bytes = what the kernels that ran really move per matvec of rank 0 (a block AUTO moved to the PATTERN family has no positions[]); "
+                             "csr_bytes_per_launch is the SURVEY 8d formula; the CSR kernel's own fraction is the one-GPU line's roofline_csr"},
         "elapsed": elapsed,
         "iters": iters,
         "nnz": nnz_total,

@@ -291,6 +291,13 @@ class CSRMatrix:
         check(_lib.load().smm_hip_csr_pattern_info(self._h, ctypes.byref(enc), ctypes.byref(k)))
         return enc.value, k.value
 
+    def kernel_desc(self):
+        """(kernel name without template arguments, bytes one launch of it moves by ITS data layout) for the next SpMV of this matrix"""
+        buf = ctypes.create_string_buffer(64)
+        nbytes = ctypes.c_longlong()
+        check(_lib.load().smm_hip_csr_kernel_desc(self._h, buf, 64, ctypes.byref(nbytes)))
+        return buf.value.decode(), nbytes.value
+
     def pattern_allow_const(self, allow):
         """False: a matrix with constant diagonals keeps reading values[] (measurements); same bits either way"""
         check(_lib.load().smm_hip_csr_pattern_allow_const(self._h, 1 if allow else 0))

@@ -15,8 +15,15 @@ def test_committed_traffic_measurement_belongs_to_the_committed_kernel():
     with open(os.path.join(ROOT, "profiles", "spmv_traffic.json")) as f:
         stamp = json.load(f)
     assert stamp["kernel_source_sha16"] == bench.spmv_kernel_source_sha()
-    t = bench.load_traffic(argparse.Namespace(rows=10_000_000, dtype="f32", band_k=25))
+    args = argparse.Namespace(rows=10_000_000, dtype="f32", band_k=25)
+    t = bench.load_traffic(args, "spmvTileKernel")  # roofline_csr.traffic
     assert t is not None and 3.9e9 < t < 6.0e9  # algorithmic 3.996 GB <= traffic
+    # ... and the kernel the timed region runs (AUTO: the PATTERN tile kernel) has an entry of its own, stamped with ITS sources
+    pat = stamp["other_kernels"]["pattern_family_same_matrix"]
+    assert pat["kernel_source_sha16"] == bench.pattern_kernel_source_sha()
+    tp = bench.load_traffic(args, "spmvPatternTileKernel")  # roofline.traffic
+    assert tp is not None and 2.1e9 < tp < t  # 2.138 GB of its own bytes <= traffic < the CSR kernel's
+    assert bench.load_traffic(args, "spmvStreamKernel") is None  # never another kernel's number
 
 
 def test_kernel_hash_ignores_comments_and_white_space(tmp_path, monkeypatch):

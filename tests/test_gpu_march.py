@@ -1,0 +1,104 @@
+"""The 2.5-D form of the constant-diagonal SpMV (spmvPatternConstMarchKernel, csrc/smm_spmv_march.hip): grid-shaped matrices of at
+least 2^21 rows march along the far direction with the plane's window of x in LDS.  Same products in the same order as the reference's
+row loop (ref:1484-1499): every comparison below is bit for bit against the oracle."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OP_ADD, OP_ASSIGN, OP_SUB
+
+pytestmark = pytest.mark.gpu
+PATTERN, CONST = 3, 3
+
+
+def _stencil(smm, torch, nx, ny, nz, dtype, diag=6.0, lo=-1.25, hi=-0.75):
+    dev = torch.device("cuda:0")
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = nx * ny * nz
+    stream = torch.cuda.current_stream().cuda_stream
+    if nz > 1:
+        nnz = smm.host.gen_stencil3d_nnz(nx, ny, nz)
+    else:
+        nnz = smm.host.gen_poisson2d_nnz(nx, ny)
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=td, device=dev)
+    if nz > 1:
+        smm.host.gen_stencil3d_dev(nx, ny, nz, diag, lo, hi, d_start, d_pos, d_val, dtype, stream)
+    else:
+        smm.host.gen_poisson2d_dev(nx, ny, d_start, d_pos, d_val, dtype, stream)
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, dtype)
+    return A, (d_start, d_pos, d_val), n, td, dev, stream
+
+
+# (nx, ny, nz): a cube; planes that are no whole number of tiles (96 x 112 = 5.25 tiles) with an odd number of them; ONE plane whose every
+# offset is near (a 2-D grid 1000 wide: halo 1000 of the 1024 a lane can hold in fp64)
+GRIDS = [(128, 128, 128), (96, 112, 201), (1000, 2200, 1)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("grid", GRIDS)
+def test_march_kernel_matches_oracle(smm, oracle, dtype, grid):
+    import torch
+
+    nx, ny, nz = grid
+    A, (d_start, d_pos, d_val), n, td, dev, stream = _stencil(smm, torch, nx, ny, nz, dtype)
+    A.set_kernel(PATTERN, 1)
+    assert A.pattern_info()[0] == CONST
+    name, nbytes = A.kernel_desc()
+    assert name == "spmvPatternConstMarchKernel", name
+    assert nbytes == n * 8 + 2 * n * np.dtype(dtype).itemsize
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(n, dtype=td, device=dev, generator=g) - 0.5
+    lhs = torch.rand(n, dtype=td, device=dev, generator=g) - 0.5
+    y = torch.empty(n, dtype=td, device=dev)
+    csr = (d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy())
+    xh, lh = x.cpu().numpy(), lhs.cpu().numpy()
+    for op in (OP_ASSIGN, OP_ADD, OP_SUB):
+        y.fill_(float("nan"))
+        A.spmv_dev(op, lhs if op != OP_ASSIGN else None, x, y, stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(y.cpu().numpy(), oracle.spmv(csr, op, lh, xh))
+    # in place (out aliases lhs, ref:1507-1515) and the fused dot products finished inside the launch
+    z = lhs.clone()
+    A.spmv_dev(OP_SUB, z, x, z, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(z.cpu().numpy(), oracle.spmv(csr, OP_SUB, lh, xh))
+    fin = torch.zeros(smm.host.finish_len(), dtype=td, device=dev)
+    A.spmv_fused_dev(OP_ASSIGN, None, x, y, 2, x, fin, stream, finish=True)
+    torch.cuda.synchronize()
+    ref = oracle.spmv(csr, OP_ASSIGN, None, xh)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    off = smm.host.finish_totals_offset()
+    totals = fin.cpu().numpy().astype(np.float64)
+    r64, x64 = ref.astype(np.float64), xh.astype(np.float64)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert abs(totals[off] - float(r64 @ r64)) <= tol * float(r64 @ r64)
+    assert abs(totals[off + 1] - float(r64 @ x64)) <= tol * float(np.abs(r64 * x64).sum())
+    # the gather kernel it replaces gives the same bits (the env switch is read once per process, so compare through the MASKS kernels,
+    # which read values[]: same products, same order)
+    A.pattern_allow_const(False)
+    A.spmv_dev(OP_ASSIGN, None, x, y, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    A.close()
+
+
+def test_march_in_cg_at_scale(smm, oracle):
+    """ConjugateGradient on a 160^3 Laplacian (4.1 M rows, fp64) with AUTO: the solver adopts PATTERN / CONST, the SpMV is the march kernel;
+    x after 25 iterations against the oracle (fixed iterations: eps = 0)"""
+    import torch
+
+    N = 160
+    A, (d_start, d_pos, d_val), n, td, dev, stream = _stencil(smm, torch, N, N, N, np.float64, 6.0, -1.0, -1.0)
+    ones = torch.ones(n, dtype=td, device=dev)
+    b = torch.empty(n, dtype=td, device=dev)
+    A.spmv_dev(OP_ASSIGN, None, ones, b, stream)
+    x = torch.zeros(n, dtype=td, device=dev)
+    st, it, _res = smm.host.cg_dev(A, b, x, x, 25, 0.0, None, stream)
+    torch.cuda.synchronize()
+    assert A.get_kernel() == (PATTERN, 1) and A.kernel_desc()[0] == "spmvPatternConstMarchKernel"
+    csr = (d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy())
+    st_ref, x_ref, it_ref, _ = oracle.cg(csr, b.cpu().numpy(), np.zeros(n), 25, 0.0)
+    assert int(st) == st_ref and it == it_ref == 25
+    np.testing.assert_allclose(x.cpu().numpy(), x_ref, rtol=0, atol=1e-10 * float(np.abs(x_ref).max()))
+    A.close()

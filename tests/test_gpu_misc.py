@@ -120,6 +120,67 @@ def test_concurrent_host_api_solves(smm, oracle):
         np.testing.assert_allclose(x, x_ref, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("kind", ["convdiff64_auto_adopts", "iid_auto_refuses"])
+def test_concurrent_solves_while_auto_switches_the_kernel_family(smm, oracle, kind):
+    """concurrent solves on one const matrix are safe (ref:2316-2324 take `const CSRMatrix<T>&`).  Above 2^20 stored
+    entries the FIRST solve of an AUTO matrix runs the PATTERN analysis and switches the kernel family from inside the solve: four
+    threads start their solves on a fresh matrix together -- one analyses (adoptMutex), the others wait and read the published
+    family | lanes word -- and every one of them must get the oracle's answer.  Repeated for a matrix whose analysis says no (i.i.d.
+    columns), which must stay on STREAM, quietly."""
+    if kind == "convdiff64_auto_adopts":
+        csr = gen.convdiff3d(64, 0.3, dtype=np.float64)  # 262 144 rows, 1.8 M entries
+    else:
+        rng = np.random.default_rng(3)
+        n, width = 120_000, 9  # 1.08 M entries, i.i.d. columns + a dominant diagonal: no pattern
+        cols = np.sort(rng.integers(0, n, (n, width - 1)), axis=1)
+        rows_idx = np.arange(n)[:, None]
+        cols = np.where(cols == rows_idx, (cols + 1) % n, cols)
+        allc = np.sort(np.concatenate([cols, rows_idx], axis=1), axis=1)
+        keep = np.ones_like(allc, dtype=bool)
+        keep[:, 1:] = allc[:, 1:] != allc[:, :-1]
+        lens = keep.sum(axis=1)
+        start = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+        pos = allc[keep].astype(np.int32)
+        vals = rng.uniform(-1, 1, len(pos))
+        rr = np.repeat(np.arange(n), lens)
+        vals[pos == rr] = 6.0
+        csr = (start, pos, vals)
+    n = len(csr[0]) - 1
+    assert csr[0][-1] >= 1 << 20
+    b = gen.row_sums(csr[0], csr[2])
+    x_ref_b = oracle.bicgstab(csr, b, np.zeros(n), 20, 0.0)[1]  # (the solvers adopt the family when >= 16 iterations are allowed)
+    for attempt in range(3):  # a fresh handle each time: the switch happens once per matrix
+        A = smm.CSRMatrix(n, n, *csr)
+        results, errors = [None] * 4, []
+        gate = threading.Barrier(4)
+
+        def work(i):
+            try:
+                x = np.zeros(n)
+                info = {}
+                gate.wait()
+                st = smm.BiCGStab(A, b.copy(), x, 20, 0.0, info=info)
+                results[i] = (int(st), info["iterations"], x)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        fam, lanes = A.get_kernel()
+        if kind == "convdiff64_auto_adopts":
+            assert (fam, lanes) == (3, 1) and A.pattern_info()[0] == 3  # PATTERN, one lane per row, constant diagonals
+        else:
+            assert fam == 2 and A.pattern_info()[0] == 0  # refused quietly: STREAM
+        for st, it, x in results:
+            assert it == 20
+            np.testing.assert_allclose(x, x_ref_b, rtol=0, atol=1e-7 * float(np.abs(x_ref_b).max()))
+        A.close()
+
+
 def test_handle_destroyed_behind_an_async_launch_does_not_corrupt_it(smm, oracle):
     """`_dev` entry points only enqueue, and destroy / __del__ hand buffers back to the caching allocator.  A block must not
     be reused while a queued kernel still reads it: the matrix (library-owned copy of the arrays) is destroyed right behind an SpMV

@@ -16,7 +16,9 @@ echo "bench exit $?"
 python - <<'PY'
 import json,os
 d=json.load(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/final_bench.json"))
-print("value",d["value"],"roofline",d["roofline"]["frac"],d["roofline"]["traffic"],"stream",d.get("stream_family",{}).get("value"),"auto frac",d.get("auto_family",{}).get("frac"))
+r,c=d["roofline"],d["roofline_csr"]
+print("value",d["value"],"ms/step",d["ms_per_step"],"| roofline",r["kernel"],r["frac"],r["avg_launch_ms"],r["traffic"],"| csr",c["kernel"],c["frac"],c["avg_launch_ms"],c["value"],c["traffic"])
+print("consistent:",2*r["avg_launch_ms"]<=d["ms_per_step"],"cpu",{k:v for k,v in d.get("cpu_baseline",{}).items() if k not in ("sample","cpu_model")})
 e=d["extras"]["bicgstab_convdiff108_f64"]
 print({k:(round(v["create_plus_solve_ms"],2),v["iterations"],round(v.get("apply_us",0),1)) for k,v in e.items() if isinstance(v,dict) and "iterations" in v})
 print(d["extras"]["spmv_laplacian512_f64"])

@@ -28,7 +28,8 @@ def main():
     read_req = 128 * vals.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * vals.get("TCC_EA0_RDREQ_64B_sum", 0) + 32 * vals.get("TCC_EA0_RDREQ_32B_sum", 0)
     write = vals["WRITE_SIZE"] * 1024
     def family_bytes(name):
-        """the same corrections for another kernel's summary (no stamp: only the roofline's kernel is quoted by bench.py)"""
+        """the same corrections for another kernel's summary, stamped with the PATTERN sources' sha (bench.py quotes the PATTERN tile kernel's
+        entry as roofline.traffic when AUTO runs the bench matrix on it)"""
         path = os.path.join(src, name)
         if not os.path.exists(path):
             return None
@@ -42,7 +43,8 @@ def main():
         if "FETCH_SIZE" not in v:
             return None
         rq = 128 * v.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * v.get("TCC_EA0_RDREQ_64B_sum", 0) + 32 * v.get("TCC_EA0_RDREQ_32B_sum", 0)
-        return {"kernel": k.replace("void smm::", ""), "read_bytes_per_launch": 2 * v["FETCH_SIZE"] * 1024, "read_bytes_per_launch_from_request_sizes": rq,
+        return {"kernel": k.replace("void smm::", ""), "kernel_source_sha16": bench.pattern_kernel_source_sha(),
+                "read_bytes_per_launch": 2 * v["FETCH_SIZE"] * 1024, "read_bytes_per_launch_from_request_sizes": rq,
                 "write_bytes_per_launch": v.get("WRITE_SIZE", 0) * 1024, "TCC_HIT_sum": v.get("TCC_HIT_sum"), "TCC_MISS_sum": v.get("TCC_MISS_sum")}
 
     out = {
