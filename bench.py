@@ -49,7 +49,8 @@ def parse_args():
     ap.add_argument("--autotune", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) PATTERN-family measurement")
     ap.add_argument("--mtx", default=None, help="extras leg (BASELINE config 5): a Matrix Market file read by the drop-in header's direct-to-CSR loader and "
-                    "solved with BiCGStab + none / Jacobi / ILU0 (tests/cpp/mtx_bicgstab); default: ./atmosmodd.mtx when it exists")
+                    "solved with BiCGStab + none / Jacobi / BLOCK_ILU0 / ILU0 (tests/cpp/mtx_bicgstab); default: ./atmosmodd.mtx when it exists, else a "
+                    "generated 1.26 M-row general file with varying coefficients")
     ap.add_argument("--dist", action="store_true", help="take the row-partitioned multi-GPU code path even with one rank")
     ap.add_argument("--dist-driver", choices=["native", "python"], default="native",
                     help="N > 1: the loop behind the C ABI (csrc/smm_dist.hip, RCCL) or the Python driver over torch.distributed")
@@ -421,22 +422,54 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
     return out
 
 
-def mtx_leg(path):
-    """BASELINE config 5 on a real file through the C++ drop-in header (tests/cpp/mtx_bicgstab.cpp): not the headline"""
+def mtx_leg(path=None):
+    """BASELINE config 5 -- "Matrix Market nonsymmetric (e.g. SuiteSparse atmosmodd), BiCGStab + Jacobi/ILU0" -- FROM A FILE, through the C++
+    drop-in header (tests/cpp/mtx_bicgstab.cpp: SMM::loadMatrix direct to CSR, then the C ABI's BiCGStab): not the headline.  Without
+    --mtx (atmosmodd cannot be fetched offline) the file is written here, once per run, into a temporary directory: the 108^3
+    convection-diffusion operator with SPATIALLY VARYING coefficients (generators.convdiff3d_varying; 1.26 M rows, 8.75 M entries, entries
+    shuffled, `general` banner) -- a matrix whose diagonals are not constant, so the SpMV reads values[] as it would for atmosmodd."""
+    import shutil
     import subprocess
+    import tempfile
 
     tool = os.path.join(ROOT, "tests", "cpp", "mtx_bicgstab")
     if not os.path.exists(tool):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "mtx_bicgstab"], check=True)
-    out = {"file": os.path.basename(path)}
-    for kind in ("none", "jacobi", "ilu0"):
-        r = subprocess.run([tool, path, kind, "2000", "1e-8"], capture_output=True, text=True, timeout=1800)
+    tmp = None
+    out = {}
+    try:
+        if path is None:
+            import numpy as np
+
+            from sparse_matrix_math_amd import generators as gen
+
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from write_mtx import write_mtx
+
+            tmp = tempfile.mkdtemp(prefix="smm_bench_mtx_")
+            path = os.path.join(tmp, "convdiff_varying108.mtx")
+            t0 = time.perf_counter()
+            entries = write_mtx(path, gen.convdiff3d_varying(108, 0.3, dtype=np.float64), shuffle=True, seed=1)
+            out.update(generated="generators.convdiff3d_varying(108, 0.3): general, shuffled", write_s=time.perf_counter() - t0, entries=entries,
+                       file_bytes=os.path.getsize(path))
+        out["file"] = os.path.basename(path)
+        r = subprocess.run([tool, path, "none,jacobi,block_ilu0,ilu0", "2000", "1e-8"], capture_output=True, text=True, timeout=1800)
         if r.returncode != 0:
-            out[kind] = {"error": (r.stderr or r.stdout)[-300:]}
-            continue
-        j = json.loads(r.stdout.strip().splitlines()[-1])
-        out.update(rows=j["rows"], nnz=j["nnz"], load_s=j["load_s"])
-        out[kind] = {k: j[k] for k in ("status", "iterations", "resnorm", "solve_s", "precond_setup_s", "max_abs_err_vs_ones")}
+            out["error"] = (r.stderr or r.stdout)[-300:]
+            return out
+        for ln in r.stdout.strip().splitlines():
+            j = json.loads(ln)
+            out.update(rows=j["rows"], nnz=j["nnz"], load_s=j["load_s"], spmv_kernel=j["spmv_kernel"], pattern_encoding=j["pattern_encoding"])
+            out[j["precond"]] = {"status": j["status"], "iterations": j["iterations"], "resnorm": j["resnorm"], "create_ms": j["precond_setup_s"] * 1e3,
+                                 "solve_ms": j["solve_s"] * 1e3, "create_plus_solve_ms": (j["precond_setup_s"] + j["solve_s"]) * 1e3,
+                                 "max_abs_err_vs_ones": j["max_abs_err_vs_ones"]}
+        out["note"] = ("host-pointer API of the drop-in header: every solve_ms includes the PCIe copies of b and x; create / solve are the second "
+                       "(steady-state) run of each kind; pattern_encoding 1 = row masks + values[]")
+    except Exception as e:  # noqa: BLE001 -- extras never fail the bench line
+        out["error"] = str(e)[:300]
+    finally:
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -617,8 +650,9 @@ def main():
         if not args.no_extras:
             result.setdefault("extras", {}).update(extra_spmv_legs(args, smm, host, torch, np, dev, stream))
         mtx = args.mtx or (os.path.join(ROOT, "atmosmodd.mtx") if os.path.exists(os.path.join(ROOT, "atmosmodd.mtx")) else None)
-        if mtx:
-            result.setdefault("extras", {})["mtx_bicgstab"] = mtx_leg(mtx)
+        if mtx or not args.no_extras:
+            torch.cuda.empty_cache()
+            result.setdefault("extras", {})["mtx_bicgstab"] = mtx_leg(mtx)  # config 5 on a file, every run
         if args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, np_dtype, d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy(),
                                                   b.cpu().numpy(), args.cpu_seconds)

@@ -125,6 +125,10 @@ int smm_hip_stream_synchronize(smm_hip_stream stream);
  * in milliseconds and the number of launches since the last reset, and optionally resets the tally. */
 int smm_hip_profile_enable(int on);
 int smm_hip_profile_read(double* spmv_ms, long long* spmv_launches, int reset);
+/* The row-partitioned SpMV (smm_hip_dist_*): while profiling is on, every halo exchange leaves a pair of events -- the end of the local
+ * block A_loc on the caller's stream, the end of the exchange on the communicator's stream.  exposed_ms = the sum over the pairs of
+ * max(0, exchange end - A_loc end): the part of the exchanges the local block did NOT cover; pairs = the number of exchanges. */
+int smm_hip_profile_read_waits(double* exposed_ms, long long* pairs, int reset);
 
 /* ---- CSRMatrix<T> (ref:1243-1259; replaces CSRMatrix::init(TripletMatrix) ref:1326-1349 as the way in) ---- */
 /* Copies the three host arrays of a CSRMatrix (values[nnz], positions[nnz] ascending per row, start[rows+1])

@@ -650,8 +650,9 @@ inline MatrixLoadStatus loadMatrixMarketMatrix(const char* filepath, CSRMatrix<T
 // The dense text format the reference's saveDenseText writes and ref:2611-2643 reads: `rows cols { {a, b, ...}, {...}, ... }`.
 // Written from that format description with a parser of its own: the file is read whole and scanned once as a token stream --
 // numbers by strtod, `{` `}` tracked as a nesting depth, commas and white space skipped -- and the shape is CHECKED (exactly `rows`
-// inner groups of exactly `cols` numbers, a closed outer group), which the format allows and a stream of >> / ignore calls cannot.
-// Zeros are not stored.
+// inner groups of exactly `cols` numbers, a closed outer group), which the format allows and a stream of >> / ignore calls cannot:
+// STRICTER than the reference, which reads `cols` numbers per row and skips whatever else the line holds (INTEGRATION.md lists the
+// difference).  Text after the closing brace is ignored, as there.  Zeros are not stored.
 template <typename T>
 inline MatrixLoadStatus loadSMMDTMatrix(const char* filepath, TripletMatrix<T>& out) {
 	std::FILE* f = std::fopen(filepath, "rb");
@@ -690,10 +691,18 @@ inline MatrixLoadStatus loadSMMDTMatrix(const char* filepath, TripletMatrix<T>& 
 		} else if (c == ',' || std::isspace(static_cast<unsigned char>(c))) {
 			++p;
 		} else {
+			// a number as `file >> val` with val of type T reads it (ref:2629-2634): parsed straight to T -- strtof for float, so that the
+			// rounding is the one-step rounding of the reference and not double -> float --, plain decimal notation only (operator>> takes
+			// neither "inf" / "nan" nor hexadecimal floats), and the zero test is made on the T value (a number that underflows to 0 in T
+			// is not stored, as in the reference)
+			const char* q = p + ((*p == '+' || *p == '-') ? 1 : 0);
+			if (!(std::isdigit(static_cast<unsigned char>(*q)) || *q == '.') || (q[0] == '0' && (q[1] == 'x' || q[1] == 'X'))) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
 			char* after = nullptr;
-			const double v = std::strtod(p, &after);
+			T v;
+			if (sizeof(T) == sizeof(float)) v = static_cast<T>(std::strtof(p, &after));
+			else v = static_cast<T>(std::strtod(p, &after));
 			if (after == p || depth != 2 || col >= cols) return MatrixLoadStatus::FAILED_TO_PARSE_FILE;
-			if (v != 0.0) out.addEntry(row, col, static_cast<T>(v));
+			if (v != T(0)) out.addEntry(row, col, v);
 			++col;
 			p = after;
 		}

@@ -83,6 +83,7 @@ _PLAIN = {
     "smm_hip_stream_synchronize": (c_int, [_P]),
     "smm_hip_profile_enable": (c_int, [c_int]),
     "smm_hip_profile_read": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),
+    "smm_hip_profile_read_waits": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),
     "smm_hip_csr_destroy": (c_int, [_P]),
     "smm_hip_csr_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "smm_hip_csr_set_kernel": (c_int, [_P, c_int, c_int]),

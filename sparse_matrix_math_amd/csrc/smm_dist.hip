@@ -196,8 +196,12 @@ static int boundedSync(smm_hip_comm* c, hipStream_t s) {
 	}
 }
 
+// Only failures that can leave the ranks out of step tear the communicator down: a HIP or RCCL failure somewhere inside the call.  A
+// caller's mistake that is found before anything was enqueued (SMM_HIP_ERR_INVALID: a wrong dtype, a null vector, a foreign
+// preconditioner; SMM_HIP_ERR_PRECOND) is returned as it is and the communicator stays usable -- every rank makes the same call with
+// the same kind of arguments, so every rank gets the same refusal.
 static int guardComm(smm_hip_comm* c, int rc) {
-	if (rc != SMM_HIP_OK && c && c->kind == SMM_COMM_RCCL) commAbort(c);
+	if ((rc == SMM_HIP_ERR_HIP || rc == SMM_HIP_ERR_COMM || rc == SMM_HIP_ERR_NOMEM) && c && c->kind == SMM_COMM_RCCL) commAbort(c);
 	return rc;
 }
 
@@ -617,7 +621,10 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 	// the local block runs while the halo is in flight; with RCCL the exchange is itself a kernel (a few workgroups per peer), and the
 	// persistent SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
 	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, landed ? SPMV_LEAVE_ROOM : 0));
-	if (landed) SMM_HIP_TRY(hipStreamWaitEvent(s, landed, 0));
+	if (landed) {
+		profWaitPair(s, c->stream);  // (profiling on: how long A_rem waits for the halo after A_loc has ended -- the exposed part of the exchange)
+		SMM_HIP_TRY(hipStreamWaitEvent(s, landed, 0));
+	}
 	if (jacobiDiag) return launchSpmv<T>(D->aRem, SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_ADD_DIV, jacobiDiag);
 	return launchSpmv<T>(D->aRem, op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
 }
@@ -1068,6 +1075,7 @@ int smm_hip_comm_create_rccl(int rank, int world, const void* id, smm_hip_comm**
 		std::mutex mu;
 		std::condition_variable cv;
 		bool done = false;
+		bool abandoned = false;  // the waiter gave up: a communicator that arrives later belongs to nobody and is aborted by the helper
 		ncclResult_t result = ncclSuccess;
 		ncclComm_t comm = nullptr;
 	};
@@ -1079,6 +1087,10 @@ int smm_hip_comm_create_rccl(int rank, int world, const void* id, smm_hip_comm**
 		ncclComm_t comm = nullptr;
 		const ncclResult_t r = api->CommInitRank(&comm, world, u, rank);
 		std::lock_guard<std::mutex> lock(state->mu);
+		if (state->abandoned) {  // (a peer that arrived after the time-out: nothing may leak into a process that went on without it)
+			if (r == ncclSuccess && comm && api->CommAbort) api->CommAbort(comm);
+			return;
+		}
 		state->result = r;
 		state->comm = comm;
 		state->done = true;
@@ -1087,6 +1099,7 @@ int smm_hip_comm_create_rccl(int rank, int world, const void* id, smm_hip_comm**
 	{
 		std::unique_lock<std::mutex> lock(state->mu);
 		if (!state->cv.wait_for(lock, std::chrono::duration<double>(commTimeoutSeconds()), [&] { return state->done; })) {
+			state->abandoned = true;
 			delete c;
 			setError("comm_create_rccl: rank %d of %d waited %.0f s in ncclCommInitRank (is every rank running, with the same unique id?)", rank, world,
 			         commTimeoutSeconds());

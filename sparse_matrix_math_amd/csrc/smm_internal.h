@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -38,6 +39,28 @@ int hipFail(hipError_t e, const char* what, const char* file, int line);
 			return _s;             \
 		}                          \
 	} while (0)
+
+// SMM_HIP_TRACE_SETUP=1: the host-side stages of the one-off set-up work (PATTERN analysis, tile tables) print their wall time on stderr
+struct SetupTrace {
+	const char* what;
+	std::chrono::steady_clock::time_point t0;
+	static bool on() {
+		static const bool v = [] {
+			const char* env = getenv("SMM_HIP_TRACE_SETUP");
+			return env && atoi(env) != 0;
+		}();
+		return v;
+	}
+	explicit SetupTrace(const char* w) : what(w) {
+		if (on()) t0 = std::chrono::steady_clock::now();
+	}
+	~SetupTrace() {
+		if (on()) {
+			const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+			std::fprintf(stderr, "[smm-hip setup] %-40s %8.3f ms\n", what, ms);
+		}
+	}
+};
 
 // make sure a device is selected; returns SMM_HIP_ERR_NO_DEVICE when there is none
 int ensureInit();
@@ -138,6 +161,7 @@ struct smm_hip_csr {
 	// CONST on grid-shaped matrices: the plan of the 2.5-D kernel (smm_spmv_march.hip), made once at the end of the CONST analysis
 	bool march_ok = false;
 	int march_P = 0, march_H = 0, march_lo = 0, march_hi = 0;  // rows per plane, halo (elements), whether -P / +P are offsets
+	unsigned* d_pat_masks32 = nullptr;  // the low halves of d_pat_masks, what the 2.5-D kernel streams (4 bytes per row)
 	std::vector<int> pat_offs_host;  // MASKS: the sorted offsets (host copy: the brick partition of the block preconditioners reads the grid from them)
 	int pat_k = 0;
 	int* d_pat_off = nullptr;
@@ -182,6 +206,8 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 // live event timing of SpMV launches (smm_hip_profile_*): begin returns a slot or -1 when profiling is off
 int profBegin(hipStream_t s);
 void profEnd(int slot, hipStream_t s);
+// the waiting stream's own work ends here / the awaited stream's work ends here: smm_hip_profile_read_waits sums max(0, awaited - waiting)
+void profWaitPair(hipStream_t waiting, hipStream_t awaited);
 
 // flag ORed into the `op` argument of the STREAM / PATTERN kernels: write out[] with non-temporal stores.  Set for outputs too
 // large to still be in cache when the next kernel reads them (measured on the 512^3 fp64 Laplacian: 3.15 -> 2.97 ms; written
@@ -232,6 +258,7 @@ int patternLanesFor(const smm_hip_csr* m);
 // the PATTERN kernel launchPat picks for `lanes` and the bytes one launch moves (smm_hip_csr_kernel_desc)
 const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes);
 void planConstMarch(smm_hip_csr* m);
+int marchBuildMasks32(smm_hip_csr* m, hipStream_t s);
 template <typename T>
 bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s);

@@ -1,5 +1,6 @@
 // smm_runtime.hip -- device selection, error text, library stream, caching allocator, CSR handles.
 #include <cstdarg>
+#include <chrono>
 #include <map>
 #include <thread>
 
@@ -98,10 +99,26 @@ static std::vector<hipStream_t> g_recentStreams;  // every stream the library ha
 static std::vector<hipEvent_t> g_eventPool;
 static std::mutex g_streamMutex;
 
+// The list is bounded: the most recently used MAX_NOTED_STREAMS caller streams, most recent last.  A stream that falls
+// off the end may still have work queued that reads a block freed later, and no event will be recorded on it any more: the next epoch
+// that is closed drains the device once instead (g_evictedSinceClose) -- rare (a process that cycles through more than 32 streams), safe.
+constexpr size_t MAX_NOTED_STREAMS = 32;
+static bool g_evictedSinceClose = false;
+
 void noteStream(hipStream_t s) {
 	std::lock_guard<std::mutex> lock(g_streamMutex);
-	for (hipStream_t k : g_recentStreams) {
-		if (k == s) return;
+	for (size_t i = 0; i < g_recentStreams.size(); ++i) {
+		if (g_recentStreams[i] == s) {
+			if (i + 1 != g_recentStreams.size()) {  // move to the back: most recently used
+				g_recentStreams.erase(g_recentStreams.begin() + static_cast<long>(i));
+				g_recentStreams.push_back(s);
+			}
+			return;
+		}
+	}
+	if (g_recentStreams.size() >= MAX_NOTED_STREAMS) {
+		g_recentStreams.erase(g_recentStreams.begin());
+		g_evictedSinceClose = true;
 	}
 	g_recentStreams.push_back(s);
 }
@@ -127,11 +144,18 @@ static void closeEpochLocked() {
 	{
 		std::lock_guard<std::mutex> lock(g_streamMutex);
 		streams = g_recentStreams;
+		if (g_evictedSinceClose) ep.drainInstead = true;
+		g_evictedSinceClose = false;
 	}
 	bool haveLib = false;
 	for (hipStream_t k : streams) haveLib = haveLib || k == g_stream;
 	if (!haveLib && g_stream) streams.push_back(g_stream);  // the host-pointer entry points run here
 	for (hipStream_t k : streams) {
+		// a stream the caller is capturing into a hipGraph executes nothing now: recording on it would put a node into the caller's graph
+		// (or invalidate the capture), and there is nothing queued on it to wait for
+		hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+		if (hipStreamIsCapturing(k, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) continue;
+		(void)hipGetLastError();
 		hipEvent_t ev = nullptr;
 		if (!g_eventPool.empty()) {
 			ev = g_eventPool.back();
@@ -179,13 +203,16 @@ static void reapEpochsLocked(std::unique_lock<std::mutex>& lock, size_t waitFor)
 				if (g_epochs.empty() || g_epochs.front().id != id) continue;
 				g_epochs.front().drainInstead = false;
 			}
-			for (;;) {
+			for (unsigned polls = 0;; ++polls) {
 				if (g_epochs.empty() || g_epochs.front().id != id) break;  // another thread reaped it meanwhile
 				bool all = true;
 				for (hipEvent_t ev : g_epochs.front().events) all = all && hipEventQuery(ev) != hipErrorNotReady;
 				if (all) break;
 				lock.unlock();
-				std::this_thread::yield();
+				// (the first polls spin -- an epoch usually completes within microseconds --, then the thread sleeps between polls: another
+				// thread's whole solve may be what the events wait for, and a core must not burn for that long)
+				if (polls < 64) std::this_thread::yield();
+				else std::this_thread::sleep_for(std::chrono::microseconds(polls < 1024 ? 20 : 200));
 				lock.lock();
 			}
 			if (g_epochs.empty() || g_epochs.front().id != id) continue;
@@ -268,6 +295,8 @@ static std::mutex g_profMutex;
 static bool g_profOn = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_profEvents;  // pool, reused after reset
 static size_t g_profUsed = 0;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_profWaitEvents;  // (end of own work on the waiting stream, end of the awaited work)
+static size_t g_profWaitUsed = 0;
 
 int profBegin(hipStream_t s) {
 	std::lock_guard<std::mutex> lock(g_profMutex);
@@ -280,6 +309,22 @@ int profBegin(hipStream_t s) {
 	const int slot = static_cast<int>(g_profUsed++);
 	(void)hipEventRecord(g_profEvents[slot].first, s);
 	return slot;
+}
+
+// second channel: how long a stream had to WAIT for another one (the row-partitioned SpMV: A_rem on the caller's stream waits for the
+// halo exchange on the communicator's).  `first` is recorded on the waiting stream where its own work ends, `second` on the other
+// stream where the awaited work ends; the exposed wait of the pair is max(0, second - first).
+void profWaitPair(hipStream_t waiting, hipStream_t awaited) {
+	std::lock_guard<std::mutex> lock(g_profMutex);
+	if (!g_profOn) return;
+	if (g_profWaitUsed == g_profWaitEvents.size()) {
+		hipEvent_t a, b;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+		g_profWaitEvents.emplace_back(a, b);
+	}
+	const size_t slot = g_profWaitUsed++;
+	(void)hipEventRecord(g_profWaitEvents[slot].first, waiting);
+	(void)hipEventRecord(g_profWaitEvents[slot].second, awaited);
 }
 
 void profEnd(int slot, hipStream_t s) {
@@ -302,6 +347,7 @@ int ensureCsrReady(const smm_hip_csr* cm, hipStream_t s, bool streamKnown) {
 	auto* m = const_cast<smm_hip_csr*>(cm);
 	std::lock_guard<std::mutex> lock(m->readyMutex);
 	if (m->ready) return SMM_HIP_OK;
+	SetupTrace trace("csr: nnz / first active row / typical row");
 	if (!streamKnown) {
 		// a host-side query (csr_info, set_kernel, precond_create ...) has no stream to be ordered behind: the arrays may still be
 		// being written on any of the caller's streams
@@ -470,6 +516,26 @@ int smm_hip_profile_read(double* spmv_ms, long long* spmv_launches, int reset) {
 	return SMM_HIP_OK;
 }
 
+int smm_hip_profile_read_waits(double* exposed_ms, long long* pairs, int reset) {
+	SMM_TRY(ensureInit());
+	std::lock_guard<std::mutex> lock(g_profMutex);
+	double total = 0.0;
+	for (size_t i = 0; i < g_profWaitUsed; ++i) {
+		SMM_HIP_TRY(hipEventSynchronize(g_profWaitEvents[i].first));
+		SMM_HIP_TRY(hipEventSynchronize(g_profWaitEvents[i].second));
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, g_profWaitEvents[i].first, g_profWaitEvents[i].second) != hipSuccess) {
+			(void)hipGetLastError();
+			ms = 0.f;
+		}
+		if (ms > 0.f) total += ms;
+	}
+	if (exposed_ms) *exposed_ms = total;
+	if (pairs) *pairs = static_cast<long long>(g_profWaitUsed);
+	if (reset) g_profWaitUsed = 0;
+	return SMM_HIP_OK;
+}
+
 int smm_hip_csr_create_f32(int rows, int cols, const int* start, const int* positions, const float* values, smm_hip_csr** out) {
 	return csrCreate<float>(rows, cols, start, positions, values, false, out);
 }
@@ -495,6 +561,7 @@ int smm_hip_csr_destroy(smm_hip_csr* m) {
 	devFree(m->d_pat_masks);
 	devFree(m->d_pat_codes);
 	devFree(m->d_pat_cval);
+	devFree(m->d_pat_masks32);
 	devFree(m->d_pat_rowblocks);
 	delete m;
 	return SMM_HIP_OK;

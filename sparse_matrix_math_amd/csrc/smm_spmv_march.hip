@@ -30,36 +30,37 @@ namespace smm {
 namespace {
 
 constexpr int TPB = 256;
-constexpr int MARCH_R = 8;              // rows per lane and plane
-constexpr int MARCH_B = TPB * MARCH_R;  // rows of a tile
-constexpr int MARCH_HP = 4;             // halo packs a lane can hold: 2 H <= MARCH_HP * TPB * VEC
+constexpr int MARCH_RMAX = 8;  // rows per lane and plane: 8 or 4 (template argument R; a tile is B = TPB * R rows)
 
-template <typename T>
+template <typename T, int R>
 struct MarchCfg {
-	static constexpr int VEC = 16 / sizeof(T);      // rows per 16-byte pack
-	static constexpr int PACKS = MARCH_R / VEC;     // packs per lane and plane
-	static constexpr int MH = VEC / 2;              // 16-byte packs of two 64-bit masks per row pack
-	static constexpr int MPACKS = PACKS * MH;       // (4 for fp32 and fp64 alike: 8 masks per lane and plane)
+	static constexpr int VEC = 16 / sizeof(T);  // rows per 16-byte pack
+	static constexpr int PACKS = R / VEC;       // packs per lane and plane
+	static constexpr int B = TPB * R;           // rows of a tile
 };
 
-// 16-byte packs at ELEMENT alignment (a plane need not start on a 16-byte boundary; gfx950 global accesses may be unaligned): vector
-// types, so that the non-temporal builtins take them, with the alignment lowered through the typedef
+// 16-byte packs of x / out at ELEMENT alignment (a plane need not start on a 16-byte boundary; gfx950 global accesses may be
+// unaligned): vector types, so that the non-temporal builtins take them, with the alignment lowered through the typedef
 template <typename T>
 struct PackOf;
 template <>
 struct PackOf<float> {
 	typedef float V __attribute__((ext_vector_type(4)));
 	typedef V U __attribute__((aligned(4)));
+	typedef unsigned M __attribute__((ext_vector_type(4)));  // the 32-bit masks of the pack's 4 rows
 };
 template <>
 struct PackOf<double> {
 	typedef double V __attribute__((ext_vector_type(2)));
 	typedef V U __attribute__((aligned(8)));
+	typedef unsigned M __attribute__((ext_vector_type(2)));
 };
 template <typename T>
 using PackU = typename PackOf<T>::U;
-typedef unsigned long long MaskV __attribute__((ext_vector_type(2)));
-typedef MaskV MaskU __attribute__((aligned(8)));
+template <typename T>
+using PackV = typename PackOf<T>::V;  // the same pack where 16-byte alignment is known (LDS windows)
+template <typename T>
+using MaskP = typename PackOf<T>::M;
 
 template <typename T>
 __device__ __forceinline__ T marchApplyOp(int op, const T* __restrict__ lhs, const T* __restrict__ divisor, long long row, T dot) {
@@ -82,25 +83,51 @@ __device__ __forceinline__ T bitsToValue(unsigned long long bits) {
 	return c;
 }
 
+// what a lane requests for one plane of its tile: its 8 centre values of x, its share of the two halos, the masks of its 8 rows
+template <typename T, int R, int HP>
+struct MarchSet {
+	PackU<T> c[MarchCfg<T, R>::PACKS];
+	PackU<T> h[HP];
+	MaskP<T> m[MarchCfg<T, R>::PACKS];
+};
+
 }  // namespace
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smmMarchLds[];
 
-// KN > 0: the number of near offsets is known at compile time (5: the 5- and 7-point stencils; 3: 1-D chains inside a plane); 0: run time.
+// the 32-bit copy of the row masks the kernel streams (CONST: at most 32 offsets, so the upper halves of the 64-bit masks are empty)
+__global__ __launch_bounds__(256) void marchNarrowMasks(long long rows, const unsigned long long* __restrict__ masks, unsigned* __restrict__ masks32) {
+	for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < rows; i += static_cast<long long>(gridDim.x) * blockDim.x) {
+		masks32[i] = static_cast<unsigned>(masks[i]);
+	}
+}
+
+// KN > 0: the number of near offsets is known at compile time (5: the 5- and 7-point stencils); 0: run time.  NT: out[] with non-temporal
+// stores.  HP: halo packs a lane can hold (2 H <= HP * TPB * VEC).
 // grid <= NPART persistent workgroups; unit u = (tile, z-chunk); XCD group g = blockIdx % 8 owns the tiles [g nT / 8, (g + 1) nT / 8) when
-// xcdTiles (nT a multiple of 8: neighbouring tiles, which share their halos, then run on one L2), else the units are dealt round-robin.
-template <typename T, int KN, bool NT>
-__global__ __launch_bounds__(TPB) void spmvPatternConstMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
+// xcdTiles (neighbouring tiles, which share their halos, then run on one L2), else the units are dealt round-robin.
+//
+// Pipeline of a unit: TWO request sets alternate.  In step z (plane z's window is in LDS) the set that held plane z is re-issued for
+// plane z + 2 -- centre values, halos, masks -- while the other one, requested a step earlier, supplies plane z + 1: its centre values
+// are this step's +P operands and, with its halos, the next window.  No register that a load is still in flight for is ever copied
+// (the z loop is unrolled by two instead), so nothing waits for a request issued in the same step.
+// Registers: fp64 with 8 rows per lane needs ~185 VGPRs (two workgroups per CU; capped at 168 for three it spills and loses, 0.60 ->
+// 0.65 ms on the 512^3 grid), fp32 fits three either way and schedules better when told so (0.354 -> 0.322 ms): the bound below.
+#ifndef SMM_MARCH_MIN_WAVES
+#define SMM_MARCH_MIN_WAVES(T, R) ((sizeof(T) == 4 || (R) < 8) ? 3 : 1)
+#endif
+template <typename T, int R, int KN, bool NT, int HP>
+__global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternConstMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
                                                                    int nOff, int hasLo, int hasHi, const int* __restrict__ offs,
-                                                                   const unsigned long long* __restrict__ cvalBits,
-                                                                   const unsigned long long* __restrict__ masks, int opFlags, const T* lhs,
-                                                                   const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode,
-                                                                   const T* __restrict__ w1, T* __restrict__ partials, const int* __restrict__ doneFlag) {
-	using Cfg = MarchCfg<T>;
+                                                                   const unsigned long long* __restrict__ cvalBits, const unsigned* __restrict__ masks32,
+                                                                   int opFlags, const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out,
+                                                                   int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
+                                                                   const int* __restrict__ doneFlag) {
+	using Cfg = MarchCfg<T, R>;
+	using Set = MarchSet<T, R, HP>;
 	constexpr int VEC = Cfg::VEC;
 	constexpr int PACKS = Cfg::PACKS;
-	constexpr int MPACKS = Cfg::MPACKS;
-	constexpr int MH = Cfg::MH;
+	constexpr int MARCH_B = Cfg::B;
 	const int winLen = MARCH_B + 2 * H;  // elements of one window buffer (H is a multiple of VEC)
 	T* sWin0 = reinterpret_cast<T*>(smmMarchLds);
 	T* sWin1 = sWin0 + winLen;
@@ -112,6 +139,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstMarchKernel(int rows, int
 	const T cLo = hasLo ? bitsToValue<T>(cvalBits[0]) : T(0);
 	const T cHi = hasHi ? bitsToValue<T>(cvalBits[nOff - 1]) : T(0);
 	const int haloPacks = 2 * H / VEC;
+	const unsigned fullMask = nOff >= 32 ? 0xFFFFFFFFu : ((1u << nOff) - 1u);
 
 	const int nGroups = min(8, static_cast<int>(gridDim.x));
 	const int units = nT * nChunks;
@@ -129,6 +157,9 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstMarchKernel(int rows, int
 		uEnd = units;
 	}
 	T acc0 = T(0), acc1 = T(0);
+	int loc[PACKS];  // first local row of the lane's pack p
+#pragma unroll
+	for (int p = 0; p < PACKS; ++p) loc[p] = (p * TPB + t) * VEC;
 
 	for (int u = uFirst; u < uEnd; u += uStride) {
 		// chunk-major inside the group: neighbouring tiles of one z-chunk are in flight together
@@ -139,90 +170,68 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstMarchKernel(int rows, int
 		const int r0 = tile * MARCH_B;           // first row of the tile inside its plane
 		const int bAct = min(MARCH_B, P - r0);   // rows of this tile (P and MARCH_B are multiples of VEC)
 		bool act[PACKS];
-		int loc[PACKS];                          // first local row of the lane's pack p
 #pragma unroll
-		for (int p = 0; p < PACKS; ++p) {
-			loc[p] = (p * TPB + t) * VEC;
-			act[p] = loc[p] < bAct;
-		}
-		PackU<T> xp[PACKS], xc[PACKS], xn[PACKS], xnn[PACKS];
-		PackU<T> hh[MARCH_HP];
-		MaskU mk[MPACKS], mkNext[MPACKS];
-		auto loadCentre = [&](PackU<T>(&dst)[PACKS], int z) {
-			const bool ok = z >= 0 && z < nPlanes;
+		for (int p = 0; p < PACKS; ++p) act[p] = loc[p] < bAct;
+
+		// halo pack i of a plane: window index i VEC for the left halo (i < H / VEC), H + bAct + (i - H / VEC) VEC for the right one
+		auto haloWin = [&](int i) { return i < H / VEC ? i * VEC : H + bAct + (i - H / VEC) * VEC; };
+		// requests for plane z: centre (when wantCentre), halos and masks (when wantWindow: the plane will be a window of this unit)
+		auto issue = [&](Set& f, int z, bool wantCentre, bool wantWindow) {
+			const bool inside = z >= 0 && z < nPlanes;
 			const long long base = static_cast<long long>(z) * P + r0;
 #pragma unroll
 			for (int p = 0; p < PACKS; ++p) {
-				if (ok && act[p]) {
-					dst[p] = *reinterpret_cast<const PackU<T>*>(x + base + loc[p]);  // (kept cacheable: a neighbouring tile reads these lines as its halo)
+				if (inside && wantCentre && act[p]) {
+					f.c[p] = *reinterpret_cast<const PackU<T>*>(x + base + loc[p]);  // (kept cacheable: a neighbouring tile reads these lines as its halo)
 				} else {
 #pragma unroll
-					for (int e = 0; e < VEC; ++e) dst[p][e] = T(0);
+					for (int e = 0; e < VEC; ++e) f.c[p][e] = T(0);
 				}
 			}
-		};
-		// halo pack i of plane z: window index w = i VEC for the left halo (i < H / VEC), H + bAct + (i - H / VEC) VEC for the right one
-		auto haloWin = [&](int i) { return i < H / VEC ? i * VEC : H + bAct + (i - H / VEC) * VEC; };
-		auto loadHalo = [&](int z) {
-			const long long base = static_cast<long long>(z) * P + r0 - H;
+			if (inside && wantWindow) {
 #pragma unroll
-			for (int k = 0; k < MARCH_HP; ++k) {
-				const int i = k * TPB + t;
-				if (i < haloPacks) {
-					long long gidx = base + haloWin(i);
-					// a pack that sticks out of x (the first / last rows of the matrix) is never used by a live entry: any valid address will do
-					gidx = gidx < 0 ? 0 : (gidx + VEC > cols ? cols - VEC : gidx);
-					hh[k] = *reinterpret_cast<const PackU<T>*>(x + gidx);
+				for (int k = 0; k < HP; ++k) {
+					const int i = k * TPB + t;
+					if (i < haloPacks) {
+						long long gidx = base - H + haloWin(i);
+						// a pack that sticks out of x (the first / last rows of the matrix) is never used by a live entry: any valid address will do
+						gidx = gidx < 0 ? 0 : (gidx + VEC > cols ? cols - VEC : gidx);
+						f.h[k] = *reinterpret_cast<const PackU<T>*>(x + gidx);
+					}
 				}
-			}
-		};
-		// the masks of the lane's own rows: row pack p = mask packs p MH .. p MH + MH - 1 (two rows each)
-		auto loadMasks = [&](MaskU(&dst)[MPACKS], int z) {
-			const long long base = static_cast<long long>(z) * P + r0;
 #pragma unroll
-			for (int p = 0; p < PACKS; ++p) {
-#pragma unroll
-				for (int h = 0; h < MH; ++h) {
+				for (int p = 0; p < PACKS; ++p) {
 					if (act[p]) {
-						dst[p * MH + h] = __builtin_nontemporal_load(reinterpret_cast<const MaskU*>(masks + base + loc[p] + 2 * h));
+						f.m[p] = __builtin_nontemporal_load(reinterpret_cast<const MaskP<T>*>(masks32 + base + loc[p]));
 					} else {
-						dst[p * MH + h] = MaskU{0ULL, 0ULL};
+#pragma unroll
+						for (int e = 0; e < VEC; ++e) f.m[p][e] = 0u;
 					}
 				}
 			}
 		};
-		auto storeWindow = [&](T* win, const PackU<T>(&centre)[PACKS]) {
+		auto storeWindow = [&](T* win, const Set& f) {
 #pragma unroll
 			for (int p = 0; p < PACKS; ++p) {
-				if (act[p]) *reinterpret_cast<PackU<T>*>(win + H + loc[p]) = centre[p];
+				if (act[p]) *reinterpret_cast<PackV<T>*>(win + H + loc[p]) = f.c[p];
 			}
 #pragma unroll
-			for (int k = 0; k < MARCH_HP; ++k) {
+			for (int k = 0; k < HP; ++k) {
 				const int i = k * TPB + t;
-				if (i < haloPacks) *reinterpret_cast<PackU<T>*>(win + haloWin(i)) = hh[k];
+				if (i < haloPacks) *reinterpret_cast<PackV<T>*>(win + haloWin(i)) = f.h[k];
 			}
 		};
 
-		// prologue: planes z0 - 1 (far below), z0 (window), z0 + 1 in registers; z0 + 2 is requested inside the first step
-		loadCentre(xp, hasLo ? z0 - 1 : -1);
-		loadCentre(xc, z0);
-		loadCentre(xn, z0 + 1);
-		loadHalo(z0);
-		loadMasks(mk, z0);
-		__syncthreads();  // (the previous unit's last window reads are over)
-		storeWindow(sWin0, xc);
-		__syncthreads();
+		PackU<T> xp[PACKS];      // centre of the plane below the window's (the -P operands)
+		MaskP<T> mk[PACKS];      // masks of the window's plane
+		Set fa, fb;
 
-		for (int z = z0; z < z1; ++z) {
+		// one plane: `use` holds plane z + 1 (requested a step ago), `re` is free and is re-issued for plane z + 2
+		auto step = [&](int z, Set& use, Set& re) {
 			T* win = ((z - z0) & 1) ? sWin1 : sWin0;
 			T* winNext = ((z - z0) & 1) ? sWin0 : sWin1;
 			const bool more = z + 1 < z1;
-			// requests for the next steps, issued before this plane's arithmetic
-			if (more) {
-				loadCentre(xnn, hasHi || z + 2 < z1 ? z + 2 : -1);
-				loadHalo(z + 1);
-				loadMasks(mkNext, z + 1);
-			}
+			if (more) issue(re, z + 2, z + 2 < z1 || hasHi, z + 2 < z1);
 			const long long base = static_cast<long long>(z) * P + r0;
 			T dot[PACKS][VEC];
 #pragma unroll
@@ -230,40 +239,36 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstMarchKernel(int rows, int
 #pragma unroll
 				for (int e = 0; e < VEC; ++e) dot[p][e] = T(0);
 			}
-			// the rows' masks as 32 bits (CONST: at most 32 offsets)
-			auto bitOn = [&](unsigned m, int b) { return ((m >> b) & 1u) != 0u; };
-			unsigned m32[PACKS][VEC];
+			// interior rows hold every offset: when that is true for all rows of the wavefront the per-entry selects are skipped
+			bool full = true;
 #pragma unroll
 			for (int p = 0; p < PACKS; ++p) {
 #pragma unroll
-				for (int e = 0; e < VEC; ++e) m32[p][e] = static_cast<unsigned>(mk[p * MH + e / 2][e & 1]);
+				for (int e = 0; e < VEC; ++e) full = full && (mk[p][e] == fullMask || !act[p]);
 			}
-			int bit = 0;
+			const bool masked = !__all(full);
+			auto fold = [&](T c, T xv, T d, unsigned m, int b) {
+				const T next = smmFma(c, xv, d);
+				return (!masked || ((m >> b) & 1u) != 0u) ? next : d;
+			};
 			if (hasLo) {
 #pragma unroll
 				for (int p = 0; p < PACKS; ++p) {
 #pragma unroll
-					for (int e = 0; e < VEC; ++e) {
-						const T next = smmFma(cLo, xp[p][e], dot[p][e]);
-						dot[p][e] = bitOn(m32[p][e], 0) ? next : dot[p][e];
-					}
+					for (int e = 0; e < VEC; ++e) dot[p][e] = fold(cLo, xp[p][e], dot[p][e], mk[p][e], 0);
 				}
-				bit = 1;
 			}
 			auto nearStep = [&](int j) {
 				const int off = offs[hasLo + j];
 				const T c = bitsToValue<T>(cvalBits[hasLo + j]);
-				const int b = bit + j;
+				const int b = hasLo + j;
 #pragma unroll
 				for (int p = 0; p < PACKS; ++p) {
 					T xv[VEC];
 #pragma unroll
 					for (int e = 0; e < VEC; ++e) xv[e] = win[H + loc[p] + e + off];
 #pragma unroll
-					for (int e = 0; e < VEC; ++e) {
-						const T next = smmFma(c, xv[e], dot[p][e]);
-						dot[p][e] = bitOn(m32[p][e], b) ? next : dot[p][e];
-					}
+					for (int e = 0; e < VEC; ++e) dot[p][e] = fold(c, xv[e], dot[p][e], mk[p][e], b);
 				}
 			};
 			if constexpr (KN > 0) {
@@ -273,14 +278,11 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstMarchKernel(int rows, int
 				for (int j = 0; j < nNear; ++j) nearStep(j);
 			}
 			if (hasHi) {
-				const int b = bit + nNear;
+				const int b = hasLo + nNear;
 #pragma unroll
 				for (int p = 0; p < PACKS; ++p) {
 #pragma unroll
-					for (int e = 0; e < VEC; ++e) {
-						const T next = smmFma(cHi, xn[p][e], dot[p][e]);
-						dot[p][e] = bitOn(m32[p][e], b) ? next : dot[p][e];
-					}
+					for (int e = 0; e < VEC; ++e) dot[p][e] = fold(cHi, use.c[p][e], dot[p][e], mk[p][e], b);
 				}
 			}
 			// epilogue: op(lhs, dot), out[] as 16-byte packs, the fused dot products
@@ -306,17 +308,30 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstMarchKernel(int rows, int
 				}
 			}
 			if (more) {
-				storeWindow(winNext, xn);
+				// the window's own centre becomes the plane below; the next window and its masks come out of `use`
 #pragma unroll
-				for (int p = 0; p < PACKS; ++p) {
-					xp[p] = xc[p];
-					xc[p] = xn[p];
-					xn[p] = xnn[p];
-				}
+				for (int p = 0; p < PACKS; ++p) xp[p] = *reinterpret_cast<const PackV<T>*>(win + H + loc[p]);
+				storeWindow(winNext, use);
 #pragma unroll
-				for (int q = 0; q < MPACKS; ++q) mk[q] = mkNext[q];
+				for (int p = 0; p < PACKS; ++p) mk[p] = use.m[p];
 				ldsBarrier();  // winNext is complete; everyone is done reading `win` (it is overwritten in the step after next)
 			}
+		};
+
+		// prologue: plane z0 - 1 (far below) and plane z0 itself, then the requests for plane z0 + 1
+		issue(fa, z0 - 1, hasLo != 0, false);
+#pragma unroll
+		for (int p = 0; p < PACKS; ++p) xp[p] = fa.c[p];
+		issue(fa, z0, true, true);
+		issue(fb, z0 + 1, z0 + 1 < z1 || hasHi, z0 + 1 < z1);
+		__syncthreads();  // (the previous unit's last window reads are over)
+		storeWindow(sWin0, fa);
+#pragma unroll
+		for (int p = 0; p < PACKS; ++p) mk[p] = fa.m[p];
+		__syncthreads();
+		for (int z = z0; z < z1; z += 2) {
+			step(z, fb, fa);
+			if (z + 1 < z1) step(z + 1, fa, fb);
 		}
 	}
 	if (dotMode) {
@@ -349,11 +364,11 @@ void planConstMarch(smm_hip_csr* m) {
 	const int k = static_cast<int>(offs.size());
 	if (!m->pat_const || k < 1 || k > 32 || m->rows != m->cols || m->rows < minRows) return;
 	const int vec = m->dtype == SMM_DTYPE_F32 ? 4 : 2;
-	const int hCap = MARCH_HP * TPB * vec / 2;  // 2 H / VEC halo packs <= MARCH_HP per lane
+	const int hCap = 4 * TPB * vec / 2;  // 2 H / VEC halo packs <= 4 per lane (the kernel is compiled for 2 and for 4)
 	auto roundUp = [vec](int h) { return (h + vec - 1) / vec * vec; };
 	const int far = std::max(std::abs(offs.front()), std::abs(offs.back()));
 	// (a) the far pair
-	if (far >= 4 * MARCH_B && m->rows % far == 0 && far % vec == 0 && m->rows / far >= 2) {
+	if (far >= 4 * TPB * MARCH_RMAX && m->rows % far == 0 && far % vec == 0 && m->rows / far >= 2) {
 		const int lo = offs.front() == -far ? 1 : 0, hi = offs.back() == far ? 1 : 0;
 		int h = 0;
 		for (int j = lo; j < k - hi; ++j) h = std::max(h, std::abs(offs[j]));
@@ -375,20 +390,33 @@ void planConstMarch(smm_hip_csr* m) {
 	}
 }
 
-template <typename T, int KN, bool NT>
+// the 32-bit copy of the masks (caller: the CONST analysis, after the plan said yes; enqueued on `s`, the buffer is the handle's)
+int marchBuildMasks32(smm_hip_csr* m, hipStream_t s) {
+	if (!m->march_ok || m->d_pat_masks32) return SMM_HIP_OK;
+	void* p = nullptr;
+	SMM_TRY(devAlloc(&p, static_cast<size_t>(m->rows) * sizeof(unsigned) + 16));
+	m->d_pat_masks32 = static_cast<unsigned*>(p);
+	const int grid = static_cast<int>(std::min<long long>((m->rows + 255LL) / 256, numCUs() * 16LL));
+	marchNarrowMasks<<<grid, 256, 0, s>>>(m->rows, m->d_pat_masks, m->d_pat_masks32);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T, int R, int KN, bool NT, int HP>
 static int launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {
 	const int P = m->march_P, H = m->march_H;
 	const int nPlanes = m->rows / P;
+	constexpr int MARCH_B = TPB * R;
 	const int nT = (P + MARCH_B - 1) / MARCH_B;
 	const size_t lds = 2 * static_cast<size_t>(MARCH_B + 2 * H) * sizeof(T);
 	static bool raised = false;
 	if (lds > 64 * 1024 && !raised) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvPatternConstMarchKernel<T, KN, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvPatternConstMarchKernel<T, R, KN, NT, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
 		raised = true;
 	}
 	int perCU = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternConstMarchKernel<T, KN, NT>, TPB, lds) != hipSuccess || perCU < 1) perCU = 2;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternConstMarchKernel<T, R, KN, NT, HP>, TPB, lds) != hipSuccess || perCU < 1) perCU = 2;
 	if (const char* env = getenv("SMM_HIP_MARCH_WGS_PER_CU")) perCU = std::max(1, atoi(env));
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();  // room for the RCCL kernel beside A_loc (smm_dist.hip)
 	op &= ~SPMV_LEAVE_ROOM;
@@ -406,8 +434,8 @@ static int launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	int grid = static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(units, resident), NPART)));
 	const int xcdTiles = (nT % 8 == 0 || nT >= 64) && grid >= 8 ? 1 : 0;
 	if (xcdTiles) grid -= grid % 8;  // the same number of workgroups in every XCD group
-	spmvPatternConstMarchKernel<T, KN, NT><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
-	                                                             m->d_pat_off, m->d_pat_cval, m->d_pat_masks, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+	spmvPatternConstMarchKernel<T, R, KN, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
+	                                                             m->d_pat_off, m->d_pat_cval, m->d_pat_masks32, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
 	return SMM_HIP_OK;
 }
 
@@ -419,17 +447,32 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 		const char* env = getenv("SMM_HIP_CONST_MARCH");
 		return env ? atoi(env) != 0 : true;
 	}();
-	if (!enabled || !m->march_ok) return false;
+	if (!enabled || !m->march_ok || !m->d_pat_masks32) return false;
 	const int nNear = m->pat_k - m->march_lo - m->march_hi;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;  // outputs too large to still be cached when the next kernel reads them
-#define SMM_MARCH_GO(KNV)                                                                                        \
-	do {                                                                                                         \
-		if (nt) launchMarchKN<T, KNV, true>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);    \
-		else launchMarchKN<T, KNV, false>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);      \
+	// rows per lane: 8 (tiles of 2048 rows); SMM_HIP_MARCH_R=4 takes tiles of 1024 rows (A/B measurements)
+	static const int rowsPerLane = [] {
+		const char* env = getenv("SMM_HIP_MARCH_R");
+		return env && atoi(env) == 4 ? 4 : 8;
+	}();
+	const int vec = 16 / static_cast<int>(sizeof(T));
+	const bool r4 = rowsPerLane == 4 && 2 * m->march_H / vec <= 4 * TPB;
+	const bool hp2 = 2 * m->march_H / vec <= 2 * TPB;  // the halo fits two packs per lane (fewer registers)
+#define SMM_MARCH_GO2(RV, KNV)                                                                                                  \
+	do {                                                                                                                        \
+		if (nt && hp2) launchMarchKN<T, RV, KNV, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);     \
+		else if (nt) launchMarchKN<T, RV, KNV, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);       \
+		else if (hp2) launchMarchKN<T, RV, KNV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);     \
+		else launchMarchKN<T, RV, KNV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);              \
+	} while (0)
+#define SMM_MARCH_GO(KNV)             \
+	do {                              \
+		if (r4) SMM_MARCH_GO2(4, KNV); \
+		else SMM_MARCH_GO2(8, KNV);    \
 	} while (0)
 	if (nNear == 5) SMM_MARCH_GO(5);
-	else if (nNear == 3) SMM_MARCH_GO(3);
 	else SMM_MARCH_GO(0);
+#undef SMM_MARCH_GO2
 #undef SMM_MARCH_GO
 	return true;
 }

@@ -1212,6 +1212,7 @@ static bool autoDictAllowed() {
 
 // the mask encoding: SMM_HIP_OK, SMM_HIP_ERR_INVALID (no such pattern: *why says which test failed) or a HIP failure
 static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
+	SetupTrace traceAll("pattern: masks (sample + build + verify)");
 	DevBuf<int> d_state, d_off, d_flag;  // released on every early return
 	DevBuf<unsigned long long> d_masks;
 	SMM_TRY(d_state.alloc(MAXOFF + 2));
@@ -1223,7 +1224,10 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	patSampleOffsets<<<(samples + TPB - 1) / TPB, TPB, 0, s>>>(m->rows, samples, m->d_start, m->d_positions, d_state);
 	std::vector<int> got(MAXOFF + 2, 0);
 	SMM_HIP_TRY(hipMemcpyAsync(got.data(), d_state, got.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	{
+		SetupTrace trace("pattern:   wait for the sampled offsets");
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
 	auto no = [why](const char* text) {
 		*why = text;
 		return static_cast<int>(SMM_HIP_ERR_INVALID);
@@ -1237,7 +1241,10 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	if (offs.empty()) return no("no entries in the sampled rows");
 	std::sort(offs.begin(), offs.end());
 	SMM_TRY(d_off.alloc(MAXOFF));
-	SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
+	{
+		SetupTrace trace("pattern:   allocate the masks");
+		SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
+	}
 	SMM_TRY(d_flag.alloc(2));  // [0] an entry off the offset set / out of order, [1] some diagonal holds more than one value
 	DevBuf<unsigned long long> d_cval;
 	SMM_TRY(d_cval.alloc(MAXOFF));
@@ -1263,7 +1270,10 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	patBuildMasks<<<grid, TPB, 0, s>>>(m->rows, k, d_off, m->d_start, m->d_positions, d_masks, d_flag, tryConst ? m->d_values : nullptr, elemBytes, d_cval);
 	int flags[2] = {0, 0};
 	SMM_HIP_TRY(hipMemcpyAsync(flags, d_flag, sizeof(flags), hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	{
+		SetupTrace trace("pattern:   wait for build + verify");
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
 	if (flags[0]) return no("some entry's column offset is outside the offset set of the sampled rows");
 	m->pat_k = k;
 	m->pat_offs_host = offs;
@@ -1274,6 +1284,7 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	m->pat_const = tryConst && flags[1] == 0;
 	if (m->pat_const) m->d_pat_cval = d_cval.detach();
 	planConstMarch(m);
+	SMM_TRY(marchBuildMasks32(m, s));
 	return SMM_HIP_OK;
 }
 
@@ -1384,6 +1395,7 @@ void adoptPatternQuietly(const smm_hip_csr* cm, hipStream_t s) {
 	auto* m = const_cast<smm_hip_csr*>(cm);
 	std::lock_guard<std::mutex> lock(m->adoptMutex);
 	if (m->kernelForced || m->family() != SMM_SPMV_STREAM) return;  // another thread switched it while this one waited
+	SetupTrace trace("auto: PATTERN analysis, whole");
 	int state = m->pat_state.load(std::memory_order_acquire);
 	if (state < 0 && state != -2) return;
 	// (state > 0: already analysed -- e.g. by a block preconditioner that read the grid from the offsets -- and only not adopted yet)
@@ -1598,12 +1610,13 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 		return "spmvDictKernel";
 	}
 	if (L == 1 && m->pat_const && !m->pat_const_off) {
-		*bytes = rows * 8 + vectors;  // the row's mask, x, out: neither values[] nor start[]
 		static const bool marchOn = [] {
 			const char* env = getenv("SMM_HIP_CONST_MARCH");
 			return env ? atoi(env) != 0 : true;
 		}();
-		return m->march_ok && marchOn ? "spmvPatternConstMarchKernel" : "spmvPatternConstKernel";
+		const bool march = m->march_ok && marchOn && m->d_pat_masks32;
+		*bytes = rows * (march ? 4 : 8) + vectors;  // the row's mask (32 bits in the 2.5-D form), x, out: neither values[] nor start[]
+		return march ? "spmvPatternConstMarchKernel" : "spmvPatternConstKernel";
 	}
 	*bytes = nnz * s + rows * 8 + startBytes + vectors;
 	if (L == 1) {
@@ -1642,6 +1655,7 @@ int launchSpmvPattern(const smm_hip_csr* m, int lanes, int op, const T* lhs, con
 	{
 		std::lock_guard<std::mutex> lock(mm->tileMutex);
 		if (!m->d_pat_rowblocks || m->pat_nnz_cap != capNnz || m->pat_max_rows != maxRows) {
+			SetupTrace trace("pattern: tile table");
 			SMM_TRY(buildPatternTiles(mm, capNnz, maxRows, s));
 		}
 	}

@@ -686,6 +686,7 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         run(args.warmup)
     host.profile_enable(True)
     host.profile_read(reset=True)
+    host.profile_read_waits(reset=True)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -694,6 +695,9 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     dist.barrier()
     elapsed = time.perf_counter() - t0
     spmv_ms, spmv_launches = host.profile_read(reset=True)
+    # what the halo exchanges cost beyond the local block that ran beside them (events on the caller's and the communicator's stream;
+    # zero pairs: the staged / single-rank communicators exchange on the caller's own stream)
+    exposed_ms, exchanges = host.profile_read_waits(reset=True)
     host.profile_enable(False)
     err = ((x - x_true).abs() / x_true).max().reshape(1)
     if staged:
@@ -741,6 +745,11 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         "rccl_ranks": comm_info["rccl_ranks"],  # the communicator's size as RCCL reports it (ncclCommCount); 0: not an RCCL communicator
         "distributed": {"driver": driver, "comm": comm_info["kind"], "comm_ranks": comm_info["world"],
                         "kernels_per_iteration": 8 if driver == "native" else 13, "allreduces_per_iteration": 3, "halo_exchanges_per_iteration": 2},
+        # the first thing to read in a multi-GPU line that scales worse than hoped: milliseconds per BiCGStab iteration (two exchanges) that
+        # rank 0's A_rem waited for its halo AFTER A_loc had ended -- the exchange's share that no compute covered
+        "exposed_comm_ms": exposed_ms / max(iters, 1),
+        "exposed_comm": {"total_ms": exposed_ms, "exchanges": exchanges, "ms_per_exchange": exposed_ms / max(exchanges, 1),
+                         "note": "rank 0; events: end of A_loc on the solver's stream -> end of the halo exchange on the communicator's stream, clipped at 0"},
         "per_rank": {"rows": hi - lo, "nnz": nnz_local, "halo_elements": halo,
                      "spmv_launch_ms_rank0": spmv_ms / max(spmv_launches, 1), "spmv_launches_rank0": spmv_launches},
     }

@@ -131,6 +131,38 @@ def convdiff3d(n, c=0.3, dtype=np.float64):
     return stencil3d(n, n, n, 6.0, -1.0 - c, -1.0 + c, dtype)
 
 
+def convdiff3d_varying(n, c=0.3, dtype=np.float64):
+    """The 7-point convection-diffusion operator of config 5's stand-in with SPATIALLY VARYING coefficients, as a real atmosmodd-like
+    matrix has them: diffusion 1, a smooth rotating velocity field (u, v, w)(x, y, z) of amplitude c discretised with central
+    differences (west / east = -1 -+ u, south / north = -1 -+ v, down / up = -1 -+ w) and a reaction term 0 <= r < 0.1 on the diagonal
+    (6 + r).  Non-symmetric, every diagonal varies from row to row: the SpMV needs values[] (PATTERN / MASKS, not CONST)."""
+    dtype = np.dtype(dtype).type
+    N = n * n * n
+    i = np.arange(N, dtype=np.int64)
+    ix, iy, iz = i % n, (i // n) % n, i // (n * n)
+    fx, fy, fz = (ix + 0.5) / n, (iy + 0.5) / n, (iz + 0.5) / n
+    two_pi = 2.0 * np.pi
+    u = c * np.sin(two_pi * fy) * np.cos(two_pi * fz)
+    v = c * np.sin(two_pi * fz) * np.cos(two_pi * fx)
+    w = c * np.sin(two_pi * fx) * np.cos(two_pi * fy)
+    r = 0.1 * fx * fy * fz
+    cand = [
+        (i - n * n, iz > 0, -1.0 - w),
+        (i - n, iy > 0, -1.0 - v),
+        (i - 1, ix > 0, -1.0 - u),
+        (i, np.ones(N, dtype=bool), 6.0 + r),
+        (i + 1, ix < n - 1, -1.0 + u),
+        (i + n, iy < n - 1, -1.0 + v),
+        (i + n * n, iz < n - 1, -1.0 + w),
+    ]
+    cols = np.stack([cc for cc, _, _ in cand], axis=1)
+    valid = np.stack([m for _, m, _ in cand], axis=1)
+    vals = np.stack([vv for _, _, vv in cand], axis=1)
+    start = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(valid.sum(axis=1), out=start[1:])
+    return start.astype(np.int32), cols[valid].astype(np.int32), vals[valid].astype(dtype)
+
+
 def poisson2d(nx, ny=None, dtype=np.float64):
     """5-point Laplacian (diag 4, off-diagonals -1, Dirichlet truncation) -- configs 1 and 2 with nx = ny = 1000."""
     ny = nx if ny is None else ny

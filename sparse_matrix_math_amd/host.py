@@ -117,6 +117,13 @@ def profile_read(reset=True):
     return ms.value, n.value
 
 
+def profile_read_waits(reset=True):
+    """(exposed ms, exchanges): what the halo exchanges of the row-partitioned SpMVs cost BEYOND the local block that ran beside them"""
+    ms, n = ctypes.c_double(), ctypes.c_longlong()
+    check(_lib.load().smm_hip_profile_read_waits(ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
+    return ms.value, n.value
+
+
 class Preconditioner:
     """`int apply(const T* rhs, T* x) const` (ref:1173-1235).  Created by CSRMatrix.getPreconditioner."""
 

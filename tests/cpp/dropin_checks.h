@@ -136,6 +136,23 @@ static void testLoader(const bool withGpu) {
 		CHECK(SMM::loadMatrix(dpath.c_str(), t) == St::SUCCESS);
 		CHECK(t.getNonZeroCount() == 0);
 	}
+	// numbers are read as `file >> val` with val of type T reads them (ref:2629-2634): one rounding straight to T (0.1 + 2^-28 is the
+	// classic double-rounding case: to double first, then to float, lands one ulp off), no "inf" / "nan" / hexadecimal floats, a value
+	// that underflows to zero in T is not stored, and text after the closing brace is ignored as in the reference
+	writeFile(dpath, "1 3\n{\n{0.100000003725290298461914062500000001, 1e-60, 2}\n}\ntrailing text\n");
+	{
+		SMM::TripletMatrix<T> t;
+		CHECK(SMM::loadMatrix(dpath.c_str(), t) == St::SUCCESS);
+		const T expect = sizeof(T) == sizeof(float) ? static_cast<T>(std::strtof("0.100000003725290298461914062500000001", nullptr))
+		                                            : static_cast<T>(std::strtod("0.100000003725290298461914062500000001", nullptr));
+		CHECK(t.getValue(0, 0) == expect);
+		CHECK(t.getNonZeroCount() == (sizeof(T) == sizeof(float) ? 2 : 3));  // 1e-60 is zero in float
+	}
+	for (const char* bad : {"1 1\n{\n{nan}\n}\n", "1 1\n{\n{inf}\n}\n", "1 1\n{\n{0x1p3}\n}\n", "1 1\n{\n{-inf}\n}\n"}) {
+		writeFile(dpath, bad);
+		SMM::TripletMatrix<T> t;
+		CHECK(SMM::loadMatrix(dpath.c_str(), t) == St::FAILED_TO_PARSE_FILE);
+	}
 	std::remove(dpath.c_str());
 }
 

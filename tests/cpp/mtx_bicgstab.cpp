@@ -2,11 +2,14 @@
 // CSR by SMM::loadMatrix (include/smm_hip/sparse_matrix_math.h), then BiCGStab [+ Jacobi / ILU0 / SGS] runs on the GPU through the
 // drop-in header's own calls.  b = A * 1 (the reference's test convention, test/include/test_common.h:13-21), x0 = 0.
 //
-//   mtx_bicgstab <file.mtx> <none|jacobi|ilu0|sgs> <maxIterations> <eps> [dump_dir]
+//   mtx_bicgstab <file.mtx> <none|jacobi|ilu0|sgs|block_ilu0|block_sgs>[,<kind>...] <maxIterations> <eps> [dump_dir]
 //
-// Prints one JSON line (load / solve seconds, status, iterations, residual).  With dump_dir it writes start.i32, positions.i32,
+// Prints one JSON line per kind (load / create / solve seconds, status, iterations, residual, the SpMV kernel that served the solve) -- the
+// file is loaded ONCE.  With dump_dir it writes start.i32, positions.i32,
 // values.f64 and x.f64 there for the tests to compare with the oracle.
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -22,13 +25,39 @@ static void dump(const std::string& dir, const char* name, const V* data, size_t
 	std::fclose(f);
 }
 
+static int kindOf(const std::string& kind) {
+	if (kind == "none") return SMM_PRECOND_NONE;
+	if (kind == "jacobi") return SMM_PRECOND_JACOBI;
+	if (kind == "ilu0") return SMM_PRECOND_ILU0;
+	if (kind == "sgs") return SMM_PRECOND_SGS;
+	if (kind == "block_ilu0") return SMM_PRECOND_BLOCK_ILU0;
+	if (kind == "block_sgs") return SMM_PRECOND_BLOCK_SGS;
+	return -1;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 5) {
-		std::fprintf(stderr, "usage: %s <file.mtx> <none|jacobi|ilu0|sgs> <maxIterations> <eps> [dump_dir]\n", argv[0]);
+		std::fprintf(stderr, "usage: %s <file.mtx> <none|jacobi|ilu0|sgs|block_ilu0|block_sgs>[,<kind>...] <maxIterations> <eps> [dump_dir]\n", argv[0]);
 		return 2;
 	}
 	using clock = std::chrono::steady_clock;
-	const std::string kind = argv[2];
+	std::vector<std::string> kinds;
+	{
+		std::string list = argv[2];
+		size_t at = 0;
+		while (at <= list.size()) {
+			const size_t comma = list.find(',', at);
+			kinds.push_back(list.substr(at, comma == std::string::npos ? std::string::npos : comma - at));
+			if (comma == std::string::npos) break;
+			at = comma + 1;
+		}
+	}
+	for (const std::string& k : kinds) {
+		if (kindOf(k) < 0) {
+			std::fprintf(stderr, "unknown preconditioner %s\n", k.c_str());
+			return 2;
+		}
+	}
 	const int maxIt = std::atoi(argv[3]);
 	const double eps = std::atof(argv[4]);
 	if (smm_hip_init(0) != SMM_HIP_OK) {
@@ -51,36 +80,49 @@ int main(int argc, char** argv) {
 		std::fprintf(stderr, "device mirror failed: %s\n", smm_hip_last_error());
 		return 4;
 	}
-	int pk = SMM_PRECOND_NONE;
-	if (kind == "jacobi") pk = SMM_PRECOND_JACOBI;
-	else if (kind == "ilu0") pk = SMM_PRECOND_ILU0;
-	else if (kind == "sgs") pk = SMM_PRECOND_SGS;
-	else if (kind != "none") {
-		std::fprintf(stderr, "unknown preconditioner %s\n", kind.c_str());
-		return 2;
+	// one JSON line per preconditioner kind, all from the ONE load above.  With several kinds every solve is run twice and the second
+	// one is reported (steady state: device allocations cached, the SpMV family settled); a single kind runs once, as the tests expect.
+	const int reps = kinds.size() > 1 ? 2 : 1;
+	for (const std::string& kind : kinds) {
+		const int pk = kindOf(kind);
+		smm_hip_precond* M = nullptr;
+		double setupS = 0, solveS = 0, res = 0;
+		int status = -1, iterations = 0;
+		for (int rep = 0; rep < reps; ++rep) {
+			if (M) smm_hip_precond_destroy(M);
+			M = nullptr;
+			const auto t1 = clock::now();
+			if (pk != SMM_PRECOND_NONE && smm_hip_precond_create(dev, pk, &M) != SMM_HIP_OK) {
+				std::fprintf(stderr, "preconditioner: %s\n", smm_hip_last_error());
+				return 5;
+			}
+			setupS = std::chrono::duration<double>(clock::now() - t1).count();
+			std::fill(x.begin(), x.end(), 0.0);
+			std::vector<double> rhs = b;  // (BiCGStab takes b as T*, ref:2294-2301)
+			const auto t2 = clock::now();
+			// the C ABI call the header's SMM::BiCGStab<Preconditioner, T> makes (it also reports iterations / residual)
+			const int rc = smm_hip_bicgstab_f64(dev, rhs.data(), x.data(), maxIt, eps, M, &status, &iterations, &res);
+			solveS = std::chrono::duration<double>(clock::now() - t2).count();
+			if (rc != SMM_HIP_OK) {
+				std::fprintf(stderr, "bicgstab: %s\n", smm_hip_last_error());
+				return 6;
+			}
+		}
+		double maxErr = 0;
+		for (int i = 0; i < n; ++i) maxErr = std::max(maxErr, std::fabs(x[static_cast<size_t>(i)] - 1.0));
+		char kernel[64] = "";
+		long long kernelBytes = 0;
+		int encoding = 0, offsets = 0;
+		smm_hip_csr_kernel_desc(dev, kernel, sizeof(kernel), &kernelBytes);
+		smm_hip_csr_pattern_info(dev, &encoding, &offsets);
+		std::printf("{\"file\": \"%s\", \"rows\": %d, \"cols\": %d, \"nnz\": %d, \"precond\": \"%s\", \"load_s\": %.6f, \"precond_setup_s\": %.6f, \"solve_s\": %.6f, "
+		            "\"status\": %d, \"iterations\": %d, \"resnorm\": %.9e, \"max_abs_err_vs_ones\": %.3e, \"spmv_kernel\": \"%s\", \"spmv_bytes_per_launch\": %lld, "
+		            "\"pattern_encoding\": %d, \"pattern_offsets\": %d}\n",
+		            argv[1], n, a.getDenseColCount(), a.getNonZeroCount(), kind.c_str(), loadS, setupS, solveS, status, iterations, res, maxErr, kernel, kernelBytes,
+		            encoding, offsets);
+		std::fflush(stdout);
+		smm_hip_precond_destroy(M);
 	}
-	smm_hip_precond* M = nullptr;
-	const auto t1 = clock::now();
-	if (pk != SMM_PRECOND_NONE && smm_hip_precond_create(dev, pk, &M) != SMM_HIP_OK) {
-		std::fprintf(stderr, "preconditioner: %s\n", smm_hip_last_error());
-		return 5;
-	}
-	const double setupS = std::chrono::duration<double>(clock::now() - t1).count();
-	int status = -1, iterations = 0;
-	double res = 0;
-	const auto t2 = clock::now();
-	// the C ABI call the header's SMM::BiCGStab<Preconditioner, T> makes (it also reports iterations / residual)
-	const int rc = smm_hip_bicgstab_f64(dev, b.data(), x.data(), maxIt, eps, M, &status, &iterations, &res);
-	const double solveS = std::chrono::duration<double>(clock::now() - t2).count();
-	if (rc != SMM_HIP_OK) {
-		std::fprintf(stderr, "bicgstab: %s\n", smm_hip_last_error());
-		return 6;
-	}
-	double maxErr = 0;
-	for (int i = 0; i < n; ++i) maxErr = std::max(maxErr, std::fabs(x[static_cast<size_t>(i)] - 1.0));
-	std::printf("{\"file\": \"%s\", \"rows\": %d, \"cols\": %d, \"nnz\": %d, \"precond\": \"%s\", \"load_s\": %.6f, \"precond_setup_s\": %.6f, \"solve_s\": %.6f, "
-	            "\"status\": %d, \"iterations\": %d, \"resnorm\": %.9e, \"max_abs_err_vs_ones\": %.3e}\n",
-	            argv[1], n, a.getDenseColCount(), a.getNonZeroCount(), kind.c_str(), loadS, setupS, solveS, status, iterations, res, maxErr);
 	if (argc > 5) {
 		const std::string dir = argv[5];
 		dump(dir, "start.i32", a.rawStart(), static_cast<size_t>(n) + 1);
@@ -88,6 +130,5 @@ int main(int argc, char** argv) {
 		dump(dir, "values.f64", a.rawValues(), static_cast<size_t>(a.getNonZeroCount()));
 		dump(dir, "x.f64", x.data(), x.size());
 	}
-	smm_hip_precond_destroy(M);
 	return 0;
 }

@@ -56,6 +56,41 @@ def test_mtx_general_file_bicgstab_preconditioned(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_mtx_varying_coefficients_all_kinds_from_one_load(tmp_path, oracle):
+    """what bench.py's extras.mtx_bicgstab runs on every line, at 24^3: the convection-diffusion matrix with SPATIALLY VARYING coefficients
+    (every diagonal varies, so the PATTERN family must keep reading values[]: MASKS, never CONST) written as a shuffled `general` file,
+    loaded ONCE by SMM::loadMatrix and solved with none / Jacobi / ILU0 / BLOCK_ILU0; x of the last kind against the oracle"""
+    from write_mtx import write_mtx
+
+    csr = gen.convdiff3d_varying(24, 0.3, dtype=np.float64)
+    n = len(csr[0]) - 1
+    path = str(tmp_path / "convdiff_varying24.mtx")
+    write_mtx(path, csr, shuffle=True, seed=11)
+    if not os.path.exists(TOOL):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "mtx_bicgstab"], check=True)
+    r = subprocess.run([TOOL, path, "none,ilu0,block_ilu0,jacobi", "-1", "1e-10", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(ln) for ln in r.stdout.strip().splitlines()]
+    assert [ln["precond"] for ln in lines] == ["none", "ilu0", "block_ilu0", "jacobi"]
+    np.testing.assert_array_equal(np.fromfile(tmp_path / "positions.i32", dtype=np.int32), csr[1])
+    np.testing.assert_array_equal(np.fromfile(tmp_path / "values.f64", dtype=np.float64), csr[2])
+    b = gen.row_sums(csr[0], csr[2])
+    for ln in lines:
+        assert ln["status"] == 0 and ln["resnorm"] <= 1e-10 and ln["max_abs_err_vs_ones"] < 1e-8
+        assert ln["pattern_encoding"] in (0, 1)  # row masks + values[] (or no adoption below the solvers' threshold): never constant diagonals
+    _, diag = oracle.jacobi_setup(csr)
+    from oracle.oracle import PRECOND_JACOBI
+
+    st_ref, x_ref, it_ref, _ = oracle.bicgstab(csr, b.copy(), np.zeros(n), -1, 1e-10, PRECOND_JACOBI, diag)
+    x = np.fromfile(tmp_path / "x.f64", dtype=np.float64)  # the last kind's solution
+    assert st_ref == 0 and abs(lines[-1]["iterations"] - it_ref) <= max(2, it_ref // 10)
+    np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-8)
+    # the strong preconditioners need fewer iterations than none (ILU0 fewest)
+    its = {ln["precond"]: ln["iterations"] for ln in lines}
+    assert its["ilu0"] < its["block_ilu0"] < its["none"]
+
+
+@pytest.mark.gpu
 def test_mtx_symmetric_and_pattern_files(tmp_path, oracle):
     from write_mtx import write_mtx
 

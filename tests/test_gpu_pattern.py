@@ -415,6 +415,60 @@ def test_constant_diagonals_at_scale(smm, oracle):
     assert abs(totals[off] - float(ref @ ref)) <= 1e-10 * float(ref @ ref)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wave_kernel_16_at_scale(smm, oracle, dtype):
+    """spmvPatternWaveKernel<T, 16> (rows of 9-16 entries at one lane per row) on 2.2 M rows x 13 diagonals with varying values: many
+    groups per wavefront, the XCD chunk walk, the ragged first / last rows -- rMult, rMultSub, rMultAdd in place and the fused dot
+    products finished inside the launch, bit for bit against the oracle (one lane per row = the reference's order, ref:1484-1499)"""
+    import torch
+
+    dev = torch.device("cuda:0")
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n, k, seed, max_off = 2_200_000, 6, 0xBEEF, 1 << 17
+    stream = torch.cuda.current_stream().cuda_stream
+    nnz = smm.host.gen_banded_nnz(n, k, seed, max_off)
+    d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+    d_val = torch.empty(nnz, dtype=td, device=dev)
+    smm.host.gen_banded_dev(n, k, seed, max_off, d_start, d_pos, d_val, dtype, stream)
+    A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, dtype)
+    A.set_kernel(PATTERN, 1)
+    assert A.pattern_info() == (MASKS, 2 * k + 1)
+    assert A.kernel_desc()[0] == "spmvPatternWaveKernel"
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.rand(n, dtype=td, device=dev, generator=g) - 0.5
+    lhs = torch.rand(n, dtype=td, device=dev, generator=g) - 0.5
+    y = torch.empty(n, dtype=td, device=dev)
+    csr = (d_start.cpu().numpy(), d_pos.cpu().numpy(), d_val.cpu().numpy())
+    xh, lh = x.cpu().numpy(), lhs.cpu().numpy()
+    for op in (OP_ASSIGN, OP_SUB):
+        y.fill_(float("nan"))
+        A.spmv_dev(op, lhs if op != OP_ASSIGN else None, x, y, stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(y.cpu().numpy(), oracle.spmv(csr, op, lh, xh))
+    z = lhs.clone()
+    A.spmv_dev(OP_ADD, z, x, z, stream)  # in place
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(z.cpu().numpy(), oracle.spmv(csr, OP_ADD, lh, xh))
+    fin = torch.zeros(smm.host.finish_len(), dtype=td, device=dev)
+    A.spmv_fused_dev(OP_ASSIGN, None, x, y, 2, x, fin, stream, finish=True)
+    torch.cuda.synchronize()
+    ref = oracle.spmv(csr, OP_ASSIGN, None, xh)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    off = smm.host.finish_totals_offset()
+    totals = fin.cpu().numpy().astype(np.float64)
+    r64, x64 = ref.astype(np.float64), xh.astype(np.float64)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert abs(totals[off] - float(r64 @ r64)) <= tol * float(r64 @ r64)
+    assert abs(totals[off + 1] - float(r64 @ x64)) <= tol * float(np.abs(r64 * x64).sum())
+    # ... and the same bits as the STREAM family at one lane per row
+    A.set_kernel(STREAM, 1)
+    A.spmv_dev(OP_ASSIGN, None, x, y, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    A.close()
+
+
 def test_auto_keeps_stream_for_a_large_matrix_without_a_pattern(smm):
     """i.i.d. columns (SURVEY.md section 8d's secondary matrix): far more than 64 offsets -- AUTO's attempt is refused quietly, the
     matrix stays with STREAM and the result is right"""
