@@ -425,6 +425,10 @@ int smm_hip_dist_csr_create_dev_f64(smm_hip_comm* comm, int n_global, const int*
 int smm_hip_dist_csr_destroy(smm_hip_dist_csr* A);
 int smm_hip_dist_csr_info(const smm_hip_dist_csr* A, int* n_local, int* ext_len, int* own_offset, int* halo_elements, long long* nnz_loc,
                           long long* nnz_rem);
+/* Pieces the halo of this matrix is exchanged in (1 unless SMM_HIP_HALO_CHUNKS asked for 2 .. 4 on EVERY rank when the matrix was created):
+ * with k pieces every SpMV issues k exchanges back to back, and the remote block is cut by columns into k parts, part j starting as soon as
+ * piece j has landed (row sums are then formed as ((loc + rem_0) + rem_1) + ...: deterministic, rounding differs from the one-piece form). */
+int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks);
 /* the two local blocks (owned by A): a_loc is the square diagonal block a block-Jacobi preconditioner is built on
  * (smm_hip_precond_create(a_loc, kind, &M)); both accept smm_hip_csr_set_kernel */
 int smm_hip_dist_csr_local_block(const smm_hip_dist_csr* A, smm_hip_csr** a_loc, smm_hip_csr** a_rem);

@@ -378,8 +378,16 @@ public:
 	void rMultAdd(const T* const lhs, const T* const mult, T* const out) const noexcept { spmv(SMM_OP_ADD, lhs, mult, out); }
 	void rMultSub(const T* const lhs, const T* const mult, T* const out) const noexcept { spmv(SMM_OP_SUB, lhs, mult, out); }
 
+	// ref:1643-1651.  WHAT THE KINDS COST ON THE GPU (measured, MI355X, BiCGStab to 1e-8 on the 1.26 M-row convection-diffusion problem of
+	// BASELINE config 5; INTEGRATION.md "What a preconditioner costs"): the reference's own kind, SYMMETRIC_GAUS_SEIDEL, and ILU0 are EXACT
+	// triangular sweeps -- bit-identical to the sequential loops (ref:1658-1713), and bound by one memory-fabric round trip per dependency
+	// level: 79 / 67 iterations but ~200 / ~167 ms, against ~23 ms for 321 iterations with NONE.  They are kept because they are the
+	// reference's semantics, not because they are fast.  The kinds that WIN on a GPU are BLOCK_ILU0 / BLOCK_SGS (the same algorithms on
+	// the block-diagonal part of A, one wavefront per block: ~18 ms, 105 iterations, create included) and JACOBI (folded into the SpMV
+	// rows: the price of NONE).  A caller of getPreconditioner<SYMMETRIC_GAUS_SEIDEL>() (test/cpp/bicgstab.cpp:160-162) gets the slow,
+	// exact one -- switching to BLOCK_SGS is a one-word change, but a different preconditioner (different iteration counts).
 	template <SolverPreconditioner precond>
-	decltype(auto) getPreconditioner() const noexcept {  // ref:1643-1651
+	decltype(auto) getPreconditioner() const noexcept {
 		if constexpr (precond == SolverPreconditioner::NONE) {
 			return IDPreconditioner();
 		} else if constexpr (precond == SolverPreconditioner::SYMMETRIC_GAUS_SEIDEL) {

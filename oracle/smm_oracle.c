@@ -22,21 +22,24 @@ int smm_oracle_first_active_start(int rows, const int* start) {
 	return rows;
 }
 
+/* The team size is handed to every parallel region explicitly (num_threads(SMM_ORACLE_NT) in smm_oracle_impl.inc): two OpenMP run-times
+ * can live in one process (the gcc build's libgomp, the clang-built timing flavour's libomp, torch's own), and a call to
+ * omp_set_num_threads() binds to whichever the dynamic loader finds first -- not necessarily the one that runs this library's regions. */
+static int smm_oracle_threads_ = 0; /* 0: the run-time's default */
+
 int smm_oracle_omp_max_threads(void) {
 #ifdef _OPENMP
-	return omp_get_max_threads();
+	return smm_oracle_threads_ > 0 ? smm_oracle_threads_ : omp_get_max_threads();
 #else
 	return 1;
 #endif
 }
 
 void smm_oracle_omp_set_threads(int n) {
-#ifdef _OPENMP
-	if (n > 0) omp_set_num_threads(n);
-#else
-	(void)n;
-#endif
+	if (n > 0) smm_oracle_threads_ = n;
 }
+
+#define SMM_ORACLE_NT smm_oracle_omp_max_threads()
 
 int smm_oracle_uses_std_fma(void) {
 #ifdef SMM_WITH_STD_FMA

@@ -397,6 +397,60 @@ __global__ void splitScatterKernel(int nLocal, const int* __restrict__ start, co
 	}
 }
 
+// piece of the halo a column of A_rem (numbered from the first column of the halo-extended vector) falls into: segment [off, off + cnt)
+// is cut at off + floor(k cnt / K), k = 0 .. K; at most MAX_CHUNK_SEGS segments (more: the matrix keeps one piece)
+constexpr int MAX_CHUNK_SEGS = 16;
+constexpr int MAX_HALO_CHUNKS = 4;
+struct ChunkSegs {
+	int n, K;
+	int off[MAX_CHUNK_SEGS], cnt[MAX_CHUNK_SEGS];
+};
+__host__ __device__ inline int chunkBound(int cnt, int k, int K) { return static_cast<int>(static_cast<long long>(cnt) * k / K); }
+__device__ __forceinline__ int chunkOfColumn(const ChunkSegs& g, int col) {
+	for (int i = 0; i < g.n; ++i) {
+		const int rel = col - g.off[i];
+		if (rel >= 0 && rel < g.cnt[i]) {
+			int k = static_cast<int>(static_cast<long long>(rel) * g.K / g.cnt[i]);
+			while (k + 1 < g.K && rel >= chunkBound(g.cnt[i], k + 1, g.K)) ++k;  // (the floor of the inverse can land one piece early)
+			while (k > 0 && rel < chunkBound(g.cnt[i], k, g.K)) --k;
+			return k;
+		}
+	}
+	return g.K - 1;  // (a column outside every received segment cannot occur: A_rem's columns are what the segments were made from)
+}
+
+// counts[k * (nLocal + 1) + row] = entries of A_rem's row in piece k
+__global__ void chunkCountKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, ChunkSegs segs, int* __restrict__ counts) {
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row <= nLocal; row += gridDim.x * blockDim.x) {
+		int n[MAX_HALO_CHUNKS] = {0, 0, 0, 0};
+		if (row < nLocal) {
+			const int e = start[row + 1];
+			for (int k = start[row]; k < e; ++k) ++n[chunkOfColumn(segs, positions[k])];
+		}
+		for (int k = 0; k < segs.K; ++k) counts[static_cast<size_t>(k) * (nLocal + 1) + row] = n[k];
+	}
+}
+
+struct ChunkOut {
+	int* pos[MAX_HALO_CHUNKS];
+	void* val[MAX_HALO_CHUNKS];
+};
+template <typename T>
+__global__ void chunkScatterKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ values, ChunkSegs segs,
+                                   const int* __restrict__ starts, ChunkOut out) {
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nLocal; row += gridDim.x * blockDim.x) {
+		int at[MAX_HALO_CHUNKS];
+		for (int k = 0; k < segs.K; ++k) at[k] = starts[static_cast<size_t>(k) * (nLocal + 1) + row];
+		const int e = start[row + 1];
+		for (int i = start[row]; i < e; ++i) {  // order inside a row is preserved
+			const int k = chunkOfColumn(segs, positions[i]);
+			out.pos[k][at[k]] = positions[i];
+			static_cast<T*>(out.val[k])[at[k]] = values[i];
+			++at[k];
+		}
+	}
+}
+
 static int exclusiveScan(int* d_inout, int count, hipStream_t s) {
 	size_t tempBytes = 0;
 	SMM_HIP_TRY(rocprim::exclusive_scan(nullptr, tempBytes, d_inout, d_inout, 0, static_cast<size_t>(count), rocprim::plus<int>(), s));
@@ -431,6 +485,13 @@ struct smm_hip_dist_csr {
 	void* arrays[6] = {};  // startLoc, posLoc, valLoc, startRem, posRem, valRem (owned)
 	std::vector<smm::Seg> sends, recvs;
 	bool remEmpty = true;
+	// the halo in `chunks` pieces (SMM_HIP_HALO_CHUNKS, default 1 = one exchange, one remote block): piece k of every segment travels in
+	// exchange k, and A_rem is cut by columns into aRemK[k] = its entries in piece k of any received segment -- the part of A_rem that
+	// needs only piece k runs while the later pieces are still in flight
+	int chunks = 1;
+	std::vector<std::vector<smm::Seg>> sendsK, recvsK;
+	std::vector<smm_hip_csr*> aRemK;
+	std::vector<void*> chunkArrays;  // start / positions / values of the pieces (owned)
 	// workspace of the solvers, kept across solves
 	void *r = nullptr, *r0 = nullptr, *ap = nullptr, *as = nullptr, *scratch = nullptr;
 	void *pExt = nullptr, *sExt = nullptr, *xExt = nullptr;
@@ -584,6 +645,79 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 		SMM_TRY(smm_hip_csr_create_dev_f64(nLocal, nLocal, startLoc, static_cast<int*>(D->arrays[1]), static_cast<double*>(D->arrays[2]), &D->aLoc));
 		SMM_TRY(smm_hip_csr_create_dev_f64(nLocal, D->extLen, startRem, static_cast<int*>(D->arrays[4]), static_cast<double*>(D->arrays[5]), &D->aRem));
 	}
+	// ---- the halo in pieces (opt-in): every rank must cut alike, so the ranks agree on the smallest request
+	{
+		const char* env = getenv("SMM_HIP_HALO_CHUNKS");  // (read at every create: a property of the matrix, not of the process)
+		const int wanted = env ? std::max(1, std::min(MAX_HALO_CHUNKS, atoi(env))) : 1;
+		std::vector<long long> votes(static_cast<size_t>(world), 0);
+		// (a rank whose segments do not fit the cut's table asks for one piece)
+		votes[static_cast<size_t>(rank)] = D->recvs.size() > static_cast<size_t>(MAX_CHUNK_SEGS) ? 1 : wanted;
+		SMM_TRY(commAllreduceI64(comm, votes.data(), world));
+		int K = MAX_HALO_CHUNKS;
+		for (long long v : votes) K = std::min<long long>(K, std::max<long long>(1, v));
+		D->chunks = K;
+	}
+	if (D->chunks > 1) {
+		const int K = D->chunks;
+		auto piece = [K](const Seg& g, int k) {
+			const int a = chunkBound(g.count, k, K), b = chunkBound(g.count, k + 1, K);
+			return Seg{g.peer, g.offset + a, b - a};
+		};
+		D->sendsK.assign(static_cast<size_t>(K), {});
+		D->recvsK.assign(static_cast<size_t>(K), {});
+		for (int k = 0; k < K; ++k) {
+			for (const Seg& g : D->sends) {
+				const Seg q = piece(g, k);
+				if (q.count > 0) D->sendsK[static_cast<size_t>(k)].push_back(q);
+			}
+			for (const Seg& g : D->recvs) {
+				const Seg q = piece(g, k);
+				if (q.count > 0) D->recvsK[static_cast<size_t>(k)].push_back(q);
+			}
+		}
+		ChunkSegs segs{};
+		segs.n = static_cast<int>(D->recvs.size());
+		segs.K = K;
+		for (int i = 0; i < segs.n; ++i) {
+			segs.off[i] = D->recvs[static_cast<size_t>(i)].offset;
+			segs.cnt[i] = D->recvs[static_cast<size_t>(i)].count;
+		}
+		int* starts = nullptr;
+		SMM_TRY(devAlloc(reinterpret_cast<void**>(&starts), static_cast<size_t>(K) * (nLocal + 1) * sizeof(int)));
+		D->chunkArrays.push_back(starts);
+		chunkCountKernel<<<grid, 256, 0, s>>>(nLocal, startRem, static_cast<const int*>(D->arrays[4]), segs, starts);
+		SMM_HIP_TRY(hipGetLastError());
+		ChunkOut outs{};
+		std::vector<int> totalsK(static_cast<size_t>(K), 0);
+		for (int k = 0; k < K; ++k) SMM_TRY(exclusiveScan(starts + static_cast<size_t>(k) * (nLocal + 1), nLocal + 1, s));
+		for (int k = 0; k < K; ++k) {
+			SMM_HIP_TRY(hipMemcpyAsync(&totalsK[static_cast<size_t>(k)], starts + static_cast<size_t>(k) * (nLocal + 1) + nLocal, sizeof(int), hipMemcpyDeviceToHost, s));
+		}
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		for (int k = 0; k < K; ++k) {
+			void *pp = nullptr, *pv = nullptr;
+			SMM_TRY(devAlloc(&pp, std::max<size_t>(1, totalsK[static_cast<size_t>(k)]) * sizeof(int)));
+			D->chunkArrays.push_back(pp);
+			SMM_TRY(devAlloc(&pv, std::max<size_t>(1, totalsK[static_cast<size_t>(k)]) * sizeof(T)));
+			D->chunkArrays.push_back(pv);
+			outs.pos[k] = static_cast<int*>(pp);
+			outs.val[k] = pv;
+		}
+		if (nLocal > 0) {
+			chunkScatterKernel<T><<<grid, 256, 0, s>>>(nLocal, startRem, static_cast<const int*>(D->arrays[4]), static_cast<const T*>(D->arrays[5]), segs, starts, outs);
+			SMM_HIP_TRY(hipGetLastError());
+		}
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		D->aRemK.assign(static_cast<size_t>(K), nullptr);
+		for (int k = 0; k < K; ++k) {
+			int* st = starts + static_cast<size_t>(k) * (nLocal + 1);
+			if (dtypeOf<T>() == SMM_DTYPE_F32) {
+				SMM_TRY(smm_hip_csr_create_dev_f32(nLocal, D->extLen, st, outs.pos[k], static_cast<float*>(outs.val[k]), &D->aRemK[static_cast<size_t>(k)]));
+			} else {
+				SMM_TRY(smm_hip_csr_create_dev_f64(nLocal, D->extLen, st, outs.pos[k], static_cast<double*>(outs.val[k]), &D->aRemK[static_cast<size_t>(k)]));
+			}
+		}
+	}
 	SMM_TRY(distWorkspace<T>(D));
 	guard.d = nullptr;
 	*out = D;
@@ -607,7 +741,45 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 		if (jacobiDiag) return launchSpmv<T>(D->aLoc, op, jacobiDiag, own, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_DIV_LHS);
 		return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
 	}
+	if (D->chunks > 1 && exchange && !D->remEmpty) {
+		// The halo in pieces: every piece is an exchange of its own on the communicator's stream (all of them enqueued at once, so the
+		// links never idle between them), A_loc runs beside them, and the part of A_rem that reads only piece k starts as soon as THAT
+		// piece has landed: out = ((A_loc x + A_rem,0 x) + A_rem,1 x) + ... -- each part a row sum of its own, added in piece order
+		// (deterministic; differs from the one-piece form only in where the row sum is cut).  The fused dot products and the Jacobi
+		// division ride in the last part's epilogue.
+		const int K = D->chunks;
+		hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;
+		noteStream(cs);
+		SMM_TRY(orderAfter(c, s, cs));
+		hipEvent_t landedK[MAX_HALO_CHUNKS] = {};
+		int waitSlot[MAX_HALO_CHUNKS] = {-1, -1, -1, -1};
+		for (int k = 0; k < K; ++k) {
+			SMM_TRY(commExchange<T>(c, ext, D->sendsK[static_cast<size_t>(k)], D->recvsK[static_cast<size_t>(k)], cs));
+			if (cs != s) {
+				landedK[k] = takeEvent(c);
+				SMM_HIP_TRY(hipEventRecord(landedK[k], cs));
+				waitSlot[k] = profWaitAwaited(cs);
+			}
+		}
+		SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, cs != s ? SPMV_LEAVE_ROOM : 0));
+		const int remOp = op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD;
+		for (int k = 0; k < K; ++k) {
+			if (landedK[k]) {
+				profWaitWaiting(waitSlot[k], s);
+				SMM_HIP_TRY(hipStreamWaitEvent(s, landedK[k], 0));
+			}
+			const bool last = k == K - 1;
+			if (!last) {
+				SMM_TRY(launchSpmv<T>(D->aRemK[static_cast<size_t>(k)], remOp, out, ext, out, 0, nullptr, nullptr, doneFlag, s, 0));
+			} else if (jacobiDiag) {
+				return launchSpmv<T>(D->aRemK[static_cast<size_t>(k)], SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_ADD_DIV, jacobiDiag);
+			} else {
+				return launchSpmv<T>(D->aRemK[static_cast<size_t>(k)], remOp, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
+			}
+		}
+	}
 	hipEvent_t landed = nullptr;
+	int waitSlot = -1;
 	if (exchange) {
 		hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;  // the callback kind blocks anyway
 		noteStream(cs);
@@ -616,13 +788,14 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 		if (cs != s) {
 			landed = takeEvent(c);
 			SMM_HIP_TRY(hipEventRecord(landed, cs));
+			waitSlot = profWaitAwaited(cs);
 		}
 	}
 	// the local block runs while the halo is in flight; with RCCL the exchange is itself a kernel (a few workgroups per peer), and the
 	// persistent SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
 	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, landed ? SPMV_LEAVE_ROOM : 0));
 	if (landed) {
-		profWaitPair(s, c->stream);  // (profiling on: how long A_rem waits for the halo after A_loc has ended -- the exposed part of the exchange)
+		profWaitWaiting(waitSlot, s);  // (profiling on: how long A_rem waits for the halo after A_loc has ended -- the exposed part of the exchange)
 		SMM_HIP_TRY(hipStreamWaitEvent(s, landed, 0));
 	}
 	if (jacobiDiag) return launchSpmv<T>(D->aRem, SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_ADD_DIV, jacobiDiag);
@@ -880,6 +1053,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	// many SpMVs ahead: both local blocks may take the index-free family (each rank decides for its own blocks; no collective involved)
 	if (D->aLoc) SMM_TRY(adoptPatternForSolver(D->aLoc, maxIterations, s));
 	if (D->aRem) SMM_TRY(adoptPatternForSolver(D->aRem, maxIterations, s));
+	for (smm_hip_csr* piece : D->aRemK) SMM_TRY(adoptPatternForSolver(piece, maxIterations, s));
 	T *r = static_cast<T*>(D->r), *r0 = static_cast<T*>(D->r0), *ap = static_cast<T*>(D->ap), *as = static_cast<T*>(D->as);
 	T *pExt = static_cast<T*>(D->pExt), *sExt = static_cast<T*>(D->sExt), *xExt = static_cast<T*>(D->xExt);
 	T *p = pExt + D->ownOffset, *sv = sExt + D->ownOffset;
@@ -969,6 +1143,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2345-2347 (no clamp otherwise)
 	if (D->aLoc) SMM_TRY(adoptPatternForSolver(D->aLoc, maxIterations, s));
 	if (D->aRem) SMM_TRY(adoptPatternForSolver(D->aRem, maxIterations, s));
+	for (smm_hip_csr* piece : D->aRemK) SMM_TRY(adoptPatternForSolver(piece, maxIterations, s));
 	T *r = static_cast<T*>(D->r), *ap = static_cast<T*>(D->ap);
 	T *pExt = static_cast<T*>(D->pExt), *xExt = static_cast<T*>(D->xExt);
 	T* p = pExt + D->ownOffset;
@@ -1256,6 +1431,8 @@ int smm_hip_dist_csr_destroy(smm_hip_dist_csr* D) {
 	if (!D) return SMM_HIP_OK;
 	smm_hip_csr_destroy(D->aLoc);
 	smm_hip_csr_destroy(D->aRem);
+	for (smm_hip_csr* piece : D->aRemK) smm_hip_csr_destroy(piece);
+	for (void* p : D->chunkArrays) devFree(p);
 	for (void* p : D->arrays) devFree(p);
 	for (void* p : {D->r, D->r0, D->ap, D->as, D->scratch, D->pExt, D->sExt, D->xExt, D->partsA, D->partsB, D->partsC, D->sc}) devFree(p);
 	delete D;
@@ -1274,6 +1451,15 @@ int smm_hip_dist_csr_info(const smm_hip_dist_csr* D, int* n_local, int* ext_len,
 	if (halo_elements) *halo_elements = D->haloElements;
 	if (nnz_loc) *nnz_loc = D->nnzLoc;
 	if (nnz_rem) *nnz_rem = D->nnzRem;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks) {
+	if (!D || !chunks) {
+		setError("dist_csr_halo_chunks: null argument");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*chunks = D->chunks;
 	return SMM_HIP_OK;
 }
 

@@ -75,6 +75,12 @@ inline hipStream_t pickStream(smm_hip_stream s) {
 	return static_cast<hipStream_t>(s);
 }
 int numCUs();
+// one kernel of each hot-path translation unit is touched at init (see smm_runtime.hip, preloadUnits)
+void preloadSpmvUnit();
+void preloadPatternUnit();
+void preloadMarchUnit();
+void preloadBlas1Unit();
+void preloadSolversUnit();
 
 // caching device allocator (solver temporaries are allocated per call like the reference's SMM::Vector,
 // ref:2336-2339, but hipMalloc is far too slow to sit in that path)
@@ -206,8 +212,10 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 // live event timing of SpMV launches (smm_hip_profile_*): begin returns a slot or -1 when profiling is off
 int profBegin(hipStream_t s);
 void profEnd(int slot, hipStream_t s);
-// the waiting stream's own work ends here / the awaited stream's work ends here: smm_hip_profile_read_waits sums max(0, awaited - waiting)
-void profWaitPair(hipStream_t waiting, hipStream_t awaited);
+// "the awaited stream's work ends here" (returns a slot, -1 when profiling is off) / "the waiting stream's own work ends here":
+// smm_hip_profile_read_waits sums max(0, awaited - waiting) over the pairs
+int profWaitAwaited(hipStream_t awaited);
+void profWaitWaiting(int slot, hipStream_t waiting);
 
 // flag ORed into the `op` argument of the STREAM / PATTERN kernels: write out[] with non-temporal stores.  Set for outputs too
 // large to still be in cache when the next kernel reads them (measured on the 512^3 fp64 Laplacian: 3.15 -> 2.97 ms; written

@@ -29,6 +29,8 @@ int hipFail(hipError_t e, const char* what, const char* file, int line) {
 	return e == hipErrorOutOfMemory ? SMM_HIP_ERR_NOMEM : SMM_HIP_ERR_HIP;
 }
 
+__global__ void countLeadingEmpty(int rows, const int* __restrict__ start, int* __restrict__ out);
+
 static int initLocked(int device) {
 	int count = 0;
 	hipError_t e = hipGetDeviceCount(&count);
@@ -55,6 +57,21 @@ static int initLocked(int device) {
 	SMM_HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
 	g_device = device;
 	g_inited = true;
+	static const bool preload = [] {
+		const char* env = getenv("SMM_HIP_PRELOAD");
+		return env ? atoi(env) != 0 : true;
+	}();
+	if (preload) {
+		SetupTrace trace("init: code objects of the hot path");
+		hipFuncAttributes attr;
+		(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(countLeadingEmpty));
+		(void)hipGetLastError();
+		preloadSpmvUnit();
+		preloadPatternUnit();
+		preloadMarchUnit();
+		preloadBlas1Unit();
+		preloadSolversUnit();
+	}
 	return SMM_HIP_OK;
 }
 
@@ -297,6 +314,7 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_profEvents;  // pool, re
 static size_t g_profUsed = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_profWaitEvents;  // (end of own work on the waiting stream, end of the awaited work)
 static size_t g_profWaitUsed = 0;
+static std::vector<bool> g_profWaitHalf;  // slot: the waiting side has been recorded too
 
 int profBegin(hipStream_t s) {
 	std::lock_guard<std::mutex> lock(g_profMutex);
@@ -312,19 +330,30 @@ int profBegin(hipStream_t s) {
 }
 
 // second channel: how long a stream had to WAIT for another one (the row-partitioned SpMV: A_rem on the caller's stream waits for the
-// halo exchange on the communicator's).  `first` is recorded on the waiting stream where its own work ends, `second` on the other
-// stream where the awaited work ends; the exposed wait of the pair is max(0, second - first).
-void profWaitPair(hipStream_t waiting, hipStream_t awaited) {
+// halo exchange on the communicator's).  profWaitAwaited records "the awaited work ends here" on the other stream and returns a slot
+// (-1: profiling off); profWaitWaiting records "the waiting stream's own work ends here".  The exposed wait of the pair is
+// max(0, awaited - waiting).
+int profWaitAwaited(hipStream_t awaited) {
 	std::lock_guard<std::mutex> lock(g_profMutex);
-	if (!g_profOn) return;
+	if (!g_profOn) return -1;
 	if (g_profWaitUsed == g_profWaitEvents.size()) {
 		hipEvent_t a, b;
-		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
 		g_profWaitEvents.emplace_back(a, b);
 	}
-	const size_t slot = g_profWaitUsed++;
-	(void)hipEventRecord(g_profWaitEvents[slot].first, waiting);
-	(void)hipEventRecord(g_profWaitEvents[slot].second, awaited);
+	const int slot = static_cast<int>(g_profWaitUsed++);
+	(void)hipEventRecord(g_profWaitEvents[static_cast<size_t>(slot)].second, awaited);
+	g_profWaitHalf.resize(g_profWaitEvents.size(), false);
+	g_profWaitHalf[static_cast<size_t>(slot)] = false;
+	return slot;
+}
+
+void profWaitWaiting(int slot, hipStream_t waiting) {
+	if (slot < 0) return;
+	std::lock_guard<std::mutex> lock(g_profMutex);
+	if (static_cast<size_t>(slot) >= g_profWaitUsed) return;  // (read and reset in between)
+	(void)hipEventRecord(g_profWaitEvents[static_cast<size_t>(slot)].first, waiting);
+	g_profWaitHalf[static_cast<size_t>(slot)] = true;
 }
 
 void profEnd(int slot, hipStream_t s) {
@@ -521,6 +550,7 @@ int smm_hip_profile_read_waits(double* exposed_ms, long long* pairs, int reset) 
 	std::lock_guard<std::mutex> lock(g_profMutex);
 	double total = 0.0;
 	for (size_t i = 0; i < g_profWaitUsed; ++i) {
+		if (i >= g_profWaitHalf.size() || !g_profWaitHalf[i]) continue;
 		SMM_HIP_TRY(hipEventSynchronize(g_profWaitEvents[i].first));
 		SMM_HIP_TRY(hipEventSynchronize(g_profWaitEvents[i].second));
 		float ms = 0.f;

@@ -866,6 +866,15 @@ static int bicgsymmetricHost(const smm_hip_csr* a, T* b, T* x, int maxIterations
 	return SMM_HIP_OK;
 }
 
+// every translation unit of the library is a code object of its own, built for the device at the FIRST launch of any of its kernels
+// (5-9 ms each, measured: profiles/r04/first_spmv_setup_trace.txt); smm_hip_init touches one kernel of each hot-path unit so that
+// the first SpMV of a process does not pay for it (SMM_HIP_PRELOAD=0: load lazily as before)
+void preloadSolversUnit() {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(cgAlphaScal<float>));
+	(void)hipGetLastError();
+}
+
 }  // namespace smm
 
 using namespace smm;

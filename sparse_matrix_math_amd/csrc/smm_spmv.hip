@@ -934,6 +934,15 @@ void chooseSpmvConfig(smm_hip_csr* m) {
 	m->setKernel(family, lanes);
 }
 
+// every translation unit of the library is a code object of its own, built for the device at the FIRST launch of any of its kernels
+// (5-9 ms each, measured: profiles/r04/first_spmv_setup_trace.txt); smm_hip_init touches one kernel of each hot-path unit so that
+// the first SpMV of a process does not pay for it (SMM_HIP_PRELOAD=0: load lazily as before)
+void preloadSpmvUnit() {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(tileCutKernel));
+	(void)hipGetLastError();
+}
+
 template <typename T, int L>
 static void launchVector(const smm_hip_csr* m, int grid, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {

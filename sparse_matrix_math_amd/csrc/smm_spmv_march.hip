@@ -349,6 +349,15 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 	}
 }
 
+// every translation unit of the library is a code object of its own, built for the device at the FIRST launch of any of its kernels
+// (5-9 ms each, measured: profiles/r04/first_spmv_setup_trace.txt); smm_hip_init touches one kernel of each hot-path unit so that
+// the first SpMV of a process does not pay for it (SMM_HIP_PRELOAD=0: load lazily as before)
+void preloadMarchUnit() {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(marchNarrowMasks));
+	(void)hipGetLastError();
+}
+
 // ---- the plan (once per matrix, at the end of the CONST analysis; caller holds tileMutex) and the launch ----------------------------------
 // From the sorted offset list: the far pair is -P / +P with P the largest |offset|, present on at least one side, when the rest of the
 // offsets is near (|off| <= the halo a lane can hold), planes are at least four tiles large and the rows are a whole number of planes
@@ -450,13 +459,15 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	if (!enabled || !m->march_ok || !m->d_pat_masks32) return false;
 	const int nNear = m->pat_k - m->march_lo - m->march_hi;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;  // outputs too large to still be cached when the next kernel reads them
-	// rows per lane: 8 (tiles of 2048 rows); SMM_HIP_MARCH_R=4 takes tiles of 1024 rows (A/B measurements)
-	static const int rowsPerLane = [] {
+	// rows per lane (profiles/r04/march_rows_per_lane.txt, 512^3): fp64 4 -- tiles of 1024 rows, 120 VGPRs, four workgroups per CU: 0.565 ms
+	// against 0.604 with 8 (185 VGPRs, two per CU); fp32 8 -- 0.318 against 0.335.  SMM_HIP_MARCH_R=4 / 8 forces one (A/B measurements).
+	static const int forcedRows = [] {
 		const char* env = getenv("SMM_HIP_MARCH_R");
-		return env && atoi(env) == 4 ? 4 : 8;
+		return env ? atoi(env) : 0;
 	}();
+	const int rowsPerLane = forcedRows == 4 || forcedRows == 8 ? forcedRows : (sizeof(T) == 8 ? 4 : 8);
 	const int vec = 16 / static_cast<int>(sizeof(T));
-	const bool r4 = rowsPerLane == 4 && 2 * m->march_H / vec <= 4 * TPB;
+	const bool r4 = rowsPerLane == 4;
 	const bool hp2 = 2 * m->march_H / vec <= 2 * TPB;  // the halo fits two packs per lane (fewer registers)
 #define SMM_MARCH_GO2(RV, KNV)                                                                                                  \
 	do {                                                                                                                        \

@@ -1200,6 +1200,15 @@ __global__ __launch_bounds__(TPB) void spmvDictKernel(int nTiles, int cap, int c
 	}
 }
 
+// every translation unit of the library is a code object of its own, built for the device at the FIRST launch of any of its kernels
+// (5-9 ms each, measured: profiles/r04/first_spmv_setup_trace.txt); smm_hip_init touches one kernel of each hot-path unit so that
+// the first SpMV of a process does not pay for it (SMM_HIP_PRELOAD=0: load lazily as before)
+void preloadPatternUnit() {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(patSampleOffsets));
+	(void)hipGetLastError();
+}
+
 // SMM_HIP_AUTO_DICT=0: the automatic attempt (first SpMV of a large matrix) stops at the masks; the dictionary encoding then needs an
 // explicit smm_hip_csr_set_kernel(m, SMM_SPMV_PATTERN, lanes)
 static bool autoDictAllowed() {

@@ -539,6 +539,11 @@ class _BlockView:
         _lib.check(_lib.load().smm_hip_csr_pattern_info(self._h, ctypes.byref(enc), ctypes.byref(k)))
         return enc.value, k.value
 
+    def kernel_desc(self):
+        from . import host
+
+        return host.CSRMatrix.kernel_desc(self)
+
 
 class NativeDistMatrix:
     """smm_hip_dist_csr: this rank's rows of a row-partitioned matrix + the native solvers on it.  Collective."""
@@ -558,6 +563,9 @@ class NativeDistMatrix:
         nl, nr = ctypes.c_longlong(), ctypes.c_longlong()
         self.check(self.lib.smm_hip_dist_csr_info(self._h, ctypes.byref(n), ctypes.byref(e), ctypes.byref(o), ctypes.byref(h), ctypes.byref(nl), ctypes.byref(nr)))
         self.n_local, self.ext_len, self.own_offset, self.halo_elements, self.nnz_loc, self.nnz_rem = n.value, e.value, o.value, h.value, nl.value, nr.value
+        k = ctypes.c_int()
+        self.check(self.lib.smm_hip_dist_csr_halo_chunks(self._h, ctypes.byref(k)))
+        self.halo_chunks = k.value  # pieces the halo travels in (SMM_HIP_HALO_CHUNKS at create time, agreed by all ranks; 1 = one exchange per SpMV)
         self._M = None
 
     def local_blocks(self):
@@ -750,6 +758,7 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         "exposed_comm_ms": exposed_ms / max(iters, 1),
         "exposed_comm": {"total_ms": exposed_ms, "exchanges": exchanges, "ms_per_exchange": exposed_ms / max(exchanges, 1),
                          "note": "rank 0; events: end of A_loc on the solver's stream -> end of the halo exchange on the communicator's stream, clipped at 0"},
+        "halo_chunks": A.halo_chunks if driver == "native" else 1,
         "per_rank": {"rows": hi - lo, "nnz": nnz_local, "halo_elements": halo,
                      "spmv_launch_ms_rank0": spmv_ms / max(spmv_launches, 1), "spmv_launches_rank0": spmv_launches},
     }
