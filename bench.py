@@ -154,7 +154,7 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
 
     from oracle.oracle import Oracle
 
-    oracle = Oracle(timing=True)  # the flavour built with the reference harness's compiler (oracle/Makefile)
+    oracle = Oracle()
     cores, share = host_cores()
     csr = (start, positions, values)
     x0 = np.zeros(len(b), dtype=np_dtype)
@@ -186,7 +186,6 @@ def cpu_baseline(args, np_dtype, start, positions, values, b, budget_s):
                   f"matrix after a warm-up solve: OpenMP port of the reference loop on all {cores} physical cores",
         "spread": [rates[0], rates[-1]],
         "cpu_model": cpu_model(),
-        "port_build": os.path.basename(oracle.path),
     }
     if share != cores:  # the 16-core share of one GPU of the box
         r16, _ = samples(share, 3, per_solve)

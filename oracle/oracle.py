@@ -15,7 +15,6 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_LIB = os.path.join(_HERE, "_build", "libsmm_oracle.so")
 ORACLE_FMA_LIB = os.path.join(_HERE, "_build", "libsmm_oracle_fma.so")
-ORACLE_TIMING_LIB = os.path.join(_HERE, "_build", "libsmm_oracle_timing.so")  # clang -O3 build of the same source (bench.py cpu_baseline)
 REF_LIB = os.path.join(_HERE, "_ref", "libsmm_ref.so")
 
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_ILU0, PRECOND_SGS = 0, 1, 2, 3
@@ -53,15 +52,12 @@ def _c(a, dtype):
 
 
 class Oracle:
-    """The C restatement.  fma=True loads the SMM_WITH_STD_FMA flavour; timing=True the flavour built like the reference harness (same
-    compiler, -O3) that bench.py's cpu_baseline leg times -- same source, same arithmetic flags, same bits."""
+    """The C restatement.  fma=True loads the SMM_WITH_STD_FMA flavour."""
 
-    def __init__(self, fma=False, timing=False):
-        path = ORACLE_FMA_LIB if fma else ORACLE_TIMING_LIB if timing else ORACLE_LIB
+    def __init__(self, fma=False):
+        path = ORACLE_FMA_LIB if fma else ORACLE_LIB
         if not os.path.exists(path):
             build(ref=False)
-        if timing and not os.path.exists(path):
-            path = ORACLE_LIB
         self.path = path
         self.lib = ctypes.CDLL(path)
         self.lib.smm_oracle_omp_max_threads.restype = c_int
@@ -254,6 +250,10 @@ class Oracle:
         s2 = np.zeros(n + 1, dtype=np.int32)
         np.cumsum(np.bincount(rowof[keep], minlength=n), out=s2[1:])
         return (s2, pos[keep].copy(), val[keep].copy()), keep, deepest
+
+    def set_spmv_form(self, rows_in_lock_step):
+        """1, 2 or 4 rows walked in lock step by the OpenMP port's SpMV (same bits every way; tools/cpu_port_ab.py)"""
+        self.lib.smm_oracle_omp_set_spmv_form(int(rows_in_lock_step))
 
     def omp_threads(self):
         return self.lib.smm_oracle_omp_max_threads()

@@ -41,6 +41,14 @@ void smm_oracle_omp_set_threads(int n) {
 
 #define SMM_ORACLE_NT smm_oracle_omp_max_threads()
 
+/* form of the OpenMP port's SpMV row loop: 1 = one row at a time (the reference's loop under a parallel for), 2 / 4 = that many rows
+ * walked in lock step (independent multiply-add chains; every row's own sum keeps its order: same bits).  tools/cpu_port_ab.py times
+ * them against the real reference on the GPU box's host; the default is what won there. */
+static int smm_oracle_spmv_form_ = 4;
+void smm_oracle_omp_set_spmv_form(int rows_in_lock_step) {
+	if (rows_in_lock_step == 1 || rows_in_lock_step == 2 || rows_in_lock_step == 4) smm_oracle_spmv_form_ = rows_in_lock_step;
+}
+
 int smm_oracle_uses_std_fma(void) {
 #ifdef SMM_WITH_STD_FMA
 	return 1;
