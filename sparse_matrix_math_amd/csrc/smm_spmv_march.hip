@@ -181,7 +181,7 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 			const long long base = static_cast<long long>(z) * P + r0;
 #pragma unroll
 			for (int p = 0; p < PACKS; ++p) {
-				if (inside && wantCentre && act[p]) {
+				if (inside && wantCentre && act[p] && base + loc[p] < rows) {  // (the last plane may be a partial one)
 					f.c[p] = *reinterpret_cast<const PackU<T>*>(x + base + loc[p]);  // (kept cacheable: a neighbouring tile reads these lines as its halo)
 				} else {
 #pragma unroll
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 				}
 #pragma unroll
 				for (int p = 0; p < PACKS; ++p) {
-					if (act[p]) {
+					if (act[p] && base + loc[p] < rows) {
 						f.m[p] = __builtin_nontemporal_load(reinterpret_cast<const MaskP<T>*>(masks32 + base + loc[p]));
 					} else {
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 			// epilogue: op(lhs, dot), out[] as 16-byte packs, the fused dot products
 #pragma unroll
 			for (int p = 0; p < PACKS; ++p) {
-				if (act[p]) {
+				if (act[p] && base + loc[p] < rows) {
 					const long long row = base + loc[p];
 					PackU<T> o;
 #pragma unroll
@@ -377,7 +377,7 @@ void planConstMarch(smm_hip_csr* m) {
 	auto roundUp = [vec](int h) { return (h + vec - 1) / vec * vec; };
 	const int far = std::max(std::abs(offs.front()), std::abs(offs.back()));
 	// (a) the far pair
-	if (far >= 4 * TPB * MARCH_RMAX && m->rows % far == 0 && far % vec == 0 && m->rows / far >= 2) {
+	if (far >= 4 * TPB * MARCH_RMAX && m->rows % vec == 0 && far % vec == 0 && m->rows / far >= 2) {  // (the last plane may be partial: a slab of a partitioned grid)
 		const int lo = offs.front() == -far ? 1 : 0, hi = offs.back() == far ? 1 : 0;
 		int h = 0;
 		for (int j = lo; j < k - hi; ++j) h = std::max(h, std::abs(offs[j]));
@@ -415,7 +415,7 @@ template <typename T, int R, int KN, bool NT, int HP>
 static int launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {
 	const int P = m->march_P, H = m->march_H;
-	const int nPlanes = m->rows / P;
+	const int nPlanes = (m->rows + P - 1) / P;
 	constexpr int MARCH_B = TPB * R;
 	const int nT = (P + MARCH_B - 1) / MARCH_B;
 	const size_t lds = 2 * static_cast<size_t>(MARCH_B + 2 * H) * sizeof(T);

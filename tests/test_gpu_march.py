@@ -83,6 +83,35 @@ def test_march_kernel_matches_oracle(smm, oracle, dtype, grid):
     A.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_march_kernel_on_a_slab_that_ends_inside_a_plane(smm, oracle, dtype):
+    """the rows of a row-partitioned grid are a slab that starts and ends anywhere: the leading 2 108 536 rows (and columns) of a
+    128 x 128 x 129 stencil -- the last plane is a partial one -- still march (the offsets are linear in the row index; the masks carry
+    the boundaries), bit for bit with the oracle"""
+    import torch
+
+    from sparse_matrix_math_amd import generators as gen
+
+    start, pos, val = gen.stencil3d(128, 128, 129, 6.0, -1.25, -0.75, dtype=dtype)
+    n = 128 * 128 * 129 - 5000
+    keep = pos[: start[n]] < n
+    rows_of = np.repeat(np.arange(n), np.diff(start[: n + 1]))
+    s2 = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows_of[keep], minlength=n), out=s2[1:])
+    csr = (s2, pos[: start[n]][keep].copy(), val[: start[n]][keep].copy())
+    A = smm.CSRMatrix(n, n, *csr)
+    A.set_kernel(PATTERN, 1)
+    assert A.pattern_info()[0] == CONST and A.kernel_desc()[0] == "spmvPatternConstMarchKernel"
+    rng = np.random.default_rng(6)
+    x, lhs = rng.uniform(-0.5, 0.5, n).astype(dtype), rng.uniform(-0.5, 0.5, n).astype(dtype)
+    out = np.zeros(n, dtype=dtype)
+    A.rMult(x, out)
+    np.testing.assert_array_equal(out, oracle.spmv(csr, OP_ASSIGN, None, x))
+    A.rMultSub(lhs, x, out)
+    np.testing.assert_array_equal(out, oracle.spmv(csr, OP_SUB, lhs, x))
+    A.close()
+
+
 def test_march_in_cg_at_scale(smm, oracle):
     """ConjugateGradient on a 160^3 Laplacian (4.1 M rows, fp64) with AUTO: the solver adopts PATTERN / CONST, the SpMV is the march kernel;
     x after 25 iterations against the oracle (fixed iterations: eps = 0)"""
