@@ -59,6 +59,49 @@ def test_setup_is_ordered_behind_the_callers_stream(smm):
         assert float(interior.abs().max()) < 1e-12  # 6 - 3*1.3 - 3*0.7 == 0 in the interior
 
 
+def test_auto_analysis_is_ordered_behind_the_callers_stream(smm):
+    """the FIRST SpMV of an AUTO matrix of >= 2^25 entries runs the PATTERN analysis (sampling, mask build,
+    verification of every entry, tile table) inside an asynchronous `_dev` entry point.  The handle is created through the raw C ABI
+    (no query that would drain the device) while the generator of the arrays is still queued behind busy work on the caller's stream:
+    everything the analysis reads must be ordered behind it.  Checked against a second, fully synchronised handle, bit for bit."""
+    import torch
+
+    from sparse_matrix_math_amd import _lib, host
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    n, k, seed, max_off = 700_000, 25, 0x5EED, 1 << 16
+    nnz = host.gen_banded_nnz(n, k, seed, max_off)
+    assert nnz >= 1 << 25
+    x = torch.rand(n, dtype=torch.float32, device=dev) - 0.5
+    for _ in range(2):
+        ds = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        dp = torch.empty(nnz, dtype=torch.int32, device=dev)
+        dv = torch.empty(nnz, dtype=torch.float32, device=dev)
+        y = torch.empty(n, dtype=torch.float32, device=dev)
+        big = torch.rand(64_000_000, device=dev)
+        for _ in range(4):
+            big = big * 1.0001 + 0.5  # keeps the stream busy ahead of the generator
+        host.gen_banded_dev(n, k, seed, max_off, ds, dp, dv, np.float32, stream)
+        h = ctypes.c_void_p()
+        _lib.check(lib.smm_hip_csr_create_dev_f32(n, n, host._dptr(ds), host._dptr(dp), host._dptr(dv), ctypes.byref(h)))
+        _lib.check(lib.smm_hip_spmv_dev_f32(h, 0, None, host._dptr(x), host._dptr(y), host._dptr(stream)))  # AUTO: analysis + first launch
+        torch.cuda.synchronize()
+        fam, lanes = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.smm_hip_csr_get_kernel(h, ctypes.byref(fam), ctypes.byref(lanes)))
+        assert (fam.value, lanes.value) == (3, 2)  # PATTERN: the analysis saw the finished arrays and every entry verified
+        B = smm.CSRMatrix.from_device(n, n, ds, dp, dv, np.float32)  # (drains the device)
+        B.set_kernel(2, 2)  # STREAM at the same lanes: the same bits
+        y2 = torch.empty_like(y)
+        B.spmv_dev(0, None, x, y2, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+        B.close()
+        _lib.check(lib.smm_hip_csr_destroy(h))
+        del big
+
+
 def test_fused_dot_entry_point(smm, oracle):
     import torch
 

@@ -33,7 +33,7 @@ for dtype in (np.float64, np.float32):
     y = torch.empty_like(ones); e0.record()
     for _ in range(10): A.spmv_dev(0, None, ones, y, stream)
     e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 10
-    print(f"config4 512^3 {np.dtype(dtype).name}: CG {it} iterations in {dt*1e3:.0f} ms = {it/dt:.1f} it/s ({dt/it*1e3:.2f} ms/it); SpMV {ms:.3f} ms (family, lanes {A.get_kernel()}, PATTERN encoding {A.pattern_info()[0]}: 3 = constant diagonals, the kernel moves {n * (8 + 2 * np.dtype(dtype).itemsize) / 1e9:.2f} GB; the CSR layout holds {bytes_spmv/1e9:.2f} GB)")
+    print(f"config4 512^3 {np.dtype(dtype).name}: CG {it} iterations in {dt*1e3:.0f} ms = {it/dt:.1f} it/s ({dt/it*1e3:.2f} ms/it); SpMV {ms:.3f} ms (family, lanes {A.get_kernel()}, PATTERN encoding {A.pattern_info()[0]}: 3 = constant diagonals, {A.kernel_desc()[0]} moves {A.kernel_desc()[1] / 1e9:.2f} GB; the CSR layout holds {bytes_spmv/1e9:.2f} GB)")
     del A, b, x, y, ones
 
 # ---- config 5 stand-in: convection-diffusion 108^3, fp64, BiCGStab none / Jacobi / ILU0 / SGS to 1e-8 ----
