@@ -87,7 +87,8 @@ extern "C" {
  *   MASKS  <= 64 distinct offsets and rows of <= 64 entries: one 64-bit mask per ROW, verified against EVERY entry on the device before
  *          the family is used; an SpMV streams only values[] (half the bytes for fp32);
  *          When in addition every entry of a diagonal holds the same value (constant-coefficient stencils: the Laplacians) -- CONST --
- *          values[] is not read either: 24 bytes per fp64 row instead of 104;
+ *          values[] is not read either: 24 bytes per fp64 row instead of 104 -- 20 for grid-shaped matrices of >= 2^21 rows, which run the
+ *          2.5-D kernel (csrc/smm_spmv_march.hip: a plane's window of x in LDS, the planes above and below in registers, 32-bit masks);
  *   CODES  <= 65536 distinct offsets: one 16-bit index into the matrix's sorted offset dictionary per ENTRY (6 instead of 8 bytes per
  *          fp32 entry), built on the device from all entries.
  * Same result bit for bit as the other families at the same lanes_per_row.  Selected explicitly (smm_hip_csr_set_kernel returns

@@ -44,7 +44,7 @@ void smm_oracle_omp_set_threads(int n) {
 /* form of the OpenMP port's SpMV row loop: 1 = one row at a time (the reference's loop under a parallel for), 2 / 4 = that many rows
  * walked in lock step (independent multiply-add chains; every row's own sum keeps its order: same bits).  tools/cpu_port_ab.py times
  * them against the real reference on the GPU box's host; the default is what won there. */
-static int smm_oracle_spmv_form_ = 4;
+static int smm_oracle_spmv_form_ = 2; /* profiles/r04/cpu_port_ab.txt: 10 M rows, one core of an EPYC 9575F: 2 rows 2.80 it/s, 1 row 2.60, 4 rows 2.47; the real reference 2.67 */
 void smm_oracle_omp_set_spmv_form(int rows_in_lock_step) {
 	if (rows_in_lock_step == 1 || rows_in_lock_step == 2 || rows_in_lock_step == 4) smm_oracle_spmv_form_ = rows_in_lock_step;
 }

@@ -265,8 +265,11 @@ void adoptPatternQuietly(const smm_hip_csr* m, hipStream_t s);
 int patternLanesFor(const smm_hip_csr* m);
 // the PATTERN kernel launchPat picks for `lanes` and the bytes one launch moves (smm_hip_csr_kernel_desc)
 const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes);
-void planConstMarch(smm_hip_csr* m);
+void planMarch(smm_hip_csr* m);
 int marchBuildMasks32(smm_hip_csr* m, hipStream_t s);
+template <typename T>
+bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                         const int* doneFlag, hipStream_t s);
 template <typename T>
 bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s);

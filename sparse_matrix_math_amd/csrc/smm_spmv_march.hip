@@ -349,6 +349,233 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same march for matrices whose diagonals VARY (MASKS: values[] is read): stencils with varying coefficients on big grids.  What
+// the wave-private mask kernel (spmvPatternWaveKernel, smm_spmv_pattern.hip) loses there is x: 13.9 GB across the fabric for the 11.3 GB
+// of the 512^3 fp64 stencil, x fetched 3.6 x.  Here x goes through the plane's LDS window and the lane's registers exactly as above;
+// values[] keeps the wave kernel's route: the 64 consecutive rows of a wavefront own ONE contiguous run of values[], fetched with
+// coalesced loads one sub-step ahead (two register sets alternate), passed through a wave-private LDS slice and read back by the row's
+// lane.  A tile is 1024 rows = 4 sub-steps of 256 (one row per lane and sub-step: 8-byte LDS reads at lane stride -- conflict-free).
+// Row starts come from ONE start[] per 64 rows plus a prefix sum of the masks' popcounts across the wavefront: no start[] stream.
+// Bytes per fp64 row of the 7-point stencil: 56 (values) + 4 (mask) + 8 (x) + 8 (out) = 76 against 84 in the wave kernel (and the
+// 104 that kernel really moves).  Same products in the same order: -P, the near offsets ascending, +P; value n of a row pairs with its
+// n-th set bit (ref:1484-1489): the reference's bits with one lane per row.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int MM_Q = 4;            // sub-steps per tile and plane
+constexpr int MM_B = MM_Q * TPB;   // rows of a tile
+
+template <typename T, int HP>
+struct MasksMarchSet {
+	T c[MM_Q];
+	PackU<T> h[HP];
+	unsigned m[MM_Q];
+	int s0[MM_Q];  // start[] of the first row of the lane's wavefront in sub-step q
+};
+
+template <typename T, int KMAX>
+struct MasksMarchVals {
+	T v[KMAX];
+	int at;  // the lane's row begins here in the wavefront's run
+};
+
+template <typename T, int KMAX, bool NT, int HP>
+__global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 ? 3 : 2)) void spmvPatternMasksMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
+                                                                      int nOff, int hasLo, int hasHi, const int* __restrict__ offs, const int* __restrict__ start,
+                                                                      const T* __restrict__ values, const unsigned* __restrict__ masks32, int opFlags,
+                                                                      const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode,
+                                                                      const T* __restrict__ w1, T* __restrict__ partials, const int* __restrict__ doneFlag) {
+	using Set = MasksMarchSet<T, HP>;
+	using Vals = MasksMarchVals<T, KMAX>;
+	constexpr int VEC = 16 / sizeof(T);
+	const int winLen = MM_B + 2 * H;
+	T* sWin0 = reinterpret_cast<T*>(smmMarchLds);
+	T* sWin1 = sWin0 + winLen;
+	__shared__ T sVal[TPB / WAVE][WAVE * KMAX + KMAX];
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	const int op = opFlags & 0xFF;
+	const int t = threadIdx.x;
+	const int lane = t & (WAVE - 1);
+	const int wv = t >> 6;
+	const int nNear = nOff - hasLo - hasHi;
+	const int haloPacks = 2 * H / VEC;
+	const unsigned fullMask = nOff >= 32 ? 0xFFFFFFFFu : ((1u << nOff) - 1u);
+	for (int i = lane; i < WAVE * KMAX + KMAX; i += WAVE) sVal[wv][i] = T(0);
+
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int units = nT * nChunks;
+	int uFirst, uStride, uEnd, tLo = 0, tCount = nT;
+	if (xcdTiles) {
+		const int g = blockIdx.x % nGroups;
+		tLo = static_cast<int>(static_cast<long long>(g) * nT / nGroups);
+		tCount = static_cast<int>(static_cast<long long>(g + 1) * nT / nGroups) - tLo;
+		uFirst = blockIdx.x / nGroups;
+		uStride = (static_cast<int>(gridDim.x) - g + nGroups - 1) / nGroups;
+		uEnd = tCount * nChunks;
+	} else {
+		uFirst = blockIdx.x;
+		uStride = gridDim.x;
+		uEnd = units;
+	}
+	T acc0 = T(0), acc1 = T(0);
+
+	for (int u = uFirst; u < uEnd; u += uStride) {
+		const int chunk = u / tCount;
+		const int tile = tLo + (u - chunk * tCount);
+		const int z0 = chunk * zc;
+		const int z1 = min(nPlanes, z0 + zc);
+		const int r0 = tile * MM_B;
+		const int bAct = min(MM_B, P - r0);
+		auto haloWin = [&](int i) { return i < H / VEC ? i * VEC : H + bAct + (i - H / VEC) * VEC; };
+		auto issue = [&](Set& f, int z, bool wantCentre, bool wantWindow) {
+			const bool inside = z >= 0 && z < nPlanes;
+			const long long base = static_cast<long long>(z) * P + r0;
+#pragma unroll
+			for (int q = 0; q < MM_Q; ++q) {
+				const int l = q * TPB + t;
+				const bool live = inside && l < bAct && base + l < rows;
+				f.c[q] = live && wantCentre ? x[base + l] : T(0);  // (cacheable: a neighbouring tile reads these lines as its halo)
+				if (wantWindow) {
+					f.m[q] = live ? __builtin_nontemporal_load(masks32 + base + l) : 0u;
+					const int lw = q * TPB + (t & ~(WAVE - 1));  // the wavefront's first row of this sub-step
+					f.s0[q] = inside && lw < bAct && base + lw < rows ? start[base + lw] : 0;
+				}
+			}
+			if (inside && wantWindow) {
+#pragma unroll
+				for (int k = 0; k < HP; ++k) {
+					const int i = k * TPB + t;
+					if (i < haloPacks) {
+						long long gidx = base - H + haloWin(i);
+						gidx = gidx < 0 ? 0 : (gidx + VEC > cols ? cols - VEC : gidx);  // (a pack that sticks out of x is never used by a live entry)
+						f.h[k] = *reinterpret_cast<const PackU<T>*>(x + gidx);
+					}
+				}
+			}
+		};
+		auto storeWindow = [&](T* win, const Set& f) {
+#pragma unroll
+			for (int q = 0; q < MM_Q; ++q) {
+				if (q * TPB + t < bAct) win[H + q * TPB + t] = f.c[q];
+			}
+#pragma unroll
+			for (int k = 0; k < HP; ++k) {
+				const int i = k * TPB + t;
+				if (i < haloPacks) *reinterpret_cast<PackV<T>*>(win + haloWin(i)) = f.h[k];
+			}
+		};
+		// the wavefront's run of values[] for one sub-step: the lanes' popcounts give every row's place in it
+		auto fetchVals = [&](Vals& V, unsigned m, int s0) {
+			const int pc = __popc(m);
+			int incl = pc;
+#pragma unroll
+			for (int o = 1; o < WAVE; o <<= 1) {
+				const int up = __shfl_up(incl, o, WAVE);
+				if (lane >= o) incl += up;
+			}
+			const int total = __shfl(incl, WAVE - 1, WAVE);
+			V.at = incl - pc;
+#pragma unroll
+			for (int k = 0; k < KMAX; ++k) {
+				const int i = k * WAVE + lane;
+				V.v[k] = i < total ? __builtin_nontemporal_load(values + s0 + i) : T(0);
+			}
+		};
+
+		T xp[MM_Q];
+		unsigned mk[MM_Q];
+		int s0c[MM_Q];
+		Set fa, fb;
+		Vals va, vb;
+
+		auto subStep = [&](int z, int q, const Vals& V, const Set& use, const T* win) {
+#pragma unroll
+			for (int k = 0; k < KMAX; ++k) sVal[wv][k * WAVE + lane] = V.v[k];
+			const long long base = static_cast<long long>(z) * P + r0;
+			const int l = q * TPB + t;
+			const bool live = l < bAct && base + l < rows;
+			const unsigned m = mk[q];
+			const bool masked = !__all(m == fullMask || !live);
+			const int at = V.at;
+			T dot = T(0);
+			auto fold = [&](int j, T xv) {
+				const int idx = masked ? at + __popc(m & ((1u << j) - 1u)) : at + j;
+				const T next = smmFma(sVal[wv][idx], xv, dot);
+				dot = (!masked || ((m >> j) & 1u) != 0u) ? next : dot;
+			};
+			if (hasLo) fold(0, xp[q]);
+			for (int j = 0; j < nNear; ++j) fold(hasLo + j, win[H + l + offs[hasLo + j]]);
+			if (hasHi) fold(hasLo + nNear, use.c[q]);
+			if (live) {
+				const long long row = base + l;
+				const T o = marchApplyOp(op, lhs, divisor, row, dot);
+				if constexpr (NT) __builtin_nontemporal_store(o, out + row);
+				else out[row] = o;
+				if (dotMode == 2) acc0 += o * o;
+				if (dotMode) acc1 += o * w1[row];
+			}
+		};
+		// one plane: `use` holds plane z + 1, `re` is re-issued for plane z + 2; the values of sub-step q + 1 are requested before q is summed
+		auto step = [&](int z, Set& use, Set& re) {
+			T* win = ((z - z0) & 1) ? sWin1 : sWin0;
+			T* winNext = ((z - z0) & 1) ? sWin0 : sWin1;
+			const bool more = z + 1 < z1;
+			if (more) issue(re, z + 2, z + 2 < z1 || hasHi, z + 2 < z1);
+			fetchVals(vb, mk[1], s0c[1]);
+			subStep(z, 0, va, use, win);
+			fetchVals(va, mk[2], s0c[2]);
+			subStep(z, 1, vb, use, win);
+			fetchVals(vb, mk[3], s0c[3]);
+			subStep(z, 2, va, use, win);
+			if (more) fetchVals(va, use.m[0], use.s0[0]);  // the next plane's first sub-step
+			subStep(z, 3, vb, use, win);
+			if (more) {
+#pragma unroll
+				for (int q = 0; q < MM_Q; ++q) xp[q] = win[H + q * TPB + t];
+				storeWindow(winNext, use);
+#pragma unroll
+				for (int q = 0; q < MM_Q; ++q) {
+					mk[q] = use.m[q];
+					s0c[q] = use.s0[q];
+				}
+				ldsBarrier();
+			}
+		};
+
+		issue(fa, z0 - 1, hasLo != 0, false);
+#pragma unroll
+		for (int q = 0; q < MM_Q; ++q) xp[q] = fa.c[q];
+		issue(fa, z0, true, true);
+		issue(fb, z0 + 1, z0 + 1 < z1 || hasHi, z0 + 1 < z1);
+		__syncthreads();  // (the previous unit's last window reads are over)
+		storeWindow(sWin0, fa);
+#pragma unroll
+		for (int q = 0; q < MM_Q; ++q) {
+			mk[q] = fa.m[q];
+			s0c[q] = fa.s0[q];
+		}
+		__syncthreads();
+		fetchVals(va, mk[0], s0c[0]);
+		for (int z = z0; z < z1; z += 2) {
+			step(z, fb, fa);
+			if (z + 1 < z1) step(z + 1, fa, fb);
+		}
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
+	}
+}
+
 // every translation unit of the library is a code object of its own, built for the device at the FIRST launch of any of its kernels
 // (5-9 ms each, measured: profiles/r04/first_spmv_setup_trace.txt); smm_hip_init touches one kernel of each hot-path unit so that
 // the first SpMV of a process does not pay for it (SMM_HIP_PRELOAD=0: load lazily as before)
@@ -358,12 +585,12 @@ void preloadMarchUnit() {
 	(void)hipGetLastError();
 }
 
-// ---- the plan (once per matrix, at the end of the CONST analysis; caller holds tileMutex) and the launch ----------------------------------
+// ---- the plan (once per matrix, at the end of the MASKS analysis; caller holds tileMutex) and the launch ----------------------------------
 // From the sorted offset list: the far pair is -P / +P with P the largest |offset|, present on at least one side, when the rest of the
 // offsets is near (|off| <= the halo a lane can hold), planes are at least four tiles large and the rows are a whole number of planes
 // (grids in natural order: P = nx ny); otherwise, when EVERY offset is near (2-D grids, narrow bands), the matrix is one plane.  A matrix
 // that is neither keeps the gather kernel (spmvPatternConstKernel).
-void planConstMarch(smm_hip_csr* m) {
+void planMarch(smm_hip_csr* m) {
 	m->march_ok = false;
 	static const long long minRows = [] {
 		const char* env = getenv("SMM_HIP_MARCH_MIN_ROWS");
@@ -371,7 +598,7 @@ void planConstMarch(smm_hip_csr* m) {
 	}();
 	const std::vector<int>& offs = m->pat_offs_host;
 	const int k = static_cast<int>(offs.size());
-	if (!m->pat_const || k < 1 || k > 32 || m->rows != m->cols || m->rows < minRows) return;
+	if (k < 1 || k > 32 || m->rows != m->cols || m->rows < minRows) return;  // (constant diagonals or not: the masks kernels march as well)
 	const int vec = m->dtype == SMM_DTYPE_F32 ? 4 : 2;
 	const int hCap = 4 * TPB * vec / 2;  // 2 H / VEC halo packs <= 4 per lane (the kernel is compiled for 2 and for 4)
 	auto roundUp = [vec](int h) { return (h + vec - 1) / vec * vec; };
@@ -487,6 +714,68 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 #undef SMM_MARCH_GO
 	return true;
 }
+
+template <typename T, int KMAX, bool NT, int HP>
+static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                              const int* doneFlag, hipStream_t s) {
+	const int P = m->march_P, H = m->march_H;
+	const int nPlanes = (m->rows + P - 1) / P;
+	const int nT = (P + MM_B - 1) / MM_B;
+	const size_t lds = 2 * static_cast<size_t>(MM_B + 2 * H) * sizeof(T);
+	static bool raised = false;
+	if (lds > 48 * 1024 && !raised) {  // (the kernel holds 8-17 KB of static LDS beside the windows)
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvPatternMasksMarchKernel<T, KMAX, NT, HP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                          static_cast<int>(lds));
+		raised = true;
+	}
+	int perCU = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternMasksMarchKernel<T, KMAX, NT, HP>, TPB, lds) != hipSuccess || perCU < 1) perCU = 2;
+	if (const char* env = getenv("SMM_HIP_MARCH_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
+	op &= ~SPMV_LEAVE_ROOM;
+	const int resident = cus * perCU;
+	int zc = nPlanes;
+	if (nPlanes > 1) {
+		const int wantChunks = std::max(1, std::min(nPlanes, (4 * resident + nT - 1) / nT));
+		zc = std::max(std::min(8, nPlanes), (nPlanes + wantChunks - 1) / wantChunks);
+		if (const char* env = getenv("SMM_HIP_MARCH_ZC")) zc = std::max(1, std::min(nPlanes, atoi(env)));
+	}
+	const int nChunks = (nPlanes + zc - 1) / zc;
+	const long long units = static_cast<long long>(nT) * nChunks;
+	int grid = static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(units, resident), NPART)));
+	const int xcdTiles = (nT % 8 == 0 || nT >= 64) && grid >= 8 ? 1 : 0;
+	if (xcdTiles) grid -= grid % 8;
+	spmvPatternMasksMarchKernel<T, KMAX, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
+	                                                                  m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks32, op, lhs, divisor, x,
+	                                                                  out, dotMode, w1, partials, doneFlag);
+}
+
+// true: the launch went to the march form of the masks kernels (values[] read).  SMM_HIP_MASKS_MARCH=0 keeps the wave kernel.
+template <typename T>
+bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+                         const int* doneFlag, hipStream_t s) {
+	static const bool enabled = [] {
+		const char* env = getenv("SMM_HIP_MASKS_MARCH");
+		return env ? atoi(env) != 0 : true;
+	}();
+	if (!enabled || !m->march_ok || !m->d_pat_masks32 || m->pat_k > 16) return false;
+	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;
+	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
+#define SMM_MM_GO(KV)                                                                                                \
+	do {                                                                                                             \
+		if (nt && hp2) launchMasksMarchK<T, KV, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);   \
+		else if (nt) launchMasksMarchK<T, KV, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);     \
+		else if (hp2) launchMasksMarchK<T, KV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);   \
+		else launchMasksMarchK<T, KV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);            \
+	} while (0)
+	if (m->pat_k <= 8) SMM_MM_GO(8);
+	else SMM_MM_GO(16);
+#undef SMM_MM_GO
+	return true;
+}
+
+template bool launchPatMasksMarch<float>(const smm_hip_csr*, int, const float*, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
+template bool launchPatMasksMarch<double>(const smm_hip_csr*, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 
 template bool launchPatConstMarch<float>(const smm_hip_csr*, int, const float*, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
 template bool launchPatConstMarch<double>(const smm_hip_csr*, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);

@@ -1292,7 +1292,7 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	m->d_pat_masks = d_masks.detach();
 	m->pat_const = tryConst && flags[1] == 0;
 	if (m->pat_const) m->d_pat_cval = d_cval.detach();
-	planConstMarch(m);
+	planMarch(m);
 	SMM_TRY(marchBuildMasks32(m, s));
 	return SMM_HIP_OK;
 }
@@ -1565,6 +1565,8 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 			return env ? atoi(env) : -1;
 		}();
 		const int waveForm = waveEnv >= 0 ? waveEnv : (sizeof(T) == 8 ? 4 : 8);
+		// grid-shaped matrices of >= 2^21 rows: the march form (x through LDS windows and registers, smm_spmv_march.hip)
+		if (m->pat_encoding == 0 && launchPatMasksMarch<T>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)) return;
 		if (waveForm && m->pat_encoding == 0 && m->pat_k <= 16) {
 			const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 			const int nTiles = (m->rows + TPB - 1) / TPB;
@@ -1628,6 +1630,16 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 		return march ? "spmvPatternConstMarchKernel" : "spmvPatternConstKernel";
 	}
 	*bytes = nnz * s + rows * 8 + startBytes + vectors;
+	if (L == 1 && m->march_ok && m->d_pat_masks32 && m->pat_k <= 16) {
+		static const bool masksMarchOn = [] {
+			const char* env = getenv("SMM_HIP_MASKS_MARCH");
+			return env ? atoi(env) != 0 : true;
+		}();
+		if (masksMarchOn) {
+			*bytes = nnz * s + rows * 4 + (rows / 64 + 1) * 4 + vectors;  // values, 32-bit masks, one start[] per 64 rows, x, out
+			return "spmvPatternMasksMarchKernel";
+		}
+	}
 	if (L == 1) {
 		static const int waveEnv = [] {
 			const char* env = getenv("SMM_HIP_PATTERN_WAVE");

@@ -97,3 +97,15 @@ def test_config4_laplacian_512_cg(smm):
     x2 = x.clone()
     host.cg_dev(A, b, x2, x2, 20, 0.0, None, stream)
     assert err_energy(x2) < e100 < err_energy(torch.zeros_like(ones))
+    # what served those SpMVs: AUTO moved this 937 M-entry stencil to PATTERN / constant diagonals, i.e. the 2.5-D kernel (r04) -- and at
+    # FULL size it gives the bits of the CSR stream at one lane per row (which the small-size tests pin to the reference bit for bit)
+    assert A.get_kernel() == (3, 1) and A.pattern_info()[0] == 3 and A.kernel_desc()[0] == "spmvPatternConstMarchKernel"
+    v = torch.rand(n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) - 0.5
+    y_march = torch.empty_like(v)
+    A.spmv_dev(0, None, v, y_march, stream)
+    A.set_kernel(2, 1)
+    y_csr = torch.empty_like(v)
+    A.spmv_dev(0, None, v, y_csr, stream)
+    torch.cuda.synchronize()
+    assert A.kernel_desc()[0] in ("spmvStreamKernel", "spmvTileKernel")
+    assert torch.equal(y_march, y_csr)

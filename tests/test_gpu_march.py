@@ -74,9 +74,10 @@ def test_march_kernel_matches_oracle(smm, oracle, dtype, grid):
     tol = 1e-10 if dtype == np.float64 else 2e-5
     assert abs(totals[off] - float(r64 @ r64)) <= tol * float(r64 @ r64)
     assert abs(totals[off + 1] - float(r64 @ x64)) <= tol * float(np.abs(r64 * x64).sum())
-    # the gather kernel it replaces gives the same bits (the env switch is read once per process, so compare through the MASKS kernels,
-    # which read values[]: same products, same order)
+    # with the constant-diagonal encoding off the same matrix is served by the kernels that read values[] (r04: their march form): same
+    # products, same order, same bits
     A.pattern_allow_const(False)
+    assert A.kernel_desc()[0] == "spmvPatternMasksMarchKernel"
     A.spmv_dev(OP_ASSIGN, None, x, y, stream)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(y.cpu().numpy(), ref)
@@ -110,6 +111,57 @@ def test_march_kernel_on_a_slab_that_ends_inside_a_plane(smm, oracle, dtype):
     A.rMultSub(lhs, x, out)
     np.testing.assert_array_equal(out, oracle.spmv(csr, OP_SUB, lhs, x))
     A.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_masks_march_kernel_with_varying_coefficients(smm, oracle, dtype):
+    """spmvPatternMasksMarchKernel: the march for stencils whose diagonals VARY (values[] read through a wave-private LDS slice, x
+    through the plane's window and the lane's registers, row starts from one start[] per 64 rows + a prefix sum of the masks'
+    popcounts).  The 128^3 convection-diffusion operator with spatially varying coefficients (2.1 M rows, every diagonal varies) and a
+    2-D one-plane case, all three ops, in place, the fused dot products: bit for bit against the oracle (ref:1484-1499)."""
+    import torch
+
+    from sparse_matrix_math_amd import generators as gen
+
+    dev = torch.device("cuda:0")
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    stream = torch.cuda.current_stream().cuda_stream
+    cases = {"convdiff_varying_128": gen.convdiff3d_varying(128, 0.3, dtype=dtype)}
+    start, pos, val = gen.poisson2d(1000, 2200, dtype=dtype)  # one plane: every offset near; values perturbed so that no diagonal is constant
+    val = (val * (1 + 0.25 * np.sin(np.arange(len(val)) * 0.37))).astype(dtype)
+    cases["poisson2d_varying_1000x2200"] = (start, pos, val)
+    for name, csr in cases.items():
+        n = len(csr[0]) - 1
+        A = smm.CSRMatrix(n, n, *csr)
+        A.set_kernel(PATTERN, 1)
+        assert A.pattern_info()[0] == 1, name  # row masks + values[]
+        kernel, nbytes = A.kernel_desc()
+        assert kernel == "spmvPatternMasksMarchKernel", (name, kernel)
+        s = np.dtype(dtype).itemsize
+        assert nbytes == len(csr[1]) * s + n * 4 + (n // 64 + 1) * 4 + 2 * n * s
+        rng = np.random.default_rng(12)
+        x, lhs = rng.uniform(-0.5, 0.5, n).astype(dtype), rng.uniform(-0.5, 0.5, n).astype(dtype)
+        out = np.zeros(n, dtype=dtype)
+        for op, call in ((OP_ASSIGN, lambda: A.rMult(x, out)), (OP_ADD, lambda: A.rMultAdd(lhs, x, out)), (OP_SUB, lambda: A.rMultSub(lhs, x, out))):
+            out[:] = np.nan
+            call()
+            np.testing.assert_array_equal(out, oracle.spmv(csr, op, lhs, x), err_msg=f"{name} op {op}")
+        z = lhs.copy()
+        A.rMultSub(z, x, z)
+        np.testing.assert_array_equal(z, oracle.spmv(csr, OP_SUB, lhs, x))
+        dx, dy = torch.from_numpy(x).to(dev), torch.empty(n, dtype=td, device=dev)
+        fin = torch.zeros(smm.host.finish_len(), dtype=td, device=dev)
+        A.spmv_fused_dev(OP_ASSIGN, None, dx, dy, 2, dx, fin, stream, finish=True)
+        torch.cuda.synchronize()
+        ref = oracle.spmv(csr, OP_ASSIGN, None, x)
+        np.testing.assert_array_equal(dy.cpu().numpy(), ref)
+        off = smm.host.finish_totals_offset()
+        totals = fin.cpu().numpy().astype(np.float64)
+        r64, x64 = ref.astype(np.float64), x.astype(np.float64)
+        tol = 1e-10 if dtype == np.float64 else 2e-5
+        assert abs(totals[off] - float(r64 @ r64)) <= tol * float(r64 @ r64)
+        assert abs(totals[off + 1] - float(r64 @ x64)) <= tol * float(np.abs(r64 * x64).sum())
+        A.close()
 
 
 def test_march_in_cg_at_scale(smm, oracle):

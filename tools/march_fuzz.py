@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: the 2.5-D constant-diagonal kernel (spmvPatternConstMarchKernel) against the oracle, bit for bit, on random grid-shaped
+"""GPU box: the 2.5-D kernels (spmvPatternConstMarchKernel, spmvPatternMasksMarchKernel) against the oracle, bit for bit, on random grid-shaped
 matrices far below its production threshold (SMM_HIP_MARCH_MIN_ROWS=1 for this process): random plane sizes (tiles that are partial,
 one tile per plane, planes that are no multiple of anything but the pack), random plane counts with a partial last plane, random near
 offsets, one or both far offsets, random holes in every diagonal (the masks), empty rows, fp32 / fp64, all three ops, in place."""
@@ -49,6 +49,9 @@ for trial in range(trials):
     r, j, c = r[ok], j[ok], c[ok]
     dv = rng.uniform(-2, 2, len(offs)).astype(dtype)
     v = dv[j]
+    varying = (trial // 2) % 2 == 1  # every diagonal varies: MASKS (values[] read) -- spmvPatternMasksMarchKernel
+    if varying:
+        v = rng.uniform(-2, 2, len(j)).astype(dtype)
     start = np.zeros(rows + 1, dtype=np.int32)
     np.cumsum(np.bincount(r, minlength=rows), out=start[1:])
     csr = (start, c.astype(np.int32), v)
@@ -80,7 +83,7 @@ for trial in range(trials):
         okk = False
         print(f"trial {trial}: MISMATCH in place")
     bad += 0 if okk else 1
-    print(f"trial {trial:3d}: rows {rows:7d} P {P:6d} offsets {len(offs):2d} {'one plane' if one_plane else 'march    '} {np.dtype(dtype).name} encoding {enc} {kernel} {'ok' if okk else 'BAD'}", flush=True)
+    print(f"trial {trial:3d}: rows {rows:7d} P {P:6d} offsets {len(offs):2d} {'one plane' if one_plane else 'march    '} {np.dtype(dtype).name} {'varying ' if varying else 'constant'} encoding {enc} {kernel} {'ok' if okk else 'BAD'}", flush=True)
     A.close()
 print("march fuzz:", "ALL OK" if bad == 0 else f"{bad} BAD")
 sys.exit(1 if bad else 0)
