@@ -354,7 +354,8 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 // the wave-private mask kernel (spmvPatternWaveKernel, smm_spmv_pattern.hip) loses there is x: 13.9 GB across the fabric for the 11.3 GB
 // of the 512^3 fp64 stencil, x fetched 3.6 x.  Here x goes through the plane's LDS window and the lane's registers exactly as above;
 // values[] keeps the wave kernel's route: the 64 consecutive rows of a wavefront own ONE contiguous run of values[], fetched with
-// coalesced loads one sub-step ahead (two register sets alternate), passed through a wave-private LDS slice and read back by the row's
+// coalesced loads a whole plane ahead (one register set per sub-step, re-issued as soon as its values sit in LDS), passed through a
+// wave-private LDS slice and read back by the row's
 // lane.  A tile is 1024 rows = 4 sub-steps of 256 (one row per lane and sub-step: 8-byte LDS reads at lane stride -- conflict-free).
 // Row starts come from ONE start[] per 64 rows plus a prefix sum of the masks' popcounts across the wavefront: no start[] stream.
 // Bytes per fp64 row of the 7-point stencil: 56 (values) + 4 (mask) + 8 (x) + 8 (out) = 76 against 84 in the wave kernel (and the
@@ -379,7 +380,7 @@ struct MasksMarchVals {
 };
 
 template <typename T, int KMAX, bool NT, int HP>
-__global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 ? 3 : 2)) void spmvPatternMasksMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
+__global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 2)) void spmvPatternMasksMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
                                                                       int nOff, int hasLo, int hasHi, const int* __restrict__ offs, const int* __restrict__ start,
                                                                       const T* __restrict__ values, const unsigned* __restrict__ masks32, int opFlags,
                                                                       const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode,
@@ -486,17 +487,18 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 ? 3 : 2)) void sp
 		unsigned mk[MM_Q];
 		int s0c[MM_Q];
 		Set fa, fb;
-		Vals va, vb;
+		Vals vals[MM_Q];  // one request set per sub-step: re-issued for the NEXT plane as soon as its values sit in LDS (a whole plane ahead)
 
-		auto subStep = [&](int z, int q, const Vals& V, const Set& use, const T* win) {
+		auto subStep = [&](int z, int q, Vals& V, const Set& use, const T* win, bool more) {
 #pragma unroll
 			for (int k = 0; k < KMAX; ++k) sVal[wv][k * WAVE + lane] = V.v[k];
+			const int at = V.at;
+			if (more) fetchVals(V, use.m[q], use.s0[q]);
 			const long long base = static_cast<long long>(z) * P + r0;
 			const int l = q * TPB + t;
 			const bool live = l < bAct && base + l < rows;
 			const unsigned m = mk[q];
 			const bool masked = !__all(m == fullMask || !live);
-			const int at = V.at;
 			T dot = T(0);
 			auto fold = [&](int j, T xv) {
 				const int idx = masked ? at + __popc(m & ((1u << j) - 1u)) : at + j;
@@ -515,20 +517,14 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 ? 3 : 2)) void sp
 				if (dotMode) acc1 += o * w1[row];
 			}
 		};
-		// one plane: `use` holds plane z + 1, `re` is re-issued for plane z + 2; the values of sub-step q + 1 are requested before q is summed
+		// one plane: `use` holds plane z + 1, `re` is re-issued for plane z + 2; every sub-step's values were requested a whole plane earlier
 		auto step = [&](int z, Set& use, Set& re) {
 			T* win = ((z - z0) & 1) ? sWin1 : sWin0;
 			T* winNext = ((z - z0) & 1) ? sWin0 : sWin1;
 			const bool more = z + 1 < z1;
 			if (more) issue(re, z + 2, z + 2 < z1 || hasHi, z + 2 < z1);
-			fetchVals(vb, mk[1], s0c[1]);
-			subStep(z, 0, va, use, win);
-			fetchVals(va, mk[2], s0c[2]);
-			subStep(z, 1, vb, use, win);
-			fetchVals(vb, mk[3], s0c[3]);
-			subStep(z, 2, va, use, win);
-			if (more) fetchVals(va, use.m[0], use.s0[0]);  // the next plane's first sub-step
-			subStep(z, 3, vb, use, win);
+#pragma unroll
+			for (int q = 0; q < MM_Q; ++q) subStep(z, q, vals[q], use, win, more);
 			if (more) {
 #pragma unroll
 				for (int q = 0; q < MM_Q; ++q) xp[q] = win[H + q * TPB + t];
@@ -555,7 +551,8 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 ? 3 : 2)) void sp
 			s0c[q] = fa.s0[q];
 		}
 		__syncthreads();
-		fetchVals(va, mk[0], s0c[0]);
+#pragma unroll
+		for (int q = 0; q < MM_Q; ++q) fetchVals(vals[q], mk[q], s0c[q]);
 		for (int z = z0; z < z1; z += 2) {
 			step(z, fb, fa);
 			if (z + 1 < z1) step(z + 1, fa, fb);
@@ -758,7 +755,7 @@ bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 		const char* env = getenv("SMM_HIP_MASKS_MARCH");
 		return env ? atoi(env) != 0 : true;
 	}();
-	if (!enabled || !m->march_ok || !m->d_pat_masks32 || m->pat_k > 16) return false;
+	if (!enabled || !m->march_ok || !m->d_pat_masks32 || m->pat_k > 8) return false;  // (rows of 9 .. 16 entries keep the wave kernel: four value sets of 16 would not fit the registers)
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
 #define SMM_MM_GO(KV)                                                                                                \
@@ -768,8 +765,7 @@ bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 		else if (hp2) launchMasksMarchK<T, KV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);   \
 		else launchMasksMarchK<T, KV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);            \
 	} while (0)
-	if (m->pat_k <= 8) SMM_MM_GO(8);
-	else SMM_MM_GO(16);
+	SMM_MM_GO(8);
 #undef SMM_MM_GO
 	return true;
 }

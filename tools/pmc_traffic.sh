@@ -3,7 +3,7 @@
 # (--kernel-trace + --pmc only), on the GPU box.   tools/pmc_traffic.sh <tag>
 #   spmv_*  the benchmark matrix, STREAM family forced (spmvTileKernel<float, 2, 13>: the roofline's kernel) and the PATTERN family AUTO picks
 #   lap_*   the 512^3 fp64 Laplacian (config 4's matrix), STREAM (spmvStreamKernel<double, 1>) and PATTERN with values[] read (SMM_HIP_PATTERN_CONST=0:
-#           spmvPatternWaveKernel<double, 8>, what a stencil with varying coefficients gets); the constant-diagonal kernel: tools/pmc_march.sh
+#           spmvPatternMasksMarchKernel<double, 8, ..>, what a big stencil with varying coefficients gets); the constant-diagonal kernel: tools/pmc_march.sh
 #   dot_*   4.000 GB read by the dot kernel: calibrates the FETCH_SIZE correction
 set -u
 TAG=${1:-r04}
@@ -28,6 +28,6 @@ done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT "spmvTileKernel<float" > $OUT/summary_spmv.txt
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT "spmvPatternTileKernel<float" > $OUT/summary_pattern.txt
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT "spmvStreamKernel<double" > $OUT/summary_lap_stream.txt
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT "spmvPatternWaveKernel<double" > $OUT/summary_lap_pattern.txt
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT "spmvPatternMasksMarchKernel<double" > $OUT/summary_lap_pattern.txt
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT dotPartials > $OUT/summary_dot.txt
 cat $OUT/summary_spmv.txt $OUT/summary_pattern.txt $OUT/summary_lap_stream.txt $OUT/summary_lap_pattern.txt $OUT/summary_dot.txt
