@@ -720,7 +720,7 @@ static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 	const int nT = (P + MM_B - 1) / MM_B;
 	const size_t lds = 2 * static_cast<size_t>(MM_B + 2 * H) * sizeof(T);
 	static bool raised = false;
-	if (lds > 48 * 1024 && !raised) {  // (the kernel holds 8-17 KB of static LDS beside the windows)
+	if (lds > 40 * 1024 && !raised) {  // (the kernel holds 8-17 KB of static LDS beside the windows: together they may pass the 64 KB default)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvPatternMasksMarchKernel<T, KMAX, NT, HP>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                          static_cast<int>(lds));
 		raised = true;
@@ -747,6 +747,10 @@ static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 	                                                                  out, dotMode, w1, partials, doneFlag);
 }
 
+bool masksMarchApplies(const smm_hip_csr* m) {
+	return m->march_ok && m->d_pat_masks32 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8;
+}
+
 // true: the launch went to the march form of the masks kernels (values[] read).  SMM_HIP_MASKS_MARCH=0 keeps the wave kernel.
 template <typename T>
 bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
@@ -755,7 +759,10 @@ bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 		const char* env = getenv("SMM_HIP_MASKS_MARCH");
 		return env ? atoi(env) != 0 : true;
 	}();
-	if (!enabled || !m->march_ok || !m->d_pat_masks32 || m->pat_k > 8) return false;  // (rows of 9 .. 16 entries keep the wave kernel: four value sets of 16 would not fit the registers)
+	// rows of 9 .. 16 entries keep the wave kernel (four value sets of 16 would not fit the registers), and so do matrices of fewer than 8
+	// planes -- in ONE-plane mode (every offset near) a unit is a single step with nothing requested ahead, and the wave kernel wins:
+	// 7 random diagonals within +-1000, 8 M rows, fp64: 0.123 ms against 0.153 (profiles/r04/one_plane_mode.txt)
+	if (!enabled || !masksMarchApplies(m)) return false;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
 #define SMM_MM_GO(KV)                                                                                                \

@@ -1630,7 +1630,7 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 		return march ? "spmvPatternConstMarchKernel" : "spmvPatternConstKernel";
 	}
 	*bytes = nnz * s + rows * 8 + startBytes + vectors;
-	if (L == 1 && m->march_ok && m->d_pat_masks32 && m->pat_k <= 8) {
+	if (L == 1 && masksMarchApplies(m)) {
 		static const bool masksMarchOn = [] {
 			const char* env = getenv("SMM_HIP_MASKS_MARCH");
 			return env ? atoi(env) != 0 : true;

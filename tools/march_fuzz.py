@@ -31,7 +31,7 @@ for trial in range(trials):
         P = rows
     else:
         P = int(rng.integers(8192, 20000)) // vec * vec
-        planes = int(rng.integers(2, 9))
+        planes = int(rng.integers(2, 14))  # (the masks kernels march from 8 planes up; below that the wave kernel is checked instead)
         rows = (P * planes - int(rng.integers(0, P // 2)) * (trial % 3 == 0)) // vec * vec  # every third trial: a partial last plane
         nnear = int(rng.integers(1, 7))
         hmax = int(rng.integers(2, 600))

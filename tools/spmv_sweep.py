@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--k", type=int, default=25)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--max-offset", type=int, default=1 << 20, help="banded: the offsets are drawn from [1, max-offset)")
+    ap.add_argument("--ny", type=int, default=0, help="poisson2d: rows of the grid (default: n)")
     ap.add_argument("--configs", default="2:1,2:2,2:4,2:8,2:16,1:4,1:8,1:16,1:32,1:64")
     ap.add_argument("--pos-mode", default="orig", choices=["orig", "row", "near", "random"],
                     help="ablation: overwrite positions[] so every gather hits x[row] (row) or x[row + j - len/2] (near)")
@@ -32,10 +34,11 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     if args.matrix == "banded":
         n = args.rows
-        nnz = host.gen_banded_nnz(n, args.k, 0x5EED, 1 << 20)
+        nnz = host.gen_banded_nnz(n, args.k, 0x5EED, args.max_offset)
     elif args.matrix == "poisson2d":
-        n = args.n * args.n
-        nnz = host.gen_poisson2d_nnz(args.n, args.n)
+        ny = args.ny or args.n
+        n = args.n * ny
+        nnz = host.gen_poisson2d_nnz(args.n, ny)
     else:
         n = args.n ** 3
         nnz = host.gen_stencil3d_nnz(args.n, args.n, args.n)
@@ -43,9 +46,9 @@ def main():
     d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
     d_val = torch.empty(nnz, dtype=td, device=dev)
     if args.matrix == "banded":
-        host.gen_banded_dev(n, args.k, 0x5EED, 1 << 20, d_start, d_pos, d_val, npd, stream)
+        host.gen_banded_dev(n, args.k, 0x5EED, args.max_offset, d_start, d_pos, d_val, npd, stream)
     elif args.matrix == "poisson2d":
-        host.gen_poisson2d_dev(args.n, args.n, d_start, d_pos, d_val, npd, stream)
+        host.gen_poisson2d_dev(args.n, args.ny or args.n, d_start, d_pos, d_val, npd, stream)
     else:
         host.gen_stencil3d_dev(args.n, args.n, args.n, 6.0, -1.0, -1.0, d_start, d_pos, d_val, npd, stream)
     if args.pos_mode != "orig":
