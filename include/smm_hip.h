@@ -120,6 +120,10 @@ int smm_hip_device_info(char* name, size_t name_cap, int* cus, size_t* hbm_bytes
 /* Blocks until everything enqueued on `stream` has finished. */
 int smm_hip_stream_synchronize(smm_hip_stream stream);
 
+/* TEST HOOK: the next device allocation of the library of at least min_bytes bytes fails ONCE with SMM_HIP_ERR_NOMEM, as if the device
+ * were full (0 disarms it).  What the tests use to check that an optional step which cannot get its memory -- the automatic PATTERN
+ * analysis -- leaves the caller's SpMV / solve untouched. */
+int smm_hip_debug_fail_next_alloc(size_t min_bytes);
 /* ---- live kernel timing (bench.py roofline) ------------------------------------------------------------------
  * When enabled every SpMV launch -- standalone or inside a solver loop -- is bracketed by a pair of HIP events on the
  * stream it is launched on.  smm_hip_profile_read waits for the recorded events, returns the summed SpMV kernel time

@@ -81,6 +81,7 @@ _PLAIN = {
     "smm_hip_uses_std_fma": (c_int, []),
     "smm_hip_device_info": (c_int, [c_char_p, c_size_t, POINTER(c_int), POINTER(c_size_t)]),
     "smm_hip_stream_synchronize": (c_int, [_P]),
+    "smm_hip_debug_fail_next_alloc": (c_int, [c_size_t]),
     "smm_hip_profile_enable": (c_int, [c_int]),
     "smm_hip_profile_read": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),
     "smm_hip_profile_read_waits": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),

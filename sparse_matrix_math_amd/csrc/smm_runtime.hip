@@ -1,4 +1,5 @@
 // smm_runtime.hip -- device selection, error text, library stream, caching allocator, CSR handles.
+#include <atomic>
 #include <cstdarg>
 #include <chrono>
 #include <map>
@@ -250,8 +251,18 @@ static bool quarantineHoldsLocked(size_t bytes) {
 	return false;
 }
 
+// test hook (smm_hip_debug_fail_next_alloc): the next device allocation of at least this many bytes fails once, as if the device were full
+static std::atomic<size_t> g_failNextAllocAtLeast{0};
+
 int devAlloc(void** p, size_t bytes) {
 	bytes = (bytes + 255) & ~static_cast<size_t>(255);
+	if (size_t want = g_failNextAllocAtLeast.load(std::memory_order_relaxed); want != 0 && bytes >= want) {
+		if (g_failNextAllocAtLeast.compare_exchange_strong(want, 0)) {
+			*p = nullptr;
+			setError("device allocation of %zu bytes refused (injected by smm_hip_debug_fail_next_alloc)", bytes);
+			return SMM_HIP_ERR_NOMEM;
+		}
+	}
 	{
 		std::unique_lock<std::mutex> lock(g_allocMutex);
 		auto it = g_free.find(bytes);
@@ -520,6 +531,11 @@ int smm_hip_device_info(char* name, size_t name_cap, int* cus, size_t* hbm_bytes
 int smm_hip_stream_synchronize(smm_hip_stream stream) {
 	SMM_TRY(ensureInit());
 	SMM_HIP_TRY(hipStreamSynchronize(pickStream(stream)));
+	return SMM_HIP_OK;
+}
+
+int smm_hip_debug_fail_next_alloc(size_t min_bytes) {
+	g_failNextAllocAtLeast.store(min_bytes, std::memory_order_relaxed);
 	return SMM_HIP_OK;
 }
 

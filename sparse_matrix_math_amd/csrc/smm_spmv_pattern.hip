@@ -11,11 +11,14 @@
 // pattern) or by AUTO: the first SpMV of a LARGE matrix (>= 2^25 stored entries, rows of <= 64 entries; launchSpmv) runs the analysis
 // below on the caller's stream -- offsets discovered from a sample of rows on the device, then EVERY entry verified -- and switches the
 // matrix to this family when it passes; a matrix that does not fit (i.i.d. columns ...) stays with STREAM.  SMM_HIP_AUTO_PATTERN=0
-// turns the automatic choice off.  bench.py's roofline stays defined on the reference's layout (values + positions + start,
-// SURVEY.md section 8d) and on the STREAM kernel; what this family moves is reported beside it with its true byte count.
+// turns the automatic choice off.  bench.py prices every kernel with the bytes ITS layout moves (smm_hip_csr_kernel_desc): `roofline` is
+// the timed region's kernel -- this family's for the benchmark matrix --, `roofline_csr` the reference's layout (values + positions +
+// start) on the STREAM kernel, measured in a leg of its own.
 //
 // When every diagonal of such a matrix holds ONE value (constant-coefficient stencils: the Laplacians) values[] is redundant too: the
-// CONST encoding further down reads the row's mask, x and <= 32 numbers.
+// CONST encoding further down reads the row's mask, x and <= 32 numbers.  Grid-shaped matrices of >= 2^21 rows -- offsets = a few near
+// ones plus the pair -P / +P -- run the 2.5-D kernels of smm_spmv_march.hip instead of the gather kernels of this file: x through a
+// plane's LDS window and the lane's registers (r04).
 // Matrices the masks cannot describe (more than 64 offsets, rows of more than 64 entries) but whose entries use <= 65 536 distinct
 // offsets get the CODES encoding instead: a 16-bit dictionary index per entry (further down: "DICTIONARY encoding").
 //

@@ -105,6 +105,62 @@ def test_auto_analysis_is_ordered_behind_the_callers_stream(smm):
         del big
 
 
+def test_automatic_pattern_attempt_never_fails_the_callers_work(smm, oracle):
+    """the switch to the PATTERN family is an optional optimisation -- when its analysis cannot get its memory (8 bytes
+    per row of masks, scratch of the sort ...) the caller's SpMV / solve must run on STREAM as if nothing had been tried, automatic
+    attempts must not try again, and an explicit request later must (and succeed).  The allocation failure is injected
+    (smm_hip_debug_fail_next_alloc)."""
+    import torch
+
+    from sparse_matrix_math_amd import _lib, host
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    # (a) the first SpMV of a matrix of >= 2^25 entries
+    n, k, seed, max_off = 700_000, 25, 0x5EED, 1 << 16
+    nnz = host.gen_banded_nnz(n, k, seed, max_off)
+    ds = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    dp = torch.empty(nnz, dtype=torch.int32, device=dev)
+    dv = torch.empty(nnz, dtype=torch.float32, device=dev)
+    host.gen_banded_dev(n, k, seed, max_off, ds, dp, dv, np.float32, stream)
+    A = smm.CSRMatrix.from_device(n, n, ds, dp, dv, np.float32)
+    x = torch.rand(n, dtype=torch.float32, device=dev) - 0.5
+    y = torch.empty_like(x)
+    _lib.check(lib.smm_hip_debug_fail_next_alloc(n * 8))  # the masks: 8 bytes per row
+    A.spmv_dev(0, None, x, y, stream)  # must not raise
+    torch.cuda.synchronize()
+    assert A.get_kernel()[0] == 2 and A.pattern_info()[0] == 0  # stayed on STREAM
+    y2 = torch.empty_like(x)
+    A.spmv_dev(0, None, x, y2, stream)  # no second automatic attempt
+    torch.cuda.synchronize()
+    assert A.get_kernel()[0] == 2 and torch.equal(y, y2)
+    A.set_kernel(3, 0)  # an explicit request tries again -- and the memory is there now
+    assert A.get_kernel() == (3, 2) and A.pattern_info()[0] == 1
+    A.spmv_dev(0, None, x, y2, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y2.cpu().numpy(), y.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    A.close()
+    _lib.check(lib.smm_hip_debug_fail_next_alloc(0))
+    # (b) a solver's own attempt (>= 2^20 entries): the solve runs on STREAM and gives the oracle's x
+    csr = gen.convdiff3d(64, 0.3, dtype=np.float64)
+    m = len(csr[0]) - 1
+    b = gen.row_sums(csr[0], csr[2])
+    B = smm.CSRMatrix(m, m, *csr)
+    db = torch.from_numpy(b).to(dev)
+    dx = torch.zeros(m, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    # (the device entry point: the analysis is the solve's FIRST allocation of that size -- the masks; its own vectors come after)
+    _lib.check(lib.smm_hip_debug_fail_next_alloc(m * 8))
+    status, iters, _res = host.bicgstab_dev(B, db, dx, 20, 0.0, None, stream)  # must not raise
+    torch.cuda.synchronize()
+    assert B.get_kernel()[0] == 2 and iters == 20
+    x_ref = oracle.bicgstab(csr, b, np.zeros(m), 20, 0.0)[1]
+    np.testing.assert_allclose(dx.cpu().numpy(), x_ref, rtol=0, atol=1e-7 * float(np.abs(x_ref).max()))
+    B.close()
+    _lib.check(lib.smm_hip_debug_fail_next_alloc(0))
+
+
 def test_fused_dot_entry_point(smm, oracle):
     import torch
 
