@@ -112,7 +112,7 @@ def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", preco
             res = A.bicgstab(b, x, max_it, eps)
         torch.cuda.synchronize()
         if families is not None:  # (kernel family, lanes, PATTERN encoding) of this rank's A_loc and A_rem after the solve
-            families[rank] = tuple(blk.get_kernel() + blk.pattern_info()[:1] for blk in A.local_blocks())
+            families[rank] = tuple(blk.get_kernel() + blk.pattern_info()[:1] for blk in A.local_blocks()) + (A.local_blocks()[0].kernel_desc()[0],)
         if chunks_seen is not None:
             chunks_seen[rank] = A.halo_chunks
         r = (res, lo, hi, x.cpu().numpy(), y.cpu().numpy(), A.halo_elements)
@@ -217,7 +217,7 @@ def test_native_loops_adopt_the_pattern_family(smm, oracle, world):
     assert status == 0 and res <= 1e-9
     np.testing.assert_allclose(x, x_true, rtol=1e-8)
     for rank in range(world):
-        loc, rem = fam[rank]
+        loc, rem = fam[rank][:2]
         assert loc[0] == 3 and loc[2] == 1, fam  # PATTERN, row masks
         assert world == 1 or rem[0] in (1, 2, 3)  # (A_rem is small: VECTOR / STREAM unless it reaches 2^20 entries)
     csr = gen.stencil3d(72, 72, 72, dtype=dtype)  # 2.6 M entries
@@ -230,6 +230,26 @@ def test_native_loops_adopt_the_pattern_family(smm, oracle, world):
     np.testing.assert_allclose(x, np.ones(n), rtol=1e-6)
     for rank in range(world):
         assert fam[rank][0] == (3, 1, 3), fam  # PATTERN, one lane per row, constant diagonals
+
+
+def test_native_cg_on_slabs_of_a_big_grid_uses_the_march_kernel(smm, oracle):
+    """BASELINE config 4 in small: CG on a 3-D Laplacian split into two slabs of > 2^21 rows each.  The partition balances stored entries,
+    so a slab starts and ends INSIDE a grid plane; its local block is still grid-shaped (offsets +-1, +-nx, +-nx ny) and must be served
+    by the 2.5-D constant-diagonal kernel (partial first / last planes, the fused dot products finished in the launch), the few remote
+    entries by the remote block.  x after 12 iterations against the single-process oracle."""
+    dtype = np.float64
+    csr = gen.stencil3d(160, 160, 172, dtype=dtype)  # 4.4 M rows
+    n = len(csr[0]) - 1
+    b = gen.row_sums(csr[0], csr[2]).astype(dtype)
+    fam = {}
+    (status, iters, res), x, y, halo = _solve(smm, csr, b, 2, dtype, 20, 0.0, solver="cg", families=fam)
+    st_ref, x_ref, it_ref, res_ref = oracle.cg(csr, b, np.zeros(n), 20, 0.0)
+    assert (status, iters) == (st_ref, it_ref) == (2, 20) and halo == 2 * 160 * 160
+    np.testing.assert_allclose(x, x_ref, rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(y, oracle.spmv(csr, 0, None, b))  # one lane per row everywhere: the reference's bits
+    for rank in range(2):
+        assert fam[rank][0] == (3, 1, 3), fam  # A_loc: PATTERN, one lane per row, constant diagonals
+        assert fam[rank][2] == "spmvPatternConstMarchKernel", fam
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
