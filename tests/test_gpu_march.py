@@ -186,3 +186,18 @@ def test_march_in_cg_at_scale(smm, oracle):
     assert int(st) == st_ref and it == it_ref == 25
     np.testing.assert_allclose(x.cpu().numpy(), x_ref, rtol=0, atol=1e-10 * float(np.abs(x_ref).max()))
     A.close()
+
+
+def test_march_kernels_fuzz_below_the_production_threshold():
+    """tools/march_fuzz.py in a process of its own (SMM_HIP_MARCH_MIN_ROWS=1 must be in the environment before the library reads it): 40
+    random grid-shaped matrices of 20 K - 300 K rows -- partial tiles, partial last planes, one or both far offsets, one-plane bands, random
+    holes in every diagonal, constant and varying values, fp32 / fp64 -- every SpMV (three ops, in place) bit-identical to the oracle"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "march_fuzz.py"), "40"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "march fuzz: ALL OK" in r.stdout
+    assert r.stdout.count("spmvPatternConstMarchKernel ok") >= 10 and r.stdout.count("spmvPatternMasksMarchKernel ok") >= 3, r.stdout[-3000:]
