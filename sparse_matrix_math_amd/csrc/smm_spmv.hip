@@ -788,7 +788,8 @@ int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(tiles), (static_cast<size_t>(n) + 1) * sizeof(int2)));
 	tileCutKernel<<<grid, 64, 0, s>>>(rows, d_start, capNnz, maxRows, chunkNnz, nChunks, nullptr, counts, *tiles);
 	SMM_HIP_TRY(hipGetLastError());
-	SMM_HIP_TRY(hipStreamSynchronize(s));  // the scratch buffers above go back to the allocator when this scope ends
+	// (no second wait, r04: the scratch buffers go back to the allocator's QUARANTINE when this scope ends and are handed out again only
+	// behind an event recorded on this stream -- smm_runtime.hip)
 	*nTiles = n;
 	return SMM_HIP_OK;
 }

@@ -92,10 +92,15 @@ __device__ __forceinline__ int selectBit(unsigned long long m, int k) {
 // row (ref:1247-1249: the kernels pair the n-th value of a row with the n-th set bit); no two entries of a row share a bit.
 // Constant diagonals (values != nullptr and the sample has not already said no -- flags[1]): every entry's value is compared, bit for
 // bit, with the one value its offset was given (cvalBits, from the sampled rows); any difference raises flags[1].
-__global__ __launch_bounds__(TPB) void patBuildMasks(int rows, int k, const int* __restrict__ offs, const int* __restrict__ start,
+// `meta` = {number of offsets, refusal code} as patSortOffsets left them on the device: the whole analysis is ONE enqueue (r04) and the
+// host learns k with the same read-back as the verdicts; a refused matrix (meta[1] != 0) costs these kernels one load.
+__global__ __launch_bounds__(TPB) void patBuildMasks(int rows, const int* __restrict__ meta, const int* __restrict__ offs, const int* __restrict__ start,
                                                      const int* __restrict__ positions, unsigned long long* __restrict__ masks,
                                                      int* __restrict__ flags, const void* __restrict__ values, int elemBytes,
                                                      const unsigned long long* __restrict__ cvalBits) {
+	if (meta[1] != 0) return;
+	const int k = meta[0];
+	if (values != nullptr && k > 32) values = nullptr;  // constant diagonals are looked for in matrices of stencil shape only (<= 32 offsets)
 	int* mismatch = flags;
 	__shared__ int sOff[MAXOFF];
 	__shared__ unsigned long long sCval[MAXOFF];
@@ -172,9 +177,11 @@ __global__ __launch_bounds__(TPB) void patBuildMasks(int rows, int k, const int*
 
 // One value per offset from the sampled rows (mode 0: plain stores -- any of them will do, the full check follows), then (mode 1) the same
 // rows compared with it: a matrix whose diagonals vary inside the sample is told apart here, and patBuildMasks never reads values[].
-__global__ __launch_bounds__(TPB) void patConstSample(int rows, int samples, int k, const int* __restrict__ offs, const int* __restrict__ start,
-                                                      const int* __restrict__ positions, const void* __restrict__ values, int elemBytes,
-                                                      unsigned long long* cvalBits, int* flags, int mode) {
+__global__ __launch_bounds__(TPB) void patConstSample(int rows, int samples, const int* __restrict__ meta, const int* __restrict__ offs,
+                                                      const int* __restrict__ start, const int* __restrict__ positions, const void* __restrict__ values,
+                                                      int elemBytes, unsigned long long* cvalBits, int* flags, int mode) {
+	if (meta[1] != 0 || meta[0] > 32) return;
+	const int k = meta[0];
 	__shared__ int sOff[MAXOFF];
 	if (threadIdx.x < k) sOff[threadIdx.x] = offs[threadIdx.x];
 	__syncthreads();
@@ -616,9 +623,10 @@ __global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap
 // ---- analysis ON THE DEVICE ---------------------------------------------------------------------------------------------------
 // (1) the offset set from a sample of rows: every workgroup collects the distinct (column - row) of its rows in an LDS table (a value is
 // looked up with plain LDS reads first; only a new one is inserted, with an LDS compare-and-swap) and then merges its table into the
-// global one the same way.  More than MAXOFF distinct offsets: `state[1]` is raised.  (2) the host sorts the <= 64 offsets (256 bytes
-// come back), (3) patBuildMasks forms the row masks and VERIFIES every entry of positions[] against the set: a matrix whose unsampled
-// rows use other offsets is refused there.  Nothing of the matrix travels to the host (r02 copied start[] and 512 rows).
+// global one the same way.  More than MAXOFF distinct offsets: `state[1]` is raised.  (2) patSortOffsets sorts the <= 64 offsets on the
+// device (r04; r03 sorted them on the host between two stream waits), (3) patBuildMasks forms the row masks and VERIFIES every entry of
+// positions[] against the set: a matrix whose unsampled rows use other offsets is refused there.  One enqueue, one wait: k, the sorted
+// offsets and the verdicts come back together.  Nothing of the matrix travels to the host (r02 copied start[] and 512 rows).
 constexpr int PAT_EMPTY = static_cast<int>(0x80000000u);
 
 __device__ __forceinline__ bool patInsert(int* table, int rel) {  // table[MAXOFF], PAT_EMPTY = free; false: the table is full
@@ -656,6 +664,33 @@ __global__ __launch_bounds__(TPB) void patSampleOffsets(int rows, int samples, c
 	}
 	__syncthreads();
 	if (threadIdx.x == 0 && sOver) atomicOr(state + MAXOFF, 1);
+}
+
+// (1b) the sampled offsets sorted ON THE DEVICE (r04: the host sorted them between two stream waits): one wavefront, a bitonic sort of
+// the 64 table slots (free slots sort last), the sorted list padded with 0 to offs[MAXOFF], meta = {k, refusal}: 1 a sampled row holds more
+// than 64 entries, 2 the sampled rows use more than 64 offsets, 3 no entries at all.
+__global__ __launch_bounds__(WAVE) void patSortOffsets(const int* __restrict__ state, int* __restrict__ offs, int* __restrict__ meta) {
+	const int lane = threadIdx.x;
+	const int raw = state[lane];
+	long long key = raw == PAT_EMPTY ? (1LL << 40) : static_cast<long long>(raw);
+#pragma unroll
+	for (int size = 2; size <= WAVE; size <<= 1) {
+#pragma unroll
+		for (int stride = size >> 1; stride > 0; stride >>= 1) {
+			const long long other = __shfl_xor(key, stride, WAVE);
+			const bool up = (lane & size) == 0;        // ascending block
+			const bool lower = (lane & stride) == 0;   // this lane keeps the smaller of the pair in an ascending block
+			const bool takeMin = up == lower;
+			key = takeMin ? (other < key ? other : key) : (other > key ? other : key);
+		}
+	}
+	const bool valid = key < (1LL << 40);
+	const int k = __popcll(__ballot(valid));
+	offs[lane] = valid ? static_cast<int>(key) : 0;
+	if (lane == 0) {
+		meta[0] = k;
+		meta[1] = state[MAXOFF + 1] > MAXOFF ? 1 : state[MAXOFF] ? 2 : k == 0 ? 3 : 0;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1224,76 +1259,70 @@ static bool autoDictAllowed() {
 
 // the mask encoding: SMM_HIP_OK, SMM_HIP_ERR_INVALID (no such pattern: *why says which test failed) or a HIP failure
 static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
-	SetupTrace traceAll("pattern: masks (sample + build + verify)");
-	DevBuf<int> d_state, d_off, d_flag;  // released on every early return
-	DevBuf<unsigned long long> d_masks;
+	SetupTrace traceAll("pattern: masks (sample + sort + build + verify)");
+	// ONE enqueue, ONE wait (r04; r03: sample -> wait -> host sort -> build -> wait): the offsets of the sampled rows are sorted on the
+	// device, the kernels behind read k from device memory and return at once for a refused matrix, and everything the host has to
+	// know -- the refusal, k, the sorted offsets, the two verdicts -- comes back in one copy.
+	DevBuf<int> d_state, d_off, d_flag, d_meta;  // released on every early return
+	DevBuf<unsigned long long> d_masks, d_cval;
 	SMM_TRY(d_state.alloc(MAXOFF + 2));
+	SMM_TRY(d_off.alloc(MAXOFF));
+	SMM_TRY(d_flag.alloc(2));  // [0] an entry off the offset set / out of order, [1] some diagonal holds more than one value
+	SMM_TRY(d_meta.alloc(2));
+	SMM_TRY(d_cval.alloc(MAXOFF));
+	{
+		SetupTrace trace("pattern:   allocate the masks");
+		SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
+	}
 	std::vector<int> init(MAXOFF + 2, PAT_EMPTY);
 	init[MAXOFF] = 0;
 	init[MAXOFF + 1] = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(d_state, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));
+	SMM_HIP_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), s));
+	SMM_HIP_TRY(hipMemsetAsync(d_cval, 0, MAXOFF * sizeof(unsigned long long), s));
 	const int samples = std::min(m->rows, 16384);
 	patSampleOffsets<<<(samples + TPB - 1) / TPB, TPB, 0, s>>>(m->rows, samples, m->d_start, m->d_positions, d_state);
-	std::vector<int> got(MAXOFF + 2, 0);
-	SMM_HIP_TRY(hipMemcpyAsync(got.data(), d_state, got.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+	patSortOffsets<<<1, WAVE, 0, s>>>(d_state, d_off, d_meta);
+	const int elemBytes = m->dtype == SMM_DTYPE_F32 ? 4 : 8;
+	// constant diagonals are looked for in matrices of stencil shape only (<= 32 offsets: the kernels check); SMM_HIP_PATTERN_CONST=0 turns the encoding off
+	static const bool constAllowed = [] {
+		const char* env = getenv("SMM_HIP_PATTERN_CONST");
+		return env ? atoi(env) != 0 : true;
+	}();
+	if (constAllowed) {
+		const int sgrid = (samples + TPB - 1) / TPB;
+		patConstSample<<<sgrid, TPB, 0, s>>>(m->rows, samples, d_meta, d_off, m->d_start, m->d_positions, m->d_values, elemBytes, d_cval, d_flag, 0);
+		patConstSample<<<sgrid, TPB, 0, s>>>(m->rows, samples, d_meta, d_off, m->d_start, m->d_positions, m->d_values, elemBytes, d_cval, d_flag, 1);
+	}
+	const int grid = static_cast<int>(std::min<long long>((m->rows + TPB - 1LL) / TPB, numCUs() * 8LL));
+	patBuildMasks<<<grid, TPB, 0, s>>>(m->rows, d_meta, d_off, m->d_start, m->d_positions, d_masks, d_flag, constAllowed ? m->d_values : nullptr, elemBytes, d_cval);
+	struct Back {
+		int meta[2], flags[2], offs[MAXOFF];
+	} back{};
+	SMM_HIP_TRY(hipMemcpyAsync(back.meta, d_meta, sizeof(back.meta), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipMemcpyAsync(back.flags, d_flag, sizeof(back.flags), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipMemcpyAsync(back.offs, d_off, sizeof(back.offs), hipMemcpyDeviceToHost, s));
 	{
-		SetupTrace trace("pattern:   wait for the sampled offsets");
+		SetupTrace trace("pattern:   wait for the whole analysis");
 		SMM_HIP_TRY(hipStreamSynchronize(s));
 	}
 	auto no = [why](const char* text) {
 		*why = text;
 		return static_cast<int>(SMM_HIP_ERR_INVALID);
 	};
-	if (got[MAXOFF + 1] > MAXOFF) return no("a row holds more than 64 entries");
-	if (got[MAXOFF]) return no("the rows do not share a set of <= 64 column offsets");
-	std::vector<int> offs;
-	for (int i = 0; i < MAXOFF; ++i) {
-		if (got[i] != PAT_EMPTY) offs.push_back(got[i]);
-	}
-	if (offs.empty()) return no("no entries in the sampled rows");
-	std::sort(offs.begin(), offs.end());
-	SMM_TRY(d_off.alloc(MAXOFF));
-	{
-		SetupTrace trace("pattern:   allocate the masks");
-		SMM_TRY(d_masks.alloc(static_cast<size_t>(m->rows)));
-	}
-	SMM_TRY(d_flag.alloc(2));  // [0] an entry off the offset set / out of order, [1] some diagonal holds more than one value
-	DevBuf<unsigned long long> d_cval;
-	SMM_TRY(d_cval.alloc(MAXOFF));
-	std::vector<int> padded(MAXOFF, 0);
-	std::copy(offs.begin(), offs.end(), padded.begin());
-	SMM_HIP_TRY(hipMemcpyAsync(d_off, padded.data(), MAXOFF * sizeof(int), hipMemcpyHostToDevice, s));
-	SMM_HIP_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), s));
-	SMM_HIP_TRY(hipMemsetAsync(d_cval, 0, MAXOFF * sizeof(unsigned long long), s));
-	const int k = static_cast<int>(offs.size());
-	const int elemBytes = m->dtype == SMM_DTYPE_F32 ? 4 : 8;
-	// constant diagonals are looked for in matrices of stencil shape only (<= 32 offsets); SMM_HIP_PATTERN_CONST=0 turns the encoding off
-	static const bool constAllowed = [] {
-		const char* env = getenv("SMM_HIP_PATTERN_CONST");
-		return env ? atoi(env) != 0 : true;
-	}();
-	const bool tryConst = constAllowed && k <= 32;
-	if (tryConst) {
-		const int sgrid = (samples + TPB - 1) / TPB;
-		patConstSample<<<sgrid, TPB, 0, s>>>(m->rows, samples, k, d_off, m->d_start, m->d_positions, m->d_values, elemBytes, d_cval, d_flag, 0);
-		patConstSample<<<sgrid, TPB, 0, s>>>(m->rows, samples, k, d_off, m->d_start, m->d_positions, m->d_values, elemBytes, d_cval, d_flag, 1);
-	}
-	const int grid = static_cast<int>(std::min<long long>((m->rows + TPB - 1LL) / TPB, numCUs() * 8LL));
-	patBuildMasks<<<grid, TPB, 0, s>>>(m->rows, k, d_off, m->d_start, m->d_positions, d_masks, d_flag, tryConst ? m->d_values : nullptr, elemBytes, d_cval);
-	int flags[2] = {0, 0};
-	SMM_HIP_TRY(hipMemcpyAsync(flags, d_flag, sizeof(flags), hipMemcpyDeviceToHost, s));
-	{
-		SetupTrace trace("pattern:   wait for build + verify");
-		SMM_HIP_TRY(hipStreamSynchronize(s));
-	}
-	if (flags[0]) return no("some entry's column offset is outside the offset set of the sampled rows");
+	if (back.meta[1] == 1) return no("a row holds more than 64 entries");
+	if (back.meta[1] == 2) return no("the rows do not share a set of <= 64 column offsets");
+	if (back.meta[1] == 3) return no("no entries in the sampled rows");
+	if (back.flags[0]) return no("some entry's column offset is outside the offset set of the sampled rows");
+	const int k = back.meta[0];
+	std::vector<int> offs(back.offs, back.offs + k);
 	m->pat_k = k;
 	m->pat_offs_host = offs;
 	m->pat_encoding = 0;
 	m->pat_max_off = std::max(std::abs(offs.front()), std::abs(offs.back()));
 	m->d_pat_off = d_off.detach();
 	m->d_pat_masks = d_masks.detach();
-	m->pat_const = tryConst && flags[1] == 0;
+	m->pat_const = constAllowed && k <= 32 && back.flags[1] == 0;
 	if (m->pat_const) m->d_pat_cval = d_cval.detach();
 	planMarch(m);
 	SMM_TRY(marchBuildMasks32(m, s));
@@ -1654,6 +1683,17 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 	return "spmvPatternKernel";
 }
 
+// mirrors launchPat: which launches read the tile table at all
+static bool patNeedsTiles(const smm_hip_csr* m, int L) {
+	if (L != 1 || m->pat_encoding != 0) return true;
+	if (m->pat_const && !m->pat_const_off) return false;  // the constant-diagonal kernels
+	static const int waveEnv = [] {
+		const char* env = getenv("SMM_HIP_PATTERN_WAVE");
+		return env ? atoi(env) : -1;
+	}();
+	return !(waveEnv != 0 && m->pat_k <= 16);  // the wave kernel and the masks march walk rows
+}
+
 // tiles for this family are cut for its own LDS capacity (values only): kept beside the STREAM family's table
 static int buildPatternTiles(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s) {
 	int* blocks = nullptr;
@@ -1676,7 +1716,7 @@ int launchSpmvPattern(const smm_hip_csr* m, int lanes, int op, const T* lhs, con
 	const int L = std::min(lanes, WAVE);
 	const int capNnz = patCap<T>(m, L) - 3;
 	const int maxRows = TPB / L;
-	{
+	if (patNeedsTiles(m, L)) {  // (the one-lane kernels of stencil shape -- gather, wave, march -- walk rows, not tiles)
 		std::lock_guard<std::mutex> lock(mm->tileMutex);
 		if (!m->d_pat_rowblocks || m->pat_nnz_cap != capNnz || m->pat_max_rows != maxRows) {
 			SetupTrace trace("pattern: tile table");
