@@ -689,7 +689,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "configs[2]: banded-random symmetric diagonally dominant CSR, 10M rows ~49 nnz/row, BiCGStab, b = A*x_true, x0 = 0, eps = 0 (fixed iterations)",
+                "workload": f"configs[2]: banded-random symmetric diagonally dominant CSR, {n / 1e6:g}M rows ~49 nnz/row, BiCGStab, b = A*x_true, x0 = 0, eps = 0 (fixed iterations)",
                 "rows": n,
                 "nnz": result.pop("nnz"),
                 "band_offsets_per_side": args.band_k,
