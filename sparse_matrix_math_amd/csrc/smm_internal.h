@@ -268,6 +268,7 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 void planMarch(smm_hip_csr* m);
 int marchBuildMasks32(smm_hip_csr* m, hipStream_t s);
 bool masksMarchApplies(const smm_hip_csr* m);  // the masks kernels' march form serves this (analysed) matrix
+bool constMarchApplies(const smm_hip_csr* m);  // ... the constant-diagonal march
 template <typename T>
 bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s);

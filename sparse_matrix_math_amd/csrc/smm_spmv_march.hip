@@ -21,6 +21,7 @@
 // column order (-P, the near offsets ascending, +P -- the bit order of the row's mask), each product is c_j * x[col] with c_j the bit
 // pattern verified against every values[k] of that diagonal, folded left to right with smmFma: the reference's bits (ref:1484-1489).
 #include <algorithm>
+#include <atomic>
 
 #include "smm_device.h"
 #include "smm_internal.h"
@@ -587,12 +588,27 @@ void preloadMarchUnit() {
 // offsets is near (|off| <= the halo a lane can hold), planes are at least four tiles large and the rows are a whole number of planes
 // (grids in natural order: P = nx ny); otherwise, when EVERY offset is near (2-D grids, narrow bands), the matrix is one plane.  A matrix
 // that is neither keeps the gather kernel (spmvPatternConstKernel).
+// From how many rows the march kernels serve a matrix (profiles/r04/march_threshold.txt, cubic grids, fp64, one box): constant diagonals
+// -- 128^3 (2.1 M rows) gather 16.7 us / march 19.4; 144^3 22.1 / 22.5; 160^3 (4.1 M) 29.8 / 24.0; 200^3 55.7 / 34.6 -> from 3 x 2^20 rows;
+// values read -- 128^3 wave 35.3 / march 51.9; 160^3 66.3 / 65.6; 200^3 (8 M) 129.8 / 122.7; 256^3 302 / 249 -> from 6 x 2^20 rows (below, a
+// unit's few planes do not fill the chip's workgroup slots).  SMM_HIP_MARCH_MIN_ROWS (environment, both) and smm_hip_set_march_min_rows
+// (tests run the kernels on smaller grids) override them.
+static std::atomic<long long> g_marchMinRowsConst{-1}, g_marchMinRowsMasks{-1};
+
+static long long marchMinRows(bool masksKernel) {
+	const long long forced = (masksKernel ? g_marchMinRowsMasks : g_marchMinRowsConst).load(std::memory_order_relaxed);
+	if (forced >= 0) return forced;
+	static const long long env = [] {
+		const char* e = getenv("SMM_HIP_MARCH_MIN_ROWS");
+		return e ? atoll(e) : -1LL;
+	}();
+	if (env >= 0) return env;
+	return masksKernel ? 6LL << 20 : 3LL << 20;
+}
+
 void planMarch(smm_hip_csr* m) {
 	m->march_ok = false;
-	static const long long minRows = [] {
-		const char* env = getenv("SMM_HIP_MARCH_MIN_ROWS");
-		return env ? atoll(env) : (1LL << 21);  // below that an SpMV of this encoding is a handful of microseconds: launch-bound either way
-	}();
+	const long long minRows = std::min(marchMinRows(false), marchMinRows(true));
 	const std::vector<int>& offs = m->pat_offs_host;
 	const int k = static_cast<int>(offs.size());
 	if (k < 1 || k > 32 || m->rows != m->cols || m->rows < minRows) return;  // (constant diagonals or not: the masks kernels march as well)
@@ -680,7 +696,7 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 		const char* env = getenv("SMM_HIP_CONST_MARCH");
 		return env ? atoi(env) != 0 : true;
 	}();
-	if (!enabled || !m->march_ok || !m->d_pat_masks32) return false;
+	if (!enabled || !constMarchApplies(m)) return false;
 	const int nNear = m->pat_k - m->march_lo - m->march_hi;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;  // outputs too large to still be cached when the next kernel reads them
 	// rows per lane (profiles/r04/march_rows_per_lane.txt, 512^3): fp64 4 -- tiles of 1024 rows, 120 VGPRs, four workgroups per CU: 0.565 ms
@@ -748,8 +764,10 @@ static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 }
 
 bool masksMarchApplies(const smm_hip_csr* m) {
-	return m->march_ok && m->d_pat_masks32 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8;
+	return m->march_ok && m->d_pat_masks32 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8 &&
+	       m->rows >= marchMinRows(true);
 }
+bool constMarchApplies(const smm_hip_csr* m) { return m->march_ok && m->d_pat_masks32 && m->rows >= marchMinRows(false); }
 
 // true: the launch went to the march form of the masks kernels (values[] read).  SMM_HIP_MASKS_MARCH=0 keeps the wave kernel.
 template <typename T>
@@ -784,3 +802,9 @@ template bool launchPatConstMarch<float>(const smm_hip_csr*, int, const float*, 
 template bool launchPatConstMarch<double>(const smm_hip_csr*, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 
 }  // namespace smm
+
+extern "C" int smm_hip_set_march_min_rows(long long const_diagonals_rows, long long values_read_rows) {
+	smm::g_marchMinRowsConst.store(const_diagonals_rows, std::memory_order_relaxed);
+	smm::g_marchMinRowsMasks.store(values_read_rows, std::memory_order_relaxed);
+	return SMM_HIP_OK;
+}

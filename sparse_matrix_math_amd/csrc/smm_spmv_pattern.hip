@@ -16,7 +16,7 @@
 // start) on the STREAM kernel, measured in a leg of its own.
 //
 // When every diagonal of such a matrix holds ONE value (constant-coefficient stencils: the Laplacians) values[] is redundant too: the
-// CONST encoding further down reads the row's mask, x and <= 32 numbers.  Grid-shaped matrices of >= 2^21 rows -- offsets = a few near
+// CONST encoding further down reads the row's mask, x and <= 32 numbers.  Grid-shaped matrices of some millions of rows -- offsets = a few near
 // ones plus the pair -P / +P -- run the 2.5-D kernels of smm_spmv_march.hip instead of the gather kernels of this file: x through a
 // plane's LDS window and the lane's registers (r04).
 // Matrices the masks cannot describe (more than 64 offsets, rows of more than 64 entries) but whose entries use <= 65 536 distinct
@@ -1597,7 +1597,7 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 			return env ? atoi(env) : -1;
 		}();
 		const int waveForm = waveEnv >= 0 ? waveEnv : (sizeof(T) == 8 ? 4 : 8);
-		// grid-shaped matrices of >= 2^21 rows: the march form (x through LDS windows and registers, smm_spmv_march.hip)
+		// big grid-shaped matrices (masksMarchApplies): the march form (x through LDS windows and registers, smm_spmv_march.hip)
 		if (m->pat_encoding == 0 && launchPatMasksMarch<T>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)) return;
 		if (waveForm && m->pat_encoding == 0 && m->pat_k <= 16) {
 			const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
@@ -1657,7 +1657,7 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 			const char* env = getenv("SMM_HIP_CONST_MARCH");
 			return env ? atoi(env) != 0 : true;
 		}();
-		const bool march = m->march_ok && marchOn && m->d_pat_masks32;
+		const bool march = marchOn && constMarchApplies(m);
 		*bytes = rows * (march ? 4 : 8) + vectors;  // the row's mask (32 bits in the 2.5-D form), x, out: neither values[] nor start[]
 		return march ? "spmvPatternConstMarchKernel" : "spmvPatternConstKernel";
 	}

@@ -117,6 +117,11 @@ def profile_read(reset=True):
     return ms.value, n.value
 
 
+def set_march_min_rows(const_diagonals_rows=-1, values_read_rows=-1):
+    """from how many rows grid-shaped matrices run the 2.5-D kernels (-1: the default); applies to matrices analysed afterwards"""
+    check(_lib.load().smm_hip_set_march_min_rows(int(const_diagonals_rows), int(values_read_rows)))
+
+
 def profile_read_waits(reset=True):
     """(exposed ms, exchanges): what the halo exchanges of the row-partitioned SpMVs cost BEYOND the local block that ran beside them"""
     ms, n = ctypes.c_double(), ctypes.c_longlong()
