@@ -87,7 +87,7 @@ extern "C" {
  *   MASKS  <= 64 distinct offsets and rows of <= 64 entries: one 64-bit mask per ROW, verified against EVERY entry on the device before
  *          the family is used; an SpMV streams only values[] (half the bytes for fp32);
  *          When in addition every entry of a diagonal holds the same value (constant-coefficient stencils: the Laplacians) -- CONST --
- *          values[] is not read either: 24 bytes per fp64 row instead of 104 -- 20 for grid-shaped matrices of >= 3 x 2^20 rows, which run the
+ *          values[] is not read either: 24 bytes per fp64 row instead of 104 -- 20 for grid-shaped matrices of >= 2^21 rows, which run the
  *          2.5-D kernel (csrc/smm_spmv_march.hip: a plane's window of x in LDS, the planes above and below in registers, 32-bit masks);
  *   CODES  <= 65536 distinct offsets: one 16-bit index into the matrix's sorted offset dictionary per ENTRY (6 instead of 8 bytes per
  *          fp32 entry), built on the device from all entries.
@@ -164,7 +164,8 @@ int smm_hip_csr_pattern_info(const smm_hip_csr* m, int* encoding, int* offsets);
  * out.  Benchmarks price a kernel's launch time with THIS number, never with another layout's.  Diagnostics, like tile_info. */
 int smm_hip_csr_kernel_desc(const smm_hip_csr* m, char* name, int name_cap, long long* bytes_per_launch);
 /* From how many rows grid-shaped matrices are served by the 2.5-D kernels (csrc/smm_spmv_march.hip): constant diagonals (default
- * 3 x 2^20) and values read (default 6 x 2^20) -- below, the gather / wave kernels are as fast or faster (profiles/r04/march_threshold.txt).
+ * 2^21) and values read (default 12 x 2^20 fp64 / 2^26 fp32) -- below, the gather / wave kernels are as fast or faster
+ * (profiles/r04/march_threshold.txt).
  * -1 restores a default.  Applies to matrices analysed afterwards.  Tuning knob; the tests use it to run the kernels on small grids. */
 int smm_hip_set_march_min_rows(long long const_diagonals_rows, long long values_read_rows);
 /* allow = 0: a matrix with constant diagonals keeps reading values[] (the MASKS kernels); 1 (default): CONST where it applies.  For

@@ -588,14 +588,18 @@ void preloadMarchUnit() {
 // offsets is near (|off| <= the halo a lane can hold), planes are at least four tiles large and the rows are a whole number of planes
 // (grids in natural order: P = nx ny); otherwise, when EVERY offset is near (2-D grids, narrow bands), the matrix is one plane.  A matrix
 // that is neither keeps the gather kernel (spmvPatternConstKernel).
-// From how many rows the march kernels serve a matrix (profiles/r04/march_threshold.txt, cubic grids, fp64, one box): constant diagonals
-// -- 128^3 (2.1 M rows) gather 16.7 us / march 19.4; 144^3 22.1 / 22.5; 160^3 (4.1 M) 29.8 / 24.0; 200^3 55.7 / 34.6 -> from 3 x 2^20 rows;
-// values read -- 128^3 wave 35.3 / march 51.9; 160^3 66.3 / 65.6; 200^3 (8 M) 129.8 / 122.7; 256^3 302 / 249 -> from 6 x 2^20 rows (below, a
-// unit's few planes do not fill the chip's workgroup slots).  SMM_HIP_MARCH_MIN_ROWS (environment, both) and smm_hip_set_march_min_rows
-// (tests run the kernels on smaller grids) override them.
+// From how many rows the march kernels serve a matrix (profiles/r04/march_threshold.txt: cubic grids, march forced on / off, one box;
+// gather / march for constant diagonals, wave / march for values read, microseconds):
+//   fp64 constant: 96^3 8.0 / 8.0, 108^3 10.4 / 9.5, 128^3 16.2 / 12.4, 160^3 28.9 / 24.4, 256^3 143 / 70      -> from 2^21 rows (at 108^3 the
+//                  9 % of the bare SpMV do not survive inside BiCGStab: 24.4 against 23.4 ms for config 5's stand-in, Jacobi fold 26.2 / 24.1)
+//   fp32 constant: 108^3 8.5 / 9.0, 128^3 13.0 / 9.5, 144^3 17.1 / 17.6, 160^3 22.0 / 20.4, 256^3 86 / 55      -> from 2^21 rows
+//   fp64 values:   160^3 63.5 / 65.2, 200^3 122 / 124, 256^3 299 / 234, 512^3 2470 / 1840                       -> from 12 x 2^20 rows
+//   fp32 values:   200^3 72 / 109, 256^3 156 / 171, 512^3 1417 / 1261                                          -> from 2^26 rows
+// (below, a unit's few planes do not fill the chip's workgroup slots, and the masks march holds four value sets per lane).
+// SMM_HIP_MARCH_MIN_ROWS (environment, all four) and smm_hip_set_march_min_rows (tests run the kernels on smaller grids) override them.
 static std::atomic<long long> g_marchMinRowsConst{-1}, g_marchMinRowsMasks{-1};
 
-static long long marchMinRows(bool masksKernel) {
+static long long marchMinRows(bool masksKernel, int dtype) {
 	const long long forced = (masksKernel ? g_marchMinRowsMasks : g_marchMinRowsConst).load(std::memory_order_relaxed);
 	if (forced >= 0) return forced;
 	static const long long env = [] {
@@ -603,12 +607,14 @@ static long long marchMinRows(bool masksKernel) {
 		return e ? atoll(e) : -1LL;
 	}();
 	if (env >= 0) return env;
-	return masksKernel ? 6LL << 20 : 3LL << 20;
+	const bool f32 = dtype == SMM_DTYPE_F32;
+	if (masksKernel) return f32 ? 1LL << 26 : 12LL << 20;
+	return 1LL << 21;
 }
 
 void planMarch(smm_hip_csr* m) {
 	m->march_ok = false;
-	const long long minRows = std::min(marchMinRows(false), marchMinRows(true));
+	const long long minRows = std::min(marchMinRows(false, m->dtype), marchMinRows(true, m->dtype));
 	const std::vector<int>& offs = m->pat_offs_host;
 	const int k = static_cast<int>(offs.size());
 	if (k < 1 || k > 32 || m->rows != m->cols || m->rows < minRows) return;  // (constant diagonals or not: the masks kernels march as well)
@@ -670,12 +676,14 @@ static int launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();  // room for the RCCL kernel beside A_loc (smm_dist.hip)
 	op &= ~SPMV_LEAVE_ROOM;
 	const int resident = cus * perCU;
-	// planes per unit: ~4 units per resident workgroup (the tail of the launch stays short), at least 8 planes (the two extra planes a
-	// unit loads for its first and last plane's far entries then cost <= 25 %)
+	// planes per unit: enough units for ~1.5 x the chip's workgroup slots -- on mid-size grids THAT is what matters, not the two extra
+	// planes a unit loads for its first and last plane's far entries (they are L2 hits): 128^3 with 8 / 4 / 2 planes per unit 19.6 / 13.9 /
+	// 12.2 us (the gather kernel: 16.6), 160^3 24.2 / 21.6 / 24.0 (29.7), 512^3 flat from 16 to 128 (profiles/r04/march_threshold.txt); at
+	// least 2 planes, so that something is requested ahead
 	int zc = nPlanes;
 	if (nPlanes > 1) {
-		const int wantChunks = std::max(1, std::min(nPlanes, (4 * resident + nT - 1) / nT));
-		zc = std::max(std::min(8, nPlanes), (nPlanes + wantChunks - 1) / wantChunks);
+		const int wantChunks = std::max(1, std::min(nPlanes, (3 * resident / 2 + nT - 1) / nT));
+		zc = std::max(std::min(2, nPlanes), (nPlanes + wantChunks - 1) / wantChunks);
 		if (const char* env = getenv("SMM_HIP_MARCH_ZC")) zc = std::max(1, std::min(nPlanes, atoi(env)));
 	}
 	const int nChunks = (nPlanes + zc - 1) / zc;
@@ -765,9 +773,9 @@ static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 
 bool masksMarchApplies(const smm_hip_csr* m) {
 	return m->march_ok && m->d_pat_masks32 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8 &&
-	       m->rows >= marchMinRows(true);
+	       m->rows >= marchMinRows(true, m->dtype);
 }
-bool constMarchApplies(const smm_hip_csr* m) { return m->march_ok && m->d_pat_masks32 && m->rows >= marchMinRows(false); }
+bool constMarchApplies(const smm_hip_csr* m) { return m->march_ok && m->d_pat_masks32 && m->rows >= marchMinRows(false, m->dtype); }
 
 // true: the launch went to the march form of the masks kernels (values[] read).  SMM_HIP_MASKS_MARCH=0 keeps the wave kernel.
 template <typename T>

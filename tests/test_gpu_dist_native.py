@@ -238,7 +238,6 @@ def test_native_cg_on_slabs_of_a_big_grid_uses_the_march_kernel(smm, oracle):
     by the 2.5-D constant-diagonal kernel (partial first / last planes, the fused dot products finished in the launch), the few remote
     entries by the remote block.  x after 12 iterations against the single-process oracle."""
     dtype = np.float64
-    smm.host.set_march_min_rows(1 << 21, 1 << 21)  # (production: from 3 x 2^20 rows; a slab here has 2.2 M)
     csr = gen.stencil3d(160, 160, 172, dtype=dtype)  # 4.4 M rows
     n = len(csr[0]) - 1
     b = gen.row_sums(csr[0], csr[2]).astype(dtype)
@@ -251,7 +250,6 @@ def test_native_cg_on_slabs_of_a_big_grid_uses_the_march_kernel(smm, oracle):
     for rank in range(2):
         assert fam[rank][0] == (3, 1, 3), fam  # A_loc: PATTERN, one lane per row, constant diagonals
         assert fam[rank][2] == "spmvPatternConstMarchKernel", fam
-    smm.host.set_march_min_rows(-1, -1)
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
