@@ -109,3 +109,13 @@ def test_config4_laplacian_512_cg(smm):
     torch.cuda.synchronize()
     assert A.kernel_desc()[0] in ("spmvStreamKernel", "spmvTileKernel")
     assert torch.equal(y_march, y_csr)
+    # ... and so does the march of the kernels that READ values[] (what a stencil with varying coefficients of this size runs), under the
+    # production thresholds
+    A.set_kernel(3, 1)
+    A.pattern_allow_const(False)
+    assert A.kernel_desc()[0] == "spmvPatternMasksMarchKernel"
+    y_masks = torch.empty_like(v)
+    A.spmv_dev(0, None, v, y_masks, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(y_masks, y_csr)
+    A.pattern_allow_const(True)
