@@ -229,6 +229,15 @@ int smm_hip_cg_dev_f64(const smm_hip_csr* a, const double* d_b, const double* d_
 #define SMM_CG_RESIDENT_REQUIRE 2
 int smm_hip_cg_resident(int mode);
 
+/* Single-launch BiCGStab (csrc/smm_resident_bicg.hip).  A BiCGStab without a preconditioner, or with the library's Jacobi, whose matrix is in
+ * the PATTERN family's row-mask encoding (banded / stencil matrices: what the solvers adopt from 2^20 stored entries) with at most 16
+ * column offsets and whose vectors fit the register file (rows <= 512 * CUs * 12 in fp64, * 24 in fp32: BASELINE config 5 does) runs as
+ * ONE launch: r, p, s, A p, A s in registers, x and r0 in LDS, five grid-wide barriers per iteration instead of seven dependent launches.
+ * Same per-row arithmetic and update expressions as the loop; the global sums add the rows in another (fixed) partition, so alpha / omega /
+ * beta differ from the loop's in the last bits.  mode as for smm_hip_cg_resident (OFF / AUTO / REQUIRE; any other value only queries);
+ * returns the previous mode.  Initial value from the environment variable SMM_HIP_BICGSTAB_RESIDENT (0 / 1 / 2). */
+int smm_hip_bicgstab_resident(int mode);
+
 int smm_hip_bicgstab_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps,
                          const smm_hip_precond* M, int* solver_status, int* iterations, float* resnorm);
 int smm_hip_bicgstab_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps,

@@ -116,6 +116,7 @@ _PLAIN = {
     "smm_hip_finish_len": (c_int, []),
     "smm_hip_finish_totals_offset": (c_int, []),
     "smm_hip_cg_resident": (c_int, [c_int]),
+    "smm_hip_bicgstab_resident": (c_int, [c_int]),
     "smm_hip_bicgstab_ws_destroy": (c_int, [_P]),
     "smm_hip_cg_ws_status": (c_int, [_P, _P, POINTER(c_int)]),
     "smm_hip_bicgstab_ws_bind": (c_int, [_P, _P, _P, _P]),

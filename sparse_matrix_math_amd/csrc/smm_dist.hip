@@ -491,6 +491,7 @@ struct smm_hip_dist_csr {
 	int chunks = 1;
 	std::vector<std::vector<smm::Seg>> sendsK, recvsK;
 	std::vector<smm_hip_csr*> aRemK;
+	std::vector<long long> nnzRemK;  // entries of each piece (a piece without entries is not launched unless it carries the epilogue)
 	std::vector<void*> chunkArrays;  // start / positions / values of the pieces (owned)
 	// workspace of the solvers, kept across solves
 	void *r = nullptr, *r0 = nullptr, *ap = nullptr, *as = nullptr, *scratch = nullptr;
@@ -709,6 +710,7 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 		}
 		SMM_HIP_TRY(hipStreamSynchronize(s));
 		D->aRemK.assign(static_cast<size_t>(K), nullptr);
+		D->nnzRemK.assign(totalsK.begin(), totalsK.end());
 		for (int k = 0; k < K; ++k) {
 			int* st = starts + static_cast<size_t>(k) * (nLocal + 1);
 			if (dtypeOf<T>() == SMM_DTYPE_F32) {
@@ -741,7 +743,11 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 		if (jacobiDiag) return launchSpmv<T>(D->aLoc, op, jacobiDiag, own, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_DIV_LHS);
 		return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
 	}
-	if (D->chunks > 1 && exchange && !D->remEmpty) {
+	if (D->chunks > 1 && exchange) {
+		// (`chunks` is agreed by all ranks at create time and decides ALONE which form of the exchange runs: a rank whose own A_rem is empty --
+		// one-sided / upwind stencils, any structurally non-symmetric matrix: it sends but receives nothing -- must still post the K piece-sized
+		// sends its peers' K receives are waiting for; r04 tested `!remEmpty` here as well and such a rank fell through to ONE full-count
+		// exchange: mismatched RCCL call sequences, a hang or a corrupt halo.  ADVICE r04.)
 		// The halo in pieces: every piece is an exchange of its own on the communicator's stream (all of them enqueued at once, so the
 		// links never idle between them), A_loc runs beside them, and the part of A_rem that reads only piece k starts as soon as THAT
 		// piece has landed: out = ((A_loc x + A_rem,0 x) + A_rem,1 x) + ... -- each part a row sum of its own, added in piece order
@@ -770,6 +776,7 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 			}
 			const bool last = k == K - 1;
 			if (!last) {
+				if (D->nnzRemK[static_cast<size_t>(k)] == 0) continue;  // nothing of A_rem reads this piece (the last part always runs: it carries the epilogue)
 				SMM_TRY(launchSpmv<T>(D->aRemK[static_cast<size_t>(k)], remOp, out, ext, out, 0, nullptr, nullptr, doneFlag, s, 0));
 			} else if (jacobiDiag) {
 				return launchSpmv<T>(D->aRemK[static_cast<size_t>(k)], SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_ADD_DIV, jacobiDiag);

@@ -162,6 +162,8 @@ struct smm_hip_csr {
 	unsigned short* d_pat_codes = nullptr;
 	bool pat_const = false;  // masks + every diagonal holds one value (d_pat_cval[j], raw bits): the CONST kernel needs no values[]
 	unsigned long long* d_pat_cval = nullptr;
+	std::vector<unsigned long long> pat_cval_host;  // the same raw bits on the host (the single-launch BiCGStab passes them as kernel arguments)
+	void* d_res_ell = nullptr;  // MASKS with varying diagonals: values by offset slot, [pat_k][rows], built on first use by smm_resident_bicg.hip (under tileMutex)
 	bool pat_const_off = false;  // smm_hip_csr_pattern_allow_const(m, 0): keep reading values[] (A/B measurements)
 	int pat_max_off = 0;  // largest |column - row| of the offset list
 	// CONST on grid-shaped matrices: the plan of the 2.5-D kernel (smm_spmv_march.hip), made once at the end of the CONST analysis
@@ -366,6 +368,11 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
                 int* status, int* iterations, T* resnorm);
 template <typename T>
 int bicgsymmetricDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, hipStream_t s, int* status, int* iterations);
+
+// single-launch BiCGStab (smm_resident_bicg.hip): *handled = false when the matrix does not qualify or a barrier timed out (x untouched)
+template <typename T>
+int bicgstabResidentTry(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps, const T* jacobiDiag, hipStream_t s, int* status,
+                        int* iterations, T* resnorm, bool* handled);
 
 // preconditioner apply (smm_precond.hip); doneFlag may be null
 template <typename T>

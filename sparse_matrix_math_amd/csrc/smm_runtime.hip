@@ -174,6 +174,14 @@ static void closeEpochLocked() {
 		hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
 		if (hipStreamIsCapturing(k, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) continue;
 		(void)hipGetLastError();
+		// A stream with nothing pending needs no event: whatever was queued on it before the frees is done.  This is the steady state of
+		// solve after solve (a solve ends with a synchronise of its stream), and it is not only cheaper: r05 found 18-22 ms in the SECOND
+		// host-pointer solve of a process ("none.solve_ms 53 ms against Jacobi's 33") in exactly this wait -- an event recorded
+		// on the idle stream right after the process's first large copy to pageable host memory was reported complete by hipEventQuery only
+		// ~20 ms later (the runtime's completion-callback thread was busy; under rocprofv3's API trace the delay disappears), while
+		// hipStreamQuery answers from the state hipStreamSynchronize itself left behind (profiles/r05/second_solve_trace.txt).
+		if (hipStreamQuery(k) == hipSuccess) continue;
+		(void)hipGetLastError();
 		hipEvent_t ev = nullptr;
 		if (!g_eventPool.empty()) {
 			ev = g_eventPool.back();
@@ -267,6 +275,7 @@ int devAlloc(void** p, size_t bytes) {
 		std::unique_lock<std::mutex> lock(g_allocMutex);
 		auto it = g_free.find(bytes);
 		if (it == g_free.end() && quarantineHoldsLocked(bytes)) {
+			SetupTrace trace("allocator: close the epoch + wait for a quarantined block");
 			closeEpochLocked();
 			reapEpochsLocked(lock, bytes);
 			it = g_free.find(bytes);
@@ -278,6 +287,7 @@ int devAlloc(void** p, size_t bytes) {
 			return SMM_HIP_OK;
 		}
 	}
+	SetupTrace traceMalloc("allocator: hipMalloc");
 	hipError_t e = hipMalloc(p, bytes);
 	if (e == hipErrorOutOfMemory) {
 		devTrim();
@@ -607,6 +617,7 @@ int smm_hip_csr_destroy(smm_hip_csr* m) {
 	devFree(m->d_pat_masks);
 	devFree(m->d_pat_codes);
 	devFree(m->d_pat_cval);
+	devFree(m->d_res_ell);
 	devFree(m->d_pat_masks32);
 	devFree(m->d_pat_rowblocks);
 	delete m;

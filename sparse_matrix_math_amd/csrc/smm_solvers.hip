@@ -567,16 +567,20 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 	if (maxIterations == -1) maxIterations = n;  // ref:2201-2203
 	DevBuf<T> r, r0, p, ap, sv, as, scratch, parts, parts2;
 	DevBuf<Scal<T>> sc;
-	SMM_TRY(r.alloc(n));
-	SMM_TRY(r0.alloc(n));
-	SMM_TRY(p.alloc(n));
-	SMM_TRY(ap.alloc(n));
-	SMM_TRY(sv.alloc(n));
-	SMM_TRY(as.alloc(n));
-	if (precondition) SMM_TRY(scratch.alloc(n));
-	SMM_TRY(parts.alloc(2 * NPART));   // [ap.r0] then [as.as | as.s]
-	SMM_TRY(parts2.alloc(2 * NPART));  // [r.r | r.r0]
-	SMM_TRY(sc.alloc(1));
+	{
+		SetupTrace trace("bicgstab loop:   allocate the temporaries");
+		SMM_TRY(r.alloc(n));
+		SMM_TRY(r0.alloc(n));
+		SMM_TRY(p.alloc(n));
+		SMM_TRY(ap.alloc(n));
+		SMM_TRY(sv.alloc(n));
+		SMM_TRY(as.alloc(n));
+		if (precondition) SMM_TRY(scratch.alloc(n));
+		SMM_TRY(parts.alloc(2 * NPART));   // [ap.r0] then [as.as | as.s]
+		SMM_TRY(parts2.alloc(2 * NPART));  // [r.r | r.r0]
+		SMM_TRY(sc.alloc(1));
+	}
+	SetupTrace traceLoop("bicgstab loop:   enqueue + run + read back");
 	const int g = NPART;  // update kernels that write partials use the full partial grid
 
 	if (precondition) {
@@ -678,6 +682,12 @@ int bicgstabDev(const smm_hip_csr* a, const T* b, T* x, int maxIterations, T eps
 	SMM_TRY(adoptPatternForSolver(a, maxIterations, s));
 	const T* jacobiDiag = precondition && M->kind == SMM_PRECOND_JACOBI ? static_cast<const T*>(M->d_values) : nullptr;
 	const smm_hip_precond* blockM = precondition && isBlockKind(M->kind) ? M : nullptr;
+	if (!precondition || jacobiDiag) {
+		// a matrix in the row-mask encoding whose vectors fit the register file is solved in ONE launch (smm_resident_bicg.hip)
+		bool handled = false;
+		SMM_TRY(bicgstabResidentTry<T>(a, b, x, maxIterations, eps, jacobiDiag, s, status, iterations, resnorm, &handled));
+		if (handled) return SMM_HIP_OK;
+	}
 	SMM_TRY((bicgstabLoop<T, DevApplier<T>>(a, b, x, maxIterations, eps, precondition, apply, s, status, iterations, resnorm, jacobiDiag, blockM)));
 	return precondition ? precondTakeError(M, s) : SMM_HIP_OK;
 }
@@ -823,15 +833,25 @@ static int bicgstabHost(const smm_hip_csr* a, T* b, T* x, int maxIterations, T e
 		return SMM_HIP_ERR_INVALID;
 	}
 	hipStream_t s = libStream();
+	SetupTrace traceAll("bicgstab (host pointers): whole call");
 	DevBuf<T> db, dx;
-	SMM_TRY(db.alloc(n));
-	SMM_TRY(dx.alloc(n));
+	{
+		SetupTrace trace("bicgstab (host pointers):   allocate b, x");
+		SMM_TRY(db.alloc(n));
+		SMM_TRY(dx.alloc(n));
+	}
 	if (n) {
+		SetupTrace trace("bicgstab (host pointers):   copy b, x in");
 		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
 		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		if (SetupTrace::on()) SMM_HIP_TRY(hipStreamSynchronize(s));
 	}
-	SMM_TRY(bicgstabDev<T>(a, db, dx, maxIterations, eps, M, s, status, iterations, resnorm));
+	{
+		SetupTrace trace("bicgstab (host pointers):   device loop");
+		SMM_TRY(bicgstabDev<T>(a, db, dx, maxIterations, eps, M, s, status, iterations, resnorm));
+	}
 	if (n) {
+		SetupTrace trace("bicgstab (host pointers):   copy x out");
 		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
 		SMM_HIP_TRY(hipStreamSynchronize(s));
 	}

@@ -788,8 +788,10 @@ int cutRows(const int* d_start, int rows, long long nnz, int capNnz, int maxRows
 	SMM_TRY(devAlloc(reinterpret_cast<void**>(tiles), (static_cast<size_t>(n) + 1) * sizeof(int2)));
 	tileCutKernel<<<grid, 64, 0, s>>>(rows, d_start, capNnz, maxRows, chunkNnz, nChunks, nullptr, counts, *tiles);
 	SMM_HIP_TRY(hipGetLastError());
-	// (no second wait, r04: the scratch buffers go back to the allocator's QUARANTINE when this scope ends and are handed out again only
-	// behind an event recorded on this stream -- smm_runtime.hip)
+	// One more wait, once per table (r05): the callers publish the table in the handle as soon as this returns, and a
+	// concurrent solve of the same const matrix on ANOTHER stream would otherwise launch a kernel that reads a table still being written
+	// on `s` (the allocator's quarantine only protects the freed scratch buffers, not readers of the new table).
+	SMM_HIP_TRY(hipStreamSynchronize(s));
 	*nTiles = n;
 	return SMM_HIP_OK;
 }

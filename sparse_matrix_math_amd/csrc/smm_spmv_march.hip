@@ -645,34 +645,94 @@ void planMarch(smm_hip_csr* m) {
 	}
 }
 
-// the 32-bit copy of the masks (caller: the CONST analysis, after the plan said yes; enqueued on `s`, the buffer is the handle's)
+// the 32-bit copy of the masks (caller: the MASKS analysis, after the plan said yes; the buffer is the handle's).  Built only where a march
+// kernel can ever serve the matrix: constant diagonals, or the structural conditions of the masks march (masksMarchApplies without the row
+// threshold, which tests move).  Waits for the narrowing kernel (r05): ensurePattern publishes pat_state = 1 right after this
+// returns, and a concurrent SpMV of the same matrix on ANOTHER stream would otherwise run a march kernel on masks that are not written yet.
 int marchBuildMasks32(smm_hip_csr* m, hipStream_t s) {
 	if (!m->march_ok || m->d_pat_masks32) return SMM_HIP_OK;
+	const bool masksShape = m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8;
+	if (!m->pat_const && !masksShape) return SMM_HIP_OK;
 	void* p = nullptr;
 	SMM_TRY(devAlloc(&p, static_cast<size_t>(m->rows) * sizeof(unsigned) + 16));
-	m->d_pat_masks32 = static_cast<unsigned*>(p);
 	const int grid = static_cast<int>(std::min<long long>((m->rows + 255LL) / 256, numCUs() * 16LL));
-	marchNarrowMasks<<<grid, 256, 0, s>>>(m->rows, m->d_pat_masks, m->d_pat_masks32);
-	SMM_HIP_TRY(hipGetLastError());
+	marchNarrowMasks<<<grid, 256, 0, s>>>(m->rows, m->d_pat_masks, static_cast<unsigned*>(p));
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	if (e != hipSuccess) {
+		devFree(p);
+		return hipFail(e, "marchNarrowMasks", __FILE__, __LINE__);
+	}
+	m->d_pat_masks32 = static_cast<unsigned*>(p);
 	return SMM_HIP_OK;
 }
 
+// Launch plumbing shared by the march kernels, per template instantiation (`State` is a static of the launcher):
+//   * hipFuncAttributeMaxDynamicSharedMemorySize is raised whenever a launch needs more dynamic LDS than the largest size granted so far
+//     (r04 raised it once, to the FIRST qualifying matrix's size: a later matrix with a larger halo got a failed launch; the flag was a plain
+//     bool written by concurrent solves).  A failed raise is reported to the caller, who falls back to the gather / wave kernel.
+//   * the occupancy query is cached per LDS size (it sat on the solvers' hot path beside kernels of 10-20 us), the environment overrides are
+//     read once.
+struct MarchLaunchState {
+	std::atomic<int> granted{0};       // largest dynamic LDS size the attribute was set to
+	std::atomic<long long> occ{0};     // (lds << 8) | perCU of the last occupancy query
+	std::mutex mu;
+};
+static int marchEnvInt(const char* name) {
+	const char* env = getenv(name);
+	return env ? atoi(env) : 0;
+}
+static int marchWgsPerCuOverride() {
+	static const int v = std::max(0, marchEnvInt("SMM_HIP_MARCH_WGS_PER_CU"));
+	return v;
+}
+static int marchZcOverride() {
+	static const int v = std::max(0, marchEnvInt("SMM_HIP_MARCH_ZC"));
+	return v;
+}
+// false: this launch cannot have its LDS (the caller keeps the kernel that needs none)
+template <typename Kernel>
+static bool marchPrepare(MarchLaunchState& st, Kernel kernel, size_t lds, size_t staticLds, int* perCU) {
+	constexpr size_t DEFAULT_LIMIT = 64 * 1024, HW_LIMIT = 160 * 1024;
+	if (lds + staticLds > HW_LIMIT) return false;
+	if (lds + staticLds > DEFAULT_LIMIT && static_cast<int>(lds) > st.granted.load(std::memory_order_acquire)) {
+		std::lock_guard<std::mutex> lock(st.mu);
+		if (static_cast<int>(lds) > st.granted.load(std::memory_order_relaxed)) {
+			if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+				(void)hipGetLastError();
+				return false;
+			}
+			st.granted.store(static_cast<int>(lds), std::memory_order_release);
+		}
+	}
+	const long long cached = st.occ.load(std::memory_order_acquire);
+	if (cached != 0 && static_cast<size_t>(cached >> 8) == lds) {
+		*perCU = static_cast<int>(cached & 0xFF);
+	} else {
+		int n = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, TPB, lds) != hipSuccess || n < 1) {
+			(void)hipGetLastError();
+			n = 2;
+		}
+		n = std::min(n, 255);
+		st.occ.store((static_cast<long long>(lds) << 8) | n, std::memory_order_release);
+		*perCU = n;
+	}
+	if (marchWgsPerCuOverride() > 0) *perCU = marchWgsPerCuOverride();
+	return true;
+}
+
 template <typename T, int R, int KN, bool NT, int HP>
-static int launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+static bool launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                          const int* doneFlag, hipStream_t s) {
 	const int P = m->march_P, H = m->march_H;
 	const int nPlanes = (m->rows + P - 1) / P;
 	constexpr int MARCH_B = TPB * R;
 	const int nT = (P + MARCH_B - 1) / MARCH_B;
 	const size_t lds = 2 * static_cast<size_t>(MARCH_B + 2 * H) * sizeof(T);
-	static bool raised = false;
-	if (lds > 64 * 1024 && !raised) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvPatternConstMarchKernel<T, R, KN, NT, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-		raised = true;
-	}
+	static MarchLaunchState state;
 	int perCU = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternConstMarchKernel<T, R, KN, NT, HP>, TPB, lds) != hipSuccess || perCU < 1) perCU = 2;
-	if (const char* env = getenv("SMM_HIP_MARCH_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	if (!marchPrepare(state, spmvPatternConstMarchKernel<T, R, KN, NT, HP>, lds, 64 /* red[] */, &perCU)) return false;
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();  // room for the RCCL kernel beside A_loc (smm_dist.hip)
 	op &= ~SPMV_LEAVE_ROOM;
 	const int resident = cus * perCU;
@@ -684,7 +744,7 @@ static int launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	if (nPlanes > 1) {
 		const int wantChunks = std::max(1, std::min(nPlanes, (3 * resident / 2 + nT - 1) / nT));
 		zc = std::max(std::min(2, nPlanes), (nPlanes + wantChunks - 1) / wantChunks);
-		if (const char* env = getenv("SMM_HIP_MARCH_ZC")) zc = std::max(1, std::min(nPlanes, atoi(env)));
+		if (marchZcOverride() > 0) zc = std::max(1, std::min(nPlanes, marchZcOverride()));
 	}
 	const int nChunks = (nPlanes + zc - 1) / zc;
 	const long long units = static_cast<long long>(nT) * nChunks;
@@ -693,7 +753,7 @@ static int launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	if (xcdTiles) grid -= grid % 8;  // the same number of workgroups in every XCD group
 	spmvPatternConstMarchKernel<T, R, KN, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
 	                                                             m->d_pat_off, m->d_pat_cval, m->d_pat_masks32, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
-	return SMM_HIP_OK;
+	return true;
 }
 
 // true: the launch went to the march kernel.  SMM_HIP_CONST_MARCH=0 keeps the gather kernel (A/B measurements).
@@ -717,41 +777,29 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	const int vec = 16 / static_cast<int>(sizeof(T));
 	const bool r4 = rowsPerLane == 4;
 	const bool hp2 = 2 * m->march_H / vec <= 2 * TPB;  // the halo fits two packs per lane (fewer registers)
-#define SMM_MARCH_GO2(RV, KNV)                                                                                                  \
-	do {                                                                                                                        \
-		if (nt && hp2) launchMarchKN<T, RV, KNV, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);     \
-		else if (nt) launchMarchKN<T, RV, KNV, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);       \
-		else if (hp2) launchMarchKN<T, RV, KNV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);     \
-		else launchMarchKN<T, RV, KNV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);              \
-	} while (0)
-#define SMM_MARCH_GO(KNV)             \
-	do {                              \
-		if (r4) SMM_MARCH_GO2(4, KNV); \
-		else SMM_MARCH_GO2(8, KNV);    \
-	} while (0)
-	if (nNear == 5) SMM_MARCH_GO(5);
-	else SMM_MARCH_GO(0);
+#define SMM_MARCH_GO2(RV, KNV)                                                                                                        \
+	(nt && hp2 ? launchMarchKN<T, RV, KNV, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)                  \
+	 : nt      ? launchMarchKN<T, RV, KNV, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)                  \
+	 : hp2     ? launchMarchKN<T, RV, KNV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)                 \
+	           : launchMarchKN<T, RV, KNV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s))
+#define SMM_MARCH_GO(KNV) (r4 ? SMM_MARCH_GO2(4, KNV) : SMM_MARCH_GO2(8, KNV))
+	const bool launched = nNear == 5 ? SMM_MARCH_GO(5) : SMM_MARCH_GO(0);
 #undef SMM_MARCH_GO2
 #undef SMM_MARCH_GO
-	return true;
+	return launched;  // false: the windows do not fit the LDS a launch can be granted -- the gather kernel serves the matrix
 }
 
 template <typename T, int KMAX, bool NT, int HP>
-static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
+static bool launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                               const int* doneFlag, hipStream_t s) {
 	const int P = m->march_P, H = m->march_H;
 	const int nPlanes = (m->rows + P - 1) / P;
 	const int nT = (P + MM_B - 1) / MM_B;
 	const size_t lds = 2 * static_cast<size_t>(MM_B + 2 * H) * sizeof(T);
-	static bool raised = false;
-	if (lds > 40 * 1024 && !raised) {  // (the kernel holds 8-17 KB of static LDS beside the windows: together they may pass the 64 KB default)
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvPatternMasksMarchKernel<T, KMAX, NT, HP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                          static_cast<int>(lds));
-		raised = true;
-	}
+	static MarchLaunchState state;
 	int perCU = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternMasksMarchKernel<T, KMAX, NT, HP>, TPB, lds) != hipSuccess || perCU < 1) perCU = 2;
-	if (const char* env = getenv("SMM_HIP_MARCH_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	// (the kernel holds 8-17 KB of static LDS beside the windows: together they may pass the 64 KB default)
+	if (!marchPrepare(state, spmvPatternMasksMarchKernel<T, KMAX, NT, HP>, lds, (TPB / WAVE) * (WAVE * KMAX + KMAX) * sizeof(T) + 64 /* sVal[], red[] */, &perCU)) return false;
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 	op &= ~SPMV_LEAVE_ROOM;
 	const int resident = cus * perCU;
@@ -759,7 +807,7 @@ static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 	if (nPlanes > 1) {
 		const int wantChunks = std::max(1, std::min(nPlanes, (4 * resident + nT - 1) / nT));
 		zc = std::max(std::min(8, nPlanes), (nPlanes + wantChunks - 1) / wantChunks);
-		if (const char* env = getenv("SMM_HIP_MARCH_ZC")) zc = std::max(1, std::min(nPlanes, atoi(env)));
+		if (marchZcOverride() > 0) zc = std::max(1, std::min(nPlanes, marchZcOverride()));
 	}
 	const int nChunks = (nPlanes + zc - 1) / zc;
 	const long long units = static_cast<long long>(nT) * nChunks;
@@ -769,6 +817,7 @@ static void launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 	spmvPatternMasksMarchKernel<T, KMAX, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
 	                                                                  m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks32, op, lhs, divisor, x,
 	                                                                  out, dotMode, w1, partials, doneFlag);
+	return true;
 }
 
 bool masksMarchApplies(const smm_hip_csr* m) {
@@ -791,16 +840,14 @@ bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	if (!enabled || !masksMarchApplies(m)) return false;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
-#define SMM_MM_GO(KV)                                                                                                \
-	do {                                                                                                             \
-		if (nt && hp2) launchMasksMarchK<T, KV, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);   \
-		else if (nt) launchMasksMarchK<T, KV, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);     \
-		else if (hp2) launchMasksMarchK<T, KV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);   \
-		else launchMasksMarchK<T, KV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);            \
-	} while (0)
-	SMM_MM_GO(8);
+#define SMM_MM_GO(KV)                                                                                                       \
+	(nt && hp2 ? launchMasksMarchK<T, KV, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)          \
+	 : nt      ? launchMasksMarchK<T, KV, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)          \
+	 : hp2     ? launchMasksMarchK<T, KV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)         \
+	           : launchMasksMarchK<T, KV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s))
+	const bool launched = SMM_MM_GO(8);
 #undef SMM_MM_GO
-	return true;
+	return launched;  // false: the wave kernel serves the matrix
 }
 
 template bool launchPatMasksMarch<float>(const smm_hip_csr*, int, const float*, const float*, const float*, float*, int, const float*, float*, const int*, hipStream_t);

@@ -1298,10 +1298,12 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	patBuildMasks<<<grid, TPB, 0, s>>>(m->rows, d_meta, d_off, m->d_start, m->d_positions, d_masks, d_flag, constAllowed ? m->d_values : nullptr, elemBytes, d_cval);
 	struct Back {
 		int meta[2], flags[2], offs[MAXOFF];
+		unsigned long long cval[MAXOFF];
 	} back{};
 	SMM_HIP_TRY(hipMemcpyAsync(back.meta, d_meta, sizeof(back.meta), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipMemcpyAsync(back.flags, d_flag, sizeof(back.flags), hipMemcpyDeviceToHost, s));
 	SMM_HIP_TRY(hipMemcpyAsync(back.offs, d_off, sizeof(back.offs), hipMemcpyDeviceToHost, s));
+	SMM_HIP_TRY(hipMemcpyAsync(back.cval, d_cval, sizeof(back.cval), hipMemcpyDeviceToHost, s));
 	{
 		SetupTrace trace("pattern:   wait for the whole analysis");
 		SMM_HIP_TRY(hipStreamSynchronize(s));
@@ -1323,7 +1325,10 @@ static int tryMasks(smm_hip_csr* m, hipStream_t s, const char** why) {
 	m->d_pat_off = d_off.detach();
 	m->d_pat_masks = d_masks.detach();
 	m->pat_const = constAllowed && k <= 32 && back.flags[1] == 0;
-	if (m->pat_const) m->d_pat_cval = d_cval.detach();
+	if (m->pat_const) {
+		m->d_pat_cval = d_cval.detach();
+		m->pat_cval_host.assign(back.cval, back.cval + k);
+	}
 	planMarch(m);
 	SMM_TRY(marchBuildMasks32(m, s));
 	return SMM_HIP_OK;

@@ -404,6 +404,11 @@ def cg_resident(mode=-1):
     return int(_lib.load().smm_hip_cg_resident(int(mode)))
 
 
+def bicgstab_resident(mode=-1):
+    """sets (0 off, 1 auto, 2 require) or only queries (-1) the single-launch BiCGStab path; returns the previous mode"""
+    return int(_lib.load().smm_hip_bicgstab_resident(int(mode)))
+
+
 def bicgstab_dev(a, d_b, d_x, maxIterations, eps, M=None, stream=None):
     """device-pointer BiCGStab; returns (SolverStatus, iterations, resnorm).  Synchronises `stream`."""
     suf = a._suf

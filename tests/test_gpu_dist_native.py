@@ -203,6 +203,47 @@ def test_halo_in_pieces(smm, oracle, world, chunks, monkeypatch):
     np.testing.assert_allclose(x, x_ref, rtol=1e-10, atol=1e-12)
 
 
+def _upwind_matrix(n, far, dtype):
+    """structurally NON-symmetric: row i holds the diagonal and the two upwind entries i - 1, i - far (lower triangular)"""
+    rows = np.arange(n)
+    cols = np.stack([rows - far, rows - 1, rows], axis=1)
+    vals = np.broadcast_to(np.array([-1.0, -0.5, 4.0]), cols.shape) * (1.0 + 0.25 * np.sin(0.37 * rows))[:, None]
+    keep = cols >= 0
+    start = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int32)
+    return start, cols[keep].astype(np.int32), vals[keep].astype(dtype)
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2), (4, 4)])
+def test_one_sided_halo(smm, oracle, world, chunks, monkeypatch):
+    """An upwind (lower triangular) matrix: rank 0 RECEIVES nothing -- its A_rem is empty -- but sends to rank 1, the last rank sends
+    nothing.  With the halo in pieces every rank must still run the K-exchange form (`chunks` is agreed collectively; r04 let a rank
+    with an empty A_rem fall through to one full-count exchange while its peer posted K piece-sized receives: ADVICE r04), and the fused
+    dot products of the rank without remote entries ride in its (empty) last part."""
+    monkeypatch.setenv("SMM_HIP_HALO_CHUNKS", str(chunks))
+    for dtype in (np.float32, np.float64):
+        tol = 3e-4 if dtype == np.float32 else 1e-10
+        csr = _upwind_matrix(30000, 700, dtype)
+        n = len(csr[0]) - 1
+        x_true = np.random.default_rng(5).uniform(0.5, 1.5, n).astype(dtype)
+        b = oracle.spmv(csr, 0, None, x_true)
+        seen = {}
+        for precond in (None, smm.SolverPreconditioner.JACOBI):
+            (status, iters, res), x, y, halo = _solve(smm, csr, b, world, dtype, 6, 1e-30, precond=precond, chunks_seen=seen)
+            assert set(seen.values()) == {chunks}, seen
+            if precond is None:
+                st_ref, x_ref, it_ref, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 6, 1e-30)
+            else:
+                from oracle.oracle import PRECOND_JACOBI
+
+                _, diag = oracle.jacobi_setup(csr)
+                st_ref, x_ref, it_ref, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 6, 1e-30, PRECOND_JACOBI, diag)
+            assert status == st_ref == 0 and iters == it_ref == 6
+            assert halo == (world - 1) * 700  # every rank but the first receives the `far` rows above its own
+            assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref)))
+            y_ref = oracle.spmv(csr, 0, None, b)
+            assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_native_loops_adopt_the_pattern_family(smm, oracle, world):
     """a solve with many iterations ahead lets both local blocks take the index-free family (>= 2^20 entries; adoptPatternForSolver):

@@ -177,6 +177,37 @@ def test_masks_march_kernel_with_varying_coefficients(smm, oracle, dtype):
         A.close()
 
 
+def test_march_lds_is_raised_again_for_a_larger_halo(smm):
+    """Two grids in ONE process, the second with the larger halo (nx = 800, then nx = 1024; 13.1 M rows each, fp64, production thresholds):
+    the masks march needs 42 KB of dynamic LDS for the first and 49 KB -- with its 16.6 KB of static LDS more than the 64 KB a launch gets
+    by default -- for the second.  r04 set hipFuncAttributeMaxDynamicSharedMemorySize ONCE per instantiation, to the first qualifying
+    launch's size, so the second matrix got a failed launch; now the largest size granted so far is tracked and raised on demand (VERDICT
+    r04 item 5b).  Both kernels (constant diagonals, values read) against the CSR stream at one lane per row, bit for bit."""
+    import torch
+
+    smm.host.set_march_min_rows(-1, -1)  # production thresholds
+    for nx, ny, nz in ((800, 16, 1024), (1024, 16, 800)):
+        A, _, n, td, dev, stream = _stencil(smm, torch, nx, ny, nz, np.float64)
+        x = torch.rand(n, dtype=td, device=dev, generator=torch.Generator(device=dev).manual_seed(nx)) - 0.5
+        A.set_kernel(2, 1)
+        y_csr = torch.empty_like(x)
+        A.spmv_dev(0, None, x, y_csr, stream)
+        A.set_kernel(PATTERN, 1)
+        assert A.kernel_desc()[0] == "spmvPatternConstMarchKernel"
+        y = torch.full_like(x, float("nan"))
+        A.spmv_dev(0, None, x, y, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_csr), (nx, "const")
+        A.pattern_allow_const(False)
+        assert A.kernel_desc()[0] == "spmvPatternMasksMarchKernel"
+        y.fill_(float("nan"))
+        A.spmv_dev(0, None, x, y, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_csr), (nx, "masks")
+        del A, x, y, y_csr
+        torch.cuda.empty_cache()
+
+
 def test_march_in_cg_at_scale(smm, oracle):
     """ConjugateGradient on a 160^3 Laplacian (4.1 M rows, fp64) with AUTO: the solver adopts PATTERN / CONST, the SpMV is the march kernel;
     x after 25 iterations against the oracle (fixed iterations: eps = 0)"""
