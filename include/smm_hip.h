@@ -448,6 +448,18 @@ int smm_hip_dist_csr_info(const smm_hip_dist_csr* A, int* n_local, int* ext_len,
  * with k pieces every SpMV issues k exchanges back to back, and the remote block is cut by columns into k parts, part j starting as soon as
  * piece j has landed (row sums are then formed as ((loc + rem_0) + rem_1) + ...: deterministic, rounding differs from the one-piece form). */
 int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks);
+/* How this matrix's halo and scalars travel (decided collectively when it was created):
+ *   p2p          1: peer to peer (csrc/smm_p2p.h) -- every rank maps every rank's block of fine-grained device memory (hipIpcMemHandle; over
+ *                xGMI between GPUs), pushes the boundary slices of a vector straight into the neighbours' landing areas and completes the
+ *                dot products by one single-workgroup kernel that writes into / reads from per-rank slots: no collective is launched inside
+ *                the loop.  Asked for with SMM_HIP_P2P=1 on EVERY rank; stays 0 (the communicator's grouped send / receive and all-reduce)
+ *                unless every rank could map every peer and passed a self-test through every path.  Results: the halo is pure data
+ *                movement (same bits); the scalars are added in rank order on every rank (deterministic, identical on all ranks).
+ *   relays       relay ranks per halo segment (SMM_HIP_P2P_RELAYS; default world - 4, i.e. 4 at 8 ranks): the segment's direct_share goes
+ *                over the link src -> dst, the rest in equal shares src -> relay -> dst over links a nearest-neighbour exchange leaves idle.
+ *   halo_first   1: the rows of an updated vector that a peer receives are produced by a small launch of their own and the exchange is
+ *                posted right behind it, before the bulk of the update runs (SMM_HIP_HALO_FIRST=0 turns it off); same bits either way. */
+int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, int* halo_first, double* direct_share);
 /* the two local blocks (owned by A): a_loc is the square diagonal block a block-Jacobi preconditioner is built on
  * (smm_hip_precond_create(a_loc, kind, &M)); both accept smm_hip_csr_set_kernel */
 int smm_hip_dist_csr_local_block(const smm_hip_dist_csr* A, smm_hip_csr** a_loc, smm_hip_csr** a_rem);

@@ -141,11 +141,11 @@ static int dotHost(int n, const T* a, const T* b, T* result) {
 	DevBuf<T> da, db, dr;
 	SMM_TRY(da.alloc(n));
 	SMM_TRY(dr.alloc(1));
-	if (n) SMM_HIP_TRY(hipMemcpyAsync(da, a, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	SMM_TRY(hostToDev(da, a, sizeof(T) * n, s));
 	const T* pb = da;
 	if (b != a) {
 		SMM_TRY(db.alloc(n));
-		if (n) SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_TRY(hostToDev(db, b, sizeof(T) * n, s));
 		pb = db;
 	}
 	SMM_TRY(dotDev<T>(n, da, pb, dr, s));

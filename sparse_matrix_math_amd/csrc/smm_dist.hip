@@ -33,8 +33,11 @@
 #include <rccl/rccl.h>  // types and prototypes only: every call goes through dlsym'd pointers
 #include <rocprim/device/device_scan.hpp>
 
+#include <unistd.h>
+
 #include "smm_device.h"
 #include "smm_internal.h"
+#include "smm_p2p.h"
 
 namespace smm {
 
@@ -471,6 +474,40 @@ struct DistScal {
 	int done, iters, status, pad;
 };
 
+// up to four [lo, hi) runs of rows, passed to the update kernels by value
+struct RowRanges {
+	int n = 0;
+	int lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+	long long rows() const {
+		long long t = 0;
+		for (int i = 0; i < n; ++i) t += hi[i] - lo[i];
+		return t;
+	}
+};
+
+struct P2PState {
+	int world = 1, rank = 0;
+	int relays = 0;          // relay ranks per segment (0: the direct path only)
+	double directShare = 1;  // share of a segment that takes the direct path
+	void* block = nullptr;   // this rank's symmetric block (fine-grained device memory)
+	size_t bytes = 0;
+	std::vector<char*> peer;   // every rank's block as mapped here (peer[rank] == block)
+	std::vector<bool> opened;  // mapped with hipIpcOpenMemHandle (to be closed)
+	size_t landOff[P2P_KINDS] = {}, stageOff[P2P_KINDS] = {};  // byte offsets inside MY block
+	long long landElems = 0, stageElems = 0;
+	P2PJob* d_push = nullptr;
+	int nPush = 0;
+	P2PJob* d_fwd = nullptr;
+	int nFwd = 0;
+	P2PLandSeg* d_land = nullptr;
+	int nLand = 0;
+	unsigned* d_counters = nullptr;
+	P2PPeers peers{};
+	unsigned long long haloSeq[P2P_KINDS] = {}, redSeq[P2P_RED_POINTS] = {};
+	long long ticks = 0;
+	P2PHeader* hdr() const { return reinterpret_cast<P2PHeader*>(block); }
+};
+
 }  // namespace smm
 
 struct smm_hip_dist_csr {
@@ -498,6 +535,23 @@ struct smm_hip_dist_csr {
 	void *pExt = nullptr, *sExt = nullptr, *xExt = nullptr;
 	void *partsA = nullptr, *partsB = nullptr, *partsC = nullptr;  // finishing buffers (PARTS_LEN): totals are all-reduced in place
 	void* sc = nullptr;
+	// every rank's column range [cmin, cmaxExcl) and the row bounds (global knowledge: any rank can derive any rank's halo plan)
+	std::vector<long long> needs;
+	std::vector<int> bounds;
+	// halo first (r05): the rows of an updated vector that some peer receives -- merged, clipped, aligned ranges in owned-local numbering --
+	// are produced by a small launch of their own, the exchange is posted right behind it, and the bulk launch takes the complement
+	smm::RowRanges boundary, bulk;
+	bool haloFirst = false;
+	// the exchange begun by distExchangeBegin and not yet consumed by distMatvecCompute
+	struct Pending {
+		bool active = false;
+		int kind = 0;
+		unsigned long long seq = 0;
+		hipEvent_t landed[smm::MAX_HALO_CHUNKS] = {};
+		int waitSlot[smm::MAX_HALO_CHUNKS] = {-1, -1, -1, -1};
+		bool async = false;
+	} pending;
+	smm::P2PState* p2p = nullptr;  // peer-to-peer data movement (smm_p2p.h); null: collectives of the communicator
 };
 
 namespace smm {
@@ -528,6 +582,474 @@ static int distWorkspace(smm_hip_dist_csr* D) {
 	SMM_HIP_TRY(hipMemsetAsync(D->partsC, 0, PARTS_LEN * sizeof(T), s));
 	SMM_HIP_TRY(hipStreamSynchronize(s));
 	return SMM_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// halo first: which rows of an updated vector some peer receives
+// ---------------------------------------------------------------------------------------------------------
+// The send segments in owned-local numbering, merged, clipped and widened to multiples of 16 bytes (the update kernels' fast path needs
+// 16-byte aligned runs; a few extra rows in the small launch cost nothing).  No split when (almost) every row is a boundary row.
+template <typename T>
+static void planHaloFirst(smm_hip_dist_csr* D) {
+	D->haloFirst = false;
+	D->boundary = RowRanges{};
+	D->bulk = RowRanges{};
+	const int n = D->nLocal;
+	D->bulk.n = 1;
+	D->bulk.lo[0] = 0;
+	D->bulk.hi[0] = n;
+	static const bool allowed = [] {
+		const char* env = getenv("SMM_HIP_HALO_FIRST");
+		return env ? atoi(env) != 0 : true;
+	}();
+	if (!allowed || D->sends.empty() || n <= 0) return;
+	constexpr int VEC = 16 / sizeof(T);
+	std::vector<std::pair<int, int>> runs;
+	for (const Seg& g : D->sends) {
+		int lo = g.offset - D->ownOffset, hi = lo + g.count;
+		lo = std::max(0, lo / VEC * VEC);
+		hi = std::min(n, (hi + VEC - 1) / VEC * VEC);
+		if (lo < hi) runs.emplace_back(lo, hi);
+	}
+	std::sort(runs.begin(), runs.end());
+	std::vector<std::pair<int, int>> merged;
+	for (const auto& r : runs) {
+		if (!merged.empty() && r.first <= merged.back().second) merged.back().second = std::max(merged.back().second, r.second);
+		else merged.push_back(r);
+	}
+	long long total = 0;
+	for (const auto& r : merged) total += r.second - r.first;
+	if (merged.empty() || merged.size() > 3 || total * 4 > static_cast<long long>(n) * 3) return;  // (too scattered, or nothing left for a bulk launch)
+	RowRanges b{}, rest{};
+	int at = 0;
+	for (const auto& r : merged) {
+		b.lo[b.n] = r.first;
+		b.hi[b.n] = r.second;
+		++b.n;
+		if (at < r.first) {
+			rest.lo[rest.n] = at;
+			rest.hi[rest.n] = r.first;
+			++rest.n;
+		}
+		at = r.second;
+	}
+	if (at < n) {
+		rest.lo[rest.n] = at;
+		rest.hi[rest.n] = n;
+		++rest.n;
+	}
+	D->boundary = b;
+	D->bulk = rest;
+	D->haloFirst = true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// peer-to-peer set-up (smm_p2p.h)
+// ---------------------------------------------------------------------------------------------------------
+// The halo plan of ANY rank from what every rank knows (the column ranges and the row bounds): the segments rank q receives, in
+// ascending source order, with their positions in q's landing area.
+struct PlanSeg {
+	int src, dst;
+	long long extOff;   // element offset in dst's halo-extended vector
+	long long landOff;  // element offset in dst's landing area
+	int count;
+};
+static std::vector<PlanSeg> planRecvs(const smm_hip_dist_csr* D, int q) {
+	std::vector<PlanSeg> out;
+	const int world = D->comm->world;
+	long long at = 0;
+	for (int p = 0; p < world; ++p) {
+		if (p == q) continue;
+		const long long lo = std::max<long long>(D->needs[2 * static_cast<size_t>(q)], D->bounds[static_cast<size_t>(p)]);
+		const long long hi = std::min<long long>(D->needs[2 * static_cast<size_t>(q) + 1], D->bounds[static_cast<size_t>(p) + 1]);
+		if (lo < hi) {
+			out.push_back({p, q, lo - D->needs[2 * static_cast<size_t>(q)], at, static_cast<int>(hi - lo)});
+			at += hi - lo;
+		}
+	}
+	return out;
+}
+
+// relay ranks of the segment p -> q: the ranks farthest (on the ring of ranks) from both ends first -- halo partners are near neighbours in
+// a row partition, so those are the ranks whose links to p and to q carry nothing else
+static std::vector<int> planRelays(int world, int p, int q, int want) {
+	std::vector<int> cand;
+	for (int r = 0; r < world; ++r) {
+		if (r != p && r != q) cand.push_back(r);
+	}
+	auto ring = [world](int a, int b) {
+		const int d = std::abs(a - b);
+		return std::min(d, world - d);
+	};
+	std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return std::min(ring(a, p), ring(a, q)) > std::min(ring(b, p), ring(b, q)); });
+	if (static_cast<int>(cand.size()) > want) cand.resize(static_cast<size_t>(std::max(0, want)));
+	return cand;
+}
+
+// the parts of a segment of `count` elements: part 0 is the direct one, part k >= 1 goes through relay k - 1; cuts at multiples of 4
+// elements.  bounds has parts + 1 entries.
+static std::vector<int> planParts(int count, int relays, double directShare) {
+	std::vector<int> cut(static_cast<size_t>(relays) + 2, 0);
+	cut[static_cast<size_t>(relays) + 1] = count;
+	const double rest = relays > 0 ? (1.0 - directShare) / relays : 0.0;
+	double cum = directShare;
+	for (int k = 1; k <= relays; ++k) {
+		int c = static_cast<int>(count * cum) & ~3;
+		c = std::max(cut[static_cast<size_t>(k) - 1], std::min(count, c));
+		cut[static_cast<size_t>(k)] = c;
+		cum += rest;
+	}
+	return cut;
+}
+
+static void p2pTeardown(smm_hip_dist_csr* D) {
+	P2PState* P = D->p2p;
+	if (!P) return;
+	for (size_t q = 0; q < P->peer.size(); ++q) {
+		if (P->opened[q] && P->peer[q]) (void)hipIpcCloseMemHandle(P->peer[q]);
+	}
+	for (void* p : {static_cast<void*>(P->d_push), static_cast<void*>(P->d_fwd), static_cast<void*>(P->d_land), static_cast<void*>(P->d_counters)}) devFree(p);
+	if (P->block) (void)hipFree(P->block);
+	delete P;
+	D->p2p = nullptr;
+}
+
+static long long p2pTicks() {
+	static const long long t = [] {
+		const char* env = getenv("SMM_HIP_P2P_TIMEOUT_S");
+		const double sec = env && atof(env) > 0 ? atof(env) : 20.0;
+		return static_cast<long long>(sec * 1.0e8);  // wall_clock64 counts at 100 MHz on gfx9
+	}();
+	return t;
+}
+
+// sum of one 0 / 1 vote per rank == world?
+static int p2pAllAgree(smm_hip_comm* c, bool mine, bool* all) {
+	std::vector<long long> v(1, mine ? 1 : 0);
+	SMM_TRY(commAllreduceI64(c, v.data(), 1));
+	*all = v[0] == c->world;
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int p2pHaloLaunch(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t cs);
+template <typename T>
+static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long long seq, hipStream_t s);
+template <typename T>
+static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int count, const int* doneFlag, hipStream_t s);
+
+// Collective.  Leaves D->p2p null (the communicator's collectives are used) unless EVERY rank asked for the peer-to-peer path, could
+// allocate and export its block, map every peer's and pass the self-test through every path.
+template <typename T>
+static int p2pSetup(smm_hip_dist_csr* D) {
+	smm_hip_comm* c = D->comm;
+	const int world = c->world, rank = c->rank;
+	if (world < 2 || world > P2P_MAX_WORLD) return SMM_HIP_OK;
+	const char* env = getenv("SMM_HIP_P2P");  // (read at every create, like SMM_HIP_HALO_CHUNKS)
+	bool all = false;
+	SMM_TRY(p2pAllAgree(c, env && atoi(env) != 0 && D->chunks == 1, &all));
+	if (!all) return SMM_HIP_OK;
+	std::unique_ptr<P2PState> owner(new P2PState());
+	P2PState* P = owner.get();
+	P->world = world;
+	P->rank = rank;
+	P->ticks = p2pTicks();
+	{
+		const char* r = getenv("SMM_HIP_P2P_RELAYS");
+		P->relays = r ? atoi(r) : std::max(0, world - 4);  // 8 ranks: 4 relays per segment -- half of it direct, an eighth through each relay
+		P->relays = std::max(0, std::min(std::min(P->relays, world - 2), P2P_MAX_PATHS - 1));
+		// the direct link carries its share once; a relay's links carry up to two shares in each of the two stages: d = 4 rho, d + R rho = 1
+		P->directShare = 4.0 / (P->relays + 4.0);
+		if (const char* d = getenv("SMM_HIP_P2P_DIRECT_SHARE")) P->directShare = std::min(1.0, std::max(0.05, atof(d)));
+		if (P->relays == 0) P->directShare = 1.0;
+	}
+	// ---- the plan, from global knowledge: what I receive, what I send (directly / staged at a relay), what I forward
+	const std::vector<PlanSeg> mine = planRecvs(D, rank);
+	std::vector<long long> stageTotal(static_cast<size_t>(world), 0);
+	std::vector<int> jobCount(static_cast<size_t>(world), 0);
+	struct Route {
+		PlanSeg seg;
+		int part, relay, a, b;  // elements [a, b) of the segment; relay < 0: direct
+		int job;                // index among the relay's jobs
+		long long stagePos;     // element offset in the relay's staging area
+	};
+	std::vector<Route> routes;
+	bool tooMany = false;
+	for (int q = 0; q < world; ++q) {
+		for (const PlanSeg& g : planRecvs(D, q)) {
+			const std::vector<int> relays = planRelays(world, g.src, q, P->relays);
+			const std::vector<int> cut = planParts(g.count, static_cast<int>(relays.size()), P->directShare);
+			for (size_t k = 0; k + 1 < cut.size(); ++k) {
+				Route rt{g, static_cast<int>(k), k == 0 ? -1 : relays[k - 1], cut[k], cut[k + 1], -1, 0};
+				if (rt.relay >= 0) {
+					rt.job = jobCount[static_cast<size_t>(rt.relay)]++;
+					rt.stagePos = stageTotal[static_cast<size_t>(rt.relay)];
+					stageTotal[static_cast<size_t>(rt.relay)] += (rt.b - rt.a + 3) & ~3;
+					if (rt.job >= P2P_MAX_JOBS) tooMany = true;
+				}
+				routes.push_back(rt);
+			}
+		}
+	}
+	// ---- my block: header | landing x 3 | staging x 3, element-aligned to 256 bytes
+	long long landElems = 0;
+	for (const PlanSeg& g : mine) landElems += g.count;
+	P->landElems = landElems;
+	P->stageElems = stageTotal[static_cast<size_t>(rank)];
+	auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+	size_t at = up(sizeof(P2PHeader));
+	for (int k = 0; k < P2P_KINDS; ++k) {
+		P->landOff[k] = at;
+		at += up(static_cast<size_t>(std::max<long long>(1, landElems)) * sizeof(T) + 64);
+	}
+	for (int k = 0; k < P2P_KINDS; ++k) {
+		P->stageOff[k] = at;
+		at += up(static_cast<size_t>(std::max<long long>(1, P->stageElems)) * sizeof(T) + 64);
+	}
+	P->bytes = at;
+	bool ok = !tooMany;
+	if (ok) {
+		hipError_t e = hipExtMallocWithFlags(&P->block, P->bytes, hipDeviceMallocFinegrained);
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			P->block = nullptr;
+			e = hipExtMallocWithFlags(&P->block, P->bytes, hipDeviceMallocUncached);
+		}
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			P->block = nullptr;
+			ok = false;
+		} else {
+			ok = hipMemset(P->block, 0, P->bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+		}
+	}
+	// ---- every rank learns every rank's handle, process, address and layout
+	constexpr int WORDS = 8 + 2 + 2 * P2P_KINDS + 1;
+	std::vector<long long> table(static_cast<size_t>(world) * WORDS, 0);
+	long long* me = table.data() + static_cast<size_t>(rank) * WORDS;
+	hipIpcMemHandle_t handle{};
+	static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+	if (ok && hipIpcGetMemHandle(&handle, P->block) != hipSuccess) {
+		(void)hipGetLastError();
+		ok = false;
+	}
+	memcpy(me, &handle, 64);
+	me[8] = static_cast<long long>(getpid());
+	me[9] = static_cast<long long>(reinterpret_cast<uintptr_t>(P->block));
+	for (int k = 0; k < P2P_KINDS; ++k) {
+		me[10 + k] = static_cast<long long>(P->landOff[k]);
+		me[10 + P2P_KINDS + k] = static_cast<long long>(P->stageOff[k]);
+	}
+	me[10 + 2 * P2P_KINDS] = ok ? 1 : 0;
+	SMM_TRY(commAllreduceI64(c, table.data(), world * WORDS));
+	for (int q = 0; q < world; ++q) ok = ok && table[static_cast<size_t>(q) * WORDS + 10 + 2 * P2P_KINDS] == 1;
+	P->peer.assign(static_cast<size_t>(world), nullptr);
+	P->opened.assign(static_cast<size_t>(world), false);
+	if (ok) {
+		for (int q = 0; q < world && ok; ++q) {
+			const long long* row = table.data() + static_cast<size_t>(q) * WORDS;
+			if (q == rank) {
+				P->peer[static_cast<size_t>(q)] = static_cast<char*>(P->block);
+			} else if (row[8] == static_cast<long long>(getpid())) {
+				// a rank of this very process (the thread-rank tests): its block is already mapped here
+				P->peer[static_cast<size_t>(q)] = reinterpret_cast<char*>(static_cast<uintptr_t>(row[9]));
+			} else {
+				hipIpcMemHandle_t h{};
+				memcpy(&h, row, 64);
+				void* ptr = nullptr;
+				if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+					(void)hipGetLastError();
+					ok = false;
+				} else {
+					P->peer[static_cast<size_t>(q)] = static_cast<char*>(ptr);
+					P->opened[static_cast<size_t>(q)] = true;
+				}
+			}
+		}
+	}
+	// ---- device tables
+	std::vector<P2PJob> push, fwd;
+	std::vector<P2PLandSeg> land;
+	if (ok) {
+		auto hdrOf = [&](int q) { return reinterpret_cast<P2PHeader*>(P->peer[static_cast<size_t>(q)]); };
+		auto rowOf = [&](int q) { return table.data() + static_cast<size_t>(q) * WORDS; };
+		for (const Route& rt : routes) {
+			const int n = rt.b - rt.a;
+			if (n <= 0) continue;
+			const int q = rt.seg.dst;
+			if (rt.seg.src == rank) {  // I push this part: straight into q's landing area, or into the relay's staging area
+				P2PJob j{};
+				j.srcOff = (static_cast<long long>(D->bounds[static_cast<size_t>(rank)]) - D->cmin) +
+				           (D->needs[2 * static_cast<size_t>(q)] + rt.seg.extOff - D->bounds[static_cast<size_t>(rank)]) + rt.a;
+				j.count = n;
+				j.waitJob = -1;
+				j.ackFrom = q;
+				for (int k = 0; k < P2P_KINDS; ++k) {
+					if (rt.relay < 0) {
+						j.dst[k] = P->peer[static_cast<size_t>(q)] + rowOf(q)[10 + k] + (rt.seg.landOff + rt.a) * static_cast<long long>(sizeof(T));
+						j.flag[k] = &hdrOf(q)->haloFlag[k][rank][0];
+					} else {
+						j.dst[k] = P->peer[static_cast<size_t>(rt.relay)] + rowOf(rt.relay)[10 + P2P_KINDS + k] + rt.stagePos * static_cast<long long>(sizeof(T));
+						j.flag[k] = &hdrOf(rt.relay)->stageFlag[k][rt.job];
+					}
+				}
+				push.push_back(j);
+			}
+			if (rt.relay == rank) {  // I forward this part from my staging area into q's landing area
+				P2PJob j{};
+				j.srcOff = rt.stagePos;
+				j.count = n;
+				j.waitJob = rt.job;
+				j.ackFrom = q;
+				for (int k = 0; k < P2P_KINDS; ++k) {
+					j.dst[k] = P->peer[static_cast<size_t>(q)] + rowOf(q)[10 + k] + (rt.seg.landOff + rt.a) * static_cast<long long>(sizeof(T));
+					j.flag[k] = &hdrOf(q)->haloFlag[k][rt.seg.src][rt.part];
+				}
+				fwd.push_back(j);
+			}
+		}
+		for (const PlanSeg& g : mine) {
+			int paths = 0;
+			for (const Route& rt : routes) {
+				if (rt.seg.dst == rank && rt.seg.src == g.src && rt.b > rt.a) paths = std::max(paths, rt.part + 1);
+			}
+			// (a part without elements is never signalled: the land kernel waits for the parts that exist -- they are the first `paths` ones only when
+			// no part in between is empty, which planParts guarantees except for tiny segments, where every part but the direct one may be empty)
+			bool gaps = false;
+			for (const Route& rt : routes) {
+				if (rt.seg.dst == rank && rt.seg.src == g.src && rt.b <= rt.a && rt.part < paths) gaps = true;
+			}
+			if (gaps) ok = false;
+			P2PLandSeg ls{g.landOff, g.extOff, g.count, g.src, paths, {}};
+			for (int k = 0; k < P2P_KINDS; ++k) ls.ack[k] = &hdrOf(g.src)->ackFlag[k][rank];
+			land.push_back(ls);
+		}
+		P->nPush = static_cast<int>(push.size());
+		P->nFwd = static_cast<int>(fwd.size());
+		P->nLand = static_cast<int>(land.size());
+		for (int q = 0; q < world; ++q) P->peers.hdr[q] = hdrOf(q);
+		auto upload = [&](auto& vec, auto** d) -> int {
+			using E = typename std::remove_reference<decltype(vec)>::type::value_type;
+			void* p = nullptr;
+			SMM_TRY(devAlloc(&p, std::max<size_t>(1, vec.size()) * sizeof(E)));
+			*d = static_cast<E*>(p);
+			if (!vec.empty()) SMM_HIP_TRY(hipMemcpy(p, vec.data(), vec.size() * sizeof(E), hipMemcpyHostToDevice));
+			return SMM_HIP_OK;
+		};
+		SMM_TRY(upload(push, &P->d_push));
+		SMM_TRY(upload(fwd, &P->d_fwd));
+		SMM_TRY(upload(land, &P->d_land));
+		void* cnt = nullptr;
+		const size_t nCounters = static_cast<size_t>(std::max(1, P->nPush + P->nFwd + P->nLand));
+		SMM_TRY(devAlloc(&cnt, nCounters * sizeof(unsigned)));
+		P->d_counters = static_cast<unsigned*>(cnt);
+		SMM_HIP_TRY(hipMemset(cnt, 0, nCounters * sizeof(unsigned)));
+	}
+	SMM_TRY(p2pAllAgree(c, ok, &all));
+	D->p2p = owner.release();  // (torn down below unless everything checks out; the peers' mappings must be closed either way)
+	if (!all) {
+		p2pTeardown(D);
+		return SMM_HIP_OK;
+	}
+	// ---- self-test through every path: x's halo-extended vector carries the global column number of every owned element; after one
+	// exchange every halo element of every rank must hold ITS column number; one reduction must give world (world + 1) / 2
+	bool pass = true;
+	{
+		// (on the communicator's own stream: kernels of this rank WAIT for kernels of its peers, and ranks that are threads of one process
+		// share the library's stream -- a waiting kernel there would sit in front of the very kernel it waits for)
+		hipStream_t s = c->stream;
+		noteStream(s);
+		T* xExt = static_cast<T*>(D->xExt);
+		std::vector<T> host(static_cast<size_t>(D->extLen), T(-1));
+		for (int i = 0; i < D->nLocal; ++i) host[static_cast<size_t>(D->ownOffset + i)] = static_cast<T>((D->rowBegin + i) % 8191);
+		SMM_HIP_TRY(hipMemcpyAsync(xExt, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, s));
+		int rc = p2pHaloLaunch<T>(D, xExt, 2, s);
+		if (rc == SMM_HIP_OK) rc = p2pLandLaunch<T>(D, xExt, 2, D->p2p->haloSeq[2], s);
+		DevBuf<T> tot;
+		SMM_TRY(tot.alloc(2));
+		const T mineTot[2] = {static_cast<T>(rank + 1), static_cast<T>(2 * (rank + 1))};
+		SMM_HIP_TRY(hipMemcpyAsync(tot, mineTot, sizeof(mineTot), hipMemcpyHostToDevice, s));
+		if (rc == SMM_HIP_OK) rc = p2pAllreduceLaunch<T>(D, P2P_RED_POINTS - 1, tot.p, 2, nullptr, s);
+		T got[2] = {T(0), T(0)};
+		unsigned long long err = 0;
+		SMM_HIP_TRY(hipMemcpyAsync(host.data(), xExt, host.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipMemcpyAsync(got, tot, sizeof(got), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipMemcpyAsync(&err, &D->p2p->hdr()->err, sizeof(err), hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		pass = rc == SMM_HIP_OK && err == 0;
+		for (const PlanSeg& g : mine) {
+			for (int i = 0; i < g.count && pass; ++i) {
+				const long long col = D->cmin + g.extOff + i;
+				pass = host[static_cast<size_t>(g.extOff + i)] == static_cast<T>(col % 8191);
+			}
+		}
+		const T want = static_cast<T>(0.5 * world * (world + 1));
+		pass = pass && got[0] == want && got[1] == 2 * want;
+		SMM_HIP_TRY(hipMemsetAsync(xExt, 0, host.size() * sizeof(T), s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+	}
+	SMM_TRY(p2pAllAgree(c, pass, &all));
+	if (!all) {
+		if (!pass) fprintf(stderr, "libsmm_hip: rank %d: the peer-to-peer self-test failed; every rank stays with the communicator's collectives\n", rank);
+		p2pTeardown(D);
+	}
+	return SMM_HIP_OK;
+}
+
+// the exchange of `ext`'s boundary slices: push kernel (direct parts + the shares staged at relays), then this rank's forwards
+template <typename T>
+static int p2pHaloLaunch(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t cs) {
+	P2PState* P = D->p2p;
+	const unsigned long long seq = ++P->haloSeq[kind];
+	if (P->nPush > 0) {
+		p2pCopyKernel<T, false><<<dim3(P2P_BLOCKS_PER_JOB, static_cast<unsigned>(P->nPush)), P2P_TPB, 0, cs>>>(P->d_push, P->d_counters, ext, kind, seq, P->hdr(), P->ticks);
+	}
+	if (P->nFwd > 0) {
+		const T* staging = reinterpret_cast<const T*>(static_cast<char*>(P->block) + P->stageOff[kind]);
+		p2pCopyKernel<T, true><<<dim3(P2P_BLOCKS_PER_JOB, static_cast<unsigned>(P->nFwd)), P2P_TPB, 0, cs>>>(P->d_fwd, P->d_counters + P->nPush, staging, kind, seq, P->hdr(),
+		                                                                                              P->ticks);
+	}
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long long seq, hipStream_t s) {
+	P2PState* P = D->p2p;
+	if (P->nLand == 0) return SMM_HIP_OK;
+	const T* landing = reinterpret_cast<const T*>(static_cast<char*>(P->block) + P->landOff[kind]);
+	p2pLandKernel<T><<<dim3(16, static_cast<unsigned>(P->nLand)), P2P_TPB, 0, s>>>(P->d_land, P->d_counters + P->nPush + P->nFwd, landing, ext, kind, seq, P->hdr(), P->ticks);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int count, const int* doneFlag, hipStream_t s) {
+	P2PState* P = D->p2p;
+	const unsigned long long seq = ++P->redSeq[point];
+	p2pAllreduceKernel<T><<<1, 64, 0, s>>>(P->peers, P->world, P->rank, point, seq, count, totals, P->ticks, doneFlag);
+	SMM_HIP_TRY(hipGetLastError());
+	return SMM_HIP_OK;
+}
+
+// the error word of the peer-to-peer path, read wherever the host reads `done` (stream `s` is synchronised by the caller afterwards)
+static int p2pPostErrRead(smm_hip_dist_csr* D, unsigned long long* err, hipStream_t s) {
+	*err = 0;
+	if (!D->p2p) return SMM_HIP_OK;
+	SMM_HIP_TRY(hipMemcpyAsync(err, &D->p2p->hdr()->err, sizeof(*err), hipMemcpyDeviceToHost, s));
+	return SMM_HIP_OK;
+}
+static int p2pFailIf(smm_hip_dist_csr* D, unsigned long long err) {
+	if (!err) return SMM_HIP_OK;
+	const unsigned what = static_cast<unsigned>(err >> 32);
+	static const char* const names[] = {"?", "a push for the destination's acknowledgement of the previous exchange (vector, destination rank)",
+	                                    "a forward for its staged share (vector, relay job)", "the land kernel for a part (vector, source rank, path)",
+	                                    "a reduction for a rank's slot (reduction point, rank)"};
+	setError("dist: rank %d waited longer than SMM_HIP_P2P_TIMEOUT_S for a peer (peer-to-peer path): %s = (%u, %u, %u), sequence number %llu; the communicator "
+	         "is unusable", D->comm->rank, names[std::min(4u, what >> 12)], (what >> 8) & 0xFu, (what >> 4) & 0xFu, what & 0xFu, err & 0xFFFFFFFFull);
+	fprintf(stderr, "libsmm_hip: %s\n", smm_hip_last_error());
+	D->comm->broken = true;
+	return SMM_HIP_ERR_COMM;
 }
 
 template <typename T>
@@ -599,6 +1121,8 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 	needs[2 * rank] = D->cmin;
 	needs[2 * rank + 1] = D->cmaxExcl;
 	SMM_TRY(commAllreduceI64(comm, needs.data(), 2 * world));
+	D->needs = needs;
+	D->bounds.assign(bounds, bounds + world + 1);
 	for (int q = 0; q < world; ++q) {
 		if (q == rank) continue;
 		long long lo = std::max<long long>(needs[2 * rank], bounds[q]), hi = std::min<long long>(needs[2 * rank + 1], bounds[q + 1]);
@@ -721,20 +1245,75 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 		}
 	}
 	SMM_TRY(distWorkspace<T>(D));
+	planHaloFirst<T>(D);
+	SMM_TRY(p2pSetup<T>(D));
 	guard.d = nullptr;
 	*out = D;
 	return SMM_HIP_OK;
 }
 
-// out = op(lhs, A ext) on the owned rows.  `ext` is a halo-extended vector whose owned slice is current; the halo is fetched here.
-// dotMode / w1 / parts as in launchSpmv; with dotMode != 0 parts is a finishing buffer and its totals are complete (locally) when
-// the last launch ends.
+// ---- one row-partitioned SpMV in two halves ---------------------------------------------------------------------------------------
+// distExchangeBegin: the boundary slices of `ext`'s owned part are final on `s` -- post the halo exchange (side stream; peer-to-peer
+// pushes or the communicator's grouped send / receive, in one piece or in `chunks`).  Called right behind the small "boundary" launch
+// of a vector update (halo first), so that the transfer starts before the bulk of the update has run.
+// distMatvecCompute: out = op(lhs, A ext) on the owned rows: the local block while the halo is in flight, then -- once it has landed --
+// the remote block(s), with the dot products of the freshly computed vector (dotMode / w1 / parts as in launchSpmv; parts a finishing
+// buffer) and the Jacobi division in the epilogue of the launch that completes a row.
 template <typename T>
-static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s,
-                      const T* jacobiDiag = nullptr) {
+static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t s) {
 	smm_hip_comm* c = D->comm;
-	const T* own = ext + D->ownOffset;
+	auto& pend = D->pending;
+	pend = smm_hip_dist_csr::Pending{};
 	const bool exchange = !D->sends.empty() || !D->recvs.empty();
+	if (!exchange) return SMM_HIP_OK;
+	pend.active = true;
+	pend.kind = kind;
+	if (D->p2p) {
+		hipStream_t cs = c->stream;
+		noteStream(cs);
+		SMM_TRY(orderAfter(c, s, cs));
+		SMM_TRY(p2pHaloLaunch<T>(D, ext, kind, cs));
+		pend.seq = D->p2p->haloSeq[kind];
+		pend.async = true;
+		return SMM_HIP_OK;
+	}
+	hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;  // the callback kind blocks anyway
+	noteStream(cs);
+	SMM_TRY(orderAfter(c, s, cs));
+	pend.async = cs != s;
+	if (D->chunks > 1) {
+		// (`chunks` is agreed by all ranks at create time and decides ALONE which form of the exchange runs: a rank whose own A_rem is empty --
+		// one-sided / upwind stencils, any structurally non-symmetric matrix: it sends but receives nothing -- must still post the K piece-sized
+		// sends its peers' K receives are waiting for; r04 tested `!remEmpty` as well and such a rank fell through to ONE full-count exchange:
+		// mismatched RCCL call sequences, a hang or a corrupt halo.  ADVICE r04.)
+		// The halo in pieces: every piece is an exchange of its own on the communicator's stream (all of them enqueued at once, so the links
+		// never idle between them)
+		for (int k = 0; k < D->chunks; ++k) {
+			SMM_TRY(commExchange<T>(c, ext, D->sendsK[static_cast<size_t>(k)], D->recvsK[static_cast<size_t>(k)], cs));
+			if (cs != s) {
+				pend.landed[k] = takeEvent(c);
+				SMM_HIP_TRY(hipEventRecord(pend.landed[k], cs));
+				pend.waitSlot[k] = profWaitAwaited(cs);
+			}
+		}
+		return SMM_HIP_OK;
+	}
+	SMM_TRY(commExchange<T>(c, ext, D->sends, D->recvs, cs));
+	if (cs != s) {
+		pend.landed[0] = takeEvent(c);
+		SMM_HIP_TRY(hipEventRecord(pend.landed[0], cs));
+		pend.waitSlot[0] = profWaitAwaited(cs);
+	}
+	return SMM_HIP_OK;
+}
+
+template <typename T>
+static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s,
+                             const T* jacobiDiag = nullptr) {
+	const T* own = ext + D->ownOffset;
+	auto& pend = D->pending;
+	const bool exchange = pend.active;
+	pend.active = false;
 	const int finish = dotMode ? SPMV_FINISH : 0;
 	// jacobiDiag (op must be SMM_OP_ASSIGN): out = (A x) / diag with the division folded into the launch that completes a row -- the
 	// local block's when nothing is remote, else the remote block's epilogue ("add, then divide"): the loop then has the kernel count
@@ -743,36 +1322,20 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 		if (jacobiDiag) return launchSpmv<T>(D->aLoc, op, jacobiDiag, own, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_DIV_LHS);
 		return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
 	}
-	if (D->chunks > 1 && exchange) {
-		// (`chunks` is agreed by all ranks at create time and decides ALONE which form of the exchange runs: a rank whose own A_rem is empty --
-		// one-sided / upwind stencils, any structurally non-symmetric matrix: it sends but receives nothing -- must still post the K piece-sized
-		// sends its peers' K receives are waiting for; r04 tested `!remEmpty` here as well and such a rank fell through to ONE full-count
-		// exchange: mismatched RCCL call sequences, a hang or a corrupt halo.  ADVICE r04.)
-		// The halo in pieces: every piece is an exchange of its own on the communicator's stream (all of them enqueued at once, so the
-		// links never idle between them), A_loc runs beside them, and the part of A_rem that reads only piece k starts as soon as THAT
-		// piece has landed: out = ((A_loc x + A_rem,0 x) + A_rem,1 x) + ... -- each part a row sum of its own, added in piece order
-		// (deterministic; differs from the one-piece form only in where the row sum is cut).  The fused dot products and the Jacobi
-		// division ride in the last part's epilogue.
+	// the local block runs while the halo is in flight; the exchange is itself a kernel (a few workgroups per peer), and the persistent
+	// SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
+	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, exchange && pend.async ? SPMV_LEAVE_ROOM : 0));
+	const int remOp = op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD;
+	if (exchange && D->p2p) {
+		SMM_TRY(p2pLandLaunch<T>(D, ext, pend.kind, pend.seq, s));  // waits for every part of every segment, then landing area -> halo
+	} else if (exchange && D->chunks > 1) {
+		// part k of A_rem reads only piece k and starts as soon as THAT piece has landed: out = ((A_loc x + A_rem,0 x) + A_rem,1 x) + ... -- each
+		// part a row sum of its own, added in piece order (deterministic; differs from the one-piece form only in where the row sum is cut)
 		const int K = D->chunks;
-		hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;
-		noteStream(cs);
-		SMM_TRY(orderAfter(c, s, cs));
-		hipEvent_t landedK[MAX_HALO_CHUNKS] = {};
-		int waitSlot[MAX_HALO_CHUNKS] = {-1, -1, -1, -1};
 		for (int k = 0; k < K; ++k) {
-			SMM_TRY(commExchange<T>(c, ext, D->sendsK[static_cast<size_t>(k)], D->recvsK[static_cast<size_t>(k)], cs));
-			if (cs != s) {
-				landedK[k] = takeEvent(c);
-				SMM_HIP_TRY(hipEventRecord(landedK[k], cs));
-				waitSlot[k] = profWaitAwaited(cs);
-			}
-		}
-		SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, cs != s ? SPMV_LEAVE_ROOM : 0));
-		const int remOp = op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD;
-		for (int k = 0; k < K; ++k) {
-			if (landedK[k]) {
-				profWaitWaiting(waitSlot[k], s);
-				SMM_HIP_TRY(hipStreamWaitEvent(s, landedK[k], 0));
+			if (pend.landed[k]) {
+				profWaitWaiting(pend.waitSlot[k], s);
+				SMM_HIP_TRY(hipStreamWaitEvent(s, pend.landed[k], 0));
 			}
 			const bool last = k == K - 1;
 			if (!last) {
@@ -784,39 +1347,33 @@ static int distMatvec(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out,
 				return launchSpmv<T>(D->aRemK[static_cast<size_t>(k)], remOp, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
 			}
 		}
-	}
-	hipEvent_t landed = nullptr;
-	int waitSlot = -1;
-	if (exchange) {
-		hipStream_t cs = c->kind == SMM_COMM_RCCL ? c->stream : s;  // the callback kind blocks anyway
-		noteStream(cs);
-		SMM_TRY(orderAfter(c, s, cs));
-		SMM_TRY(commExchange<T>(c, ext, D->sends, D->recvs, cs));
-		if (cs != s) {
-			landed = takeEvent(c);
-			SMM_HIP_TRY(hipEventRecord(landed, cs));
-			waitSlot = profWaitAwaited(cs);
-		}
-	}
-	// the local block runs while the halo is in flight; with RCCL the exchange is itself a kernel (a few workgroups per peer), and the
-	// persistent SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
-	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, landed ? SPMV_LEAVE_ROOM : 0));
-	if (landed) {
-		profWaitWaiting(waitSlot, s);  // (profiling on: how long A_rem waits for the halo after A_loc has ended -- the exposed part of the exchange)
-		SMM_HIP_TRY(hipStreamWaitEvent(s, landed, 0));
+	} else if (exchange && pend.landed[0]) {
+		profWaitWaiting(pend.waitSlot[0], s);  // (profiling on: how long A_rem waits for the halo after A_loc has ended -- the exposed part of the exchange)
+		SMM_HIP_TRY(hipStreamWaitEvent(s, pend.landed[0], 0));
 	}
 	if (jacobiDiag) return launchSpmv<T>(D->aRem, SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_ADD_DIV, jacobiDiag);
-	return launchSpmv<T>(D->aRem, op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
+	return launchSpmv<T>(D->aRem, remOp, out, ext, out, dotMode, w1, parts, doneFlag, s, finish);
+}
+
+// both halves back to back (the set-up SpMVs, the stand-alone distributed SpMV)
+template <typename T>
+static int distMatvec(smm_hip_dist_csr* D, T* ext, int kind, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s,
+                      const T* jacobiDiag = nullptr) {
+	SMM_TRY(distExchangeBegin<T>(D, ext, kind, s));
+	return distMatvecCompute<T>(D, ext, op, lhs, out, dotMode, w1, parts, doneFlag, s, jacobiDiag);
 }
 
 // all-reduce of the totals of a finishing buffer on the side stream; *joined = event the caller's stream must wait for (null when
 // nothing is pending)
 template <typename T>
-static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t s, hipEvent_t* joined) {
+static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t s, hipEvent_t* joined, int point = 0, const int* doneFlag = nullptr) {
 	smm_hip_comm* c = D->comm;
 	*joined = nullptr;
 	if (c->kind == SMM_COMM_SELF) return SMM_HIP_OK;
 	T* totals = parts + PARTS_TOTALS;
+	// peer to peer: ONE single-workgroup kernel on the solver's own stream writes this rank's totals into every rank's slot, waits for all
+	// slots of this sequence number and adds them in rank order (smm_p2p.h) -- no collective launch, no cross-stream events
+	if (D->p2p) return p2pAllreduceLaunch<T>(D, point, totals, count, doneFlag, s);
 	if (c->kind == SMM_COMM_HOST) return commAllreduce<T>(c, totals, count, s);
 	noteStream(c->stream);
 	SMM_TRY(orderAfter(c, s, c->stream));
@@ -868,15 +1425,30 @@ __global__ void distBicgInit(const T* __restrict__ totals, DistScal<T>* sc) {
 	sc->status = SMM_SOLVER_SUCCESS;
 }
 
-// alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247)
+// an element-wise map over up to four runs of rows (the boundary rows some peer receives / the rest: halo first)
+template <typename T, int NIN, int NOUT, typename F>
+__device__ __forceinline__ void rangesMap(const RowRanges& rg, const T* const* in, T* const* out, F&& f) {
+	for (int i = 0; i < rg.n; ++i) {
+		const T* in2[NIN];
+		T* out2[NOUT];
+#pragma unroll
+		for (int k = 0; k < NIN; ++k) in2[k] = in[k] + rg.lo[i];
+#pragma unroll
+		for (int k = 0; k < NOUT; ++k) out2[k] = out[k] + rg.lo[i];
+		streamMap<T, false, NIN, NOUT>(rg.hi[i] - rg.lo[i], in2, out2, f);
+	}
+}
+
+// alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247).  book: this launch records alpha (the other launch of the pair -- boundary
+// rows first, then the bulk -- forms the same alpha from the same operands and only uses it)
 template <typename T>
-__global__ __launch_bounds__(TPB) void distBicgS(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsA, const T* ap, const T* r, T* sv) {
+__global__ __launch_bounds__(TPB) void distBicgS(RowRanges rg, int book, DistScal<T>* sc, int par, const T* __restrict__ totalsA, const T* ap, const T* r, T* sv) {
 	if (sc->done) return;
 	const T alpha = sc->rrPing[par] / totalsA[0];
-	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
+	if (book && blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
 	const T* const in[2] = {ap, r};
 	T* const out[1] = {sv};
-	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(-alpha, v[0], v[1]); });
+	rangesMap<T, 2, 1>(rg, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(-alpha, v[0], v[1]); });
 }
 
 // omega = (as.s) / (as.as) ; r = -omega as + s ; local ||r||^2 and r.r0   (ref:2259-2261, 2265)
@@ -915,16 +1487,16 @@ __global__ __launch_bounds__(TPB) void distBicgX(int n, const DistScal<T>* __res
 	streamMap<T, false, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) { o[0] = smmFma(alpha, v[2], smmFma(omega, v[0], v[1])); });
 }
 
-// resL2Norm, loop test, beta, p = beta (-omega ap + p) + r   (ref:2268-2277)
+// resL2Norm, loop test, beta, p = beta (-omega ap + p) + r   (ref:2268-2277).  book: this launch does the scalar bookkeeping (once per pair)
 template <typename T>
-__global__ __launch_bounds__(TPB) void distBicgP(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, const T* ap, const T* r, T* p) {
+__global__ __launch_bounds__(TPB) void distBicgP(RowRanges rg, int book, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, const T* ap, const T* r, T* p) {
 	if (sc->done) return;
 	const T rr = totalsC[0];
 	const T newRR0 = totalsC[1];
 	const T res = sizeof(T) == 4 ? static_cast<T>(__fsqrt_rn(static_cast<float>(rr))) : static_cast<T>(__dsqrt_rn(static_cast<double>(rr)));
 	const T alpha = sc->alpha, omega = sc->omega, rr0 = sc->rrPing[par];
 	const bool leave = !(res > eps);
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
+	if (book && blockIdx.x == 0 && threadIdx.x == 0) {
 		sc->res = res;
 		sc->rrPing[par ^ 1] = newRR0;
 		sc->iters += 1;
@@ -934,7 +1506,7 @@ __global__ __launch_bounds__(TPB) void distBicgP(int n, DistScal<T>* sc, int par
 	const T beta = (newRR0 * alpha) / (rr0 * omega);  // ref:2271
 	const T* const in[3] = {ap, p, r};
 	T* const out[1] = {p};
-	streamMap<T, false, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) { o[0] = smmFma(beta, smmFma(-omega, v[0], v[1]), v[2]); });
+	rangesMap<T, 3, 1>(rg, in, out, [&](const T(&v)[3], T(&o)[1]) { o[0] = smmFma(beta, smmFma(-omega, v[0], v[1]), v[2]); });
 }
 
 template <typename T>
@@ -981,14 +1553,14 @@ __global__ __launch_bounds__(TPB) void distCgX(int n, const DistScal<T>* __restr
 	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(alpha, v[0], v[1]); });
 }
 
-// convergence test, beta, p = beta p + r   (ref:2377-2394)
+// convergence test, beta, p = beta p + r   (ref:2377-2394).  book: as in distBicgP
 template <typename T>
-__global__ __launch_bounds__(TPB) void distCgP(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, T* p, const T* r) {
+__global__ __launch_bounds__(TPB) void distCgP(RowRanges rg, int book, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, T* p, const T* r) {
 	if (sc->done) return;
 	const T rrNew = totalsC[0];
 	const T rrOld = sc->rrPing[par];
 	const bool converged = eps * eps > rrNew;
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
+	if (book && blockIdx.x == 0 && threadIdx.x == 0) {
 		sc->iters += 1;
 		sc->res = rrNew;
 		if (converged) {
@@ -1002,7 +1574,7 @@ __global__ __launch_bounds__(TPB) void distCgP(int n, DistScal<T>* sc, int par, 
 	const T beta = rrNew / rrOld;
 	const T* const in[2] = {p, r};
 	T* const out[1] = {p};
-	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
+	rangesMap<T, 2, 1>(rg, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
 }
 
 static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, NPART))); }
@@ -1011,9 +1583,45 @@ static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1,
 // iteration on every rank, so a BLOCKING read of it at fixed iteration numbers is consistent; the asynchronous mailbox of the single-GPU
 // loops (whose answer depends on how far the host has run ahead) is not.  One pipeline drain every CHECK_EVERY iterations.
 constexpr int CHECK_EVERY = 16;
-static int readDone(smm_hip_comm* c, const int* d_done, hipStream_t s, int* done) {
+static int readDone(smm_hip_dist_csr* D, const int* d_done, hipStream_t s, int* done) {
+	unsigned long long err = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(done, d_done, sizeof(int), hipMemcpyDeviceToHost, s));
-	return boundedSync(c, s);
+	SMM_TRY(p2pPostErrRead(D, &err, s));
+	SMM_TRY(boundedSync(D->comm, s));
+	return p2pFailIf(D, err);
+}
+
+// A vector update whose result feeds the next SpMV, halo first: the boundary rows some peer receives in a small launch, the exchange posted
+// right behind it, the bulk in a second launch -- the same expressions on the same operands, the same bits as one launch.
+// LAUNCH(ranges, book) enqueues the update kernel on `s` for those rows; `book`: that launch does the kernel's scalar bookkeeping.
+template <typename T, typename Launch>
+static int updateThenExchange(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t s, Launch&& launch) {
+	if (D->haloFirst) {
+		launch(D->boundary, 0);
+		SMM_TRY(distExchangeBegin<T>(D, ext, kind, s));
+		launch(D->bulk, 1);
+	} else {
+		RowRanges all{};
+		all.n = 1;
+		all.hi[0] = D->nLocal;
+		launch(all, 1);
+		SMM_TRY(distExchangeBegin<T>(D, ext, kind, s));
+	}
+	return SMM_HIP_OK;
+}
+
+// an exchange that was posted but whose SpMV never runs (the loop was left): the peer-to-peer path must still empty the landing area and
+// acknowledge, or the sources' next push of that vector would wait for ever; the communicator's collectives are complete in themselves
+template <typename T>
+static int distExchangeDrain(smm_hip_dist_csr* D, T* ext, hipStream_t s) {
+	auto& pend = D->pending;
+	if (!pend.active) return SMM_HIP_OK;
+	pend.active = false;
+	if (D->p2p) return p2pLandLaunch<T>(D, ext, pend.kind, pend.seq, s);
+	for (hipEvent_t e : pend.landed) {
+		if (e) SMM_HIP_TRY(hipStreamWaitEvent(s, e, 0));  // (the next use of `ext` on `s` must not overtake the receive)
+	}
+	return SMM_HIP_OK;
 }
 
 template <typename T>
@@ -1035,7 +1643,7 @@ static int distSpmv(smm_hip_dist_csr* D, int op, const T* lhs, const T* xOwn, T*
 	}
 	T* xExt = static_cast<T*>(D->xExt);
 	if (D->nLocal > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, xOwn, sizeof(T) * D->nLocal, hipMemcpyDeviceToDevice, s));
-	return distMatvec<T>(D, xExt, op, lhs, out, 0, nullptr, nullptr, nullptr, s);
+	return distMatvec<T>(D, xExt, 2, op, lhs, out, 0, nullptr, nullptr, nullptr, s);
 }
 
 template <typename T>
@@ -1076,14 +1684,15 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	// r = b - A x (ref:2215) [; r = M^-1 r, ref:2217-2224]
 	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
 	if (pre) {
-		SMM_TRY(distMatvec<T>(D, xExt, SMM_OP_SUB, b, scratch, 0, nullptr, nullptr, nullptr, s));
+		SMM_TRY(distMatvec<T>(D, xExt, 2, SMM_OP_SUB, b, scratch, 0, nullptr, nullptr, nullptr, s));
 		SMM_TRY(precondApplyDev<T>(M, scratch, r, nullptr, s));
 	} else {
-		SMM_TRY(distMatvec<T>(D, xExt, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));
+		SMM_TRY(distMatvec<T>(D, xExt, 2, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));
 	}
 	SMM_TRY(launchCopy2<T>(n, r, r0, p, s));                              // r0 = p = r, ref:2225-2226
+	SMM_TRY(distExchangeBegin<T>(D, pExt, 0, s));                         // the halo of p travels while r.r0 is reduced
 	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);  // r.r0 with r0 == r, ref:2231
-	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev));
+	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
 	SMM_TRY(join(s, ev));
 	distBicgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc);
 
@@ -1092,45 +1701,60 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	for (int i = 0; i < planned; ++i) {
 		if (i > 0 && i % CHECK_EVERY == 0) {
 			int seen = 0;
-			SMM_TRY(readDone(D->comm, doneFlag, s, &seen));
+			SMM_TRY(readDone(D, doneFlag, s, &seen));
 			if (seen) break;
 		}
 		const int par = i & 1;
-		// ap = [M^-1] A p ; ap.r0 (ref:2233-2243)
+		// ap = [M^-1] A p ; ap.r0 (ref:2233-2243) -- the exchange of p was posted behind its update
 		if (jacobiDiag) {
-			SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s, jacobiDiag));
+			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s, jacobiDiag));
 		} else if (pre) {
-			SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
+			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, ap, r0, nullptr, 1, partsA, doneFlag);
 		} else {
-			SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s));
+			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s));
 		}
-		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev));
+		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
 		SMM_TRY(join(s, ev));
-		distBicgS<T><<<gridFor(n), TPB, 0, s>>>(n, sc, par, partsA + PARTS_TOTALS, ap, r, sv);
+		SMM_TRY((updateThenExchange<T>(D, sExt, 1, s, [&](const RowRanges& rg, int book) {
+			distBicgS<T><<<gridFor(rg.rows()), TPB, 0, s>>>(rg, book, sc, par, partsA + PARTS_TOTALS, ap, r, sv);
+		})));
 		// as = [M^-1] A s ; as.as, as.s (ref:2249-2261)
 		if (jacobiDiag) {
-			SMM_TRY(distMatvec<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s, jacobiDiag));
+			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s, jacobiDiag));
 		} else if (pre) {
-			SMM_TRY(distMatvec<T>(D, sExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
+			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, as, as, sv, 2, partsB, doneFlag);
 		} else {
-			SMM_TRY(distMatvec<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s));
+			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s));
 		}
-		SMM_TRY(allreduceTotals<T>(D, partsB, 2, s, &ev));
+		SMM_TRY(allreduceTotals<T>(D, partsB, 2, s, &ev, 1, doneFlag));
 		SMM_TRY(join(s, ev));
 		distBicgR<T><<<NPART, TPB, 0, s>>>(n, sc, partsB + PARTS_TOTALS, sv, as, r0, r, partsC);
-		SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev));  // on the side stream ...
-		distBicgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, sv, x);  // ... while x is updated
+		SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev, 2, doneFlag));  // (the communicator's collectives: on the side stream ...
+		distBicgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, sv, x);         // ... while x is updated)
 		SMM_TRY(join(s, ev));
-		distBicgP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, par, partsC + PARTS_TOTALS, eps, ap, r, p);
+		if (i + 1 < planned) {
+			SMM_TRY((updateThenExchange<T>(D, pExt, 0, s, [&](const RowRanges& rg, int book) {
+				distBicgP<T><<<gridFor(rg.rows()), TPB, 0, s>>>(rg, book, sc, par, partsC + PARTS_TOTALS, eps, ap, r, p);
+			})));
+		} else {
+			RowRanges all{};
+			all.n = 1;
+			all.hi[0] = n;
+			distBicgP<T><<<gridFor(n), TPB, 0, s>>>(all, 1, sc, par, partsC + PARTS_TOTALS, eps, ap, r, p);  // the last pass: no SpMV follows
+		}
 	}
+	SMM_TRY(distExchangeDrain<T>(D, pExt, s));  // (left early: the exchange posted for the pass that never ran)
 	SMM_HIP_TRY(hipGetLastError());
 	DistScal<T> h;
+	unsigned long long p2pErr = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
+	SMM_TRY(p2pPostErrRead(D, &p2pErr, s));
 	SMM_TRY(boundedSync(D->comm, s));
+	SMM_TRY(p2pFailIf(D, p2pErr));
 	if (status) *status = h.iters > maxIterations ? SMM_SOLVER_MAX_ITERATIONS_REACHED : SMM_SOLVER_SUCCESS;  // ref:2279-2282
 	if (iterations) *iterations = h.iters;
 	if (resnorm) *resnorm = h.res;
@@ -1158,33 +1782,47 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	auto* sc = static_cast<DistScal<T>*>(D->sc);
 	hipEvent_t ev = nullptr;
 	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x0, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
-	SMM_TRY(distMatvec<T>(D, xExt, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
-	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));                                        // p = r, ref:2340
+	SMM_TRY(distMatvec<T>(D, xExt, 2, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
+	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));                                           // p = r, ref:2340
 	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);
-	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev));
+	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
 	SMM_TRY(join(s, ev));
 	distCgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc, eps);
 	const int* doneFlag = &sc->done;
 	for (int i = 0; i < maxIterations; ++i) {
 		if (i % CHECK_EVERY == 0) {  // i == 0: the early exit of ref:2342-2344 costs nothing more than this read
 			int seen = 0;
-			SMM_TRY(readDone(D->comm, doneFlag, s, &seen));
+			SMM_TRY(readDone(D, doneFlag, s, &seen));
 			if (seen) break;
 		}
 		const int par = i & 1;
-		SMM_TRY(distMatvec<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, p, partsA, doneFlag, s));  // Ap = A p ; p.Ap, ref:2353-2354
-		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev));
+		if (i == 0) SMM_TRY(distExchangeBegin<T>(D, pExt, 0, s));  // (later passes: posted behind the update of p)
+		SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, p, partsA, doneFlag, s));  // Ap = A p ; p.Ap, ref:2353-2354
+		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
 		SMM_TRY(join(s, ev));
 		distCgR<T><<<NPART, TPB, 0, s>>>(n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC);
-		SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev));                        // on the side stream ...
-		distCgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, i == 0 ? x0 : x, x);      // ... while x is updated (ref:2351, 2395)
+		SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2, doneFlag));           // (the communicator's collectives: on the side stream ...
+		distCgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, i == 0 ? x0 : x, x);      // ... while x is updated; ref:2351, 2395)
 		SMM_TRY(join(s, ev));
-		distCgP<T><<<gridFor(n), TPB, 0, s>>>(n, sc, par, partsC + PARTS_TOTALS, eps, p, r);
+		if (i + 1 < maxIterations) {
+			SMM_TRY((updateThenExchange<T>(D, pExt, 0, s, [&](const RowRanges& rg, int book) {
+				distCgP<T><<<gridFor(rg.rows()), TPB, 0, s>>>(rg, book, sc, par, partsC + PARTS_TOTALS, eps, p, r);
+			})));
+		} else {
+			RowRanges all{};
+			all.n = 1;
+			all.hi[0] = n;
+			distCgP<T><<<gridFor(n), TPB, 0, s>>>(all, 1, sc, par, partsC + PARTS_TOTALS, eps, p, r);
+		}
 	}
+	SMM_TRY(distExchangeDrain<T>(D, pExt, s));
 	SMM_HIP_TRY(hipGetLastError());
 	DistScal<T> h;
+	unsigned long long p2pErr = 0;
 	SMM_HIP_TRY(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
+	SMM_TRY(p2pPostErrRead(D, &p2pErr, s));
 	SMM_TRY(boundedSync(D->comm, s));
+	SMM_TRY(p2pFailIf(D, p2pErr));
 	if (status) *status = h.status;
 	if (iterations) *iterations = h.iters;
 	if (resnorm2) *resnorm2 = h.res;
@@ -1436,6 +2074,7 @@ int smm_hip_dist_csr_create_dev_f64(smm_hip_comm* comm, int n_global, const int*
 
 int smm_hip_dist_csr_destroy(smm_hip_dist_csr* D) {
 	if (!D) return SMM_HIP_OK;
+	p2pTeardown(D);
 	smm_hip_csr_destroy(D->aLoc);
 	smm_hip_csr_destroy(D->aRem);
 	for (smm_hip_csr* piece : D->aRemK) smm_hip_csr_destroy(piece);
@@ -1467,6 +2106,18 @@ int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks) {
 		return SMM_HIP_ERR_INVALID;
 	}
 	*chunks = D->chunks;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, int* halo_first, double* direct_share) {
+	if (!D) {
+		setError("dist_csr_options: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (p2p) *p2p = D->p2p ? 1 : 0;
+	if (relays) *relays = D->p2p ? D->p2p->relays : 0;
+	if (halo_first) *halo_first = D->haloFirst ? 1 : 0;
+	if (direct_share) *direct_share = D->p2p ? D->p2p->directShare : 1.0;
 	return SMM_HIP_OK;
 }
 

@@ -88,6 +88,15 @@ int devAlloc(void** p, size_t bytes);
 void devFree(void* p);
 void devTrim();
 
+// Host <-> device copies of the host-pointer entry points (the reference's calling convention: caller-owned, PAGEABLE arrays), staged
+// through pinned chunks of the library's own instead of letting the HIP runtime pin the caller's pages in place.  r05 measurement
+// (tools/lab/pageable_copy_probe.hip, profiles/r05/pageable_copy_probe.txt): with in-place pinning the SECOND pair of 10 MB copies of a
+// process takes 21-28 ms instead of 0.4 (and 40 MB vectors 14-16 ms instead of 3.5 for four calls in a row) -- hipHostRegister around the
+// call behaves the same --, staged copies take 0.8 / 6 ms every time.  hostToDev returns when `h_src` has been read (the device copy may
+// still be in flight on `s`); devToHost synchronises `s`.
+int hostToDev(void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
+int devToHost(void* h_dst, const void* d_src, size_t bytes, hipStream_t s);
+
 template <typename T>
 struct DevBuf {
 	T* p = nullptr;

@@ -1003,10 +1003,9 @@ static int applyHost(const smm_hip_precond* M, const T* rhs, T* x) {
 	DevBuf<T> dr, dx;
 	SMM_TRY(dr.alloc(n));
 	SMM_TRY(dx.alloc(n));
-	if (n) SMM_HIP_TRY(hipMemcpyAsync(dr, rhs, sizeof(T) * n, hipMemcpyHostToDevice, s));
+	SMM_TRY(hostToDev(dr, rhs, sizeof(T) * n, s));
 	SMM_TRY(precondApplyDev<T>(M, dr, dx, nullptr, s));
-	if (n) SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	SMM_TRY(devToHost(x, dx, sizeof(T) * n, s));
 	return precondTakeError(M, s);
 }
 

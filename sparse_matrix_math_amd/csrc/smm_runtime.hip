@@ -175,11 +175,9 @@ static void closeEpochLocked() {
 		if (hipStreamIsCapturing(k, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) continue;
 		(void)hipGetLastError();
 		// A stream with nothing pending needs no event: whatever was queued on it before the frees is done.  This is the steady state of
-		// solve after solve (a solve ends with a synchronise of its stream), and it is not only cheaper: r05 found 18-22 ms in the SECOND
-		// host-pointer solve of a process ("none.solve_ms 53 ms against Jacobi's 33") in exactly this wait -- an event recorded
-		// on the idle stream right after the process's first large copy to pageable host memory was reported complete by hipEventQuery only
-		// ~20 ms later (the runtime's completion-callback thread was busy; under rocprofv3's API trace the delay disappears), while
-		// hipStreamQuery answers from the state hipStreamSynchronize itself left behind (profiles/r05/second_solve_trace.txt).
+		// solve after solve (a solve ends with a synchronise of its stream): no record, no polls.  (r05 first suspected this wait of the 18-22 ms
+		// the SECOND host-pointer solve of a process lost; with the events gone the same delay showed up in the next copy from the caller's
+		// pageable memory -- the HIP runtime's in-place pinning, see hostToDev below.)
 		if (hipStreamQuery(k) == hipSuccess) continue;
 		(void)hipGetLastError();
 		hipEvent_t ev = nullptr;
@@ -326,6 +324,108 @@ void devTrim() {
 	g_epochs.clear();
 	for (auto& kv : g_free) hipFree(kv.second);
 	g_free.clear();
+}
+
+// ---- staged host <-> device copies (declared in smm_internal.h) ---------------------------------------------------------------
+namespace {
+struct CopyStage {
+	static constexpr int SLOTS = 4;
+	static constexpr size_t CHUNK = 8u << 20;
+	char* buf[SLOTS] = {};
+	hipEvent_t ev[SLOTS] = {};
+	bool busy[SLOTS] = {};
+	int next = 0;
+	int init() {
+		if (buf[0]) return SMM_HIP_OK;
+		for (int i = 0; i < SLOTS; ++i) {
+			SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&buf[i]), CHUNK, hipHostMallocDefault));
+			SMM_HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+		}
+		return SMM_HIP_OK;
+	}
+	int wait(int i) {
+		if (busy[i]) SMM_HIP_TRY(hipEventSynchronize(ev[i]));
+		busy[i] = false;
+		return SMM_HIP_OK;
+	}
+	~CopyStage() {
+		for (int i = 0; i < SLOTS; ++i) {
+			if (ev[i]) {
+				(void)hipEventSynchronize(ev[i]);
+				(void)hipEventDestroy(ev[i]);
+			}
+			if (buf[i]) (void)hipHostFree(buf[i]);
+		}
+	}
+};
+}  // namespace
+
+static CopyStage& copyStage() {
+	static thread_local CopyStage st;  // per host thread: concurrent solves of different threads never share a chunk
+	return st;
+}
+
+static bool stagedCopies() {
+	static const bool on = [] {
+		const char* env = getenv("SMM_HIP_STAGED_COPIES");  // 0: hand the caller's pointers to hipMemcpyAsync as before (measurements)
+		return env ? atoi(env) != 0 : true;
+	}();
+	return on;
+}
+
+int hostToDev(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+	if (!bytes) return SMM_HIP_OK;
+	if (!stagedCopies()) {
+		SMM_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+		return SMM_HIP_OK;
+	}
+	CopyStage& st = copyStage();
+	SMM_TRY(st.init());
+	for (size_t at = 0; at < bytes; at += CopyStage::CHUNK) {
+		const size_t len = std::min(CopyStage::CHUNK, bytes - at);
+		const int i = st.next;
+		st.next = (st.next + 1) % CopyStage::SLOTS;
+		SMM_TRY(st.wait(i));  // (the chunk's previous device copy has ended)
+		memcpy(st.buf[i], static_cast<const char*>(h_src) + at, len);
+		SMM_HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_dst) + at, st.buf[i], len, hipMemcpyHostToDevice, s));
+		SMM_HIP_TRY(hipEventRecord(st.ev[i], s));
+		st.busy[i] = true;
+	}
+	return SMM_HIP_OK;
+}
+
+int devToHost(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
+	if (!stagedCopies() || !bytes) {
+		if (bytes) SMM_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		return SMM_HIP_OK;
+	}
+	CopyStage& st = copyStage();
+	SMM_TRY(st.init());
+	const size_t nChunks = (bytes + CopyStage::CHUNK - 1) / CopyStage::CHUNK;
+	int slotOf[CopyStage::SLOTS];
+	size_t issued = 0, drained = 0;
+	while (drained < nChunks) {
+		// keep up to SLOTS device copies in flight, hand finished chunks to the caller's array in order
+		while (issued < nChunks && issued - drained < static_cast<size_t>(CopyStage::SLOTS)) {
+			const int i = st.next;
+			st.next = (st.next + 1) % CopyStage::SLOTS;
+			SMM_TRY(st.wait(i));
+			const size_t at = issued * CopyStage::CHUNK, len = std::min(CopyStage::CHUNK, bytes - at);
+			SMM_HIP_TRY(hipMemcpyAsync(st.buf[i], static_cast<const char*>(d_src) + at, len, hipMemcpyDeviceToHost, s));
+			SMM_HIP_TRY(hipEventRecord(st.ev[i], s));
+			st.busy[i] = true;
+			slotOf[issued % CopyStage::SLOTS] = i;
+			++issued;
+		}
+		const int i = slotOf[drained % CopyStage::SLOTS];
+		SMM_TRY(st.wait(i));
+		const size_t at = drained * CopyStage::CHUNK, len = std::min(CopyStage::CHUNK, bytes - at);
+		memcpy(static_cast<char*>(h_dst) + at, st.buf[i], len);
+		++drained;
+	}
+	SMM_HIP_TRY(hipStreamSynchronize(s));  // (everything else queued on `s` too: the callers' contract)
+	return SMM_HIP_OK;
 }
 
 // ---- live SpMV timing -------------------------------------------------------------------------------------

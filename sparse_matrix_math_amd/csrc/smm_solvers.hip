@@ -714,8 +714,8 @@ static int bicgstabFunctorHost(const smm_hip_csr* a, T* b, T* x, int maxIteratio
 		~Unpin() { hipHostFree(p); }
 	} unpin{pinned};
 	if (n) {
-		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
-		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_TRY(hostToDev(db, b, sizeof(T) * n, s));
+		SMM_TRY(hostToDev(dx, x, sizeof(T) * n, s));
 	}
 	const HostApplier<T> apply{fn, user, n, pinned, pinned + std::max(1, n)};
 	const int rc = bicgstabLoop<T, HostApplier<T>>(a, db, dx, maxIterations, eps, true, apply, s, status, iterations, resnorm);
@@ -724,8 +724,7 @@ static int bicgstabFunctorHost(const smm_hip_csr* a, T* b, T* x, int maxIteratio
 		return rc;
 	}
 	if (n) {
-		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));
+		SMM_TRY(devToHost(x, dx, sizeof(T) * n, s));
 	}
 	return SMM_HIP_OK;
 }
@@ -804,17 +803,16 @@ static int cgHost(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIt
 	SMM_TRY(dx0.alloc(n));
 	SMM_TRY(dx.alloc(n));
 	if (n) {
-		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
-		SMM_HIP_TRY(hipMemcpyAsync(dx0, x0, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_TRY(hostToDev(db, b, sizeof(T) * n, s));
+		SMM_TRY(hostToDev(dx0, x0, sizeof(T) * n, s));
 		// x is only written once the loop runs (ref:2342-2344): start the device copy from the caller's x
-		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_TRY(hostToDev(dx, x, sizeof(T) * n, s));
 	}
 	int it = 0;
 	SMM_TRY(cgDev<T>(a, db, dx0, dx, maxIterations, eps, M, s, status, &it, resnorm2));
 	if (iterations) *iterations = it;
 	if (n && it > 0) {
-		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));
+		SMM_TRY(devToHost(x, dx, sizeof(T) * n, s));
 	}
 	return SMM_HIP_OK;
 }
@@ -842,8 +840,8 @@ static int bicgstabHost(const smm_hip_csr* a, T* b, T* x, int maxIterations, T e
 	}
 	if (n) {
 		SetupTrace trace("bicgstab (host pointers):   copy b, x in");
-		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
-		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_TRY(hostToDev(db, b, sizeof(T) * n, s));
+		SMM_TRY(hostToDev(dx, x, sizeof(T) * n, s));
 		if (SetupTrace::on()) SMM_HIP_TRY(hipStreamSynchronize(s));
 	}
 	{
@@ -852,8 +850,7 @@ static int bicgstabHost(const smm_hip_csr* a, T* b, T* x, int maxIterations, T e
 	}
 	if (n) {
 		SetupTrace trace("bicgstab (host pointers):   copy x out");
-		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));
+		SMM_TRY(devToHost(x, dx, sizeof(T) * n, s));
 	}
 	return SMM_HIP_OK;
 }
@@ -875,13 +872,12 @@ static int bicgsymmetricHost(const smm_hip_csr* a, T* b, T* x, int maxIterations
 	SMM_TRY(db.alloc(n));
 	SMM_TRY(dx.alloc(n));
 	if (n) {
-		SMM_HIP_TRY(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, s));
-		SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * n, hipMemcpyHostToDevice, s));
+		SMM_TRY(hostToDev(db, b, sizeof(T) * n, s));
+		SMM_TRY(hostToDev(dx, x, sizeof(T) * n, s));
 	}
 	SMM_TRY(bicgsymmetricDev<T>(a, db, dx, maxIterations, eps, s, status, iterations));
 	if (n) {
-		SMM_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * n, hipMemcpyDeviceToHost, s));
-		SMM_HIP_TRY(hipStreamSynchronize(s));
+		SMM_TRY(devToHost(x, dx, sizeof(T) * n, s));
 	}
 	return SMM_HIP_OK;
 }

@@ -1136,7 +1136,7 @@ static int spmvHost(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* o
 	DevBuf<T> dx, dl, dout;
 	SMM_TRY(dx.alloc(m->cols));
 	SMM_TRY(dout.alloc(m->rows));
-	if (m->cols) SMM_HIP_TRY(hipMemcpyAsync(dx, x, sizeof(T) * m->cols, hipMemcpyHostToDevice, s));
+	SMM_TRY(hostToDev(dx, x, sizeof(T) * m->cols, s));
 	const T* dlhs = nullptr;
 	if (op != SMM_OP_ASSIGN) {
 		if (!lhs && m->rows) {
@@ -1144,12 +1144,11 @@ static int spmvHost(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* o
 			return SMM_HIP_ERR_INVALID;
 		}
 		SMM_TRY(dl.alloc(m->rows));
-		if (m->rows) SMM_HIP_TRY(hipMemcpyAsync(dl, lhs, sizeof(T) * m->rows, hipMemcpyHostToDevice, s));
+		SMM_TRY(hostToDev(dl, lhs, sizeof(T) * m->rows, s));
 		dlhs = dl;
 	}
 	SMM_TRY(launchSpmv<T>(m, op, dlhs, dx, dout, 0, nullptr, nullptr, nullptr, s));
-	if (m->rows) SMM_HIP_TRY(hipMemcpyAsync(out, dout, sizeof(T) * m->rows, hipMemcpyDeviceToHost, s));
-	SMM_HIP_TRY(hipStreamSynchronize(s));
+	SMM_TRY(devToHost(out, dout, sizeof(T) * m->rows, s));
 	return SMM_HIP_OK;
 }
 

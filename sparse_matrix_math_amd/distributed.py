@@ -566,6 +566,10 @@ class NativeDistMatrix:
         k = ctypes.c_int()
         self.check(self.lib.smm_hip_dist_csr_halo_chunks(self._h, ctypes.byref(k)))
         self.halo_chunks = k.value  # pieces the halo travels in (SMM_HIP_HALO_CHUNKS at create time, agreed by all ranks; 1 = one exchange per SpMV)
+        p2p, relays, first, share = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        self.check(self.lib.smm_hip_dist_csr_options(self._h, ctypes.byref(p2p), ctypes.byref(relays), ctypes.byref(first), ctypes.byref(share)))
+        # how the halo and the scalars travel (smm_hip.h, smm_hip_dist_csr_options): agreed by all ranks when the matrix was created
+        self.options = {"p2p": bool(p2p.value), "relays": relays.value, "halo_first": bool(first.value), "direct_share": share.value}
         self._M = None
 
     def local_blocks(self):
@@ -759,6 +763,7 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         "exposed_comm": {"total_ms": exposed_ms, "exchanges": exchanges, "ms_per_exchange": exposed_ms / max(exchanges, 1),
                          "note": "rank 0; events: end of A_loc on the solver's stream -> end of the halo exchange on the communicator's stream, clipped at 0"},
         "halo_chunks": A.halo_chunks if driver == "native" else 1,
+        "dist_options": A.options if driver == "native" else None,
         "per_rank": {"rows": hi - lo, "nnz": nnz_local, "halo_elements": halo,
                      "spmv_launch_ms_rank0": spmv_ms / max(spmv_launches, 1), "spmv_launches_rank0": spmv_launches},
     }

@@ -80,7 +80,8 @@ def _run_ranks(world, fn):
     return out
 
 
-def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", precond=None, x0_full=None, families=None, chunks_seen=None):
+def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", precond=None, x0_full=None, families=None, chunks_seen=None, options_seen=None,
+           own_streams=False):
     import torch
 
     from sparse_matrix_math_amd.distributed import NativeDistMatrix, partition_rows_by_nnz
@@ -105,16 +106,30 @@ def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", preco
         x = torch.zeros(hi - lo, dtype=tdt, device=dev) if x0_full is None else torch.from_numpy(x0_full[lo:hi].copy()).to(dev)
         # y = A x through the distributed SpMV as well
         y = torch.empty(hi - lo, dtype=tdt, device=dev)
-        A.spmv(0, None, b, y)
+        # own_streams: every thread rank works on a stream of its own and nobody synchronises the DEVICE while a peer may be running: with the
+        # peer-to-peer path kernels of one rank wait (bounded) for kernels of another, which must neither sit behind them on the shared default
+        # stream nor be waited for by a device-wide synchronise of the rank they wait for (ranks in separate processes on separate GPUs -- the
+        # real deployment -- cannot do that to each other)
+        own = torch.cuda.Stream(device=dev) if own_streams else None
+        stream = own.cuda_stream if own_streams else None
+        if own_streams:
+            torch.cuda.synchronize()
+            shared.barrier.wait()
+        A.spmv(0, None, b, y, stream)
         if solver == "cg":
-            res = A.cg(b, x, x, max_it, eps)
+            res = A.cg(b, x, x, max_it, eps, stream)
         else:
-            res = A.bicgstab(b, x, max_it, eps)
+            res = A.bicgstab(b, x, max_it, eps, stream)
+        if own_streams:
+            own.synchronize()
+            shared.barrier.wait()
         torch.cuda.synchronize()
         if families is not None:  # (kernel family, lanes, PATTERN encoding) of this rank's A_loc and A_rem after the solve
             families[rank] = tuple(blk.get_kernel() + blk.pattern_info()[:1] for blk in A.local_blocks()) + (A.local_blocks()[0].kernel_desc()[0],)
         if chunks_seen is not None:
             chunks_seen[rank] = A.halo_chunks
+        if options_seen is not None:
+            options_seen[rank] = dict(A.options)
         r = (res, lo, hi, x.cpu().numpy(), y.cpu().numpy(), A.halo_elements)
         A.close()
         comm.close()
@@ -418,6 +433,82 @@ def test_partition_rows_by_nnz_native_matches_python(smm):
         assert list(out) == partition_rows_by_nnz(lambda i: int(start[i]), len(start) - 1, world)
 
 
+def p2p_thread_rank_cases():
+    """(run in a child process by test_peer_to_peer_thread_ranks, see there)  The row-partitioned BiCGStab / CG / SpMV with the peer-to-peer data
+    movement of csrc/smm_p2p.h -- pushes into the peers' landing areas, relays, reductions through per-rank slots -- against the same
+    solves through the communicator's collectives: pure data movement and sums in rank order, so every result is bit for bit the same."""
+    import sparse_matrix_math_amd as smm
+
+    smm.init(0)
+    report = []
+    # (two ranks, no relay: kernels of one rank wait for kernels of the other, so every stream involved needs a hardware queue of its own, and
+    # how HIP maps the streams of ONE process onto its queues is not ours to choose -- with three thread ranks or a relay's forward kernel in
+    # the mix a waiting kernel now and then sits in front of the kernel it waits for.  Ranks in separate processes have queues of their own:
+    # worlds of 3 and 4 with relay ranks run there, test_peer_to_peer_between_processes)
+    cases = [(2, 0, np.float64), (2, 0, np.float32)]
+    for world, relays, dtype in cases:
+        csr = gen.banded_random_spd(60000, k=12, seed=4, max_offset=9000, dtype=dtype)
+        n = len(csr[0]) - 1
+        x_true = np.random.default_rng(3).uniform(0.5, 1.5, n).astype(dtype)
+        import scipy.sparse as sp
+
+        b = (sp.csr_matrix((csr[2].astype(np.float64), csr[1], csr[0]), shape=(n, n)) @ x_true.astype(np.float64)).astype(dtype)
+        got = {}
+        for p2p in (0, 1):
+            os.environ["SMM_HIP_P2P"] = str(p2p)
+            os.environ["SMM_HIP_P2P_RELAYS"] = str(relays)
+            seen = {}
+            runs = []
+            for solver, precond, max_it in (("bicgstab", None, 7), ("bicgstab", smm.SolverPreconditioner.JACOBI, 7), ("cg", None, 9), ("bicgstab", None, 40)):
+                print(f"p2p case world {world} relays {relays} {np.dtype(dtype).name} p2p {p2p}: {solver} precond {precond} max_it {max_it}", file=sys.stderr, flush=True)
+                res, x, y, halo = _solve(smm, csr, b, world, dtype, max_it, 1e-30 if max_it < 40 else 1e-6, solver=solver, precond=precond, options_seen=seen, own_streams=True)
+                runs.append((res, x.tobytes(), y.tobytes()))
+            got[p2p] = (runs, seen)
+        on = got[1][1]
+        report.append({"world": world, "relays": relays, "dtype": np.dtype(dtype).name,
+                       "p2p_on": all(o["p2p"] for o in on.values()), "relays_on": sorted({o["relays"] for o in on.values()}),
+                       "halo_first": all(o["halo_first"] for o in on.values()), "p2p_off_when_not_asked": not any(o["p2p"] for o in got[0][1].values()),
+                       "bit_equal": [a == b_ for a, b_ in zip(got[0][0], got[1][0])], "status": [r[0] for r in got[1][0]]})
+    print("P2P_REPORT " + json.dumps(report, default=str))
+
+
+def test_peer_to_peer_thread_ranks():
+    """csrc/smm_p2p.h with two ranks as threads of ONE process (host-callback communicator for the set-up; the halo and the scalars go
+    peer to peer through the ranks' fine-grained blocks, raw pointers instead of hipIpcMemHandles inside one process): bit-equal to the communicator's collectives.  In a child process: kernels of one rank WAIT (bounded) for kernels of another,
+    and inside one process HIP maps streams onto a handful of hardware queues -- GPU_MAX_HW_QUEUES gives every stream of every thread rank
+    its own, as ranks in separate processes on separate GPUs have."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", SMM_HIP_P2P_TIMEOUT_S="5", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = "import sys; sys.path.insert(0, 'tests'); import test_gpu_dist_native as t; t.p2p_thread_rank_cases()"
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("P2P_REPORT ")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    for case in json.loads(lines[0][len("P2P_REPORT "):]):
+        assert case["p2p_on"] and case["p2p_off_when_not_asked"], case
+        assert case["relays_on"] == [case["relays"]], case
+        assert all(case["bit_equal"]), case
+
+
+@pytest.mark.parametrize("ranks,relays", [(2, 0), (3, 1), (4, 2)])
+def test_peer_to_peer_between_processes(ranks, relays):
+    """The same between PROCESSES: `python bench.py --gpus N` with the gloo rehearsal communicator and SMM_HIP_P2P=1 -- the ranks share the one
+    GPU, every rank exports its block with hipIpcGetMemHandle and maps the others' with hipIpcOpenMemHandle (what ranks on separate GPUs do
+    over xGMI), halos and scalars travel peer to peer; the line reports which options ran."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SMM_HIP_P2P="1", SMM_HIP_P2P_RELAYS=str(relays), SMM_HIP_P2P_TIMEOUT_S="30")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rows", "600000", "--max-offset", "65536", "--steps", "20",
+           "--warmup", "10", "--iters-per-solve", "10", "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["dist_options"] == {"p2p": True, "relays": relays, "halo_first": True, "direct_share": 4.0 / (relays + 4) if relays else 1.0}, line["dist_options"]
+    assert line["n_gpus"] == ranks and line["value"] > 0 and line["max_rel_err_vs_x_true"] < 1e-3
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_bench_self_launch_rehearsal(ranks):
     """`python bench.py --gpus N` exactly as the driver types it (no torch.distributed.run in front): bench.py starts its own N rank
@@ -451,4 +542,5 @@ def test_bench_self_launch_rehearsal(ranks):
     # what a multi-GPU line that scales worse than hoped is read by first: the exchanges' share that A_loc did not cover (events on the
     # solver's and the communicator's stream; the rehearsal's host-staged exchanges run on the solver's own stream: no pairs, 0 ms)
     assert line["exposed_comm_ms"] >= 0 and line["exposed_comm"]["exchanges"] >= 0 and line["halo_chunks"] == 1
+    assert line["dist_options"] == {"p2p": False, "relays": 0, "halo_first": True, "direct_share": 1.0}  # (peer to peer is asked for with SMM_HIP_P2P=1)
     assert "spmvTileKernel" in line["roofline"]["kernel"] or "spmvStreamKernel" in line["roofline"]["kernel"] or "Pattern" in line["roofline"]["kernel"]
