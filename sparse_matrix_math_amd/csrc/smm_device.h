@@ -95,6 +95,20 @@ __device__ __forceinline__ void lastBlockSums(const T* partials, int npart, int 
 	if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// out[] of an SpMV row with a RUN-TIME choice of the cache policy.  `if (nt) __builtin_nontemporal_store(...) else out[row] = ...` does
+// not survive the compiler -- the hint is metadata, the two arms are merged into ONE plain store (r04 finding: every kernel that had the
+// flag stored plainly whatever the flag said) -- and a template argument would double the instantiations of nine kernels.  The non-temporal
+// arm is therefore spelled out: global_store ... nt (the data depends on everything the lane loaded for the row, including lhs[row] when
+// out aliases lhs, so program order needs no memory clobber -- which would stop the compiler moving the next tile's loads across the store).
+__device__ __forceinline__ void storeOut(float* p, float v, bool nt) {
+	if (nt) asm volatile("global_store_dword %0, %1, off nt" : : "v"(p), "v"(v));
+	else *p = v;
+}
+__device__ __forceinline__ void storeOut(double* p, double v, bool nt) {
+	if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v));
+	else *p = v;
+}
+
 // Workgroup barrier for kernels whose waves meet ONLY in LDS.  __syncthreads() is a workgroup-scope fence + s_barrier, and the
 // fence (which cannot know the address space) waits for every outstanding global access of the wave as well: vmcnt(0).  In a
 // software-pipelined tile loop that drains the prefetch of the next tile and the acknowledgement of the out[] store at every

@@ -416,8 +416,7 @@ __global__ __launch_bounds__(TPB) void spmvStreamKernel(int nTiles, int cap, int
 #ifdef SMM_EXP_NOOUT  // ablation builds only: the kernel without its out[] stream
 				if (o == T(123.456)) out[row] = o;
 #else
-				if (ntOut) __builtin_nontemporal_store(o, out + row);
-				else out[row] = o;
+				storeOut(out + row, o, ntOut);
 #endif
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
@@ -684,8 +683,7 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 			if (piece == 0 && rl < nrows) {
 				const int row = r0 + rl;
 				const T o = applyOp(op, lhs, divisor, row, dot);
-				if (ntOut) __builtin_nontemporal_store(o, out + row);
-				else out[row] = o;
+				storeOut(out + row, o, ntOut);
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
 			}

@@ -402,8 +402,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternKernel(int nTiles, int cap, in
 			}
 			if (piece == 0 && rl < nrows) {
 				const T o = patApplyOp(op, lhs, divisor, row, dot);
-				if (ntOut) __builtin_nontemporal_store(o, out + row);
-				else out[row] = o;
+				storeOut(out + row, o, ntOut);
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
 			}
@@ -594,8 +593,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap
 #pragma unroll
 				for (int q = 1; q < L; ++q) dot += sPart[(q - 1) * RT + rl];
 				const T o = patApplyOp(op, lhs, divisor, row, dot);
-				if (ntOut) __builtin_nontemporal_store(o, out + row);
-				else out[row] = o;
+				storeOut(out + row, o, ntOut);
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
 			}
@@ -795,8 +793,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternConstKernel(int rows, int cols
 #if defined(SMM_EXP_CONST) && (SMM_EXP_CONST & 1)  // ablation builds only: the kernel without its out[] stream
 			if (o == T(-1.2345e30)) out[row] = o;
 #else
-			if (ntOut) __builtin_nontemporal_store(o, out + row);
-			else out[row] = o;
+			storeOut(out + row, o, ntOut);
 #endif
 			if (dotMode == 2) acc0 += o * o;
 			if (dotMode) acc1 += o * w1[row];
@@ -922,8 +919,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternWaveKernel(int rows, int cols,
 				}
 			} while (mm != 0ULL);
 			const T o = patApplyOp(op, lhs, divisor, row, dot);
-			if (ntOut) __builtin_nontemporal_store(o, out + row);
-			else out[row] = o;
+			storeOut(out + row, o, ntOut);
 			if (dotMode == 2) acc0 += o * o;
 			if (dotMode) acc1 += o * w1[row];
 		}
@@ -1212,8 +1208,7 @@ __global__ __launch_bounds__(TPB) void spmvDictKernel(int nTiles, int cap, int c
 			}
 			if (piece == 0 && rl < nrows) {
 				const T o = patApplyOp(op, lhs, divisor, row, dot);
-				if (ntOut) __builtin_nontemporal_store(o, out + row);
-				else out[row] = o;
+				storeOut(out + row, o, ntOut);
 				if (dotMode == 2) acc0 += o * o;
 				if (dotMode) acc1 += o * w1[row];
 			}
