@@ -702,14 +702,29 @@ static std::vector<int> planParts(int count, int relays, double directShare) {
 	return cut;
 }
 
+// Collective (every rank tears its matrix down in the same order as it built it): a rank's block must outlive every remote write into it
+// -- a peer's land kernel acknowledges into the SOURCE's block after the source may have returned from its solve --, so every rank first
+// drains its own device (its remote writes are done), the ranks meet, the mappings are closed, the ranks meet again, and only then is the
+// block freed.  A communicator that was aborted cannot meet: the mappings are closed and the block freed at once (the process is expected
+// to exit).
 static void p2pTeardown(smm_hip_dist_csr* D) {
 	P2PState* P = D->p2p;
 	if (!P) return;
+	smm_hip_comm* c = D->comm;
+	auto meet = [c]() {
+		if (!c || c->broken || c->kind == SMM_COMM_SELF) return;
+		long long one = 1;
+		if (commAllreduceI64(c, &one, 1) != SMM_HIP_OK) c->broken = true;
+	};
+	(void)hipDeviceSynchronize();
+	meet();
 	for (size_t q = 0; q < P->peer.size(); ++q) {
 		if (P->opened[q] && P->peer[q]) (void)hipIpcCloseMemHandle(P->peer[q]);
 	}
+	meet();
 	for (void* p : {static_cast<void*>(P->d_push), static_cast<void*>(P->d_fwd), static_cast<void*>(P->d_land), static_cast<void*>(P->d_counters)}) devFree(p);
 	if (P->block) (void)hipFree(P->block);
+	(void)hipGetLastError();
 	delete P;
 	D->p2p = nullptr;
 }
@@ -936,14 +951,15 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 			if (!vec.empty()) SMM_HIP_TRY(hipMemcpy(p, vec.data(), vec.size() * sizeof(E), hipMemcpyHostToDevice));
 			return SMM_HIP_OK;
 		};
-		SMM_TRY(upload(push, &P->d_push));
-		SMM_TRY(upload(fwd, &P->d_fwd));
-		SMM_TRY(upload(land, &P->d_land));
+		// (a failure here must not return: the other ranks are about to vote, and a rank that left would leave them alone in the collective)
 		void* cnt = nullptr;
 		const size_t nCounters = static_cast<size_t>(std::max(1, P->nPush + P->nFwd + P->nLand));
-		SMM_TRY(devAlloc(&cnt, nCounters * sizeof(unsigned)));
+		if (upload(push, &P->d_push) != SMM_HIP_OK || upload(fwd, &P->d_fwd) != SMM_HIP_OK || upload(land, &P->d_land) != SMM_HIP_OK ||
+		    devAlloc(&cnt, nCounters * sizeof(unsigned)) != SMM_HIP_OK || hipMemset(cnt, 0, nCounters * sizeof(unsigned)) != hipSuccess) {
+			(void)hipGetLastError();
+			ok = false;
+		}
 		P->d_counters = static_cast<unsigned*>(cnt);
-		SMM_HIP_TRY(hipMemset(cnt, 0, nCounters * sizeof(unsigned)));
 	}
 	SMM_TRY(p2pAllAgree(c, ok, &all));
 	D->p2p = owner.release();  // (torn down below unless everything checks out; the peers' mappings must be closed either way)
@@ -1274,6 +1290,12 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 		SMM_TRY(orderAfter(c, s, cs));
 		SMM_TRY(p2pHaloLaunch<T>(D, ext, kind, cs));
 		pend.seq = D->p2p->haloSeq[kind];
+		// the land kernel (waits for every part of every segment, then landing area -> halo of `ext`) runs on the side stream as well, beside
+		// the local block: the solver's stream only waits for its event, as it waits for a collective exchange
+		SMM_TRY(p2pLandLaunch<T>(D, ext, kind, pend.seq, cs));
+		pend.landed[0] = takeEvent(c);
+		SMM_HIP_TRY(hipEventRecord(pend.landed[0], cs));
+		pend.waitSlot[0] = profWaitAwaited(cs);
 		pend.async = true;
 		return SMM_HIP_OK;
 	}
@@ -1326,9 +1348,7 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 	// SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
 	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, exchange && pend.async ? SPMV_LEAVE_ROOM : 0));
 	const int remOp = op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD;
-	if (exchange && D->p2p) {
-		SMM_TRY(p2pLandLaunch<T>(D, ext, pend.kind, pend.seq, s));  // waits for every part of every segment, then landing area -> halo
-	} else if (exchange && D->chunks > 1) {
+	if (exchange && D->chunks > 1 && !D->p2p) {
 		// part k of A_rem reads only piece k and starts as soon as THAT piece has landed: out = ((A_loc x + A_rem,0 x) + A_rem,1 x) + ... -- each
 		// part a row sum of its own, added in piece order (deterministic; differs from the one-piece form only in where the row sum is cut)
 		const int K = D->chunks;
@@ -1610,14 +1630,14 @@ static int updateThenExchange(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t
 	return SMM_HIP_OK;
 }
 
-// an exchange that was posted but whose SpMV never runs (the loop was left): the peer-to-peer path must still empty the landing area and
-// acknowledge, or the sources' next push of that vector would wait for ever; the communicator's collectives are complete in themselves
+// an exchange that was posted but whose SpMV never runs (the loop was left): complete in itself on the side stream (the peer-to-peer land
+// kernel empties the landing area and acknowledges there); the solver's stream only has to stay behind it
 template <typename T>
 static int distExchangeDrain(smm_hip_dist_csr* D, T* ext, hipStream_t s) {
 	auto& pend = D->pending;
 	if (!pend.active) return SMM_HIP_OK;
 	pend.active = false;
-	if (D->p2p) return p2pLandLaunch<T>(D, ext, pend.kind, pend.seq, s);
+	(void)ext;
 	for (hipEvent_t e : pend.landed) {
 		if (e) SMM_HIP_TRY(hipStreamWaitEvent(s, e, 0));  // (the next use of `ext` on `s` must not overtake the receive)
 	}

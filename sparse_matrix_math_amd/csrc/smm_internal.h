@@ -178,6 +178,9 @@ struct smm_hip_csr {
 	// CONST on grid-shaped matrices: the plan of the 2.5-D kernel (smm_spmv_march.hip), made once at the end of the CONST analysis
 	bool march_ok = false;
 	int march_P = 0, march_H = 0, march_lo = 0, march_hi = 0;  // rows per plane, halo (elements), whether -P / +P are offsets
+	// far offsets in CLUSTERS around -P / +P (19- / 27-point stencils): march_lo / march_hi then count the offsets of the two clusters and the
+	// three-window kernel (spmvPatternConstMarch3Kernel) serves the matrix; constant diagonals only
+	bool march_clusters = false;
 	unsigned* d_pat_masks32 = nullptr;  // the low halves of d_pat_masks, what the 2.5-D kernel streams (4 bytes per row)
 	std::vector<int> pat_offs_host;  // MASKS: the sorted offsets (host copy: the brick partition of the block preconditioners reads the grid from them)
 	int pat_k = 0;

@@ -351,6 +351,223 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The march for stencils whose FAR offsets come in CLUSTERS (r05): 19- and 27-point stencils -- HPCG's matrix -- touch
+// the planes below and above at -P + d and +P + d for several near d, not only at -P / +P, so the lane's own centre values of the
+// neighbouring planes (registers, above) are not enough: here the planes z - 1, z and z + 1 are ALL windows in LDS.  Four window buffers
+// rotate (plane z + 2 is stored while z - 1, z, z + 1 are read; the buffer it overwrites held z - 2, which nobody reads after the barrier
+// that ended step z - 1): still ONE workgroup barrier per plane.  Request sets alternate as above, shifted by one plane (`use` holds plane
+// z + 2).  Offsets are visited in ascending order -- the cluster around -P, the near ones, the cluster around +P: ascending columns, the
+// row mask's bit order, the reference's products in the reference's order (ref:1484-1489).
+// LDS: 4 (B + 2 H) elements per workgroup; a 27-point row costs 27 LDS reads instead of 27 global gathers (spmvPatternConstKernel).
+template <typename T, int R, bool NT, int HP>
+__global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternConstMarch3Kernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles,
+                                                                    int H, int nOff, int nLo, int nHi, const int* __restrict__ offs,
+                                                                    const unsigned long long* __restrict__ cvalBits, const unsigned* __restrict__ masks32,
+                                                                    int opFlags, const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out,
+                                                                    int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
+                                                                    const int* __restrict__ doneFlag) {
+	using Cfg = MarchCfg<T, R>;
+	using Set = MarchSet<T, R, HP>;
+	constexpr int VEC = Cfg::VEC;
+	constexpr int PACKS = Cfg::PACKS;
+	constexpr int MARCH_B = Cfg::B;
+	const int winLen = MARCH_B + 2 * H;
+	T* const sWin = reinterpret_cast<T*>(smmMarchLds);  // four windows of winLen elements
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	const int op = opFlags & 0xFF;
+	const int t = threadIdx.x;
+	const int nMid = nOff - nLo - nHi;
+	const int haloPacks = 2 * H / VEC;
+	const unsigned fullMask = nOff >= 32 ? 0xFFFFFFFFu : ((1u << nOff) - 1u);
+
+	const int nGroups = min(8, static_cast<int>(gridDim.x));
+	const int units = nT * nChunks;
+	int uFirst, uStride, uEnd, tLo = 0, tCount = nT;
+	if (xcdTiles) {
+		const int g = blockIdx.x % nGroups;
+		tLo = static_cast<int>(static_cast<long long>(g) * nT / nGroups);
+		tCount = static_cast<int>(static_cast<long long>(g + 1) * nT / nGroups) - tLo;
+		uFirst = blockIdx.x / nGroups;
+		uStride = (static_cast<int>(gridDim.x) - g + nGroups - 1) / nGroups;
+		uEnd = tCount * nChunks;
+	} else {
+		uFirst = blockIdx.x;
+		uStride = gridDim.x;
+		uEnd = units;
+	}
+	T acc0 = T(0), acc1 = T(0);
+	int loc[PACKS];
+#pragma unroll
+	for (int p = 0; p < PACKS; ++p) loc[p] = (p * TPB + t) * VEC;
+
+	for (int u = uFirst; u < uEnd; u += uStride) {
+		const int chunk = u / tCount;
+		const int tile = tLo + (u - chunk * tCount);
+		const int z0 = chunk * zc;
+		const int z1 = min(nPlanes, z0 + zc);
+		const int r0 = tile * MARCH_B;
+		const int bAct = min(MARCH_B, P - r0);
+		bool act[PACKS];
+#pragma unroll
+		for (int p = 0; p < PACKS; ++p) act[p] = loc[p] < bAct;
+		auto haloWin = [&](int i) { return i < H / VEC ? i * VEC : H + bAct + (i - H / VEC) * VEC; };
+		auto winOf = [&](int z) { return sWin + static_cast<size_t>((z - z0 + 1) & 3) * winLen; };
+		// the whole window of plane z (centre + halos); masks only for the planes this unit computes.  What is loaded is decided element by
+		// element, not plane by plane: the window of the plane "below the first" still holds the first plane's leading elements in its right halo
+		// (an entry at -P + d, d > 0, of a row near the end of plane 0 points there), and likewise above the last plane
+		auto issue = [&](Set& f, int z, bool wantMasks) {
+			const long long base = static_cast<long long>(z) * P + r0;
+#pragma unroll
+			for (int p = 0; p < PACKS; ++p) {
+				const long long gi = base + loc[p];
+				if (act[p] && gi >= 0 && gi < rows) {  // (P, r0, rows are multiples of the pack: a pack is inside or outside as a whole)
+					f.c[p] = *reinterpret_cast<const PackU<T>*>(x + gi);
+				} else {
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) f.c[p][e] = T(0);
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < HP; ++k) {
+				const int i = k * TPB + t;
+				if (i < haloPacks) {
+					const long long gidx = base - H + haloWin(i);
+					if (gidx >= 0 && gidx + VEC <= cols) {
+						f.h[k] = *reinterpret_cast<const PackU<T>*>(x + gidx);
+					} else {
+#pragma unroll
+						for (int e = 0; e < VEC; ++e) f.h[k][e] = T(0);
+					}
+				}
+			}
+#pragma unroll
+			for (int p = 0; p < PACKS; ++p) {
+				const long long gi = base + loc[p];
+				if (wantMasks && act[p] && gi >= 0 && gi < rows) {
+					f.m[p] = __builtin_nontemporal_load(reinterpret_cast<const MaskP<T>*>(masks32 + gi));
+				} else {
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) f.m[p][e] = 0u;
+				}
+			}
+		};
+		auto storeWindow = [&](T* win, const Set& f) {
+#pragma unroll
+			for (int p = 0; p < PACKS; ++p) {
+				if (act[p]) *reinterpret_cast<PackV<T>*>(win + H + loc[p]) = f.c[p];
+			}
+#pragma unroll
+			for (int k = 0; k < HP; ++k) {
+				const int i = k * TPB + t;
+				if (i < haloPacks) *reinterpret_cast<PackV<T>*>(win + haloWin(i)) = f.h[k];
+			}
+		};
+
+		MaskP<T> mk[PACKS], mk1[PACKS];  // masks of plane z and of plane z + 1
+		Set fa, fb;
+
+		// one plane: windows z - 1, z, z + 1 are in LDS; `use` holds plane z + 2 (requested a step ago), `re` is re-issued for plane z + 3
+		auto step = [&](int z, Set& use, Set& re) {
+			const bool more = z + 1 < z1;
+			if (more) issue(re, z + 3, z + 3 < z1);
+			const long long base = static_cast<long long>(z) * P + r0;
+			T dot[PACKS][VEC];
+#pragma unroll
+			for (int p = 0; p < PACKS; ++p) {
+#pragma unroll
+				for (int e = 0; e < VEC; ++e) dot[p][e] = T(0);
+			}
+			bool full = true;
+#pragma unroll
+			for (int p = 0; p < PACKS; ++p) {
+#pragma unroll
+				for (int e = 0; e < VEC; ++e) full = full && (mk[p][e] == fullMask || !act[p]);
+			}
+			const bool masked = !__all(full);
+			auto entry = [&](const T* win, int j, int centre) {
+				const int off = offs[j] - centre;  // (wave-uniform: scalar loads; LDS copies of the offsets and values measured slower -- this kernel
+				const T c = bitsToValue<T>(cvalBits[j]);  // lives on its LDS reads --, and so did cluster sizes as template arguments)
+#pragma unroll
+				for (int p = 0; p < PACKS; ++p) {
+					T xv[VEC];
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) xv[e] = win[H + loc[p] + e + off];
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) {
+						const T next = smmFma(c, xv[e], dot[p][e]);
+						dot[p][e] = (!masked || ((mk[p][e] >> j) & 1u) != 0u) ? next : dot[p][e];
+					}
+				}
+			};
+			for (int jj = 0; jj < nLo; ++jj) entry(winOf(z - 1), jj, -P);
+			for (int jj = 0; jj < nMid; ++jj) entry(winOf(z), nLo + jj, 0);
+			for (int jj = 0; jj < nHi; ++jj) entry(winOf(z + 1), nLo + nMid + jj, P);
+#pragma unroll
+			for (int p = 0; p < PACKS; ++p) {
+				if (act[p] && base + loc[p] < rows) {
+					const long long row = base + loc[p];
+					PackU<T> o;
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) o[e] = marchApplyOp(op, lhs, divisor, row + e, dot[p][e]);
+					if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<PackU<T>*>(out + row));
+					else *reinterpret_cast<PackU<T>*>(out + row) = o;
+					if (dotMode) {
+						const PackU<T> w = *reinterpret_cast<const PackU<T>*>(w1 + row);
+#pragma unroll
+						for (int e = 0; e < VEC; ++e) {
+							if (dotMode == 2) acc0 += o[e] * o[e];
+							acc1 += o[e] * w[e];
+						}
+					}
+				}
+			}
+			if (more) {
+				storeWindow(winOf(z + 2), use);  // (the buffer held plane z - 2: unread since the barrier that ended step z - 1)
+#pragma unroll
+				for (int p = 0; p < PACKS; ++p) {
+					mk[p] = mk1[p];
+					mk1[p] = use.m[p];
+				}
+				ldsBarrier();
+			}
+		};
+
+		// prologue: the windows of planes z0 - 1, z0, z0 + 1, then the requests for plane z0 + 2
+		__syncthreads();  // (the previous unit's last window reads are over)
+		issue(fa, z0 - 1, false);
+		issue(fb, z0, true);
+		storeWindow(winOf(z0 - 1), fa);
+		issue(fa, z0 + 1, z0 + 1 < z1);
+		storeWindow(winOf(z0), fb);
+#pragma unroll
+		for (int p = 0; p < PACKS; ++p) mk[p] = fb.m[p];
+		issue(fb, z0 + 2, z0 + 2 < z1);
+		storeWindow(winOf(z0 + 1), fa);
+#pragma unroll
+		for (int p = 0; p < PACKS; ++p) mk1[p] = fa.m[p];
+		__syncthreads();
+		for (int z = z0; z < z1; z += 2) {
+			step(z, fb, fa);
+			if (z + 1 < z1) step(z + 1, fa, fb);
+		}
+	}
+	if (dotMode) {
+		if (dotMode == 2) {
+			const T s0 = blockSum256(acc0, red);
+			if (t == 0) partials[blockIdx.x] = s0;
+		}
+		const T s1 = blockSum256(acc1, red);
+		if (t == 0) partials[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+		for (int i = gridDim.x + blockIdx.x * TPB + t; i < NPART; i += gridDim.x * TPB) {
+			partials[i] = T(0);
+			if (dotMode == 2) partials[NPART + i] = T(0);
+		}
+		if (opFlags & SPMV_FINISH) lastBlockSums<T>(partials, NPART, dotMode == 2 ? 2 : 1, partials + PARTS_TOTALS, partsTicket(partials));
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The same march for matrices whose diagonals VARY (MASKS: values[] is read): stencils with varying coefficients on big grids.  What
 // the wave-private mask kernel (spmvPatternWaveKernel, smm_spmv_pattern.hip) loses there is x: 13.9 GB across the fabric for the 11.3 GB
 // of the 512^3 fp64 stencil, x fetched 3.6 x.  Here x goes through the plane's LDS window and the lane's registers exactly as above;
@@ -614,6 +831,7 @@ static long long marchMinRows(bool masksKernel, int dtype) {
 
 void planMarch(smm_hip_csr* m) {
 	m->march_ok = false;
+	m->march_clusters = false;
 	const long long minRows = std::min(marchMinRows(false, m->dtype), marchMinRows(true, m->dtype));
 	const std::vector<int>& offs = m->pat_offs_host;
 	const int k = static_cast<int>(offs.size());
@@ -634,6 +852,43 @@ void planMarch(smm_hip_csr* m) {
 			m->march_lo = lo;
 			m->march_hi = hi;
 			return;
+		}
+	}
+	// (a') far offsets in clusters around -P and +P (19- / 27-point stencils): the offsets beyond the halo cap split into one group below and
+	// one above, the plane size is the centre of a group (both centres must agree), every offset lies within H of -P, 0 or +P.  Constant
+	// diagonals only (the three-window kernel has no values[] form)
+	if (m->pat_const && far > hCap && m->rows % vec == 0) {
+		int nLo = 0, nHi = 0;
+		while (nLo < k && offs[nLo] < -hCap) ++nLo;
+		while (nHi < k && offs[k - 1 - nHi] > hCap) ++nHi;
+		long long P = 0;
+		bool ok = nLo + nHi < k && (nLo > 1 || nHi > 1);
+		if (ok && nHi > 0) {
+			const long long sum = static_cast<long long>(offs[k - nHi]) + offs[k - 1];
+			ok = sum % 2 == 0;
+			P = sum / 2;
+		}
+		if (ok && nLo > 0) {
+			const long long sum = -(static_cast<long long>(offs[0]) + offs[nLo - 1]);
+			ok = sum % 2 == 0 && (nHi == 0 || sum / 2 == P);
+			P = sum / 2;
+		}
+		if (ok) {
+			int h = 1;
+			for (int j = 0; j < k; ++j) {
+				const long long centre = j < nLo ? -P : (j >= k - nHi ? P : 0);
+				h = std::max<long long>(h, std::llabs(offs[j] - centre));
+			}
+			ok = P >= 4LL * TPB * MARCH_RMAX && P % vec == 0 && m->rows / P >= 2 && roundUp(h) <= hCap && 2LL * roundUp(h) < P && P < (1LL << 30);
+			if (ok) {
+				m->march_ok = true;
+				m->march_clusters = true;
+				m->march_P = static_cast<int>(P);
+				m->march_H = roundUp(h);
+				m->march_lo = nLo;
+				m->march_hi = nHi;
+				return;
+			}
 		}
 	}
 	// (b) one plane: every offset is near
@@ -756,6 +1011,37 @@ static bool launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* d
 	return true;
 }
 
+template <typename T, int R, bool NT, int HP>
+static bool launchMarch3(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials, const int* doneFlag,
+                         hipStream_t s) {
+	const int P = m->march_P, H = m->march_H;
+	const int nPlanes = (m->rows + P - 1) / P;
+	constexpr int MARCH_B = TPB * R;
+	const int nT = (P + MARCH_B - 1) / MARCH_B;
+	const size_t lds = 4 * static_cast<size_t>(MARCH_B + 2 * H) * sizeof(T);  // the windows of planes z - 1, z, z + 1 and the one being filled
+	static MarchLaunchState state;
+	int perCU = 0;
+	if (!marchPrepare(state, spmvPatternConstMarch3Kernel<T, R, NT, HP>, lds, 64 /* red[] */, &perCU)) return false;
+	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
+	op &= ~SPMV_LEAVE_ROOM;
+	const int resident = cus * perCU;
+	// (a unit loads TWO extra windows -- the planes below its first and above its last --, so longer z-chunks than the two-window kernel's)
+	int zc = nPlanes;
+	if (nPlanes > 1) {
+		const int wantChunks = std::max(1, std::min(nPlanes, (3 * resident / 2 + nT - 1) / nT));
+		zc = std::max(std::min(4, nPlanes), (nPlanes + wantChunks - 1) / wantChunks);
+		if (marchZcOverride() > 0) zc = std::max(1, std::min(nPlanes, marchZcOverride()));
+	}
+	const int nChunks = (nPlanes + zc - 1) / zc;
+	const long long units = static_cast<long long>(nT) * nChunks;
+	int grid = static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(units, resident), NPART)));
+	const int xcdTiles = (nT % 8 == 0 || nT >= 64) && grid >= 8 ? 1 : 0;
+	if (xcdTiles) grid -= grid % 8;
+	spmvPatternConstMarch3Kernel<T, R, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
+	                                                               m->d_pat_off, m->d_pat_cval, m->d_pat_masks32, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+	return true;
+}
+
 // true: the launch went to the march kernel.  SMM_HIP_CONST_MARCH=0 keeps the gather kernel (A/B measurements).
 template <typename T>
 bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
@@ -765,8 +1051,17 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 		return env ? atoi(env) != 0 : true;
 	}();
 	if (!enabled || !constMarchApplies(m)) return false;
-	const int nNear = m->pat_k - m->march_lo - m->march_hi;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;  // outputs too large to still be cached when the next kernel reads them
+	if (m->march_clusters) {
+		// far offsets in clusters: the three-window kernel, 4 rows per lane in fp64 and 8 in fp32 as below
+		const bool hp2c = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
+		constexpr int RC = sizeof(T) == 8 ? 4 : 8;
+		return nt && hp2c ? launchMarch3<T, RC, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)
+		       : nt     ? launchMarch3<T, RC, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)
+		       : hp2c   ? launchMarch3<T, RC, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)
+		                : launchMarch3<T, RC, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s);
+	}
+	const int nNear = m->pat_k - m->march_lo - m->march_hi;
 	// rows per lane (profiles/r04/march_rows_per_lane.txt, 512^3): fp64 4 -- tiles of 1024 rows, 120 VGPRs, four workgroups per CU: 0.565 ms
 	// against 0.604 with 8 (185 VGPRs, two per CU); fp32 8 -- 0.318 against 0.335.  SMM_HIP_MARCH_R=4 / 8 forces one (A/B measurements).
 	static const int forcedRows = [] {
@@ -821,10 +1116,12 @@ static bool launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 }
 
 bool masksMarchApplies(const smm_hip_csr* m) {
-	return m->march_ok && m->d_pat_masks32 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8 &&
+	return m->march_ok && !m->march_clusters && m->d_pat_masks32 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8 &&
 	       m->rows >= marchMinRows(true, m->dtype);
 }
-bool constMarchApplies(const smm_hip_csr* m) { return m->march_ok && m->d_pat_masks32 && m->rows >= marchMinRows(false, m->dtype); }
+bool constMarchApplies(const smm_hip_csr* m) {
+	return m->march_ok && m->d_pat_masks32 && m->rows >= marchMinRows(false, m->dtype) && (!m->march_clusters || (m->pat_const && !m->pat_const_off));
+}
 
 // true: the launch went to the march form of the masks kernels (values[] read).  SMM_HIP_MASKS_MARCH=0 keeps the wave kernel.
 template <typename T>

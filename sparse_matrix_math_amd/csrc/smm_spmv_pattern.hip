@@ -1659,7 +1659,7 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 		}();
 		const bool march = marchOn && constMarchApplies(m);
 		*bytes = rows * (march ? 4 : 8) + vectors;  // the row's mask (32 bits in the 2.5-D form), x, out: neither values[] nor start[]
-		return march ? "spmvPatternConstMarchKernel" : "spmvPatternConstKernel";
+		return march ? (m->march_clusters ? "spmvPatternConstMarch3Kernel" : "spmvPatternConstMarchKernel") : "spmvPatternConstKernel";
 	}
 	*bytes = nnz * s + rows * 8 + startBytes + vectors;
 	if (L == 1 && masksMarchApplies(m)) {

@@ -122,6 +122,35 @@ def stencil3d(nx, ny, nz, diag=6.0, lo=-1.0, hi=-1.0, dtype=np.float64):
     return start.astype(np.int32), cols[valid].astype(np.int32), vals[valid].astype(dtype)
 
 
+def stencil3d_wide(nx, ny, nz, points=27, dtype=np.float64):
+    """19- or 27-point stencil on an nx*ny*nz grid (x fastest, Dirichlet truncation): every neighbour (dx, dy, dz) in {-1, 0, 1}^3 -- for 19
+    points without the eight corners.  27 points with diag 26 and -1 elsewhere is HPCG's matrix; here each of the three neighbour classes
+    (face / edge / corner) has its own constant so that a wrong pairing of value and column shows.  Its far offsets come in CLUSTERS around
+    -nx*ny and +nx*ny: what the three-window march kernel (csrc/smm_spmv_march.hip, spmvPatternConstMarch3Kernel) is for."""
+    assert points in (19, 27)
+    dtype = np.dtype(dtype).type
+    n = nx * ny * nz
+    i = np.arange(n, dtype=np.int64)
+    ix, iy, iz = i % nx, (i // nx) % ny, i // (nx * ny)
+    cols, valid, vals = [], [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                order = abs(dx) + abs(dy) + abs(dz)
+                if points == 19 and order == 3:
+                    continue
+                ok = (ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny) & (iz + dz >= 0) & (iz + dz < nz)
+                cols.append(i + dz * nx * ny + dy * nx + dx)
+                valid.append(ok)
+                vals.append({0: float(points - 1), 1: -1.0, 2: -0.5, 3: -0.25}[order])
+    cols = np.stack(cols, axis=1)
+    valid = np.stack(valid, axis=1)
+    vals = np.broadcast_to(np.array(vals, dtype=dtype), cols.shape)
+    start = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(valid.sum(axis=1), out=start[1:])
+    return start.astype(np.int32), cols[valid].astype(np.int32), vals[valid].astype(dtype)
+
+
 def poisson3d(n, dtype=np.float64):
     return stencil3d(n, n, n, 6.0, -1.0, -1.0, dtype)
 

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import OP_ADD, OP_ASSIGN, OP_SUB
+from sparse_matrix_math_amd import generators as gen
 
 pytestmark = pytest.mark.gpu
 PATTERN, CONST = 3, 3
@@ -177,6 +178,57 @@ def test_masks_march_kernel_with_varying_coefficients(smm, oracle, dtype):
         A.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("grid,points", [((128, 128, 128), 27), ((96, 112, 201), 19), ((160, 100, 140), 27)])
+def test_three_window_march_for_clustered_far_offsets(smm, oracle, dtype, grid, points):
+    """19- and 27-point stencils (HPCG's matrix shape): the far offsets come in clusters around -P and +P, so the planes below and above are
+    LDS windows too (spmvPatternConstMarch3Kernel, four rotating windows, one barrier per plane).  Every operation bit for bit against the
+    oracle; planes that are no whole number of tiles, an odd number of planes, the fused dot products."""
+    import torch
+
+    nx, ny, nz = grid
+    csr = gen.stencil3d_wide(nx, ny, nz, points, dtype=dtype)
+    n = len(csr[0]) - 1
+    dev = torch.device("cuda:0")
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    stream = torch.cuda.current_stream().cuda_stream
+    d = [torch.from_numpy(a).to(dev) for a in csr]
+    A = smm.CSRMatrix.from_device(n, n, d[0], d[1], d[2], dtype)
+    A.set_kernel(PATTERN, 1)
+    assert A.pattern_info() == (CONST, points)
+    name, nbytes = A.kernel_desc()
+    assert name == "spmvPatternConstMarch3Kernel", name
+    assert nbytes == n * 4 + 2 * n * np.dtype(dtype).itemsize
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.rand(n, dtype=td, device=dev, generator=g) - 0.5
+    lhs = torch.rand(n, dtype=td, device=dev, generator=g) - 0.5
+    y = torch.empty(n, dtype=td, device=dev)
+    xh, lh = x.cpu().numpy(), lhs.cpu().numpy()
+    for op in (OP_ASSIGN, OP_ADD, OP_SUB):
+        y.fill_(float("nan"))
+        A.spmv_dev(op, lhs if op != OP_ASSIGN else None, x, y, stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(y.cpu().numpy(), oracle.spmv(csr, op, lh, xh))
+    z = lhs.clone()
+    A.spmv_dev(OP_SUB, z, x, z, stream)  # in place (out aliases lhs, ref:1507-1515)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(z.cpu().numpy(), oracle.spmv(csr, OP_SUB, lh, xh))
+    fin = torch.zeros(smm.host.finish_len(), dtype=td, device=dev)
+    A.spmv_fused_dev(OP_ASSIGN, None, x, y, 2, x, fin, stream, finish=True)
+    torch.cuda.synchronize()
+    ref = oracle.spmv(csr, OP_ASSIGN, None, xh)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    tot = fin.cpu().numpy()[smm.host.finish_totals_offset():smm.host.finish_totals_offset() + 2]
+    rtol = 1e-4 if dtype == np.float32 else 1e-11
+    np.testing.assert_allclose(tot, [np.dot(ref.astype(np.float64), ref), np.dot(ref.astype(np.float64), xh)], rtol=rtol, atol=rtol * n)
+    # the gather kernel (march off for this handle's size class is not switchable per handle: compare with the CSR stream at one lane instead)
+    A.set_kernel(2, 1)
+    y2 = torch.empty_like(y)
+    A.spmv_dev(OP_ASSIGN, None, x, y2, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y)
+
+
 def test_march_lds_is_raised_again_for_a_larger_halo(smm):
     """Two grids in ONE process, the second with the larger halo (nx = 800, then nx = 1024; 13.1 M rows each, fp64, production thresholds):
     the masks march needs 42 KB of dynamic LDS for the first and 49 KB -- with its 16.6 KB of static LDS more than the 64 KB a launch gets
@@ -230,15 +282,16 @@ def test_march_in_cg_at_scale(smm, oracle):
 
 
 def test_march_kernels_fuzz_below_the_production_threshold():
-    """tools/march_fuzz.py in a process of its own (SMM_HIP_MARCH_MIN_ROWS=1 must be in the environment before the library reads it): 40
-    random grid-shaped matrices of 20 K - 300 K rows -- partial tiles, partial last planes, one or both far offsets, one-plane bands, random
+    """tools/march_fuzz.py in a process of its own (SMM_HIP_MARCH_MIN_ROWS=1 must be in the environment before the library reads it): 48
+    random grid-shaped matrices of 20 K - 300 K rows -- partial tiles, partial last planes, one or both far offsets (single or in clusters), one-plane bands, random
     holes in every diagonal, constant and varying values, fp32 / fp64 -- every SpMV (three ops, in place) bit-identical to the oracle"""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "march_fuzz.py"), "40"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "march_fuzz.py"), "48"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "march fuzz: ALL OK" in r.stdout
     assert r.stdout.count("spmvPatternConstMarchKernel ok") >= 10 and r.stdout.count("spmvPatternMasksMarchKernel ok") >= 3, r.stdout[-3000:]
+    assert r.stdout.count("spmvPatternConstMarch3Kernel ok") >= 4, r.stdout[-3000:]

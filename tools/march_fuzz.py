@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""GPU box: the 2.5-D kernels (spmvPatternConstMarchKernel, spmvPatternMasksMarchKernel) against the oracle, bit for bit, on random grid-shaped
+"""GPU box: the 2.5-D kernels (spmvPatternConstMarchKernel, spmvPatternConstMarch3Kernel, spmvPatternMasksMarchKernel) against the oracle, bit for bit, on random grid-shaped
 matrices far below its production threshold (SMM_HIP_MARCH_MIN_ROWS=1 for this process): random plane sizes (tiles that are partial,
 one tile per plane, planes that are no multiple of anything but the pack), random plane counts with a partial last plane, random near
-offsets, one or both far offsets, random holes in every diagonal (the masks), empty rows, fp32 / fp64, all three ops, in place."""
+offsets, one or both far offsets -- single or in clusters --, random holes in every diagonal (the masks), empty rows, fp32 / fp64, all three ops, in place."""
 import os
 import sys
 
@@ -37,6 +37,13 @@ for trial in range(trials):
         hmax = int(rng.integers(2, 600))
         near = np.unique(np.concatenate(([0], rng.integers(-hmax, hmax + 1, size=nnear))))
         far = [(-P,), (P,), (-P, P)][trial % 3] if trial % 7 else (-P, P)
+        if trial % 8 in (3, 6):
+            # far offsets in CLUSTERS around -P / +P (19- / 27-point stencil shapes): spmvPatternConstMarch3Kernel.  The plan takes the plane
+            # size from the centre of a cluster, so a cluster is symmetric about its centre (holes inside are fine)
+            m = int(rng.integers(1, hmax + 1))
+            inner = rng.integers(-m, m + 1, size=int(rng.integers(0, 6)))
+            shape = np.unique(np.concatenate(([-m, m], inner)))
+            far = np.concatenate([c + shape for c in far])
         offs = np.unique(np.concatenate((near, np.array(far))))
     keep = rng.random((rows, len(offs))) < rng.uniform(0.55, 1.0)
     if trial % 6 == 0:
@@ -49,7 +56,7 @@ for trial in range(trials):
     r, j, c = r[ok], j[ok], c[ok]
     dv = rng.uniform(-2, 2, len(offs)).astype(dtype)
     v = dv[j]
-    varying = (trial // 2) % 2 == 1  # every diagonal varies: MASKS (values[] read) -- spmvPatternMasksMarchKernel
+    varying = (trial // 2) % 2 == 1 and not (not one_plane and trial % 8 in (3, 6))  # every diagonal varies: MASKS (values[] read) -- spmvPatternMasksMarchKernel (clustered far offsets: constant only)
     if varying:
         v = rng.uniform(-2, 2, len(j)).astype(dtype)
     start = np.zeros(rows + 1, dtype=np.int32)
