@@ -500,9 +500,46 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 					}
 				}
 			};
-			for (int jj = 0; jj < nLo; ++jj) entry(winOf(z - 1), jj, -P);
-			for (int jj = 0; jj < nMid; ++jj) entry(winOf(z), nLo + jj, 0);
-			for (int jj = 0; jj < nHi; ++jj) entry(winOf(z + 1), nLo + nMid + jj, P);
+			// three offsets in a row (dx = -1, 0, 1 of a stencil line) share their LDS reads: VEC + 2 elements serve the 3 x VEC products of a
+			// pack (a third fewer reads in fp64, half in fp32: this kernel lives on them); any other offset goes alone.  Same products, same order.
+			auto line3 = [&](const T* win, int j, int centre) {
+				const int off = offs[j] - centre;
+				const T c0 = bitsToValue<T>(cvalBits[j]), c1 = bitsToValue<T>(cvalBits[j + 1]), c2 = bitsToValue<T>(cvalBits[j + 2]);
+#pragma unroll
+				for (int p = 0; p < PACKS; ++p) {
+					T xv[VEC + 2];
+#pragma unroll
+					for (int e = 0; e < VEC + 2; ++e) xv[e] = win[H + loc[p] + e + off];
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) {
+						const unsigned mm = mk[p][e] >> j;
+						T d = dot[p][e];
+						T next = smmFma(c0, xv[e], d);
+						d = (!masked || (mm & 1u) != 0u) ? next : d;
+						next = smmFma(c1, xv[e + 1], d);
+						d = (!masked || (mm & 2u) != 0u) ? next : d;
+						next = smmFma(c2, xv[e + 2], d);
+						d = (!masked || (mm & 4u) != 0u) ? next : d;
+						dot[p][e] = d;
+					}
+				}
+			};
+			auto clusterRun = [&](const T* win, int jFirst, int jCount, int centre) {
+				int jj = 0;
+				while (jj < jCount) {
+					const int j = jFirst + jj;
+					if (jj + 2 < jCount && offs[j + 1] == offs[j] + 1 && offs[j + 2] == offs[j] + 2) {
+						line3(win, j, centre);
+						jj += 3;
+					} else {
+						entry(win, j, centre);
+						jj += 1;
+					}
+				}
+			};
+			if (nLo) clusterRun(winOf(z - 1), 0, nLo, -P);
+			clusterRun(winOf(z), nLo, nMid, 0);
+			if (nHi) clusterRun(winOf(z + 1), nLo + nMid, nHi, P);
 #pragma unroll
 			for (int p = 0; p < PACKS; ++p) {
 				if (act[p] && base + loc[p] < rows) {
