@@ -312,6 +312,50 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
         del A, d_start, d_pos, d_val
     except Exception as e:  # noqa: BLE001
         out["spmv_laplacian512_f64"] = {"skipped": str(e)[:200]}
+    # (b') a 27-point stencil with constant coefficients -- HPCG's matrix shape -- at 192^3 in fp64: far offsets in clusters, i.e. the
+    # three-window march kernel of r05 (AUTO's choice for it) beside the CSR stream; built on the device with torch (no host loop)
+    try:
+        N = 192
+        n = N ** 3
+        i = torch.arange(n, device=dev, dtype=torch.int64)
+        ix, iy, iz = i % N, (i // N) % N, i // (N * N)
+        cols, valid, vals = [], [], []
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    ok = (ix + dx >= 0) & (ix + dx < N) & (iy + dy >= 0) & (iy + dy < N) & (iz + dz >= 0) & (iz + dz < N)
+                    cols.append(i + dz * N * N + dy * N + dx)
+                    valid.append(ok)
+                    vals.append(26.0 if (dx, dy, dz) == (0, 0, 0) else -1.0)
+        cols, valid = torch.stack(cols, dim=1), torch.stack(valid, dim=1)
+        d_start = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        d_start[1:] = torch.cumsum(valid.sum(dim=1), dim=0)
+        d_pos = cols[valid].to(torch.int32)
+        d_val = torch.tensor(vals, dtype=torch.float64, device=dev).expand(n, 27)[valid].contiguous()
+        d_start = d_start.to(torch.int32)
+        nnz = int(d_pos.numel())
+        del i, ix, iy, iz, cols, valid
+        A = smm.CSRMatrix.from_device(n, n, d_start, d_pos, d_val, np.float64)
+        A.set_kernel(2, 1)
+        x = torch.rand(n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(11)) - 0.5
+        y_csr = torch.empty_like(x)
+        A.spmv_dev(0, None, x, y_csr, stream)
+        ms = time_spmv(A, n, torch.float64, 10)
+        bts = spmv_bytes(n, n, nnz, 8)
+        leg = {"rows": n, "nnz": nnz, "dtype": "f64", "csr_stream": {"avg_launch_ms": ms, "gbps": bts / ms / 1e6, "frac": bts / ms / 1e6 / HBM_PEAK_GBPS}}
+        A.set_kernel(3, 1)  # (one lane per row: what AUTO gives a matrix with constant diagonals -- the reference's summation order)
+        k_name, k_bytes = A.kernel_desc()
+        y = torch.empty_like(x)
+        A.spmv_dev(0, None, x, y, stream)
+        torch.cuda.synchronize()
+        ms_m = time_spmv(A, n, torch.float64, 20)
+        leg["pattern_family"] = {"kernel": k_name, "avg_launch_ms": ms_m, "true_bytes_per_launch": k_bytes, "gbps": k_bytes / ms_m / 1e6,
+                                 "frac": k_bytes / ms_m / 1e6 / HBM_PEAK_GBPS, "bit_equal_to_csr_stream": bool(torch.equal(y, y_csr))}
+        out["spmv_stencil27_192_f64"] = leg
+        A.close()
+        del A, d_start, d_pos, d_val, x, y, y_csr
+    except Exception as e:  # noqa: BLE001
+        out["spmv_stencil27_192_f64"] = {"skipped": str(e)[:200]}
     torch.cuda.empty_cache()
     # (c) BASELINE config 2: CG on the 1000 x 1000 Poisson matrix, fp64, tol 1e-6 -- the register-resident solve (one launch,
     # csrc/smm_resident.hip) and the three-launch loop, wall time of the whole call

@@ -81,6 +81,7 @@ void preloadPatternUnit();
 void preloadMarchUnit();
 void preloadBlas1Unit();
 void preloadSolversUnit();
+void preloadResidentUnits();  // the two single-launch solvers (smm_resident.hip, smm_resident_bicg.hip)
 
 // caching device allocator (solver temporaries are allocated per call like the reference's SMM::Vector,
 // ref:2336-2339, but hipMalloc is far too slow to sit in that path)

@@ -343,6 +343,14 @@ static std::atomic<int>& residentModeRef() {
 }
 static int residentMode() { return residentModeRef().load(); }
 
+void preloadBicgResidentUnit();
+void preloadResidentUnits() {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(maxRowLenKernel));
+	(void)hipGetLastError();
+	preloadBicgResidentUnit();
+}
+
 static std::mutex g_residentMutex;  // two grid-barrier kernels must never share the chip: each would wait for CUs the other holds
 std::mutex& residentMutex() { return g_residentMutex; }
 

@@ -508,6 +508,12 @@ int bicgstabResidentTry(const smm_hip_csr* ca, const T* b, T* x, int maxIteratio
 	return SMM_HIP_OK;
 }
 
+void preloadBicgResidentUnit() {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(ellFromMasksKernel<double>));
+	(void)hipGetLastError();
+}
+
 template int bicgstabResidentTry<float>(const smm_hip_csr*, const float*, float*, int, float, const float*, hipStream_t, int*, int*, float*, bool*);
 template int bicgstabResidentTry<double>(const smm_hip_csr*, const double*, double*, int, double, const double*, hipStream_t, int*, int*, double*, bool*);
 

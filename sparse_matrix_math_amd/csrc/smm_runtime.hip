@@ -72,6 +72,11 @@ static int initLocked(int device) {
 		preloadMarchUnit();
 		preloadBlas1Unit();
 		preloadSolversUnit();
+		{
+			// (r05: the first single-launch solve of a process paid 5-7 ms for its code object -- config 5's stand-in 20.4 ms instead of 13.6)
+			SetupTrace traceRes("init:   of which the single-launch solvers");
+			preloadResidentUnits();
+		}
 	}
 	return SMM_HIP_OK;
 }
