@@ -142,3 +142,16 @@ def test_quirks_and_fall_back(smm, oracle, modes):
     M = A.getPreconditioner(smm.SolverPreconditioner.ILU0)
     res = _solve(smm, A, b, 6, 1e-30, M, host.CG_RESIDENT_REQUIRE)
     assert res[:2] == (0, 6)
+
+
+def test_fuzz_random_banded_matrices():
+    """tools/resident_bicg_fuzz.py: 24 random banded matrices -- 2-16 offsets, holes in every diagonal, row counts that leave workgroups
+    partly or wholly idle, constant and varying diagonals, with and without Jacobi, fp32 / fp64 -- single launch against loop and oracle"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "resident_bicg_fuzz.py"), "24"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "single-launch BiCGStab fuzz: ALL OK" in r.stdout
