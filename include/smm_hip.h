@@ -460,6 +460,13 @@ int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks);
  *   halo_first   1: the rows of an updated vector that a peer receives are produced by a small launch of their own and the exchange is
  *                posted right behind it, before the bulk of the update runs (SMM_HIP_HALO_FIRST=0 turns it off); same bits either way. */
 int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, int* halo_first, double* direct_share);
+/* The peer-to-peer plan of one rank as plain numbers: host arithmetic only (no device, no communicator), the same function the set-up uses.
+ * needs[2 q], needs[2 q + 1] = the column range [cmin, cmax) rank q's rows touch; bounds[0 .. world] = the row partition.  Writes records of
+ * 8 values into out (capacity in values; *out_count = records): push {0, dst, relay or -1, first global column, position at dst / relay,
+ * count, path, relay job}, forward {1, src, dst, staging position, landing position at dst, count, path, job}, land {2, src, offset in the
+ * halo-extended vector, landing position, count, paths, 0, 0}.  For tests (tests/test_p2p_plan_cpu.py replays a world of 8 on the CPU). */
+int smm_hip_dist_p2p_plan(int world, int rank, const long long* needs, const int* bounds, int relays, double direct_share, long long* out, int out_capacity,
+                          int* out_count);
 /* the two local blocks (owned by A): a_loc is the square diagonal block a block-Jacobi preconditioner is built on
  * (smm_hip_precond_create(a_loc, kind, &M)); both accept smm_hip_csr_set_kernel */
 int smm_hip_dist_csr_local_block(const smm_hip_dist_csr* A, smm_hip_csr** a_loc, smm_hip_csr** a_rem);

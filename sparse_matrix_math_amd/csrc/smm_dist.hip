@@ -654,16 +654,15 @@ struct PlanSeg {
 	long long landOff;  // element offset in dst's landing area
 	int count;
 };
-static std::vector<PlanSeg> planRecvs(const smm_hip_dist_csr* D, int q) {
+static std::vector<PlanSeg> planRecvs(int world, const long long* needs, const int* bounds, int q) {
 	std::vector<PlanSeg> out;
-	const int world = D->comm->world;
 	long long at = 0;
 	for (int p = 0; p < world; ++p) {
 		if (p == q) continue;
-		const long long lo = std::max<long long>(D->needs[2 * static_cast<size_t>(q)], D->bounds[static_cast<size_t>(p)]);
-		const long long hi = std::min<long long>(D->needs[2 * static_cast<size_t>(q) + 1], D->bounds[static_cast<size_t>(p) + 1]);
+		const long long lo = std::max<long long>(needs[2 * static_cast<size_t>(q)], bounds[static_cast<size_t>(p)]);
+		const long long hi = std::min<long long>(needs[2 * static_cast<size_t>(q) + 1], bounds[static_cast<size_t>(p) + 1]);
 		if (lo < hi) {
-			out.push_back({p, q, lo - D->needs[2 * static_cast<size_t>(q)], at, static_cast<int>(hi - lo)});
+			out.push_back({p, q, lo - needs[2 * static_cast<size_t>(q)], at, static_cast<int>(hi - lo)});
 			at += hi - lo;
 		}
 	}
@@ -691,6 +690,10 @@ static std::vector<int> planRelays(int world, int p, int q, int want) {
 static std::vector<int> planParts(int count, int relays, double directShare) {
 	std::vector<int> cut(static_cast<size_t>(relays) + 2, 0);
 	cut[static_cast<size_t>(relays) + 1] = count;
+	if (count < 64 * (relays + 1)) {  // a short segment travels whole on the direct path (no empty part in front of a non-empty one, ever)
+		for (int k = 1; k <= relays; ++k) cut[static_cast<size_t>(k)] = count;
+		return cut;
+	}
 	const double rest = relays > 0 ? (1.0 - directShare) / relays : 0.0;
 	double cum = directShare;
 	for (int k = 1; k <= relays; ++k) {
@@ -700,6 +703,42 @@ static std::vector<int> planParts(int count, int relays, double directShare) {
 		cum += rest;
 	}
 	return cut;
+}
+
+// Every part of every segment of every rank, and what each relay stages where: the SAME table on every rank, from global knowledge only.
+struct P2PRoute {
+	PlanSeg seg;
+	int part, relay, a, b;  // elements [a, b) of the segment; relay < 0: the direct part
+	int job;                // index among the relay's jobs
+	long long stagePos;     // element offset in the relay's staging area
+};
+struct P2PPlan {
+	std::vector<P2PRoute> routes;
+	std::vector<long long> stageTotal;  // elements of staging area per rank
+	std::vector<int> jobCount;          // relay jobs per rank
+};
+static P2PPlan p2pMakePlan(int world, const long long* needs, const int* bounds, int relays, double directShare, bool* tooMany) {
+	P2PPlan plan;
+	plan.stageTotal.assign(static_cast<size_t>(world), 0);
+	plan.jobCount.assign(static_cast<size_t>(world), 0);
+	*tooMany = false;
+	for (int q = 0; q < world; ++q) {
+		for (const PlanSeg& g : planRecvs(world, needs, bounds, q)) {
+			const std::vector<int> via = planRelays(world, g.src, q, relays);
+			const std::vector<int> cut = planParts(g.count, static_cast<int>(via.size()), directShare);
+			for (size_t k = 0; k + 1 < cut.size(); ++k) {
+				P2PRoute rt{g, static_cast<int>(k), k == 0 ? -1 : via[k - 1], cut[k], cut[k + 1], -1, 0};
+				if (rt.relay >= 0) {
+					rt.job = plan.jobCount[static_cast<size_t>(rt.relay)]++;
+					rt.stagePos = plan.stageTotal[static_cast<size_t>(rt.relay)];
+					plan.stageTotal[static_cast<size_t>(rt.relay)] += (rt.b - rt.a + 3) & ~3;
+					if (rt.job >= P2P_MAX_JOBS) *tooMany = true;
+				}
+				plan.routes.push_back(rt);
+			}
+		}
+	}
+	return plan;
 }
 
 // Collective (every rank tears its matrix down in the same order as it built it): a rank's block must outlive every remote write into it
@@ -779,33 +818,12 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 		if (P->relays == 0) P->directShare = 1.0;
 	}
 	// ---- the plan, from global knowledge: what I receive, what I send (directly / staged at a relay), what I forward
-	const std::vector<PlanSeg> mine = planRecvs(D, rank);
-	std::vector<long long> stageTotal(static_cast<size_t>(world), 0);
-	std::vector<int> jobCount(static_cast<size_t>(world), 0);
-	struct Route {
-		PlanSeg seg;
-		int part, relay, a, b;  // elements [a, b) of the segment; relay < 0: direct
-		int job;                // index among the relay's jobs
-		long long stagePos;     // element offset in the relay's staging area
-	};
-	std::vector<Route> routes;
+	const std::vector<PlanSeg> mine = planRecvs(world, D->needs.data(), D->bounds.data(), rank);
 	bool tooMany = false;
-	for (int q = 0; q < world; ++q) {
-		for (const PlanSeg& g : planRecvs(D, q)) {
-			const std::vector<int> relays = planRelays(world, g.src, q, P->relays);
-			const std::vector<int> cut = planParts(g.count, static_cast<int>(relays.size()), P->directShare);
-			for (size_t k = 0; k + 1 < cut.size(); ++k) {
-				Route rt{g, static_cast<int>(k), k == 0 ? -1 : relays[k - 1], cut[k], cut[k + 1], -1, 0};
-				if (rt.relay >= 0) {
-					rt.job = jobCount[static_cast<size_t>(rt.relay)]++;
-					rt.stagePos = stageTotal[static_cast<size_t>(rt.relay)];
-					stageTotal[static_cast<size_t>(rt.relay)] += (rt.b - rt.a + 3) & ~3;
-					if (rt.job >= P2P_MAX_JOBS) tooMany = true;
-				}
-				routes.push_back(rt);
-			}
-		}
-	}
+	const P2PPlan plan = p2pMakePlan(world, D->needs.data(), D->bounds.data(), P->relays, P->directShare, &tooMany);
+	const std::vector<P2PRoute>& routes = plan.routes;
+	const std::vector<long long>& stageTotal = plan.stageTotal;
+	using Route = P2PRoute;
 	// ---- my block: header | landing x 3 | staging x 3, element-aligned to 256 bytes
 	long long landElems = 0;
 	for (const PlanSeg& g : mine) landElems += g.count;
@@ -2126,6 +2144,49 @@ int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks) {
 		return SMM_HIP_ERR_INVALID;
 	}
 	*chunks = D->chunks;
+	return SMM_HIP_OK;
+}
+
+// The peer-to-peer plan of one rank as plain numbers (host arithmetic only: no device, no communicator) -- what the set-up derives from
+// the globally known column ranges and row bounds.  The CPU tests replay it for every rank of a world of 8 and check that every halo
+// element arrives exactly once.  Records of 8 values:
+//   {0, dst, relay (-1: direct), first global column, position (dst's landing area / the relay's staging area), count, path, relay job (-1)}   push
+//   {1, src, dst, position in my staging area, position in dst's landing area, count, path, relay job}                                           forward
+//   {2, src, offset in my halo-extended vector, position in my landing area, count, paths, 0, 0}                                                 land
+int smm_hip_dist_p2p_plan(int world, int rank, const long long* needs, const int* bounds, int relays, double direct_share, long long* out, int out_capacity,
+                          int* out_count) {
+	if (world < 1 || world > P2P_MAX_WORLD || rank < 0 || rank >= world || !needs || !bounds || !out_count || relays < 0 || relays > P2P_MAX_PATHS - 1) {
+		setError("dist_p2p_plan: bad arguments");
+		return SMM_HIP_ERR_INVALID;
+	}
+	relays = std::min(relays, std::max(0, world - 2));
+	if (relays == 0) direct_share = 1.0;
+	bool tooMany = false;
+	const P2PPlan plan = p2pMakePlan(world, needs, bounds, relays, direct_share, &tooMany);
+	if (tooMany) {
+		setError("dist_p2p_plan: more relay jobs per rank than the header holds");
+		return SMM_HIP_ERR_INVALID;
+	}
+	std::vector<long long> rec;
+	for (const P2PRoute& rt : plan.routes) {
+		const long long n = rt.b - rt.a;
+		if (n <= 0) continue;
+		const int q = rt.seg.dst;
+		if (rt.seg.src == rank) {
+			const long long col = needs[2 * static_cast<size_t>(q)] + rt.seg.extOff + rt.a;
+			rec.insert(rec.end(), {0LL, q, rt.relay, col, rt.relay < 0 ? rt.seg.landOff + rt.a : rt.stagePos, n, rt.part, rt.relay < 0 ? -1LL : rt.job});
+		}
+		if (rt.relay == rank) rec.insert(rec.end(), {1LL, rt.seg.src, q, rt.stagePos, rt.seg.landOff + rt.a, n, rt.part, rt.job});
+	}
+	for (const PlanSeg& g : planRecvs(world, needs, bounds, rank)) {
+		long long paths = 0;
+		for (const P2PRoute& rt : plan.routes) {
+			if (rt.seg.dst == rank && rt.seg.src == g.src && rt.b > rt.a) paths = std::max<long long>(paths, rt.part + 1);
+		}
+		rec.insert(rec.end(), {2LL, g.src, g.extOff, g.landOff, g.count, paths, 0LL, 0LL});
+	}
+	*out_count = static_cast<int>(rec.size() / 8);
+	if (out && static_cast<size_t>(out_capacity) >= rec.size()) memcpy(out, rec.data(), rec.size() * sizeof(long long));
 	return SMM_HIP_OK;
 }
 
