@@ -168,6 +168,11 @@ int smm_hip_csr_kernel_desc(const smm_hip_csr* m, char* name, int name_cap, long
  * (profiles/r04/march_threshold.txt).
  * -1 restores a default.  Applies to matrices analysed afterwards.  Tuning knob; the tests use it to run the kernels on small grids. */
 int smm_hip_set_march_min_rows(long long const_diagonals_rows, long long values_read_rows);
+/* Test / measurement knob: from how many BYTES PER VECTOR the unpreconditioned ConjugateGradient defers its x update (csrc/smm_solvers.hip,
+ * cgLazyXP: the last four directions are kept and x is brought up to date every fourth iteration -- the reference's roundings in the
+ * reference's order, bit for bit, 0.75 vector pass less per iteration, four more vectors of device memory).  Default 64 MB (where five
+ * vectors no longer fit the Infinity Cache); a negative value restores the default; SMM_HIP_CG_LAZY_X=0 in the environment turns it off. */
+int smm_hip_set_cg_lazy_x_min_bytes(long long bytes);
 /* allow = 0: a matrix with constant diagonals keeps reading values[] (the MASKS kernels); 1 (default): CONST where it applies.  For
  * measurements of one against the other; the results are the same bits either way. */
 int smm_hip_csr_pattern_allow_const(smm_hip_csr* m, int allow);

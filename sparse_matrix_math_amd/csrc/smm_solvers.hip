@@ -13,6 +13,7 @@
 //   * update loops keep the reference's expression shapes (_smm_fma nesting), so given the same scalars they
 //     are bit-identical to the CPU loops.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "smm_device.h"
@@ -31,6 +32,7 @@ struct Scal {
 	T omega;
 	T res;      // CG: last ||r||^2 ; BiCGStab: last ||r||
 	T rrPing[2];  // fused loops: rr (CG) / rr0 (BiCGStab) double-buffered by iteration parity
+	T alphaRing[4];  // CG with the deferred x update: alpha of the last LAZY_M iterations
 	int done;
 	int iters;
 	int status;
@@ -160,13 +162,16 @@ __device__ __forceinline__ T sumPartsAll(const T* __restrict__ partials, T* red5
 // (the vector loops of the fused kernels go through streamMap, smm_device.h: 16-byte accesses, 4 packs per lane in flight)
 template <typename T, bool NT>
 __global__ __launch_bounds__(TPB) void cgFusedR(int n, Scal<T>* sc, int par, const T* __restrict__ partsA, const T* Ap, T* r,
-                                                T* __restrict__ partsC) {
+                                                T* __restrict__ partsC, int alphaSlot) {
 	__shared__ T red[5];
 	const int done = sc->done;
 	if (blockIdx.x == 0 && threadIdx.x == 0) sc->pad = done;
 	if (done) return;
 	const T alpha = sc->rrPing[par] / sumPartsAll(partsA, red);
-	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->alpha = alpha;
+		sc->alphaRing[alphaSlot] = alpha;
+	}
 	T acc = T(0);
 	const T* const in[2] = {Ap, r};
 	T* const out[1] = {r};
@@ -212,6 +217,83 @@ __global__ __launch_bounds__(TPB) void cgFusedXP(int n, Scal<T>* sc, int par, co
 		o[0] = smmFma(alpha, v[0], v[1]);
 		o[1] = smmFma(beta, v[0], v[2]);
 	});
+}
+
+// ---- the x update deferred (r05) ------------------------------------------------------------------------------------------------
+// For vectors that do not fit the caches an iteration of CG is 10 vector passes, 5 of them in cgFusedXP (read p, x, r; write x, p).  x is
+// only an accumulator: x_{k+1} = alpha_k p_k + x_k (ref:2362-2366).  Keeping the last LAZY_M directions in a ring, x is brought up to date
+// every LAZY_M-th iteration -- x = alpha_k p_k + (... + (alpha_{k-M+1} p_{k-M+1} + x)): the reference's roundings in the reference's order,
+// bit for bit -- in the launch that forms the next p anyway: (3 (M - 1) + M + 4) / M = 4.25 passes per iteration instead of 5 for M = 4, at
+// the price of M more vectors of device memory.  The launch that finds the iteration converged -- or is told it is the last -- flushes
+// whatever is pending, so x is complete whenever the loop ends.
+constexpr int LAZY_M = 4;
+template <typename T>
+struct LazyRing {
+	T* p[LAZY_M + 1];
+};
+
+// PENDING directions (this iteration's included) are applied to x when FLUSH; p_next = beta p_cur + r unless the iteration converged
+template <typename T, bool NT, int PENDING, bool PUPD>
+__device__ __forceinline__ void cgLazyFlush(int n, const LazyRing<T>& ring, int cur, const T (&alpha)[LAZY_M], T beta, const T* r, const T* xcur, T* x) {
+	// inputs: x, p_cur-PENDING+1 .. p_cur (oldest first) [, r]; outputs: x [, p_next]
+	const T* in[PENDING + 2];
+	in[0] = xcur;
+#pragma unroll
+	for (int k = 0; k < PENDING; ++k) in[1 + k] = ring.p[(cur + (LAZY_M + 1) - (PENDING - 1 - k)) % (LAZY_M + 1)];
+	in[PENDING + 1] = r;
+	T* out[2] = {x, ring.p[(cur + 1) % (LAZY_M + 1)]};
+	streamMap<T, NT, PENDING + 2, PUPD ? 2 : 1>(n, in, out, [&](const T(&v)[PENDING + 2], T(&o)[PUPD ? 2 : 1]) {
+		T xv = v[0];
+#pragma unroll
+		for (int k = 0; k < PENDING; ++k) xv = smmFma(alpha[LAZY_M - PENDING + k], v[1 + k], xv);  // oldest direction first
+		o[0] = xv;
+		if (PUPD) o[1] = smmFma(beta, v[PENDING], v[PENDING + 1]);
+	});
+}
+
+// convergence test ; beta ; p_next = beta p_cur + r ; x brought up to date when `flush` (host: every LAZY_M-th iteration and the last one)
+// or when the iteration converged.  pending = directions not yet applied to x, this iteration's included (1 .. LAZY_M).
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void cgLazyXP(int n, Scal<T>* sc, int par, const T* __restrict__ partsC, T eps, LazyRing<T> ring, int cur, int pending, int flush,
+                                                int alphaSlot, const T* r, const T* xcur, T* x) {
+	__shared__ T red[5];
+	if (sc->pad) return;
+	const T rrNew = sumPartsAll(partsC, red);
+	const T rrOld = sc->rrPing[par];
+	const bool converged = eps * eps > rrNew;
+	T alpha[LAZY_M];  // alpha[LAZY_M - 1] = this iteration's, alpha[LAZY_M - 2] the one before, ...
+#pragma unroll
+	for (int k = 0; k < LAZY_M; ++k) alpha[LAZY_M - 1 - k] = sc->alphaRing[(alphaSlot + LAZY_M - k) % LAZY_M];
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->iters += 1;
+		sc->res = rrNew;
+		if (converged) {
+			sc->done = 1;
+			sc->status = SMM_SOLVER_SUCCESS;
+		} else {
+			sc->rrPing[par ^ 1] = rrNew;
+		}
+	}
+	const T beta = rrNew / rrOld;
+	if (!(flush || converged)) {
+		const T* const in[2] = {ring.p[cur], r};
+		T* const out[1] = {ring.p[(cur + 1) % (LAZY_M + 1)]};
+		streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
+		return;
+	}
+#define SMM_LAZY_CASE(P)                                                                         \
+	case P:                                                                                      \
+		if (converged) cgLazyFlush<T, NT, P, false>(n, ring, cur, alpha, beta, r, xcur, x);      \
+		else cgLazyFlush<T, NT, P, true>(n, ring, cur, alpha, beta, r, xcur, x);                 \
+		break;
+	switch (pending) {
+		SMM_LAZY_CASE(1)
+		SMM_LAZY_CASE(2)
+		SMM_LAZY_CASE(3)
+		SMM_LAZY_CASE(4)
+	default: break;
+	}
+#undef SMM_LAZY_CASE
 }
 
 // alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247)
@@ -421,6 +503,19 @@ static bool updateNT(long long n, size_t elemBytes, int vectors) {
 
 static int checkInterval(int it) { return std::max(4, std::min(64, it / 4)); }
 
+// from how many bytes per vector CG defers its x update (cgLazyXP): where five vectors no longer fit the 256 MB Infinity Cache the passes
+// are what an iteration costs; below, the extra ring of directions buys nothing.  smm_hip_set_cg_lazy_x_min_bytes (tests) / SMM_HIP_CG_LAZY_X=0
+static std::atomic<long long> g_lazyMinBytes{-1};
+static long long lazyMinBytes() {
+	const long long forced = g_lazyMinBytes.load(std::memory_order_relaxed);
+	if (forced >= 0) return forced;
+	static const long long env = [] {
+		const char* e = getenv("SMM_HIP_CG_LAZY_X");
+		return e && atoi(e) == 0 ? (1LL << 62) : (64LL << 20);
+	}();
+	return env;
+}
+
 template <typename T>
 static int readScal(const Scal<T>* d_sc, Scal<T>* h, hipStream_t s) {
 	SMM_HIP_TRY(hipMemcpyAsync(h, d_sc, sizeof(Scal<T>), hipMemcpyDeviceToHost, s));
@@ -460,9 +555,20 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 	SMM_TRY(ensureCsrReady(a, s, true));
 	SMM_TRY(adoptPatternForSolver(a, maxIterations, s));  // many SpMVs ahead: a mid-size banded / stencil matrix takes the index-free family
 	DevBuf<T> r, p, Ap, z, parts, parts2;
+	DevBuf<T> ringBuf[LAZY_M];
 	DevBuf<Scal<T>> sc;
+	// the deferred x update (cgLazyXP): unpreconditioned CG on vectors too large for the caches; LAZY_M more vectors for the ring of directions
+	const bool lazy = !pcg && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= lazyMinBytes();
+	LazyRing<T> ring{};
 	SMM_TRY(r.alloc(n));
 	SMM_TRY(p.alloc(n));
+	if (lazy) {
+		ring.p[0] = p;
+		for (int k = 0; k < LAZY_M; ++k) {
+			SMM_TRY(ringBuf[k].alloc(n));
+			ring.p[k + 1] = ringBuf[k];
+		}
+	}
 	SMM_TRY(Ap.alloc(n));
 	if (pcg) SMM_TRY(z.alloc(n));
 	SMM_TRY(parts.alloc(2 * NPART));
@@ -495,6 +601,19 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			if (seenDone) break;
 			nextCheck = i + checkInterval(i);
 		}
+		if (lazy) {
+			// the direction of iteration i lives in ring slot i % (LAZY_M + 1); x is brought up to date every LAZY_M-th iteration, in the last
+			// planned one, and by whichever launch finds the iteration converged
+			const int cur = i % (LAZY_M + 1);
+			const T* pc = ring.p[cur];
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, pc, Ap, 1, pc, parts, doneFlag, s));
+			SMM_LAUNCH_UPDATE(cgFusedR, updateNT(n, sizeof(T), 3), NPART, s, n, sc, i & 1, parts, Ap, r, parts2, i % LAZY_M);
+			const int pending = i % LAZY_M + 1;
+			const int flush = (pending == LAZY_M || i == maxIterations - 1) ? 1 : 0;
+			const T* xc = i < LAZY_M ? x0 : x;  // (until the first scheduled flush x has not been written: ref:2351, 2395)
+			SMM_LAUNCH_UPDATE(cgLazyXP, updateNT(n, sizeof(T), 5), g, s, n, sc, i & 1, parts2, eps, ring, cur, pending, flush, i % LAZY_M, r, xc, x);
+			continue;
+		}
 		// Ap = A p with the p.Ap partial sums fused into the epilogue (ref:2353-2354)
 		SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, Ap, 1, p, parts, doneFlag, s));
 		const T* xcur = i == 0 ? x0 : x;  // ref:2351, 2395
@@ -508,7 +627,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			cgUpdateP<T><<<g, TPB, 0, s>>>(n, sc, p, z);
 		} else {
 			// alpha and beta are formed inside the two update kernels (no scalar launches)
-			SMM_LAUNCH_UPDATE(cgFusedR, updateNT(n, sizeof(T), 3), NPART, s, n, sc, i & 1, parts, Ap, r, parts2);
+			SMM_LAUNCH_UPDATE(cgFusedR, updateNT(n, sizeof(T), 3), NPART, s, n, sc, i & 1, parts, Ap, r, parts2, 0);
 			SMM_LAUNCH_UPDATE(cgFusedXP, updateNT(n, sizeof(T), 5), g, s, n, sc, i & 1, parts2, eps, p, r, xcur, x);
 		}
 	}
@@ -942,6 +1061,11 @@ int smm_hip_bicgstab_functor_f32(const smm_hip_csr* a, float* b, float* x, int m
 int smm_hip_bicgstab_functor_f64(const smm_hip_csr* a, double* b, double* x, int maxIterations, double eps, smm_hip_apply_fn_f64 apply, void* user,
                                  int* solver_status, int* iterations, double* resnorm) {
 	return bicgstabFunctorHost<double>(a, b, x, maxIterations, eps, apply, user, solver_status, iterations, resnorm);
+}
+
+int smm_hip_set_cg_lazy_x_min_bytes(long long bytes) {
+	g_lazyMinBytes.store(bytes, std::memory_order_relaxed);
+	return SMM_HIP_OK;
 }
 
 int smm_hip_bicgsymmetric_f32(const smm_hip_csr* a, float* b, float* x, int maxIterations, float eps, int* solver_status, int* iterations) {

@@ -404,6 +404,11 @@ def cg_resident(mode=-1):
     return int(_lib.load().smm_hip_cg_resident(int(mode)))
 
 
+def set_cg_lazy_x_min_bytes(nbytes):
+    """test / measurement knob: bytes per vector from which CG defers its x update (negative: the default, 64 MB)"""
+    check(_lib.load().smm_hip_set_cg_lazy_x_min_bytes(int(nbytes)))
+
+
 def bicgstab_resident(mode=-1):
     """sets (0 off, 1 auto, 2 require) or only queries (-1) the single-launch BiCGStab path; returns the previous mode"""
     return int(_lib.load().smm_hip_bicgstab_resident(int(mode)))

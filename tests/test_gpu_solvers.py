@@ -240,3 +240,45 @@ def test_bicgsymmetric_diverged_heuristics_match_reference(smm, golden_v2, dtype
         assert float(np.max(np.abs(x - x_ref))) <= bound * scale, name
         statuses.add(int(st))
     assert statuses == {0, 1}
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cg_deferred_x_update_is_bit_identical(smm, oracle, dtype):
+    """cgLazyXP (csrc/smm_solvers.hip): for vectors beyond the caches CG keeps its last four directions and brings x up to date every fourth
+    iteration, in the last planned one and in whichever launch finds the iteration converged -- the reference's roundings in the
+    reference's order (ref:2362-2366).  Forced on at a small size: every iteration count from 0 to 13, convergence inside a window of four,
+    x0 in place and apart, must give the bits of the eager loop."""
+    from sparse_matrix_math_amd import host
+
+    csr = gen.poisson2d(150, dtype=dtype)
+    start, pos, val = csr
+    n = len(start) - 1
+    A = smm.CSRMatrix(n, n, *csr)
+    b = gen.row_sums(start, val)
+    rng = np.random.default_rng(9)
+    before = host.cg_resident(-1)
+    host.cg_resident(host.CG_RESIDENT_OFF)  # (the register-resident solve would take a matrix of this size first)
+    try:
+        for maxit, eps in [(k, 0.0) for k in range(0, 14)] + [(-1, 1e-3 if dtype == np.float32 else 1e-8), (-1, 2.0), (500, 1e-1)]:
+            for in_place in (True, False):
+                got = {}
+                for lazy in (True, False):
+                    host.set_cg_lazy_x_min_bytes(0 if lazy else 1 << 60)
+                    x0 = rng.uniform(-1, 1, n).astype(dtype) if maxit != 3 else np.zeros(n, dtype=dtype)
+                    rng = np.random.default_rng(9 + abs(maxit))  # (the same x0 for both)
+                    x0 = rng.uniform(-1, 1, n).astype(dtype)
+                    x = x0.copy() if in_place else np.full(n, 7, dtype=dtype)
+                    info = {}
+                    st = smm.ConjugateGradient(A, b, x if in_place else x0, x, maxit, dtype(eps), info=info)
+                    got[lazy] = (int(st), info["iterations"], x.copy())
+                assert got[True][:2] == got[False][:2], (maxit, eps, in_place)
+                np.testing.assert_array_equal(got[True][2], got[False][2], err_msg=f"maxit {maxit} eps {eps} in_place {in_place}")
+        st_o, x_o, it_o, _ = oracle.cg(csr, b, np.zeros(n, dtype=dtype), 9, 0.0)
+        host.set_cg_lazy_x_min_bytes(0)
+        x = np.zeros(n, dtype=dtype)
+        st = smm.ConjugateGradient(A, b, x, x, 9, dtype(0.0))
+        assert int(st) == st_o == 2
+        np.testing.assert_allclose(x, x_o, rtol=3e-4 if dtype == np.float32 else 1e-10, atol=1e-6 if dtype == np.float32 else 1e-12)
+    finally:
+        host.set_cg_lazy_x_min_bytes(-1)
+        host.cg_resident(before)
