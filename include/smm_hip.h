@@ -173,6 +173,9 @@ int smm_hip_set_march_min_rows(long long const_diagonals_rows, long long values_
  * reference's order, bit for bit, 0.75 vector pass less per iteration, four more vectors of device memory).  Default 64 MB (where five
  * vectors no longer fit the Infinity Cache); a negative value restores the default; SMM_HIP_CG_LAZY_X=0 in the environment turns it off. */
 int smm_hip_set_cg_lazy_x_min_bytes(long long bytes);
+/* Test / measurement knob: 0 keeps ConjugateGradient from forming its next direction inside the 2.5-D SpMV kernel (MarchFuse,
+ * csrc/smm_spmv_march.hip; on by default wherever the deferred x update is on and that kernel serves the matrix): same bits either way. */
+int smm_hip_set_cg_fuse_p(int on);
 /* allow = 0: a matrix with constant diagonals keeps reading values[] (the MASKS kernels); 1 (default): CONST where it applies.  For
  * measurements of one against the other; the results are the same bits either way. */
 int smm_hip_csr_pattern_allow_const(smm_hip_csr* m, int allow);

@@ -95,6 +95,7 @@ _PLAIN = {
     "smm_hip_csr_kernel_desc": (c_int, [_P, c_char_p, c_int, POINTER(c_longlong)]),
     "smm_hip_set_march_min_rows": (c_int, [c_longlong, c_longlong]),
     "smm_hip_set_cg_lazy_x_min_bytes": (c_int, [c_longlong]),
+    "smm_hip_set_cg_fuse_p": (c_int, [c_int]),
     "smm_hip_csr_pattern_allow_const": (c_int, [_P, c_int]),
     "smm_hip_precond_create": (c_int, [_P, c_int, POINTER(_P)]),
     "smm_hip_precond_create_block": (c_int, [_P, c_int, c_int, POINTER(_P)]),

@@ -294,6 +294,22 @@ template <typename T>
 int launchSpmvPattern(const smm_hip_csr* m, int lanes, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                       const int* doneFlag, hipStream_t s);
 void chooseSpmvConfig(smm_hip_csr* m);
+// ConjugateGradient's next direction formed in the SpMV's load phase (smm_spmv_march.hip, MarchFuse): Ap = A (beta pOld + r), the new
+// direction written to pNew, p.Ap into `partials`; `sc` is the solver's Scal<T>.  constMarchFusable: the matrix is served by the 2.5-D
+// constant-diagonal kernel in the form this exists for; the launch returns false when it could not be made (the caller must not have
+// relied on it: ask constMarchFusable first).
+template <typename T>
+struct CgFuseArgs {
+	const T* r;
+	T* pNew;
+	void* sc;
+	const T* partsC;
+	T eps;
+	int par, iter;
+};
+bool constMarchFusable(const smm_hip_csr* m, size_t elemBytes);
+template <typename T>
+bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* partials, const int* doneFlag, const CgFuseArgs<T>& f, hipStream_t s);
 
 // register-resident ConjugateGradient (smm_resident.hip): *handled = false when the matrix does not fit the register file
 template <typename T>

@@ -18,33 +18,11 @@
 
 #include "smm_device.h"
 #include "smm_internal.h"
+#include "smm_solver_scal.h"
 
 namespace smm {
 
 constexpr int TPB = 256;
-
-template <typename T>
-struct Scal {
-	T rr;       // CG: residualNormSquared / rz for PCG ; BiCGStab: rr0
-	T denom;    // p.Ap / ap.r0
-	T alpha;
-	T beta;
-	T omega;
-	T res;      // CG: last ||r||^2 ; BiCGStab: last ||r||
-	T rrPing[2];  // fused loops: rr (CG) / rr0 (BiCGStab) double-buffered by iteration parity
-	T alphaRing[4];  // CG with the deferred x update: alpha of the last LAZY_M iterations
-	int done;
-	int iters;
-	int status;
-	int pad;
-};
-
-template <typename T>
-__device__ __forceinline__ T sumParts(const T* __restrict__ partials, T* red) {
-	T acc = T(0);
-	for (int i = threadIdx.x; i < NPART; i += TPB) acc += partials[i];
-	return blockSum256(acc, red);
-}
 
 // ---- scalar stages (one workgroup each) ----------------------------------------------------------------
 // CG start: rr = r.r ; if eps^2 > rr -> done, SUCCESS, x untouched (ref:2341-2344)
@@ -61,6 +39,8 @@ __global__ __launch_bounds__(TPB) void cgInitScal(const T* __restrict__ partials
 		sc->iters = 0;
 		sc->status = SMM_SOLVER_MAX_ITERATIONS_REACHED;
 		sc->done = 0;
+		sc->pad = 0;
+		sc->flushIter = -1;
 		if (eps * eps > rr) {
 			sc->done = 1;
 			sc->status = SMM_SOLVER_SUCCESS;
@@ -142,16 +122,6 @@ __global__ __launch_bounds__(TPB) void cgUpdateP(int n, const Scal<T>* __restric
 // need no kernel of their own: two launches per CG iteration and three per BiCGStab iteration disappear.  State that must
 // survive a kernel (rr, alpha, omega, done, iterations) is written by workgroup 0 only; rr is double-buffered by iteration
 // parity because workgroup 0 writes the next value while the others still read the current one.
-template <typename T>
-__device__ __forceinline__ T sumPartsAll(const T* __restrict__ partials, T* red5) {
-	const T s = sumParts(partials, red5);
-	if (threadIdx.x == 0) red5[4] = s;
-	__syncthreads();
-	const T v = red5[4];
-	__syncthreads();
-	return v;
-}
-
 // The two update kernels of a CG iteration (ref:2354-2394), split so that every vector is passed as few times as the data flow
 // allows: the first needs only Ap and r (r = -alpha Ap + r and ||r||^2 -- the next reduction point), the second reads p once for
 // BOTH of its uses (x = alpha p + xcur, the reference's :2362-2366, and p = beta p + r): 8 vector passes per iteration instead of
@@ -240,7 +210,7 @@ __device__ __forceinline__ void cgLazyFlush(int n, const LazyRing<T>& ring, int 
 	in[0] = xcur;
 #pragma unroll
 	for (int k = 0; k < PENDING; ++k) in[1 + k] = ring.p[(cur + (LAZY_M + 1) - (PENDING - 1 - k)) % (LAZY_M + 1)];
-	in[PENDING + 1] = r;
+	in[PENDING + 1] = PUPD ? r : xcur;  // (without the p update r is not read: any valid vector)
 	T* out[2] = {x, ring.p[(cur + 1) % (LAZY_M + 1)]};
 	streamMap<T, NT, PENDING + 2, PUPD ? 2 : 1>(n, in, out, [&](const T(&v)[PENDING + 2], T(&o)[PUPD ? 2 : 1]) {
 		T xv = v[0];
@@ -294,6 +264,27 @@ __global__ __launch_bounds__(TPB) void cgLazyXP(int n, Scal<T>* sc, int par, con
 	default: break;
 	}
 #undef SMM_LAZY_CASE
+}
+
+// With the next direction formed inside the SpMV (launchConstMarchFusedP) nothing is left of cgLazyXP but x: this launch sits behind
+// every such SpMV and completes x when it is scheduled (every LAZY_M-th iteration) or when that SpMV found its predecessor converged
+// (flushIter == iter: one shot -- the launches enqueued behind a finished solve find another number there).  pending directions end at
+// ring slot `cur`; alphaSlot: the ring position of the newest one's alpha.
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void cgLazyFlushOnly(int n, const Scal<T>* __restrict__ sc, LazyRing<T> ring, int cur, int pending, int scheduled, int iter,
+                                                       int alphaSlot, const T* xcur, T* x) {
+	const bool converged = sc->flushIter == iter;
+	if (!converged && (!scheduled || sc->done)) return;
+	T alpha[LAZY_M];
+#pragma unroll
+	for (int k = 0; k < LAZY_M; ++k) alpha[LAZY_M - 1 - k] = sc->alphaRing[(alphaSlot + LAZY_M - k) % LAZY_M];
+	switch (pending) {
+	case 1: cgLazyFlush<T, NT, 1, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 2: cgLazyFlush<T, NT, 2, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 3: cgLazyFlush<T, NT, 3, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 4: cgLazyFlush<T, NT, 4, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	default: break;
+	}
 }
 
 // alpha = rr0 / (ap.r0) ; s = -alpha ap + r   (ref:2243-2247)
@@ -560,6 +551,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 	// the deferred x update (cgLazyXP): unpreconditioned CG on vectors too large for the caches; LAZY_M more vectors for the ring of directions
 	const bool lazy = !pcg && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= lazyMinBytes();
 	LazyRing<T> ring{};
+	const bool fuseP = lazy && constMarchFusable(a, sizeof(T));  // (decided once per solve: the two loop forms do their bookkeeping in different launches)
 	SMM_TRY(r.alloc(n));
 	SMM_TRY(p.alloc(n));
 	if (lazy) {
@@ -600,6 +592,28 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			if (seenDone < 0) return seenDone;
 			if (seenDone) break;
 			nextCheck = i + checkInterval(i);
+		}
+		if (lazy && fuseP) {
+			// the direction is formed INSIDE the SpMV (2.5-D constant-diagonal kernel): SpMV' (bookkeeping of iteration i - 1, p_i, A p_i, p.Ap),
+			// the flush of x behind it (scheduled every LAZY_M-th iteration; or because SpMV' found iteration i - 1 converged), the r update
+			const int cur = i % (LAZY_M + 1);
+			if (i == 0) {
+				SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, ring.p[0], Ap, 1, ring.p[0], parts, doneFlag, s));
+			} else {
+				const int prev = (i - 1) % (LAZY_M + 1);
+				const CgFuseArgs<T> f{r, ring.p[cur], sc.p, parts2, eps, (i - 1) & 1, i};
+				if (!launchConstMarchFusedP<T>(a, ring.p[prev], Ap, parts, doneFlag, f, s)) {
+					setError("cg: the fused SpMV could not be launched");
+					return SMM_HIP_ERR_HIP;
+				}
+				SMM_LAUNCH_UPDATE(cgLazyFlushOnly, updateNT(n, sizeof(T), 5), g, s, n, sc, ring, prev, (i - 1) % LAZY_M + 1, i % LAZY_M == 0 ? 1 : 0, i, (i - 1) % LAZY_M,
+				                  i <= LAZY_M ? x0 : x, x);
+			}
+			SMM_LAUNCH_UPDATE(cgFusedR, updateNT(n, sizeof(T), 3), NPART, s, n, sc, i & 1, parts, Ap, r, parts2, i % LAZY_M);
+			if (i == maxIterations - 1) {  // the last planned iteration has no SpMV' behind it: its bookkeeping and the rest of x
+				SMM_LAUNCH_UPDATE(cgLazyXP, updateNT(n, sizeof(T), 5), g, s, n, sc, i & 1, parts2, eps, ring, cur, i % LAZY_M + 1, 1, i % LAZY_M, r, i < LAZY_M ? x0 : x, x);
+			}
+			continue;
 		}
 		if (lazy) {
 			// the direction of iteration i lives in ring slot i % (LAZY_M + 1); x is brought up to date every LAZY_M-th iteration, in the last

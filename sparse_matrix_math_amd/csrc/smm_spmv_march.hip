@@ -25,6 +25,7 @@
 
 #include "smm_device.h"
 #include "smm_internal.h"
+#include "smm_solver_scal.h"
 
 namespace smm {
 
@@ -85,14 +86,35 @@ __device__ __forceinline__ T bitsToValue(unsigned long long bits) {
 }
 
 // what a lane requests for one plane of its tile: its 8 centre values of x, its share of the two halos, the masks of its 8 rows
-template <typename T, int R, int HP>
+template <typename T, int R, int HP, bool FUSE = false>
 struct MarchSet {
 	PackU<T> c[MarchCfg<T, R>::PACKS];
 	PackU<T> h[HP];
 	MaskP<T> m[MarchCfg<T, R>::PACKS];
+	// FUSE (MarchFuse below): the same packs of the second stream, r -- until the set is first used, when c / h become beta * c + r
+	PackU<T> c2[FUSE ? MarchCfg<T, R>::PACKS : 1];
+	PackU<T> h2[FUSE ? HP : 1];
 };
 
 }  // namespace
+
+// ConjugateGradient's next direction formed in the SpMV's own load phase (r05): the launch reads the PREVIOUS direction
+// where it would read x, and r beside it, and every element it touches -- centre, halo, the planes above and below -- becomes
+// p = beta p_old + r (ref:2391-2393) the moment its request set is first used: the owner's expression on the owner's operands, the same bits
+// in every workgroup that needs the element.  The rows a unit computes are written to pNew (each exactly once); beta comes from the partials
+// of ||r||^2 the update before left behind, added by every workgroup in the fixed order (sumPartsAll); workgroup 0 does the iteration's
+// bookkeeping (ref:2377-2382) that cgFusedXP / cgLazyXP would have done, and a launch that finds the iteration converged only records
+// that (flushIter: the flush launch behind it completes x) and returns.  p.Ap takes p from the LDS window instead of a second read.
+template <typename T>
+struct MarchFuse {
+	const T* r = nullptr;
+	T* pNew = nullptr;
+	Scal<T>* sc = nullptr;
+	const T* partsC = nullptr;
+	T eps = T(0);
+	int par = 0;
+	int iter = 0;
+};
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smmMarchLds[];
 
@@ -117,15 +139,20 @@ __global__ __launch_bounds__(256) void marchNarrowMasks(long long rows, const un
 #ifndef SMM_MARCH_MIN_WAVES
 #define SMM_MARCH_MIN_WAVES(T, R) ((sizeof(T) == 4 || (R) < 8) ? 3 : 1)
 #endif
-template <typename T, int R, int KN, bool NT, int HP>
-__global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternConstMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
+template <typename T, int R, int KN, bool NT, int HP, bool FUSE = false>
+// (FUSE: 197-241 VGPRs in fp64, two workgroups per CU; capped at 168 for three it spills 120-400 bytes per lane and loses: 1.82 -> 2.08 ms per
+// CG iteration at 512^3 fp64, 0.97 -> 1.41 in fp32)
+#ifndef SMM_MARCH_FUSE_MIN_WAVES
+#define SMM_MARCH_FUSE_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(TPB, FUSE ? SMM_MARCH_FUSE_MIN_WAVES : SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternConstMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
                                                                    int nOff, int hasLo, int hasHi, const int* __restrict__ offs,
                                                                    const unsigned long long* __restrict__ cvalBits, const unsigned* __restrict__ masks32,
                                                                    int opFlags, const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out,
                                                                    int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
-                                                                   const int* __restrict__ doneFlag) {
+                                                                   const int* __restrict__ doneFlag, MarchFuse<T> fz = MarchFuse<T>()) {
 	using Cfg = MarchCfg<T, R>;
-	using Set = MarchSet<T, R, HP>;
+	using Set = MarchSet<T, R, HP, FUSE>;
 	constexpr int VEC = Cfg::VEC;
 	constexpr int PACKS = Cfg::PACKS;
 	constexpr int MARCH_B = Cfg::B;
@@ -136,6 +163,27 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 	if (doneFlag && *doneFlag) return;
 	const int op = opFlags & 0xFF;
 	const int t = threadIdx.x;
+	T beta = T(0);
+	if constexpr (FUSE) {
+		__shared__ T redF[5];
+		if (fz.sc->pad) return;  // (the done flag as the update before found it)
+		const T rrNew = sumPartsAll(fz.partsC, redF);
+		const T rrOld = fz.sc->rrPing[fz.par];
+		const bool converged = fz.eps * fz.eps > rrNew;
+		if (blockIdx.x == 0 && t == 0) {  // ref:2377-2382
+			fz.sc->iters += 1;
+			fz.sc->res = rrNew;
+			if (converged) {
+				fz.sc->done = 1;
+				fz.sc->status = SMM_SOLVER_SUCCESS;
+				fz.sc->flushIter = fz.iter;
+			} else {
+				fz.sc->rrPing[fz.par ^ 1] = rrNew;
+			}
+		}
+		if (converged) return;
+		beta = rrNew / rrOld;
+	}
 	const int nNear = KN > 0 ? KN : nOff - hasLo - hasHi;
 	const T cLo = hasLo ? bitsToValue<T>(cvalBits[0]) : T(0);
 	const T cHi = hasHi ? bitsToValue<T>(cvalBits[nOff - 1]) : T(0);
@@ -184,9 +232,13 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 			for (int p = 0; p < PACKS; ++p) {
 				if (inside && wantCentre && act[p] && base + loc[p] < rows) {  // (the last plane may be a partial one)
 					f.c[p] = *reinterpret_cast<const PackU<T>*>(x + base + loc[p]);  // (kept cacheable: a neighbouring tile reads these lines as its halo)
+					if constexpr (FUSE) f.c2[p] = *reinterpret_cast<const PackU<T>*>(fz.r + base + loc[p]);
 				} else {
 #pragma unroll
-					for (int e = 0; e < VEC; ++e) f.c[p][e] = T(0);
+					for (int e = 0; e < VEC; ++e) {
+						f.c[p][e] = T(0);
+						if constexpr (FUSE) f.c2[p][e] = T(0);
+					}
 				}
 			}
 			if (inside && wantWindow) {
@@ -198,6 +250,7 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 						// a pack that sticks out of x (the first / last rows of the matrix) is never used by a live entry: any valid address will do
 						gidx = gidx < 0 ? 0 : (gidx + VEC > cols ? cols - VEC : gidx);
 						f.h[k] = *reinterpret_cast<const PackU<T>*>(x + gidx);
+						if constexpr (FUSE) f.h2[k] = *reinterpret_cast<const PackU<T>*>(fz.r + gidx);
 					}
 				}
 #pragma unroll
@@ -220,6 +273,32 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 			for (int k = 0; k < HP; ++k) {
 				const int i = k * TPB + t;
 				if (i < haloPacks) *reinterpret_cast<PackV<T>*>(win + haloWin(i)) = f.h[k];
+			}
+		};
+
+		// FUSE: the set's packs become the new direction, beta * p_old + r (ref:2391-2393); the rows of plane z this unit computes are written out
+		auto combine = [&](Set& f, int z, bool write) {
+			if constexpr (FUSE) {
+#pragma unroll
+				for (int p = 0; p < PACKS; ++p) {
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) f.c[p][e] = smmFma(beta, f.c[p][e], f.c2[p][e]);
+				}
+#pragma unroll
+				for (int k = 0; k < HP; ++k) {
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) f.h[k][e] = smmFma(beta, f.h[k][e], f.h2[k][e]);
+				}
+				if (write) {
+					const long long base = static_cast<long long>(z) * P + r0;
+#pragma unroll
+					for (int p = 0; p < PACKS; ++p) {
+						if (act[p] && base + loc[p] < rows) {
+							if constexpr (NT) __builtin_nontemporal_store(f.c[p], reinterpret_cast<PackU<T>*>(fz.pNew + base + loc[p]));
+							else *reinterpret_cast<PackU<T>*>(fz.pNew + base + loc[p]) = f.c[p];
+						}
+					}
+				}
 			}
 		};
 
@@ -278,6 +357,7 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 			} else {
 				for (int j = 0; j < nNear; ++j) nearStep(j);
 			}
+			combine(use, z + 1, more);  // (FUSE: plane z + 1's set is first used here; its rows are this unit's when another step follows)
 			if (hasHi) {
 				const int b = hasLo + nNear;
 #pragma unroll
@@ -299,7 +379,9 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 					if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<PackU<T>*>(out + row));
 					else *reinterpret_cast<PackU<T>*>(out + row) = o;
 					if (dotMode) {
-						const PackU<T> w = *reinterpret_cast<const PackU<T>*>(w1 + row);
+						PackU<T> w;
+						if constexpr (FUSE) w = *reinterpret_cast<const PackV<T>*>(win + H + loc[p]);  // (p itself: the window's centre)
+						else w = *reinterpret_cast<const PackU<T>*>(w1 + row);
 #pragma unroll
 						for (int e = 0; e < VEC; ++e) {
 							if (dotMode == 2) acc0 += o[e] * o[e];
@@ -321,10 +403,19 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 
 		// prologue: plane z0 - 1 (far below) and plane z0 itself, then the requests for plane z0 + 1
 		issue(fa, z0 - 1, hasLo != 0, false);
+		if constexpr (FUSE) {
+#pragma unroll
+			for (int k = 0; k < HP; ++k) {
+#pragma unroll
+				for (int e = 0; e < VEC; ++e) fa.h[k][e] = fa.h2[k][e] = T(0);  // (no halos were requested for the plane far below)
+			}
+		}
+		combine(fa, z0 - 1, false);
 #pragma unroll
 		for (int p = 0; p < PACKS; ++p) xp[p] = fa.c[p];
 		issue(fa, z0, true, true);
 		issue(fb, z0 + 1, z0 + 1 < z1 || hasHi, z0 + 1 < z1);
+		combine(fa, z0, true);
 		__syncthreads();  // (the previous unit's last window reads are over)
 		storeWindow(sWin0, fa);
 #pragma unroll
@@ -1014,9 +1105,9 @@ static bool marchPrepare(MarchLaunchState& st, Kernel kernel, size_t lds, size_t
 	return true;
 }
 
-template <typename T, int R, int KN, bool NT, int HP>
+template <typename T, int R, int KN, bool NT, int HP, bool FUSE = false>
 static bool launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
-                         const int* doneFlag, hipStream_t s) {
+                         const int* doneFlag, hipStream_t s, const MarchFuse<T>& fz = MarchFuse<T>()) {
 	const int P = m->march_P, H = m->march_H;
 	const int nPlanes = (m->rows + P - 1) / P;
 	constexpr int MARCH_B = TPB * R;
@@ -1024,7 +1115,7 @@ static bool launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* d
 	const size_t lds = 2 * static_cast<size_t>(MARCH_B + 2 * H) * sizeof(T);
 	static MarchLaunchState state;
 	int perCU = 0;
-	if (!marchPrepare(state, spmvPatternConstMarchKernel<T, R, KN, NT, HP>, lds, 64 /* red[] */, &perCU)) return false;
+	if (!marchPrepare(state, spmvPatternConstMarchKernel<T, R, KN, NT, HP, FUSE>, lds, 128 /* red[], redF[] */, &perCU)) return false;
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();  // room for the RCCL kernel beside A_loc (smm_dist.hip)
 	op &= ~SPMV_LEAVE_ROOM;
 	const int resident = cus * perCU;
@@ -1043,8 +1134,8 @@ static bool launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* d
 	int grid = static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(units, resident), NPART)));
 	const int xcdTiles = (nT % 8 == 0 || nT >= 64) && grid >= 8 ? 1 : 0;
 	if (xcdTiles) grid -= grid % 8;  // the same number of workgroups in every XCD group
-	spmvPatternConstMarchKernel<T, R, KN, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
-	                                                             m->d_pat_off, m->d_pat_cval, m->d_pat_masks32, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag);
+	spmvPatternConstMarchKernel<T, R, KN, NT, HP, FUSE><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
+	                                                                   m->d_pat_off, m->d_pat_cval, m->d_pat_masks32, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, fz);
 	return true;
 }
 
@@ -1121,6 +1212,52 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	return launched;  // false: the windows do not fit the LDS a launch can be granted -- the gather kernel serves the matrix
 }
 
+static std::atomic<int> g_cgFuseP{1};  // smm_hip_set_cg_fuse_p (tests: A/B against the launch that forms p in cgLazyXP)
+
+static bool marchEnabled() {
+	static const bool enabled = [] {
+		const char* env = getenv("SMM_HIP_CONST_MARCH");
+		return env ? atoi(env) != 0 : true;
+	}();
+	return enabled;
+}
+
+// the form the fused launch exists in: the two-window kernel, default rows per lane, non-temporal outputs (i.e. vectors beyond 64 MB -- the
+// only size at which forming p in the SpMV pays), PATTERN family with constant diagonals at one lane per row
+bool constMarchFusable(const smm_hip_csr* m, size_t elemBytes) {
+	static const bool allowed = [] {
+		const char* env = getenv("SMM_HIP_CG_FUSE_P");
+		return env ? atoi(env) != 0 : true;
+	}();
+	static const bool rowsForced = getenv("SMM_HIP_MARCH_R") != nullptr;
+	return allowed && g_cgFuseP.load(std::memory_order_relaxed) != 0 && !rowsForced && marchEnabled() && m->family() == SMM_SPMV_PATTERN && m->lanes() == 1 && m->pat_state.load(std::memory_order_acquire) > 0 &&
+	       m->pat_encoding == 0 && m->pat_const && !m->pat_const_off && constMarchApplies(m) && !m->march_clusters && (spmvOutFlags(m, elemBytes) & SPMV_NT_OUT) != 0;
+}
+
+template <typename T>
+bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* partials, const int* doneFlag, const CgFuseArgs<T>& f, hipStream_t s) {
+	if (!constMarchFusable(m, sizeof(T))) return false;
+	MarchFuse<T> fz;
+	fz.r = f.r;
+	fz.pNew = f.pNew;
+	fz.sc = static_cast<Scal<T>*>(f.sc);
+	fz.partsC = f.partsC;
+	fz.eps = f.eps;
+	fz.par = f.par;
+	fz.iter = f.iter;
+	const int nNear = m->pat_k - m->march_lo - m->march_hi;
+	constexpr int RV = sizeof(T) == 8 ? 4 : 8;
+	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
+	if (nNear == 5) {
+		return hp2 ? launchMarchKN<T, RV, 5, true, 2, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
+		           : launchMarchKN<T, RV, 5, true, 4, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz);
+	}
+	return hp2 ? launchMarchKN<T, RV, 0, true, 2, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
+	           : launchMarchKN<T, RV, 0, true, 4, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz);
+}
+template bool launchConstMarchFusedP<float>(const smm_hip_csr*, const float*, float*, float*, const int*, const CgFuseArgs<float>&, hipStream_t);
+template bool launchConstMarchFusedP<double>(const smm_hip_csr*, const double*, double*, double*, const int*, const CgFuseArgs<double>&, hipStream_t);
+
 template <typename T, int KMAX, bool NT, int HP>
 static bool launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                               const int* doneFlag, hipStream_t s) {
@@ -1191,6 +1328,11 @@ template bool launchPatConstMarch<float>(const smm_hip_csr*, int, const float*, 
 template bool launchPatConstMarch<double>(const smm_hip_csr*, int, const double*, const double*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 
 }  // namespace smm
+
+extern "C" int smm_hip_set_cg_fuse_p(int on) {
+	smm::g_cgFuseP.store(on ? 1 : 0, std::memory_order_relaxed);
+	return SMM_HIP_OK;
+}
 
 extern "C" int smm_hip_set_march_min_rows(long long const_diagonals_rows, long long values_read_rows) {
 	smm::g_marchMinRowsConst.store(const_diagonals_rows, std::memory_order_relaxed);

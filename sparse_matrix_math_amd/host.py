@@ -409,6 +409,11 @@ def set_cg_lazy_x_min_bytes(nbytes):
     check(_lib.load().smm_hip_set_cg_lazy_x_min_bytes(int(nbytes)))
 
 
+def set_cg_fuse_p(on):
+    """test / measurement knob: False keeps CG from forming its next direction inside the 2.5-D SpMV kernel"""
+    check(_lib.load().smm_hip_set_cg_fuse_p(1 if on else 0))
+
+
 def bicgstab_resident(mode=-1):
     """sets (0 off, 1 auto, 2 require) or only queries (-1) the single-launch BiCGStab path; returns the previous mode"""
     return int(_lib.load().smm_hip_bicgstab_resident(int(mode)))

@@ -282,3 +282,18 @@ def test_cg_deferred_x_update_is_bit_identical(smm, oracle, dtype):
     finally:
         host.set_cg_lazy_x_min_bytes(-1)
         host.cg_resident(before)
+
+
+def test_cg_direction_formed_inside_the_spmv_is_bit_identical():
+    """tools/cg_fuse_check.py in a process of its own (the non-temporal policy and the march threshold are read from the environment once):
+    ConjugateGradient with p = beta p_old + r formed in the load phase of the 2.5-D SpMV kernel (MarchFuse) and x deferred, against the
+    deferred-x loop and the eager three-launch loop -- bit for bit, 3-D and 2-D stencils with partial tiles and planes, every iteration count
+    0-10, convergence inside the loop, x0 in place and apart, fp32 / fp64 -- and against the oracle"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cg_fuse_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "cg fuse check: ALL OK" in r.stdout and r.stdout.count("fused == deferred == eager") == 6
