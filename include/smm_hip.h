@@ -169,8 +169,8 @@ int smm_hip_csr_kernel_desc(const smm_hip_csr* m, char* name, int name_cap, long
  * -1 restores a default.  Applies to matrices analysed afterwards.  Tuning knob; the tests use it to run the kernels on small grids. */
 int smm_hip_set_march_min_rows(long long const_diagonals_rows, long long values_read_rows);
 /* Test / measurement knob: from how many BYTES PER VECTOR the unpreconditioned ConjugateGradient defers its x update (csrc/smm_solvers.hip,
- * cgLazyXP: the last four directions are kept and x is brought up to date every fourth iteration -- the reference's roundings in the
- * reference's order, bit for bit, 0.75 vector pass less per iteration, four more vectors of device memory).  Default 64 MB (where five
+ * cgLazyXP: the last eight directions are kept and x is brought up to date every eighth iteration -- the reference's roundings in the
+ * reference's order, bit for bit, 0.875 vector pass less per iteration, eight more vectors of device memory).  Default 64 MB (where five
  * vectors no longer fit the Infinity Cache); a negative value restores the default; SMM_HIP_CG_LAZY_X=0 in the environment turns it off. */
 int smm_hip_set_cg_lazy_x_min_bytes(long long bytes);
 /* Test / measurement knob: 0 keeps ConjugateGradient from forming its next direction inside the 2.5-D SpMV kernel (MarchFuse,

@@ -17,7 +17,7 @@ struct Scal {
 	T omega;
 	T res;      // CG: last ||r||^2 ; BiCGStab: last ||r||
 	T rrPing[2];  // fused loops: rr (CG) / rr0 (BiCGStab) double-buffered by iteration parity
-	T alphaRing[4];  // CG with the deferred x update: alpha of the last LAZY_M iterations
+	T alphaRing[8];  // CG with the deferred x update: alpha of the last LAZY_M iterations
 	int done;
 	int iters;
 	int status;

@@ -193,10 +193,10 @@ __global__ __launch_bounds__(TPB) void cgFusedXP(int n, Scal<T>* sc, int par, co
 // For vectors that do not fit the caches an iteration of CG is 10 vector passes, 5 of them in cgFusedXP (read p, x, r; write x, p).  x is
 // only an accumulator: x_{k+1} = alpha_k p_k + x_k (ref:2362-2366).  Keeping the last LAZY_M directions in a ring, x is brought up to date
 // every LAZY_M-th iteration -- x = alpha_k p_k + (... + (alpha_{k-M+1} p_{k-M+1} + x)): the reference's roundings in the reference's order,
-// bit for bit -- in the launch that forms the next p anyway: (3 (M - 1) + M + 4) / M = 4.25 passes per iteration instead of 5 for M = 4, at
-// the price of M more vectors of device memory.  The launch that finds the iteration converged -- or is told it is the last -- flushes
+// bit for bit -- in the launch that forms the next p anyway: (3 (M - 1) + M + 4) / M = 4 + 1 / M passes per iteration instead of 5 (M = 8:
+// 4.125; with p formed inside the SpMV the flush is a launch of its own, (M + 2) / M = 1.25), at the price of M more vectors of device memory.  The launch that finds the iteration converged -- or is told it is the last -- flushes
 // whatever is pending, so x is complete whenever the loop ends.
-constexpr int LAZY_M = 4;
+constexpr int LAZY_M = 8;
 template <typename T>
 struct LazyRing {
 	T* p[LAZY_M + 1];
@@ -261,6 +261,10 @@ __global__ __launch_bounds__(TPB) void cgLazyXP(int n, Scal<T>* sc, int par, con
 		SMM_LAZY_CASE(2)
 		SMM_LAZY_CASE(3)
 		SMM_LAZY_CASE(4)
+		SMM_LAZY_CASE(5)
+		SMM_LAZY_CASE(6)
+		SMM_LAZY_CASE(7)
+		SMM_LAZY_CASE(8)
 	default: break;
 	}
 #undef SMM_LAZY_CASE
@@ -283,6 +287,10 @@ __global__ __launch_bounds__(TPB) void cgLazyFlushOnly(int n, const Scal<T>* __r
 	case 2: cgLazyFlush<T, NT, 2, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
 	case 3: cgLazyFlush<T, NT, 3, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
 	case 4: cgLazyFlush<T, NT, 4, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 5: cgLazyFlush<T, NT, 5, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 6: cgLazyFlush<T, NT, 6, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 7: cgLazyFlush<T, NT, 7, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 8: cgLazyFlush<T, NT, 8, false>(n, ring, cur, alpha, T(0), nullptr, xcur, x); break;
 	default: break;
 	}
 }
@@ -549,18 +557,22 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 	DevBuf<T> ringBuf[LAZY_M];
 	DevBuf<Scal<T>> sc;
 	// the deferred x update (cgLazyXP): unpreconditioned CG on vectors too large for the caches; LAZY_M more vectors for the ring of directions
-	const bool lazy = !pcg && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= lazyMinBytes();
+	bool lazy = !pcg && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= lazyMinBytes();
 	LazyRing<T> ring{};
-	const bool fuseP = lazy && constMarchFusable(a, sizeof(T));  // (decided once per solve: the two loop forms do their bookkeeping in different launches)
 	SMM_TRY(r.alloc(n));
 	SMM_TRY(p.alloc(n));
 	if (lazy) {
 		ring.p[0] = p;
-		for (int k = 0; k < LAZY_M; ++k) {
-			SMM_TRY(ringBuf[k].alloc(n));
+		for (int k = 0; k < LAZY_M && lazy; ++k) {
+			if (ringBuf[k].alloc(n) != SMM_HIP_OK) lazy = false;  // no room for the ring: the eager loop needs none
 			ring.p[k + 1] = ringBuf[k];
 		}
+		if (!lazy) {
+			for (int k = 0; k < LAZY_M; ++k) ringBuf[k].release();
+			(void)hipGetLastError();
+		}
 	}
+	const bool fuseP = lazy && constMarchFusable(a, sizeof(T));  // (decided once per solve: the two loop forms do their bookkeeping in different launches)
 	SMM_TRY(Ap.alloc(n));
 	if (pcg) SMM_TRY(z.alloc(n));
 	SMM_TRY(parts.alloc(2 * NPART));

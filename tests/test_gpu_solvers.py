@@ -244,9 +244,9 @@ def test_bicgsymmetric_diverged_heuristics_match_reference(smm, golden_v2, dtype
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_cg_deferred_x_update_is_bit_identical(smm, oracle, dtype):
-    """cgLazyXP (csrc/smm_solvers.hip): for vectors beyond the caches CG keeps its last four directions and brings x up to date every fourth
+    """cgLazyXP (csrc/smm_solvers.hip): for vectors beyond the caches CG keeps its last eight directions and brings x up to date every eighth
     iteration, in the last planned one and in whichever launch finds the iteration converged -- the reference's roundings in the
-    reference's order (ref:2362-2366).  Forced on at a small size: every iteration count from 0 to 13, convergence inside a window of four,
+    reference's order (ref:2362-2366).  Forced on at a small size: every iteration count from 0 to 21, convergence inside a window of eight,
     x0 in place and apart, must give the bits of the eager loop."""
     from sparse_matrix_math_amd import host
 
@@ -259,7 +259,7 @@ def test_cg_deferred_x_update_is_bit_identical(smm, oracle, dtype):
     before = host.cg_resident(-1)
     host.cg_resident(host.CG_RESIDENT_OFF)  # (the register-resident solve would take a matrix of this size first)
     try:
-        for maxit, eps in [(k, 0.0) for k in range(0, 14)] + [(-1, 1e-3 if dtype == np.float32 else 1e-8), (-1, 2.0), (500, 1e-1)]:
+        for maxit, eps in [(k, 0.0) for k in range(0, 22)] + [(-1, 1e-3 if dtype == np.float32 else 1e-8), (-1, 2.0), (500, 1e-1)]:
             for in_place in (True, False):
                 got = {}
                 for lazy in (True, False):
@@ -288,7 +288,7 @@ def test_cg_direction_formed_inside_the_spmv_is_bit_identical():
     """tools/cg_fuse_check.py in a process of its own (the non-temporal policy and the march threshold are read from the environment once):
     ConjugateGradient with p = beta p_old + r formed in the load phase of the 2.5-D SpMV kernel (MarchFuse) and x deferred, against the
     deferred-x loop and the eager three-launch loop -- bit for bit, 3-D and 2-D stencils with partial tiles and planes, every iteration count
-    0-10, convergence inside the loop, x0 in place and apart, fp32 / fp64 -- and against the oracle"""
+    0-19, convergence inside the loop, x0 in place and apart, fp32 / fp64 -- and against the oracle"""
     import os
     import subprocess
     import sys

@@ -31,7 +31,7 @@ for dtype in (np.float64, np.float32):
         b = gen.row_sums(start, val).astype(dtype)
         rng = np.random.default_rng(5)
         x0s = rng.uniform(-1, 1, n).astype(dtype)
-        for maxit, eps in [(k, 0.0) for k in range(0, 11)] + [(-1, 1e-2 if dtype == np.float32 else 1e-6), (400, 3.0)]:
+        for maxit, eps in [(k, 0.0) for k in range(0, 20)] + [(-1, 1e-2 if dtype == np.float32 else 1e-6), (400, 3.0)]:
             for in_place in (True, False):
                 got = {}
                 for mode in ("fused", "lazy", "eager"):
