@@ -183,6 +183,7 @@ struct smm_hip_csr {
 	// three-window kernel (spmvPatternConstMarch3Kernel) serves the matrix; constant diagonals only
 	bool march_clusters = false;
 	unsigned* d_pat_masks32 = nullptr;  // the low halves of d_pat_masks, what the 2.5-D kernel streams (4 bytes per row)
+	unsigned char* d_pat_masks8 = nullptr;  // the low bytes (matrices of at most 8 offsets with constant diagonals: 1 byte per row)
 	std::vector<int> pat_offs_host;  // MASKS: the sorted offsets (host copy: the brick partition of the block preconditioners reads the grid from them)
 	int pat_k = 0;
 	int* d_pat_off = nullptr;

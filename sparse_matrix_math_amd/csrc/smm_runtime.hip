@@ -724,6 +724,7 @@ int smm_hip_csr_destroy(smm_hip_csr* m) {
 	devFree(m->d_pat_cval);
 	devFree(m->d_res_ell);
 	devFree(m->d_pat_masks32);
+	devFree(m->d_pat_masks8);
 	devFree(m->d_pat_rowblocks);
 	delete m;
 	return SMM_HIP_OK;

@@ -63,6 +63,16 @@ template <typename T>
 using PackV = typename PackOf<T>::V;  // the same pack where 16-byte alignment is known (LDS windows)
 template <typename T>
 using MaskP = typename PackOf<T>::M;
+template <typename T>
+struct MaskBytesOf;  // the integer that holds the byte masks of one pack's rows
+template <>
+struct MaskBytesOf<float> {
+	using type = unsigned;
+};
+template <>
+struct MaskBytesOf<double> {
+	using type = unsigned short;
+};
 
 template <typename T>
 __device__ __forceinline__ T marchApplyOp(int op, const T* __restrict__ lhs, const T* __restrict__ divisor, long long row, T dot) {
@@ -125,6 +135,14 @@ __global__ __launch_bounds__(256) void marchNarrowMasks(long long rows, const un
 	}
 }
 
+// the 8-bit copy for matrices of at most 8 offsets (the 5- and 7-point stencils: the KN = 5 instances below): at 512^3 the 32-bit masks are
+// 0.54 GB of the 2.68 GB an fp64 launch moves -- a fifth -- and a third of an fp32 launch's bytes; one byte per row makes them 0.13 GB
+__global__ __launch_bounds__(256) void marchNarrowMasks8(long long rows, const unsigned long long* __restrict__ masks, unsigned char* __restrict__ masks8) {
+	for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < rows; i += static_cast<long long>(gridDim.x) * blockDim.x) {
+		masks8[i] = static_cast<unsigned char>(masks[i]);
+	}
+}
+
 // KN > 0: the number of near offsets is known at compile time (5: the 5- and 7-point stencils); 0: run time.  NT: out[] with non-temporal
 // stores.  HP: halo packs a lane can hold (2 H <= HP * TPB * VEC).
 // grid <= NPART persistent workgroups; unit u = (tile, z-chunk); XCD group g = blockIdx % 8 owns the tiles [g nT / 8, (g + 1) nT / 8) when
@@ -147,10 +165,13 @@ template <typename T, int R, int KN, bool NT, int HP, bool FUSE = false>
 #endif
 __global__ __launch_bounds__(TPB, FUSE ? SMM_MARCH_FUSE_MIN_WAVES : SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternConstMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
                                                                    int nOff, int hasLo, int hasHi, const int* __restrict__ offs,
-                                                                   const unsigned long long* __restrict__ cvalBits, const unsigned* __restrict__ masks32,
+                                                                   const unsigned long long* __restrict__ cvalBits, const void* __restrict__ masksN,
                                                                    int opFlags, const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out,
                                                                    int dotMode, const T* __restrict__ w1, T* __restrict__ partials,
                                                                    const int* __restrict__ doneFlag, MarchFuse<T> fz = MarchFuse<T>()) {
+	// the row masks: one BYTE per row when the offset count is a compile-time one (KN = 5: at most 7 offsets), 32 bits otherwise
+	const unsigned* __restrict__ masks32 = static_cast<const unsigned*>(masksN);
+	const unsigned char* __restrict__ masks8 = static_cast<const unsigned char*>(masksN);
 	using Cfg = MarchCfg<T, R>;
 	using Set = MarchSet<T, R, HP, FUSE>;
 	constexpr int VEC = Cfg::VEC;
@@ -256,7 +277,14 @@ __global__ __launch_bounds__(TPB, FUSE ? SMM_MARCH_FUSE_MIN_WAVES : SMM_MARCH_MI
 #pragma unroll
 				for (int p = 0; p < PACKS; ++p) {
 					if (act[p] && base + loc[p] < rows) {
-						f.m[p] = __builtin_nontemporal_load(reinterpret_cast<const MaskP<T>*>(masks32 + base + loc[p]));
+						if constexpr (KN > 0) {
+							// the pack's VEC bytes in one load (base + loc[p] is a multiple of VEC: P and the tile size are)
+							using MB = typename MaskBytesOf<T>::type;
+							// (kept as loaded -- element 0 -- until the set is used: unpacking here would wait for the load in the step that issues it)
+							f.m[p][0] = __builtin_nontemporal_load(reinterpret_cast<const MB*>(masks8 + base + loc[p]));
+						} else {
+							f.m[p] = __builtin_nontemporal_load(reinterpret_cast<const MaskP<T>*>(masks32 + base + loc[p]));
+						}
 					} else {
 #pragma unroll
 						for (int e = 0; e < VEC; ++e) f.m[p][e] = 0u;
@@ -305,6 +333,16 @@ __global__ __launch_bounds__(TPB, FUSE ? SMM_MARCH_FUSE_MIN_WAVES : SMM_MARCH_MI
 		PackU<T> xp[PACKS];      // centre of the plane below the window's (the -P operands)
 		MaskP<T> mk[PACKS];      // masks of the window's plane
 		Set fa, fb;
+		auto masksOf = [&](const Set& f, int p) {
+			if constexpr (KN > 0) {
+				MaskP<T> m;
+#pragma unroll
+				for (int e = 0; e < VEC; ++e) m[e] = (f.m[p][0] >> (8 * e)) & 0xFFu;
+				return m;
+			} else {
+				return f.m[p];
+			}
+		};
 
 		// one plane: `use` holds plane z + 1 (requested a step ago), `re` is free and is re-issued for plane z + 2
 		auto step = [&](int z, Set& use, Set& re) {
@@ -396,7 +434,7 @@ __global__ __launch_bounds__(TPB, FUSE ? SMM_MARCH_FUSE_MIN_WAVES : SMM_MARCH_MI
 				for (int p = 0; p < PACKS; ++p) xp[p] = *reinterpret_cast<const PackV<T>*>(win + H + loc[p]);
 				storeWindow(winNext, use);
 #pragma unroll
-				for (int p = 0; p < PACKS; ++p) mk[p] = use.m[p];
+				for (int p = 0; p < PACKS; ++p) mk[p] = masksOf(use, p);
 				ldsBarrier();  // winNext is complete; everyone is done reading `win` (it is overwritten in the step after next)
 			}
 		};
@@ -419,7 +457,7 @@ __global__ __launch_bounds__(TPB, FUSE ? SMM_MARCH_FUSE_MIN_WAVES : SMM_MARCH_MI
 		__syncthreads();  // (the previous unit's last window reads are over)
 		storeWindow(sWin0, fa);
 #pragma unroll
-		for (int p = 0; p < PACKS; ++p) mk[p] = fa.m[p];
+		for (int p = 0; p < PACKS; ++p) mk[p] = masksOf(fa, p);
 		__syncthreads();
 		for (int z = z0; z < z1; z += 2) {
 			step(z, fb, fa);
@@ -1036,16 +1074,25 @@ int marchBuildMasks32(smm_hip_csr* m, hipStream_t s) {
 	if (!m->march_ok || m->d_pat_masks32) return SMM_HIP_OK;
 	const bool masksShape = m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8;
 	if (!m->pat_const && !masksShape) return SMM_HIP_OK;
-	void* p = nullptr;
+	// (constant diagonals, no clusters, five near offsets: the KN = 5 instances of the two-window kernel, which stream one byte per row)
+	const bool wantBytes = m->pat_const && !m->march_clusters && m->pat_k - m->march_lo - m->march_hi == 5;
+	void *p = nullptr, *p8 = nullptr;
 	SMM_TRY(devAlloc(&p, static_cast<size_t>(m->rows) * sizeof(unsigned) + 16));
+	if (wantBytes && devAlloc(&p8, static_cast<size_t>(m->rows) + 16) != SMM_HIP_OK) {
+		(void)hipGetLastError();
+		p8 = nullptr;  // (no room: the KN = 0 instances read the 32-bit masks)
+	}
 	const int grid = static_cast<int>(std::min<long long>((m->rows + 255LL) / 256, numCUs() * 16LL));
 	marchNarrowMasks<<<grid, 256, 0, s>>>(m->rows, m->d_pat_masks, static_cast<unsigned*>(p));
+	if (p8) marchNarrowMasks8<<<grid, 256, 0, s>>>(m->rows, m->d_pat_masks, static_cast<unsigned char*>(p8));
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(s);
 	if (e != hipSuccess) {
 		devFree(p);
+		if (p8) devFree(p8);
 		return hipFail(e, "marchNarrowMasks", __FILE__, __LINE__);
 	}
+	m->d_pat_masks8 = static_cast<unsigned char*>(p8);
 	m->d_pat_masks32 = static_cast<unsigned*>(p);
 	return SMM_HIP_OK;
 }
@@ -1135,7 +1182,8 @@ static bool launchMarchKN(const smm_hip_csr* m, int op, const T* lhs, const T* d
 	const int xcdTiles = (nT % 8 == 0 || nT >= 64) && grid >= 8 ? 1 : 0;
 	if (xcdTiles) grid -= grid % 8;  // the same number of workgroups in every XCD group
 	spmvPatternConstMarchKernel<T, R, KN, NT, HP, FUSE><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
-	                                                                   m->d_pat_off, m->d_pat_cval, m->d_pat_masks32, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, fz);
+	                                                                   m->d_pat_off, m->d_pat_cval, KN > 0 ? static_cast<const void*>(m->d_pat_masks8) : static_cast<const void*>(m->d_pat_masks32), op, lhs,
+	                                                                   divisor, x, out, dotMode, w1, partials, doneFlag, fz);
 	return true;
 }
 
@@ -1206,7 +1254,7 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	 : hp2     ? launchMarchKN<T, RV, KNV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)                 \
 	           : launchMarchKN<T, RV, KNV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s))
 #define SMM_MARCH_GO(KNV) (r4 ? SMM_MARCH_GO2(4, KNV) : SMM_MARCH_GO2(8, KNV))
-	const bool launched = nNear == 5 ? SMM_MARCH_GO(5) : SMM_MARCH_GO(0);
+	const bool launched = nNear == 5 && m->d_pat_masks8 ? SMM_MARCH_GO(5) : SMM_MARCH_GO(0);  // (KN = 5 reads the byte masks)
 #undef SMM_MARCH_GO2
 #undef SMM_MARCH_GO
 	return launched;  // false: the windows do not fit the LDS a launch can be granted -- the gather kernel serves the matrix
@@ -1248,7 +1296,7 @@ bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* parti
 	const int nNear = m->pat_k - m->march_lo - m->march_hi;
 	constexpr int RV = sizeof(T) == 8 ? 4 : 8;
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
-	if (nNear == 5) {
+	if (nNear == 5 && m->d_pat_masks8) {
 		return hp2 ? launchMarchKN<T, RV, 5, true, 2, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
 		           : launchMarchKN<T, RV, 5, true, 4, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz);
 	}

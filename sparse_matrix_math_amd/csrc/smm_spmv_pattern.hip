@@ -1658,7 +1658,10 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 			return env ? atoi(env) != 0 : true;
 		}();
 		const bool march = marchOn && constMarchApplies(m);
-		*bytes = rows * (march ? 4 : 8) + vectors;  // the row's mask (32 bits in the 2.5-D form), x, out: neither values[] nor start[]
+		// the row's mask (32 bits in the 2.5-D forms, 8 where the two-window kernel knows its five near offsets at compile time), x, out:
+		// neither values[] nor start[]
+		const bool bytesMasks = march && !m->march_clusters && m->d_pat_masks8 && m->pat_k - m->march_lo - m->march_hi == 5;
+		*bytes = rows * (bytesMasks ? 1 : march ? 4 : 8) + vectors;
 		return march ? (m->march_clusters ? "spmvPatternConstMarch3Kernel" : "spmvPatternConstMarchKernel") : "spmvPatternConstKernel";
 	}
 	*bytes = nnz * s + rows * 8 + startBytes + vectors;
