@@ -59,23 +59,47 @@ __device__ __forceinline__ T blockSum256(T v, T* lds4) {
 // bits are those of the separate kernel -- and stores the totals to totals[0 .. nsets).  One launch (and one dependent kernel
 // boundary, ~1.5-2 us) fewer per reduction: the row-partitioned solvers (smm_dist.hip) all-reduce `totals` right after.
 //
-// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): every storing wave drains its stores (s_waitcnt vmcnt(0)), the
-// workgroup meets at a barrier, lane 0 releases at agent scope and takes a ticket with a relaxed agent-scope atomic add; the
-// workgroup whose ticket is gridDim.x - 1 acquires at agent scope and reads the partials with agent-scope (L1-bypassing) loads.
-// The last workgroup resets the ticket counter, so the buffer is ready for the next launch on the stream.
-// All 256 threads of every workgroup of the launch must call this (it contains barriers).
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility).  r01-r04 released at agent scope in every workgroup: on gfx950 that is a
+// WRITE-BACK OF THE XCD'S L2 per workgroup, and behind a kernel that has just stored 100+ MB of vector with ordinary stores it made the
+// row-partitioned loops' update kernels 2.3 x slower than their single-GPU twins (r05: distCgR 148 us against cgFusedR's 64 us for the
+// same three passes; profiles/r05/dist_cg_kernel_stats_before.csv).  Now the few words that must cross workgroups are published the way
+// the single-launch solvers publish rows (smm_resident_sync.h): each workgroup re-stores its own slot(s) -- and its share of the slots no
+// workgroup owns, which are zero -- WRITE-THROUGH (agent-scope atomic stores), drains them (s_waitcnt vmcnt(0)), meets at a barrier and
+// lane 0 takes a ticket with a relaxed agent-scope atomic add (two levels, below); no cache is written back.  The workgroup that ends last
+// acquires at agent scope and reads the partials with agent-scope (cache-bypassing) loads.  The last workgroup resets the ticket
+// counter, so the buffer is ready for the next launch on the stream.  (The caller's own plain stores of the same values stay: a launch
+// that is not asked to finish its sums leaves them to the next kernel as before.)
+// Lane 0 of every workgroup must be the one that stored partials[k * npart + blockIdx.x]; workgroups have 256 threads; all of them must
+// call this (it contains barriers).
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void lastBlockSums(const T* partials, int npart, int nsets, T* totals, unsigned* ticket) {
+__device__ __forceinline__ void lastBlockSums(T* partials, int npart, int nsets, T* totals, unsigned* ticket) {
 	__shared__ int sIsLast;
 	__shared__ T sRed[4];
+	if (threadIdx.x == 0) {
+		for (int k = 0; k < nsets; ++k) {
+			T* slot = partials + k * npart + blockIdx.x;
+			__hip_atomic_store(slot, *slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+	for (int i = gridDim.x + blockIdx.x * 256 + threadIdx.x; i < npart; i += gridDim.x * 256) {
+		for (int k = 0; k < nsets; ++k) __hip_atomic_store(partials + k * npart + i, T(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		const unsigned mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const int last = mine == gridDim.x - 1 ? 1 : 0;
+		// two levels: the workgroups of a launch are dealt to SUBS sub-counters (ticket[1 + ...]); the last one of each takes a ticket of
+		// the top counter (ticket[0]).  With ONE counter the 2048 read-modify-writes of a launch queue up on one address: ~25 us at the end of
+		// every kernel that finishes its sums (r05: distBicgR 33 us for 20 MB of vectors).  Counters are left at 0 by whoever ends them.
+		constexpr unsigned SUBS = 16;  // = PARTS_TICKETS (smm_internal.h)
+		const unsigned nsub = gridDim.x < SUBS ? gridDim.x : SUBS;
+		const unsigned sub = blockIdx.x % nsub;
+		const unsigned members = (gridDim.x - sub + nsub - 1) / nsub;
+		int last = 0;
+		if (__hip_atomic_fetch_add(ticket + 1 + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+			__hip_atomic_store(ticket + 1 + sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1 ? 1 : 0;
+		}
 		if (last) {
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

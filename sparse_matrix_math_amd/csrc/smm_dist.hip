@@ -11,10 +11,10 @@
 //   * the local rows are split ON THE DEVICE into A_loc (owned columns) and A_rem (halo columns): A_loc x runs on the caller's
 //     stream while the exchange is in flight on the communicator's side stream; A_rem x is added in place when it has landed,
 //     with the dot products of the freshly computed vector fused into that launch and completed by its last workgroup
-//     (lastBlockSums, smm_device.h) -- no separate reduction kernels.
+//     (lastBlockSums, smm_device.h); the sums an update kernel leaves behind are added by a one-workgroup launch (distFinishSums).
 //   * the 1-2 scalars of each reduction point are all-reduced in place (ncclAllReduce) on the side stream; every workgroup of
 //     the next update kernel reads the all-reduced totals and forms alpha / omega / beta itself, so there are no scalar launches:
-//     8 kernels per BiCGStab iteration (4 SpMV launches, s, r, x, p updates), 6 per CG iteration.  The x update does not depend
+//     8 kernels per BiCGStab iteration (4 SpMV launches, s, r, x, p updates) + 1 finishing launch, 6 + 1 per CG iteration.  The x update does not depend
 //     on the last all-reduce of an iteration (||r||^2, r.r0) and runs beside it.
 //   * nothing in the loop synchronises with the host; the `done` flag is polled through a pinned mailbox (DonePoller).
 //
@@ -38,6 +38,7 @@
 #include "smm_device.h"
 #include "smm_internal.h"
 #include "smm_p2p.h"
+#include "smm_solver_scal.h"
 
 namespace smm {
 
@@ -472,6 +473,7 @@ struct DistScal {
 	T rrPing[2];  // BiCGStab: rr0 / CG: ||r||^2, double-buffered by iteration parity (workgroup 0 writes the next while others read)
 	T alpha, omega, res;
 	int done, iters, status, pad;
+	T alphaRing[LAZY_M];  // CG with the deferred x update (distCgLazyP): alpha of the last LAZY_M iterations
 };
 
 // up to four [lo, hi) runs of rows, passed to the update kernels by value
@@ -533,6 +535,7 @@ struct smm_hip_dist_csr {
 	// workspace of the solvers, kept across solves
 	void *r = nullptr, *r0 = nullptr, *ap = nullptr, *as = nullptr, *scratch = nullptr;
 	void *pExt = nullptr, *sExt = nullptr, *xExt = nullptr;
+	void* lazyExt[smm::LAZY_M] = {};  // CG with the deferred x update: LAZY_M more halo-extended direction vectors (allocated by the first such solve)
 	void *partsA = nullptr, *partsB = nullptr, *partsC = nullptr;  // finishing buffers (PARTS_LEN): totals are all-reduced in place
 	void* sc = nullptr;
 	// every rank's column range [cmin, cmaxExcl) and the row bounds (global knowledge: any rank can derive any rank's halo plan)
@@ -1430,6 +1433,24 @@ static int join(hipStream_t s, hipEvent_t e) {
 // kernels of the loops: each reads the all-reduced totals itself (no scalar launches)
 // ---------------------------------------------------------------------------------------------------------
 // totals[0] = a.b, totals[1] = a.c (nsets 2); NPART workgroups, finished by the last one
+// The totals of a reduction whose partials an UPDATE kernel left behind (distDots, distBicgR, distCgR): one workgroup adds the NPART
+// partials of each quantity in the order the fused hand-off uses (lastBlockSums, smm_device.h: i = t, t + 256, ...; then blockSum256) --
+// the same bits -- and leaves them where the all-reduce expects them.  r01-r04 had the LAST workgroup of the update kernel do this: every
+// workgroup then ends with two dependent trips to memory (publish the partial, take a ticket), which for a 5 us kernel over a rank's
+// 1.25 M rows was most of its time (distBicgR 28.6 us; this launch: 4.7-6.3 us, started without a gap; profiles/r05/rank_loop_gaps.txt).
+// The SpMV kernels keep the fused hand-off (SPMV_FINISH): there it costs what this launch would.
+template <typename T>
+__global__ __launch_bounds__(TPB) void distFinishSums(const T* __restrict__ parts, int nsets, T* totals, const int* __restrict__ doneFlag) {
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	for (int k = 0; k < nsets; ++k) {
+		T acc = T(0);
+		for (int i = threadIdx.x; i < NPART; i += TPB) acc += parts[k * NPART + i];
+		const T s = blockSum256(acc, red);
+		if (threadIdx.x == 0) totals[k] = s;
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void distDots(int n, const T* a, const T* b, const T* cvec, int nsets, T* parts, const int* __restrict__ doneFlag) {
 	__shared__ T red[4];
@@ -1451,7 +1472,6 @@ __global__ __launch_bounds__(TPB) void distDots(int n, const T* a, const T* b, c
 		const T s1 = blockSum256(acc1, red);
 		if (threadIdx.x == 0) parts[NPART + blockIdx.x] = s1;
 	}
-	lastBlockSums<T>(parts, NPART, nsets, parts + PARTS_TOTALS, partsTicket(parts));
 }
 
 template <typename T>
@@ -1464,7 +1484,7 @@ __global__ void distBicgInit(const T* __restrict__ totals, DistScal<T>* sc) {
 }
 
 // an element-wise map over up to four runs of rows (the boundary rows some peer receives / the rest: halo first)
-template <typename T, int NIN, int NOUT, typename F>
+template <typename T, int NIN, int NOUT, bool NT = false, typename F>
 __device__ __forceinline__ void rangesMap(const RowRanges& rg, const T* const* in, T* const* out, F&& f) {
 	for (int i = 0; i < rg.n; ++i) {
 		const T* in2[NIN];
@@ -1473,7 +1493,7 @@ __device__ __forceinline__ void rangesMap(const RowRanges& rg, const T* const* i
 		for (int k = 0; k < NIN; ++k) in2[k] = in[k] + rg.lo[i];
 #pragma unroll
 		for (int k = 0; k < NOUT; ++k) out2[k] = out[k] + rg.lo[i];
-		streamMap<T, false, NIN, NOUT>(rg.hi[i] - rg.lo[i], in2, out2, f);
+		streamMap<T, NT, NIN, NOUT>(rg.hi[i] - rg.lo[i], in2, out2, f);
 	}
 }
 
@@ -1512,7 +1532,6 @@ __global__ __launch_bounds__(TPB) void distBicgR(int n, DistScal<T>* sc, const T
 		partsC[blockIdx.x] = s0;
 		partsC[NPART + blockIdx.x] = s1;
 	}
-	lastBlockSums<T>(partsC, NPART, 2, partsC + PARTS_TOTALS, partsTicket(partsC));
 }
 
 // x = alpha p + (omega s + x)   (ref:2264) -- independent of the all-reduce of ||r||^2, r.r0 and runs beside it
@@ -1562,37 +1581,40 @@ __global__ void distCgInit(const T* __restrict__ totals, DistScal<T>* sc, T eps)
 }
 
 // alpha = rr / (Ap.p) ; r = -alpha Ap + r ; local ||r||^2   (ref:2354-2375)
-template <typename T>
-__global__ __launch_bounds__(TPB) void distCgR(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsA, const T* Ap, T* r, T* partsC) {
+// (NT in the CG kernels: non-temporal loads / stores when the vectors cannot stay in the Infinity Cache anyway -- updateNT, as in smm_solvers.hip)
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void distCgR(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsA, const T* Ap, T* r, T* partsC, int alphaSlot) {
 	__shared__ T red[4];
 	if (sc->done) return;
 	const T alpha = sc->rrPing[par] / totalsA[0];
-	if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->alpha = alpha;
+		sc->alphaRing[alphaSlot] = alpha;
+	}
 	T acc = T(0);
 	const T* const in[2] = {Ap, r};
 	T* const out[1] = {r};
-	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) {
+	streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) {
 		const T ri = smmFma(-alpha, v[0], v[1]);
 		o[0] = ri;
 		acc += ri * ri;
 	});
 	const T s0 = blockSum256(acc, red);
 	if (threadIdx.x == 0) partsC[blockIdx.x] = s0;
-	lastBlockSums<T>(partsC, NPART, 1, partsC + PARTS_TOTALS, partsTicket(partsC));
 }
 
 // x = alpha p + xcur   (ref:2372)
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(TPB) void distCgX(int n, const DistScal<T>* __restrict__ sc, const T* p, const T* xcur, T* x) {
 	if (sc->done) return;
 	const T alpha = sc->alpha;
 	const T* const in[2] = {p, xcur};
 	T* const out[1] = {x};
-	streamMap<T, false, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(alpha, v[0], v[1]); });
+	streamMap<T, NT, 2, 1>(n, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(alpha, v[0], v[1]); });
 }
 
 // convergence test, beta, p = beta p + r   (ref:2377-2394).  book: as in distBicgP
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(TPB) void distCgP(RowRanges rg, int book, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, T* p, const T* r) {
 	if (sc->done) return;
 	const T rrNew = totalsC[0];
@@ -1612,8 +1634,90 @@ __global__ __launch_bounds__(TPB) void distCgP(RowRanges rg, int book, DistScal<
 	const T beta = rrNew / rrOld;
 	const T* const in[2] = {p, r};
 	T* const out[1] = {p};
-	rangesMap<T, 2, 1>(rg, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
+	rangesMap<T, 2, 1, NT>(rg, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
 }
+
+// The deferred x update of the single-GPU loop (smm_solvers.hip, cgLazyXP) in the row-partitioned one: nothing inside the loop reads x
+// (ref:2362-2366), so the last LAZY_M directions stay in a ring of halo-extended vectors and x is brought up to date every LAZY_M-th
+// iteration, in the last planned one and by the launch that finds the iteration converged -- x = alpha_k p_k + (... + (alpha_{k-M+1}
+// p_{k-M+1} + x)): the reference's roundings in the reference's order.  11 vector passes per iteration become 9.125.  Range-aware like
+// distCgP (boundary rows first, then the bulk: each launch flushes its own rows).
+template <typename T>
+struct DistRing {
+	T* p[LAZY_M + 1];  // the owned part of every ring vector
+};
+
+template <typename T, bool NT, int PENDING, bool PUPD>
+__device__ __forceinline__ void distLazyFlush(const RowRanges& rg, const DistRing<T>& ring, int cur, const T (&alpha)[LAZY_M], T beta, const T* r, const T* xcur, T* x) {
+	const T* in[PENDING + 2];
+	in[0] = xcur;
+#pragma unroll
+	for (int k = 0; k < PENDING; ++k) in[1 + k] = ring.p[(cur + (LAZY_M + 1) - (PENDING - 1 - k)) % (LAZY_M + 1)];
+	in[PENDING + 1] = PUPD ? r : xcur;  // (without the p update r is not read: any valid vector)
+	T* out[2] = {x, ring.p[(cur + 1) % (LAZY_M + 1)]};
+	rangesMap<T, PENDING + 2, PUPD ? 2 : 1, NT>(rg, in, out, [&](const T(&v)[PENDING + 2], T(&o)[PUPD ? 2 : 1]) {
+		T xv = v[0];
+#pragma unroll
+		for (int k = 0; k < PENDING; ++k) xv = smmFma(alpha[LAZY_M - PENDING + k], v[1 + k], xv);  // oldest direction first, ref:2372
+		o[0] = xv;
+		if constexpr (PUPD) o[1] = smmFma(beta, v[PENDING], v[PENDING + 1]);
+	});
+}
+
+// convergence test, beta, p_next = beta p_cur + r (ref:2377-2394); x completed when `flush` (host: every LAZY_M-th iteration and the last
+// planned one) or when the iteration converged.  pending: directions not yet in x, this iteration's included.  book: as in distCgP
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void distCgLazyP(RowRanges rg, int book, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, DistRing<T> ring, int cur,
+                                                   int pending, int flush, int alphaSlot, const T* r, const T* xcur, T* x) {
+	if (sc->done) return;
+	const T rrNew = totalsC[0];
+	const T rrOld = sc->rrPing[par];
+	const bool converged = eps * eps > rrNew;
+	T alpha[LAZY_M];  // alpha[LAZY_M - 1] = this iteration's, alpha[LAZY_M - 2] the one before, ...
+#pragma unroll
+	for (int k = 0; k < LAZY_M; ++k) alpha[LAZY_M - 1 - k] = sc->alphaRing[(alphaSlot + LAZY_M - k) % LAZY_M];
+	if (book && blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->iters += 1;
+		sc->res = rrNew;
+		if (converged) {
+			sc->done = 1;
+			sc->status = SMM_SOLVER_SUCCESS;
+		} else {
+			sc->rrPing[par ^ 1] = rrNew;
+		}
+	}
+	const T beta = rrNew / rrOld;
+	if (!(flush || converged)) {
+		const T* const in[2] = {ring.p[cur], r};
+		T* const out[1] = {ring.p[(cur + 1) % (LAZY_M + 1)]};
+		rangesMap<T, 2, 1, NT>(rg, in, out, [&](const T(&v)[2], T(&o)[1]) { o[0] = smmFma(beta, v[0], v[1]); });
+		return;
+	}
+	static_assert(LAZY_M == 8, "the cases below");
+#define SMM_DIST_LAZY_CASE(P)                                                                  \
+	case P:                                                                                    \
+		if (converged) distLazyFlush<T, NT, P, false>(rg, ring, cur, alpha, beta, r, xcur, x);     \
+		else distLazyFlush<T, NT, P, true>(rg, ring, cur, alpha, beta, r, xcur, x);                \
+		break;
+	switch (pending) {
+		SMM_DIST_LAZY_CASE(1)
+		SMM_DIST_LAZY_CASE(2)
+		SMM_DIST_LAZY_CASE(3)
+		SMM_DIST_LAZY_CASE(4)
+		SMM_DIST_LAZY_CASE(5)
+		SMM_DIST_LAZY_CASE(6)
+		SMM_DIST_LAZY_CASE(7)
+		SMM_DIST_LAZY_CASE(8)
+	default: break;
+	}
+#undef SMM_DIST_LAZY_CASE
+}
+
+#define SMM_DIST_UPDATE(KERNEL, NTFLAG, GRID, STREAM, ...)                       \
+	do {                                                                        \
+		if (NTFLAG) KERNEL<T, true><<<(GRID), TPB, 0, (STREAM)>>>(__VA_ARGS__);  \
+		else KERNEL<T, false><<<(GRID), TPB, 0, (STREAM)>>>(__VA_ARGS__);        \
+	} while (0)
 
 static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1, std::min<long long>((n + TPB - 1) / TPB, NPART))); }
 // Leaving the loop early must be the SAME decision on every rank (a rank that stops issuing iterations while another goes on leaves the
@@ -1730,6 +1834,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	SMM_TRY(launchCopy2<T>(n, r, r0, p, s));                              // r0 = p = r, ref:2225-2226
 	SMM_TRY(distExchangeBegin<T>(D, pExt, 0, s));                         // the halo of p travels while r.r0 is reduced
 	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);  // r.r0 with r0 == r, ref:2231
+	distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
 	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
 	SMM_TRY(join(s, ev));
 	distBicgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc);
@@ -1750,6 +1855,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, ap, r0, nullptr, 1, partsA, doneFlag);
+			distFinishSums<T><<<1, TPB, 0, s>>>(partsA, 1, partsA + PARTS_TOTALS, doneFlag);
 		} else {
 			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s));
 		}
@@ -1765,12 +1871,14 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, as, as, sv, 2, partsB, doneFlag);
+			distFinishSums<T><<<1, TPB, 0, s>>>(partsB, 2, partsB + PARTS_TOTALS, doneFlag);
 		} else {
 			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s));
 		}
 		SMM_TRY(allreduceTotals<T>(D, partsB, 2, s, &ev, 1, doneFlag));
 		SMM_TRY(join(s, ev));
 		distBicgR<T><<<NPART, TPB, 0, s>>>(n, sc, partsB + PARTS_TOTALS, sv, as, r0, r, partsC);
+		distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 2, partsC + PARTS_TOTALS, doneFlag);
 		SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev, 2, doneFlag));  // (the communicator's collectives: on the side stream ...
 		distBicgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, sv, x);         // ... while x is updated)
 		SMM_TRY(join(s, ev));
@@ -1823,10 +1931,34 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	SMM_TRY(distMatvec<T>(D, xExt, 2, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
 	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));                                           // p = r, ref:2340
 	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);
+	distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
 	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
 	SMM_TRY(join(s, ev));
 	distCgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc, eps);
 	const int* doneFlag = &sc->done;
+	// vectors beyond the caches: x deferred through a ring of LAZY_M more direction vectors (distCgLazyP); when they cannot be had, the eager loop
+	bool lazy = n > 0 && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= cgLazyMinBytes();
+	T* ringExt[LAZY_M + 1] = {pExt};
+	DistRing<T> ring{};
+	ring.p[0] = p;
+	if (lazy) {
+		const size_t eb = static_cast<size_t>(std::max(1, D->extLen)) * sizeof(T);
+		for (int k = 0; k < LAZY_M && lazy; ++k) {
+			if (!D->lazyExt[k]) {
+				if (devAlloc(&D->lazyExt[k], eb) != SMM_HIP_OK) {
+					(void)hipGetLastError();
+					D->lazyExt[k] = nullptr;
+					lazy = false;
+					break;
+				}
+				SMM_HIP_TRY(hipMemsetAsync(D->lazyExt[k], 0, eb, s));  // (halo slots outside every recv segment are never read by A_rem; zero keeps them finite)
+			}
+			ringExt[k + 1] = static_cast<T*>(D->lazyExt[k]);
+			ring.p[k + 1] = ringExt[k + 1] + D->ownOffset;
+		}
+	}
+	T* lastExt = pExt;  // the vector the last posted exchange fills
+	const bool nt3 = updateNT(n, sizeof(T), 3);
 	for (int i = 0; i < maxIterations; ++i) {
 		if (i % CHECK_EVERY == 0) {  // i == 0: the early exit of ref:2342-2344 costs nothing more than this read
 			int seen = 0;
@@ -1834,26 +1966,44 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 			if (seen) break;
 		}
 		const int par = i & 1;
-		if (i == 0) SMM_TRY(distExchangeBegin<T>(D, pExt, 0, s));  // (later passes: posted behind the update of p)
-		SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, p, partsA, doneFlag, s));  // Ap = A p ; p.Ap, ref:2353-2354
+		const int cur = lazy ? i % (LAZY_M + 1) : 0, next = lazy ? (cur + 1) % (LAZY_M + 1) : 0;
+		T* const curExt = ringExt[cur];
+		T* const pc = ring.p[cur];
+		if (i == 0) SMM_TRY(distExchangeBegin<T>(D, curExt, 0, s));  // (later passes: posted behind the update of p)
+		SMM_TRY(distMatvecCompute<T>(D, curExt, SMM_OP_ASSIGN, nullptr, ap, 1, pc, partsA, doneFlag, s));  // Ap = A p ; p.Ap, ref:2353-2354
 		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
 		SMM_TRY(join(s, ev));
-		distCgR<T><<<NPART, TPB, 0, s>>>(n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC);
+		SMM_DIST_UPDATE(distCgR, nt3, NPART, s, n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC, i % LAZY_M);
+		distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, doneFlag);
 		SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2, doneFlag));           // (the communicator's collectives: on the side stream ...
-		distCgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, i == 0 ? x0 : x, x);      // ... while x is updated; ref:2351, 2395)
+		if (!lazy) SMM_DIST_UPDATE(distCgX, nt3, gridFor(n), s, n, sc, pc, i == 0 ? x0 : x, x);  // ... while x is updated; ref:2351, 2395)
 		SMM_TRY(join(s, ev));
-		if (i + 1 < maxIterations) {
+		const bool last = i + 1 >= maxIterations;
+		RowRanges all{};
+		all.n = 1;
+		all.hi[0] = n;
+		if (lazy) {
+			const int pending = i % LAZY_M + 1;
+			const int flush = (pending == LAZY_M || last) ? 1 : 0;
+			const T* xc = i < LAZY_M ? x0 : x;  // (until the first scheduled flush x has not been written: ref:2351, 2395)
+			auto launch = [&](const RowRanges& rg, int book) {
+				SMM_DIST_UPDATE(distCgLazyP, nt3, gridFor(rg.rows()), s, rg, book, sc, par, partsC + PARTS_TOTALS, eps, ring, cur, pending, flush, i % LAZY_M, r, xc, x);
+			};
+			if (!last) {
+				SMM_TRY((updateThenExchange<T>(D, ringExt[next], 0, s, launch)));
+				lastExt = ringExt[next];
+			} else {
+				launch(all, 1);
+			}
+		} else if (!last) {
 			SMM_TRY((updateThenExchange<T>(D, pExt, 0, s, [&](const RowRanges& rg, int book) {
-				distCgP<T><<<gridFor(rg.rows()), TPB, 0, s>>>(rg, book, sc, par, partsC + PARTS_TOTALS, eps, p, r);
+				SMM_DIST_UPDATE(distCgP, nt3, gridFor(rg.rows()), s, rg, book, sc, par, partsC + PARTS_TOTALS, eps, p, r);
 			})));
 		} else {
-			RowRanges all{};
-			all.n = 1;
-			all.hi[0] = n;
-			distCgP<T><<<gridFor(n), TPB, 0, s>>>(all, 1, sc, par, partsC + PARTS_TOTALS, eps, p, r);
+			SMM_DIST_UPDATE(distCgP, nt3, gridFor(n), s, all, 1, sc, par, partsC + PARTS_TOTALS, eps, p, r);
 		}
 	}
-	SMM_TRY(distExchangeDrain<T>(D, pExt, s));
+	SMM_TRY(distExchangeDrain<T>(D, lastExt, s));
 	SMM_HIP_TRY(hipGetLastError());
 	DistScal<T> h;
 	unsigned long long p2pErr = 0;
@@ -2119,6 +2269,7 @@ int smm_hip_dist_csr_destroy(smm_hip_dist_csr* D) {
 	for (void* p : D->chunkArrays) devFree(p);
 	for (void* p : D->arrays) devFree(p);
 	for (void* p : {D->r, D->r0, D->ap, D->as, D->scratch, D->pExt, D->sExt, D->xExt, D->partsA, D->partsB, D->partsC, D->sc}) devFree(p);
+	for (void* p : D->lazyExt) devFree(p);
 	delete D;
 	return SMM_HIP_OK;
 }

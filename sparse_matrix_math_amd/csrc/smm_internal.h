@@ -250,7 +250,8 @@ constexpr int SPMV_OP_DIV = 3;
 constexpr int SPMV_ADD_DIV = 0x1000;
 constexpr int SPMV_OP_ADD_DIV = 4;
 constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer
-constexpr int PARTS_LEN = 2 * NPART + 4;   // elements of a finishing buffer: 2 x NPART partials, 2 totals, 8 bytes for the ticket
+constexpr int PARTS_TICKETS = 16;             // sub-counters of the "last workgroup" ticket (lastBlockSums, smm_device.h)
+constexpr int PARTS_LEN = 2 * NPART + 2 + 2 * (PARTS_TICKETS + 1);  // elements of a finishing buffer: 2 x NPART partials, 2 totals, the ticket words
 template <typename T>
 __host__ __device__ inline unsigned* partsTicket(T* partials) { return reinterpret_cast<unsigned*>(partials + PARTS_TOTALS + 2); }
 inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
@@ -283,6 +284,10 @@ int patternLanesFor(const smm_hip_csr* m);
 const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes);
 void planMarch(smm_hip_csr* m);
 int marchBuildMasks32(smm_hip_csr* m, hipStream_t s);
+// bytes per vector from which ConjugateGradient defers its x update (smm_solvers.hip; the row-partitioned loop asks too)
+long long cgLazyMinBytes();
+// non-temporal loads / stores for an update kernel over `vectors` vectors of n elements (they cannot stay in the Infinity Cache anyway)
+bool updateNT(long long n, size_t elemBytes, int vectors);
 bool masksMarchApplies(const smm_hip_csr* m);  // the masks kernels' march form serves this (analysed) matrix
 bool constMarchApplies(const smm_hip_csr* m);  // ... the constant-diagonal march
 template <typename T>

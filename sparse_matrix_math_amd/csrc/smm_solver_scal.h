@@ -7,6 +7,8 @@
 namespace smm {
 
 constexpr int SCAL_TPB = 256;
+// ConjugateGradient with the deferred x update (smm_solvers.hip cgLazyXP, smm_dist.hip distCgLazyP): directions kept before x is brought up to date
+constexpr int LAZY_M = 8;
 
 template <typename T>
 struct Scal {
@@ -17,7 +19,7 @@ struct Scal {
 	T omega;
 	T res;      // CG: last ||r||^2 ; BiCGStab: last ||r||
 	T rrPing[2];  // fused loops: rr (CG) / rr0 (BiCGStab) double-buffered by iteration parity
-	T alphaRing[8];  // CG with the deferred x update: alpha of the last LAZY_M iterations
+	T alphaRing[LAZY_M];  // CG with the deferred x update: alpha of the last LAZY_M iterations
 	int done;
 	int iters;
 	int status;

@@ -196,7 +196,6 @@ __global__ __launch_bounds__(TPB) void cgFusedXP(int n, Scal<T>* sc, int par, co
 // bit for bit -- in the launch that forms the next p anyway: (3 (M - 1) + M + 4) / M = 4 + 1 / M passes per iteration instead of 5 (M = 8:
 // 4.125; with p formed inside the SpMV the flush is a launch of its own, (M + 2) / M = 1.25), at the price of M more vectors of device memory.  The launch that finds the iteration converged -- or is told it is the last -- flushes
 // whatever is pending, so x is complete whenever the loop ends.
-constexpr int LAZY_M = 8;
 template <typename T>
 struct LazyRing {
 	T* p[LAZY_M + 1];
@@ -485,7 +484,7 @@ static int gridFor(long long n) { return static_cast<int>(std::max<long long>(1,
 
 // Non-temporal loads / stores for an update kernel whose vectors cannot stay in the 256 MB Infinity Cache until the next kernel
 // reads them anyway; cache-resident problems keep the default policy.  SMM_HIP_UPDATE_NT=0/1 overrides (measurements).
-static bool updateNT(long long n, size_t elemBytes, int vectors) {
+bool updateNT(long long n, size_t elemBytes, int vectors) {
 	static const int forced = [] {
 		const char* env = getenv("SMM_HIP_UPDATE_NT");
 		return env ? atoi(env) : -1;
@@ -505,7 +504,7 @@ static int checkInterval(int it) { return std::max(4, std::min(64, it / 4)); }
 // from how many bytes per vector CG defers its x update (cgLazyXP): where five vectors no longer fit the 256 MB Infinity Cache the passes
 // are what an iteration costs; below, the extra ring of directions buys nothing.  smm_hip_set_cg_lazy_x_min_bytes (tests) / SMM_HIP_CG_LAZY_X=0
 static std::atomic<long long> g_lazyMinBytes{-1};
-static long long lazyMinBytes() {
+long long cgLazyMinBytes() {
 	const long long forced = g_lazyMinBytes.load(std::memory_order_relaxed);
 	if (forced >= 0) return forced;
 	static const long long env = [] {
@@ -557,7 +556,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 	DevBuf<T> ringBuf[LAZY_M];
 	DevBuf<Scal<T>> sc;
 	// the deferred x update (cgLazyXP): unpreconditioned CG on vectors too large for the caches; LAZY_M more vectors for the ring of directions
-	bool lazy = !pcg && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= lazyMinBytes();
+	bool lazy = !pcg && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= cgLazyMinBytes();
 	LazyRing<T> ring{};
 	SMM_TRY(r.alloc(n));
 	SMM_TRY(p.alloc(n));

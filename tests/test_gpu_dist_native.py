@@ -332,6 +332,36 @@ def test_native_cg_matches_oracle(smm, oracle, world):
 
 
 @pytest.mark.parametrize("world", [1, 2, 3])
+def test_native_cg_deferred_x_is_bit_identical(smm, oracle, world):
+    """distCgLazyP (csrc/smm_dist.hip): on vectors beyond the caches the row-partitioned CG keeps its last eight directions in a ring of
+    halo-extended vectors and brings x up to date every eighth iteration, in the last planned one and in the launch that finds the
+    iteration converged -- the reference's roundings in the reference's order (ref:2362-2366).  Forced on at a small size: iteration
+    counts around the window of eight, convergence inside a window, an early exit, a start vector away from zero -- the eager loop's bits."""
+    from sparse_matrix_math_amd import host
+
+    dtype = np.float64
+    csr = gen.poisson2d(48, dtype=dtype)
+    n = len(csr[0]) - 1
+    b = gen.row_sums(csr[0], csr[2]).astype(dtype)
+    x0 = np.random.default_rng(11).uniform(-1, 1, n)
+    try:
+        for max_it, eps in [(k, 0.0) for k in (1, 2, 7, 8, 9, 15, 16, 17, 19)] + [(-1, 1e-8), (-1, 1e-3), (40, 1e-2), (-1, 1e3)]:
+            got = {}
+            for lazy in (True, False):
+                host.set_cg_lazy_x_min_bytes(0 if lazy else 1 << 60)
+                got[lazy] = _solve(smm, csr, b, world, dtype, max_it, eps, solver="cg", x0_full=x0)
+            assert got[True][0] == got[False][0], (max_it, eps, got[True][0], got[False][0])
+            np.testing.assert_array_equal(got[True][1], got[False][1], err_msg=f"max_it {max_it} eps {eps}")
+        st_ref, x_ref, it_ref, _ = oracle.cg(csr, b, x0.copy(), 17, 0.0)
+        host.set_cg_lazy_x_min_bytes(0)
+        (status, iters, _), x, _, _ = _solve(smm, csr, b, world, dtype, 17, 0.0, solver="cg", x0_full=x0)
+        assert (status, iters) == (st_ref, it_ref)
+        np.testing.assert_allclose(x, x_ref, rtol=1e-10, atol=1e-12)
+    finally:
+        host.set_cg_lazy_x_min_bytes(-1)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
 def test_native_preconditioned(smm, oracle, world):
     """block-Jacobi by rank: one rank = the single-GPU preconditioned solver; Jacobi is the same preconditioner for any number of
     ranks; SGS / ILU0 and their block forms on several ranks are weaker preconditioners that must still converge and still help"""
