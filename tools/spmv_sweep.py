@@ -90,7 +90,9 @@ def main():
         ms = e0.elapsed_time(e1) / args.reps
         # a checksum of y: the same bits whatever order the tiles are walked in (A/B runs of tile orders compare these)
         chk = int(torch.sum(y.view(torch.int32 if args.dtype == "f32" else torch.int64).to(torch.int64) & 0xFFFFFF).item())
-        print(f"family {fam} lanes {lanes:2d}: {ms:8.4f} ms  {bytes_ / ms / 1e6:8.1f} GB/s  {100 * bytes_ / ms / 1e6 / 8000:5.1f} % of 8 TB/s  y-checksum {chk}", flush=True)
+        # priced with the bytes the kernel that ran moves by ITS OWN layout (smm_hip_csr_kernel_desc), never with another layout's
+        kname, own = A.kernel_desc()
+        print(f"family {fam} lanes {lanes:2d}: {ms:8.4f} ms  {kname} moves {own / 1e9:.3f} GB: {own / ms / 1e6:8.1f} GB/s  {100 * own / ms / 1e6 / 8000:5.1f} % of 8 TB/s  y-checksum {chk}", flush=True)
 
 
 if __name__ == "__main__":
