@@ -11,10 +11,12 @@ from sparse_matrix_math_amd.distributed import NativeComm, NativeDistMatrix
 smm.init(0)
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1250000
-nnz = host.gen_banded_nnz(n, 25, 0x5EED, 1 << 20)
+maxoff = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20  # (2^20: the benchmark matrix's band -- at 1.25 M rows most rows then lose diagonals at the edges; 2^16: full rows)
+nnz = host.gen_banded_nnz(n, 25, 0x5EED, maxoff)
 s0 = torch.cuda.current_stream().cuda_stream
 ds = torch.empty(n + 1, dtype=torch.int32, device=dev); dp = torch.empty(nnz, dtype=torch.int32, device=dev); dv = torch.empty(nnz, dtype=torch.float32, device=dev)
-host.gen_banded_dev(n, 25, 0x5EED, 1 << 20, ds, dp, dv, np.float32, s0, diag_shift=1.0)
+host.gen_banded_dev(n, 25, 0x5EED, maxoff, ds, dp, dv, np.float32, s0, diag_shift=1.0)
+print(f"{n} rows, offsets below {maxoff}: {nnz} entries ({nnz / n:.1f} per row)")
 torch.cuda.synchronize()
 xt = torch.rand(n, dtype=torch.float32, device=dev) + 0.5
 b = torch.empty_like(xt)
