@@ -793,7 +793,7 @@ static int p2pHaloLaunch(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t cs);
 template <typename T>
 static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long long seq, hipStream_t s);
 template <typename T>
-static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int count, const int* doneFlag, hipStream_t s);
+static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int count, const int* doneFlag, hipStream_t s, const T* parts = nullptr);
 
 // Collective.  Leaves D->p2p null (the communicator's collectives are used) unless EVERY rank asked for the peer-to-peer path, could
 // allocate and export its block, map every peer's and pass the self-test through every path.
@@ -1061,10 +1061,10 @@ static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long lo
 }
 
 template <typename T>
-static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int count, const int* doneFlag, hipStream_t s) {
+static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int count, const int* doneFlag, hipStream_t s, const T* parts) {
 	P2PState* P = D->p2p;
 	const unsigned long long seq = ++P->redSeq[point];
-	p2pAllreduceKernel<T><<<1, 64, 0, s>>>(P->peers, P->world, P->rank, point, seq, count, totals, P->ticks, doneFlag);
+	p2pAllreduceKernel<T><<<1, P2P_TPB, 0, s>>>(P->peers, P->world, P->rank, point, seq, count, totals, parts, NPART, P->ticks, doneFlag);
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
 }
@@ -1357,7 +1357,7 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 	auto& pend = D->pending;
 	const bool exchange = pend.active;
 	pend.active = false;
-	const int finish = dotMode ? SPMV_FINISH : 0;
+	const int finish = dotMode && !D->p2p ? SPMV_FINISH : 0;  // (peer to peer: the slot kernel adds the partials itself)
 	// jacobiDiag (op must be SMM_OP_ASSIGN): out = (A x) / diag with the division folded into the launch that completes a row -- the
 	// local block's when nothing is remote, else the remote block's epilogue ("add, then divide"): the loop then has the kernel count
 	// of the unpreconditioned one, and the dot products of the divided vector ride in the same epilogue
@@ -1414,7 +1414,7 @@ static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t
 	T* totals = parts + PARTS_TOTALS;
 	// peer to peer: ONE single-workgroup kernel on the solver's own stream writes this rank's totals into every rank's slot, waits for all
 	// slots of this sequence number and adds them in rank order (smm_p2p.h) -- no collective launch, no cross-stream events
-	if (D->p2p) return p2pAllreduceLaunch<T>(D, point, totals, count, doneFlag, s);
+	if (D->p2p) return p2pAllreduceLaunch<T>(D, point, totals, count, doneFlag, s, parts);  // (it adds the rank's partials itself: nobody finished them)
 	if (c->kind == SMM_COMM_HOST) return commAllreduce<T>(c, totals, count, s);
 	noteStream(c->stream);
 	SMM_TRY(orderAfter(c, s, c->stream));
@@ -1834,7 +1834,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	SMM_TRY(launchCopy2<T>(n, r, r0, p, s));                              // r0 = p = r, ref:2225-2226
 	SMM_TRY(distExchangeBegin<T>(D, pExt, 0, s));                         // the halo of p travels while r.r0 is reduced
 	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);  // r.r0 with r0 == r, ref:2231
-	distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
+	if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
 	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
 	SMM_TRY(join(s, ev));
 	distBicgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc);
@@ -1855,7 +1855,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, ap, r0, nullptr, 1, partsA, doneFlag);
-			distFinishSums<T><<<1, TPB, 0, s>>>(partsA, 1, partsA + PARTS_TOTALS, doneFlag);
+			if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsA, 1, partsA + PARTS_TOTALS, doneFlag);
 		} else {
 			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s));
 		}
@@ -1871,14 +1871,14 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, as, as, sv, 2, partsB, doneFlag);
-			distFinishSums<T><<<1, TPB, 0, s>>>(partsB, 2, partsB + PARTS_TOTALS, doneFlag);
+			if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsB, 2, partsB + PARTS_TOTALS, doneFlag);
 		} else {
 			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s));
 		}
 		SMM_TRY(allreduceTotals<T>(D, partsB, 2, s, &ev, 1, doneFlag));
 		SMM_TRY(join(s, ev));
 		distBicgR<T><<<NPART, TPB, 0, s>>>(n, sc, partsB + PARTS_TOTALS, sv, as, r0, r, partsC);
-		distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 2, partsC + PARTS_TOTALS, doneFlag);
+		if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 2, partsC + PARTS_TOTALS, doneFlag);
 		SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev, 2, doneFlag));  // (the communicator's collectives: on the side stream ...
 		distBicgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, sv, x);         // ... while x is updated)
 		SMM_TRY(join(s, ev));
@@ -1931,7 +1931,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	SMM_TRY(distMatvec<T>(D, xExt, 2, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
 	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));                                           // p = r, ref:2340
 	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);
-	distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
+	if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
 	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
 	SMM_TRY(join(s, ev));
 	distCgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc, eps);
@@ -1974,7 +1974,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
 		SMM_TRY(join(s, ev));
 		SMM_DIST_UPDATE(distCgR, nt3, NPART, s, n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC, i % LAZY_M);
-		distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, doneFlag);
+		if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, doneFlag);
 		SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2, doneFlag));           // (the communicator's collectives: on the side stream ...
 		if (!lazy) SMM_DIST_UPDATE(distCgX, nt3, gridFor(n), s, n, sc, pc, i == 0 ? x0 : x, x);  // ... while x is updated; ref:2351, 2395)
 		SMM_TRY(join(s, ev));

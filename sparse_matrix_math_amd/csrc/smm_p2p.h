@@ -175,22 +175,37 @@ __global__ __launch_bounds__(P2P_TPB) void p2pLandKernel(const P2PLandSeg* __res
 struct P2PPeers {
 	P2PHeader* hdr[P2P_MAX_WORLD];
 };
+// parts != nullptr: the rank's own totals are first formed HERE from the npart partials per quantity the producing kernel left behind --
+// in the order of lastBlockSums / distFinishSums (i = t, t + 256, ...; then blockSum256): the same bits -- so that in the peer-to-peer
+// transport neither the SpMV kernels finish their sums nor a finishing launch runs (r05: ~12 us per BiCGStab iteration).
 template <typename T>
-__global__ __launch_bounds__(64) void p2pAllreduceKernel(P2PPeers peers, int world, int me, int point, unsigned long long seq, int count, T* totals, long long ticks,
-                                                        const int* __restrict__ doneFlag) {
+__global__ __launch_bounds__(P2P_TPB) void p2pAllreduceKernel(P2PPeers peers, int world, int me, int point, unsigned long long seq, int count, T* totals,
+                                                             const T* __restrict__ parts, int npart, long long ticks, const int* __restrict__ doneFlag) {
 	__shared__ unsigned long long sBits[P2P_MAX_WORLD][2];
 	__shared__ int sOk;
+	__shared__ T sRed[4];
+	__shared__ T sMine[2];
 	// (no early return on `done`: every rank must publish for every reduction the others may still be waiting in; the totals of a finished
 	// solve are simply not used)
 	(void)doneFlag;
 	const int t = threadIdx.x;
 	const int par = static_cast<int>(seq & 1ull);
 	if (t == 0) sOk = 1;
+	for (int k = 0; k < count; ++k) {
+		if (parts) {
+			T acc = T(0);
+			for (int i = t; i < npart; i += P2P_TPB) acc += parts[k * npart + i];
+			const T sum = blockSum256(acc, sRed);
+			if (t == 0) sMine[k] = sum;
+		} else if (t == 0) {
+			sMine[k] = totals[k];
+		}
+	}
 	__syncthreads();
 	if (t < world) {
 		unsigned long long b[2] = {0ull, 0ull};
 		for (int k = 0; k < count; ++k) {
-			T v = totals[k];
+			T v = sMine[k];
 			__builtin_memcpy(&b[k], &v, sizeof(T));
 		}
 		P2PSlot* slot = &peers.hdr[t]->slot[point][par][me];
