@@ -742,8 +742,8 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 // wave-private LDS slice and read back by the row's
 // lane.  A tile is 1024 rows = 4 sub-steps of 256 (one row per lane and sub-step: 8-byte LDS reads at lane stride -- conflict-free).
 // Row starts come from ONE start[] per 64 rows plus a prefix sum of the masks' popcounts across the wavefront: no start[] stream.
-// Bytes per fp64 row of the 7-point stencil: 56 (values) + 4 (mask) + 8 (x) + 8 (out) = 76 against 84 in the wave kernel (and the
-// 104 that kernel really moves).  Same products in the same order: -P, the near offsets ascending, +P; value n of a row pairs with its
+// Bytes per fp64 row of the 7-point stencil: 56 (values) + 1 (mask; 4 until r05) + 8 (x) + 8 (out) = 73 against 84 in the wave kernel
+// (and the 104 that kernel really moves).  Same products in the same order: -P, the near offsets ascending, +P; value n of a row pairs with its
 // n-th set bit (ref:1484-1489): the reference's bits with one lane per row.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int MM_Q = 4;            // sub-steps per tile and plane
@@ -766,7 +766,7 @@ struct MasksMarchVals {
 template <typename T, int KMAX, bool NT, int HP>
 __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 2)) void spmvPatternMasksMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
                                                                       int nOff, int hasLo, int hasHi, const int* __restrict__ offs, const int* __restrict__ start,
-                                                                      const T* __restrict__ values, const unsigned* __restrict__ masks32, int opFlags,
+                                                                      const T* __restrict__ values, const unsigned char* __restrict__ masks8, int opFlags,
                                                                       const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode,
                                                                       const T* __restrict__ w1, T* __restrict__ partials, const int* __restrict__ doneFlag) {
 	using Set = MasksMarchSet<T, HP>;
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 
 				const bool live = inside && l < bAct && base + l < rows;
 				f.c[q] = live && wantCentre ? x[base + l] : T(0);  // (cacheable: a neighbouring tile reads these lines as its halo)
 				if (wantWindow) {
-					f.m[q] = live ? __builtin_nontemporal_load(masks32 + base + l) : 0u;
+					f.m[q] = live ? static_cast<unsigned>(__builtin_nontemporal_load(masks8 + base + l)) : 0u;  // (at most 8 offsets: one byte per row since r05)
 					const int lw = q * TPB + (t & ~(WAVE - 1));  // the wavefront's first row of this sub-step
 					f.s0[q] = inside && lw < bAct && base + lw < rows ? start[base + lw] : 0;
 				}
@@ -1074,8 +1074,9 @@ int marchBuildMasks32(smm_hip_csr* m, hipStream_t s) {
 	if (!m->march_ok || m->d_pat_masks32) return SMM_HIP_OK;
 	const bool masksShape = m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8;
 	if (!m->pat_const && !masksShape) return SMM_HIP_OK;
-	// (constant diagonals, no clusters, five near offsets: the KN = 5 instances of the two-window kernel, which stream one byte per row)
-	const bool wantBytes = m->pat_const && !m->march_clusters && m->pat_k - m->march_lo - m->march_hi == 5;
+	// (the kernels that stream one byte of mask per row: the KN = 5 instances of the constant-diagonal two-window kernel -- five near
+	// offsets, no clusters -- and the masks march, which serves matrices of at most 8 offsets only)
+	const bool wantBytes = (m->pat_const && !m->march_clusters && m->pat_k - m->march_lo - m->march_hi == 5) || masksShape;
 	void *p = nullptr, *p8 = nullptr;
 	SMM_TRY(devAlloc(&p, static_cast<size_t>(m->rows) * sizeof(unsigned) + 16));
 	if (wantBytes && devAlloc(&p8, static_cast<size_t>(m->rows) + 16) != SMM_HIP_OK) {
@@ -1332,13 +1333,13 @@ static bool launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 	const int xcdTiles = (nT % 8 == 0 || nT >= 64) && grid >= 8 ? 1 : 0;
 	if (xcdTiles) grid -= grid % 8;
 	spmvPatternMasksMarchKernel<T, KMAX, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
-	                                                                  m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks32, op, lhs, divisor, x,
+	                                                                  m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks8, op, lhs, divisor, x,
 	                                                                  out, dotMode, w1, partials, doneFlag);
 	return true;
 }
 
 bool masksMarchApplies(const smm_hip_csr* m) {
-	return m->march_ok && !m->march_clusters && m->d_pat_masks32 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8 &&
+	return m->march_ok && !m->march_clusters && m->d_pat_masks8 && m->pat_k <= 8 && m->march_P > 0 && (m->rows + m->march_P - 1) / m->march_P >= 8 &&
 	       m->rows >= marchMinRows(true, m->dtype);
 }
 bool constMarchApplies(const smm_hip_csr* m) {

@@ -1671,7 +1671,7 @@ const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes)
 			return env ? atoi(env) != 0 : true;
 		}();
 		if (masksMarchOn) {
-			*bytes = nnz * s + rows * 4 + (rows / 64 + 1) * 4 + vectors;  // values, 32-bit masks, one start[] per 64 rows, x, out
+			*bytes = nnz * s + rows + (rows / 64 + 1) * 4 + vectors;  // values, one byte of mask per row, one start[] per 64 rows, x, out
 			return "spmvPatternMasksMarchKernel";
 		}
 	}
