@@ -284,6 +284,46 @@ int patternLanesFor(const smm_hip_csr* m);
 const char* patternKernelDesc(const smm_hip_csr* m, int lanes, long long* bytes);
 void planMarch(smm_hip_csr* m);
 int marchBuildMasks32(smm_hip_csr* m, hipStream_t s);
+// Launch plumbing of the persistent SpMV kernels (per template instantiation: `slot` / `granted` are statics of the launcher).
+// occupancyCached: workgroups per CU of `kernel` at `lds` bytes of dynamic LDS, asked from the runtime once per LDS size -- the query costs
+// 10+ us of host time and sat on the solvers' hot path beside kernels of 10-20 us.  ensureDynamicLds: the kernel's
+// hipFuncAttributeMaxDynamicSharedMemorySize raised whenever a launch needs more than the largest size granted so far (r04 set it ONCE,
+// to the first qualifying matrix's size: a later matrix with longer rows got a failed launch); false: the runtime refused.
+template <typename K>
+inline int occupancyCached(std::atomic<long long>& slot, K kernel, int tpb, size_t lds, int fallback) {
+	const long long seen = slot.load(std::memory_order_acquire);
+	if (seen != 0 && static_cast<size_t>(seen >> 8) == lds) return static_cast<int>(seen & 0xFF);
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, tpb, lds) != hipSuccess || n < 1) {
+		(void)hipGetLastError();
+		n = fallback;
+	}
+	n = n > 255 ? 255 : n;
+	slot.store((static_cast<long long>(lds) << 8) | n, std::memory_order_release);
+	return n;
+}
+template <typename K>
+inline bool ensureDynamicLds(std::atomic<int>& granted, K kernel, size_t lds) {
+	if (lds <= 64 * 1024) return true;  // (what every kernel may use without asking)
+	int have = granted.load(std::memory_order_acquire);
+	while (static_cast<size_t>(have) < lds) {
+		if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+			(void)hipGetLastError();
+			return false;
+		}
+		if (granted.compare_exchange_weak(have, static_cast<int>(lds), std::memory_order_acq_rel)) break;  // (a concurrent, larger grant stays)
+	}
+	return true;
+}
+// SMM_HIP_STREAM_WGS_PER_CU (measurements): workgroups per CU of the persistent STREAM / PATTERN grids; 0: ask the runtime.  Read once.
+inline int forcedWgsPerCU() {
+	static const int forced = [] {
+		const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU");
+		return env ? (atoi(env) > 1 ? atoi(env) : 1) : 0;
+	}();
+	return forced;
+}
+
 // bytes per vector from which ConjugateGradient defers its x update (smm_solvers.hip; the row-partitioned loop asks too)
 long long cgLazyMinBytes();
 // non-temporal loads / stores for an update kernel over `vectors` vectors of n elements (they cannot stay in the Infinity Cache anyway)

@@ -958,14 +958,11 @@ static void launchTileG(const smm_hip_csr* m, int op, const T* lhs, const T* div
 	const int rt = tileRows(L);
 	const size_t lds = static_cast<size_t>(cap + TileCfg<T>::PAD) * (sizeof(T) + 4) + (rt + 4) * sizeof(int) + static_cast<size_t>(L - 1) * rt * sizeof(T) +
 	                   4 * sizeof(T) + 32;
-	static bool raised = false;  // per instantiation: allow more than 64 KB of dynamic LDS where a tile needs it
-	if (lds > 64 * 1024 && !raised) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmvTileKernel<T, L, G>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-		raised = true;
-	}
-	int perCU = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvTileKernel<T, L, G>, TPB, lds) != hipSuccess || perCU < 1) perCU = 3;
-	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	static std::atomic<int> granted{0};      // per instantiation: more than 64 KB of dynamic LDS where a tile needs it, raised on demand
+	static std::atomic<long long> occ{0};
+	(void)ensureDynamicLds(granted, spmvTileKernel<T, L, G>, lds);  // (refused: the launch below fails and launchSpmv reports it)
+	int perCU = occupancyCached(occ, spmvTileKernel<T, L, G>, TPB, lds, 3);
+	if (forcedWgsPerCU() > 0) perCU = forcedWgsPerCU();
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 	const int grid = std::max(1, std::min(std::min(m->n_rowblocks, cus * perCU), NPART));
 	const int nGroups = std::min(8, grid);
@@ -1000,9 +997,9 @@ static void launchStream(const smm_hip_csr* m, int grid, int op, const T* lhs, c
 	const int cap = m->stream_nnz_cap + 3;
 	const size_t lds = static_cast<size_t>(cap + StreamCfg<T>::PAD) * (sizeof(T) + 4) + (TPB + 8) * sizeof(int) + 4 * sizeof(T) + 16;
 	// persistent grid = exactly the workgroups that are resident together (a larger grid would run in two uneven rounds)
-	int perCU = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvStreamKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
-	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	static std::atomic<long long> occ{0};
+	int perCU = occupancyCached(occ, spmvStreamKernel<T, L>, TPB, lds, 4);
+	if (forcedWgsPerCU() > 0) perCU = forcedWgsPerCU();
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 	grid = std::max(1, std::min(std::min(m->n_rowblocks, cus * perCU), NPART));
 	const int nGroups = std::min(8, grid);

@@ -1509,9 +1509,9 @@ static void launchPatTileG(const smm_hip_csr* m, int op, const T* lhs, const T* 
 	const int cap = m->pat_nnz_cap + 3;
 	const size_t lds = static_cast<size_t>(cap + PatCfg<T>::PAD) * sizeof(T) + RT * 8 + (RT + 4) * 4 + MAXOFF * 4 + static_cast<size_t>(L - 1) * RT * sizeof(T) +
 	                   4 * sizeof(T) + 32;
-	int perCU = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternTileKernel<T, L, G>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
-	if (const char* env = getenv("SMM_HIP_STREAM_WGS_PER_CU")) perCU = std::max(1, atoi(env));
+	static std::atomic<long long> occ{0};  // (the query is cached per LDS size, the override read once: smm_internal.h)
+	int perCU = occupancyCached(occ, spmvPatternTileKernel<T, L, G>, TPB, lds, 4);
+	if (forcedWgsPerCU() > 0) perCU = forcedWgsPerCU();
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, cus * perCU), NPART));
 	const int nGroups = std::min(8, grid);
@@ -1565,9 +1565,8 @@ static void launchDict(const smm_hip_csr* m, int op, const T* lhs, const T* divi
 	const bool dlds = m->pat_k <= DICT_LDS_MAX;
 	const size_t lds = static_cast<size_t>(cap + PatCfg<T>::PAD) * sizeof(T) + (RT + 4) * 4 + static_cast<size_t>((cap + PatCfg<T>::PAD + 8 + 7) & ~7) * 2 +
 	                   (dlds ? static_cast<size_t>((m->pat_k + 1) & ~1) * 4 : 0) + 4 * sizeof(T) + 32;
-	int perCU = 0;
-	const void* fn = dlds ? reinterpret_cast<const void*>(spmvDictKernel<T, L, true>) : reinterpret_cast<const void*>(spmvDictKernel<T, L, false>);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
+	static std::atomic<long long> occLds{0}, occMem{0};
+	const int perCU = dlds ? occupancyCached(occLds, spmvDictKernel<T, L, true>, TPB, lds, 4) : occupancyCached(occMem, spmvDictKernel<T, L, false>, TPB, lds, 4);
 	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, cus * perCU), NPART));
 	const int flags = op | spmvOutFlags(m, sizeof(T));
 	const int2* tiles = reinterpret_cast<const int2*>(m->d_pat_rowblocks);
@@ -1634,8 +1633,8 @@ static void launchPat(const smm_hip_csr* m, int op, const T* lhs, const T* divis
 	constexpr int RT = (WAVE / LW) * (TPB / WAVE);
 	const int cap = m->pat_nnz_cap + 3;
 	const size_t lds = static_cast<size_t>(cap + PatCfg<T>::PAD) * sizeof(T) + RT * 8 + (RT + 4) * 4 + MAXOFF * 4 + 4 * sizeof(T) + 32;
-	int perCU = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, spmvPatternKernel<T, L>, TPB, lds) != hipSuccess || perCU < 1) perCU = 4;
+	static std::atomic<long long> occ{0};
+	const int perCU = occupancyCached(occ, spmvPatternKernel<T, L>, TPB, lds, 4);
 	const int grid = std::max(1, std::min(std::min(m->pat_n_rowblocks, cus * perCU), NPART));
 	spmvPatternKernel<T, L><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, m->cols, m->pat_k, m->d_pat_off, reinterpret_cast<const int2*>(m->d_pat_rowblocks),
 	                                             m->d_start, m->d_pat_masks, m->d_positions, static_cast<const T*>(m->d_values), op | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out, dotMode,
