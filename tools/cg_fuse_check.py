@@ -56,7 +56,7 @@ for dtype in (np.float64, np.float32):
         if int(st) != st_o or err > tol * max(1.0, float(np.max(np.abs(x_o)))):
             bad += 1
             print(f"ORACLE MISMATCH {name} {np.dtype(dtype).name}: {err:.3e}")
-        print(f"{name:20s} {np.dtype(dtype).name} kernel {kernel}: fused == deferred == eager for 13 x 2 solves; vs oracle {err:.2e}", flush=True)
+        print(f"{name:20s} {np.dtype(dtype).name} kernel {kernel}: fused == deferred == eager for 22 x 2 solves; vs oracle {err:.2e}", flush=True)
         A.close()
 print("cg fuse check:", "ALL OK" if bad == 0 else f"{bad} BAD")
 sys.exit(1 if bad else 0)
