@@ -14,7 +14,8 @@
 //     the destination's flag word.  The destination's land kernel (on the solver's stream, in front of the remote block's SpMV) waits for
 //     all parts of all its segments and copies the landing area into the halo of the ordinary, cached vector the SpMV reads.  Pure data
 //     movement: the bits of the one-path exchange;
-//   * scalars: one single-workgroup kernel per reduction point writes this rank's 1-2 partial totals into its slot in EVERY rank's block,
+//   * scalars: one single-workgroup kernel per reduction point adds the rank's own partials (what the producing kernel left: nobody else
+//     finishes them in this transport), writes the 1-2 totals into its slot in EVERY rank's block,
 //     waits for all slots of that sequence number and adds them in rank order -- the same order, hence the same bits, on every rank -- into
 //     the place the RCCL all-reduce would have left them: the update kernels are unchanged;
 //   * every wait is bounded (SMM_HIP_P2P_TIMEOUT_S, default 20 s): an expired wait raises the block's error word, every later wait of the
