@@ -249,6 +249,11 @@ constexpr int SPMV_OP_DIV = 3;
 // row-partitioned SpMV with the Jacobi division folded in ("add, then divide").  Internal operation SPMV_OP_ADD_DIV.
 constexpr int SPMV_ADD_DIV = 0x1000;
 constexpr int SPMV_OP_ADD_DIV = 4;
+// launch-side: ConjugateGradient's SpMV (+ p.Ap) launches.  On the 2.5-D constant-diagonal kernel in fp32 with outputs beyond the caches they
+// take HALF the tile height (4 rows per lane instead of 8): the launch that forms the next direction inside the SpMV (MarchFuse) holds two
+// streams' request sets and fits three workgroups per CU only with half tiles (512^3: 0.95 -> 0.82 ms per iteration); the partial sums of
+// p.Ap follow the tiles, so EVERY loop form of CG uses the same tiles and they stay bit for bit equal.  Other kernels ignore the flag.
+constexpr int SPMV_HALF_TILES = 0x2000;
 constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer
 constexpr int PARTS_TICKETS = 16;             // sub-counters of the "last workgroup" ticket (lastBlockSums, smm_device.h)
 constexpr int PARTS_LEN = 2 * NPART + 2 + 2 * (PARTS_TICKETS + 1);  // elements of a finishing buffer: 2 x NPART partials, 2 totals, the ticket words
@@ -324,6 +329,7 @@ inline int forcedWgsPerCU() {
 	return forced;
 }
 
+bool cgHalfTiles(const smm_hip_csr* m, size_t elemBytes);  // (smm_spmv_march.hip)
 // bytes per vector from which ConjugateGradient defers its x update (smm_solvers.hip; the row-partitioned loop asks too)
 long long cgLazyMinBytes();
 // non-temporal loads / stores for an update kernel over `vectors` vectors of n elements (they cannot stay in the Infinity Cache anyway)

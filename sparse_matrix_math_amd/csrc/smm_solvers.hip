@@ -609,7 +609,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			// the flush of x behind it (scheduled every LAZY_M-th iteration; or because SpMV' found iteration i - 1 converged), the r update
 			const int cur = i % (LAZY_M + 1);
 			if (i == 0) {
-				SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, ring.p[0], Ap, 1, ring.p[0], parts, doneFlag, s));
+				SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, ring.p[0], Ap, 1, ring.p[0], parts, doneFlag, s, SPMV_HALF_TILES));
 			} else {
 				const int prev = (i - 1) % (LAZY_M + 1);
 				const CgFuseArgs<T> f{r, ring.p[cur], sc.p, parts2, eps, (i - 1) & 1, i};
@@ -631,7 +631,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			// planned one, and by whichever launch finds the iteration converged
 			const int cur = i % (LAZY_M + 1);
 			const T* pc = ring.p[cur];
-			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, pc, Ap, 1, pc, parts, doneFlag, s));
+			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, pc, Ap, 1, pc, parts, doneFlag, s, SPMV_HALF_TILES));
 			SMM_LAUNCH_UPDATE(cgFusedR, updateNT(n, sizeof(T), 3), NPART, s, n, sc, i & 1, parts, Ap, r, parts2, i % LAZY_M);
 			const int pending = i % LAZY_M + 1;
 			const int flush = (pending == LAZY_M || i == maxIterations - 1) ? 1 : 0;
@@ -640,7 +640,7 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 			continue;
 		}
 		// Ap = A p with the p.Ap partial sums fused into the epilogue (ref:2353-2354)
-		SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, Ap, 1, p, parts, doneFlag, s));
+		SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, Ap, 1, p, parts, doneFlag, s, pcg ? 0 : SPMV_HALF_TILES));
 		const T* xcur = i == 0 ? x0 : x;  // ref:2351, 2395
 		if (pcg) {
 			cgAlphaScal<T><<<1, TPB, 0, s>>>(parts, sc);

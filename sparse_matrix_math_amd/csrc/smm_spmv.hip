@@ -1032,7 +1032,7 @@ int launchSpmv(const smm_hip_csr* m, int op, const T* lhs, const T* x, T* out, i
 		setError("spmv: fused dot needs w1 and partials");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if ((extraFlags & ~(SPMV_FINISH | SPMV_LEAVE_ROOM | SPMV_DIV_LHS | SPMV_ADD_DIV)) || ((extraFlags & SPMV_FINISH) && !dotMode) ||
+	if ((extraFlags & ~(SPMV_FINISH | SPMV_LEAVE_ROOM | SPMV_DIV_LHS | SPMV_ADD_DIV | SPMV_HALF_TILES)) || ((extraFlags & SPMV_FINISH) && !dotMode) ||
 	    ((extraFlags & SPMV_DIV_LHS) && (extraFlags & SPMV_ADD_DIV))) {
 		setError("spmv: bad extra flags");
 		return SMM_HIP_ERR_INVALID;

@@ -1219,6 +1219,18 @@ static bool launchMarch3(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	return true;
 }
 
+// ConjugateGradient's launches on the two-window kernel take half tiles in fp32 when the outputs are beyond the caches (the size at which
+// the direction is formed inside the SpMV: SPMV_HALF_TILES, smm_internal.h).  fp64: half tiles (2 rows per lane) gain 2 % in the fused
+// launch and would need the plain kernel at 2 rows per lane as well -- not done.  SMM_HIP_MARCH_FUSE_FULL_TILES=1: full tiles everywhere (A/B)
+bool cgHalfTiles(const smm_hip_csr* m, size_t elemBytes) {
+	static const bool fullTiles = [] {
+		const char* env = getenv("SMM_HIP_MARCH_FUSE_FULL_TILES");
+		return env && atoi(env) != 0;
+	}();
+	static const bool rowsForced = getenv("SMM_HIP_MARCH_R") != nullptr;
+	return !fullTiles && !rowsForced && elemBytes == 4 && !m->march_clusters && (spmvOutFlags(m, elemBytes) & SPMV_NT_OUT) != 0;
+}
+
 // true: the launch went to the march kernel.  SMM_HIP_CONST_MARCH=0 keeps the gather kernel (A/B measurements).
 template <typename T>
 bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
@@ -1229,6 +1241,8 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	}();
 	if (!enabled || !constMarchApplies(m)) return false;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;  // outputs too large to still be cached when the next kernel reads them
+	const bool halfTiles = (op & SPMV_HALF_TILES) != 0 && cgHalfTiles(m, sizeof(T));  // (ConjugateGradient's launches: smm_internal.h)
+	op &= ~SPMV_HALF_TILES;
 	if (m->march_clusters) {
 		// far offsets in clusters: the three-window kernel, 4 rows per lane in fp64 and 8 in fp32 as below
 		const bool hp2c = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
@@ -1245,7 +1259,7 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 		const char* env = getenv("SMM_HIP_MARCH_R");
 		return env ? atoi(env) : 0;
 	}();
-	const int rowsPerLane = forcedRows == 4 || forcedRows == 8 ? forcedRows : (sizeof(T) == 8 ? 4 : 8);
+	const int rowsPerLane = forcedRows == 4 || forcedRows == 8 ? forcedRows : (sizeof(T) == 8 || halfTiles ? 4 : 8);
 	const int vec = 16 / static_cast<int>(sizeof(T));
 	const bool r4 = rowsPerLane == 4;
 	const bool hp2 = 2 * m->march_H / vec <= 2 * TPB;  // the halo fits two packs per lane (fewer registers)
@@ -1295,14 +1309,24 @@ bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* parti
 	fz.par = f.par;
 	fz.iter = f.iter;
 	const int nNear = m->pat_k - m->march_lo - m->march_hi;
-	constexpr int RV = sizeof(T) == 8 ? 4 : 8;
+	// rows per lane: what ConjugateGradient's plain launches use for this matrix (cgHalfTiles: fp32 4 instead of 8 -- the fused launch holds
+	// two streams' request sets and fits three workgroups per CU at 143 VGPRs instead of two at 205: 512^3 fp32 0.95 -> 0.82 ms per CG
+	// iteration, profiles/r05/cg_fuse_half_tiles.txt); the partial sums of p.Ap follow the tiles, so all loop forms share them
+	constexpr int RF = sizeof(T) == 8 ? 4 : 8;
+	const bool half = cgHalfTiles(m, sizeof(T));
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
-	if (nNear == 5 && m->d_pat_masks8) {
-		return hp2 ? launchMarchKN<T, RV, 5, true, 2, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
-		           : launchMarchKN<T, RV, 5, true, 4, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz);
+	const bool kn5 = nNear == 5 && m->d_pat_masks8;
+#define SMM_FUSE_GO(RV, KNV, HPV) launchMarchKN<T, RV, KNV, true, HPV, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
+	bool launched;
+	if constexpr (sizeof(T) == 4) {
+		if (half) {
+			launched = kn5 ? (hp2 ? SMM_FUSE_GO(4, 5, 2) : SMM_FUSE_GO(4, 5, 4)) : (hp2 ? SMM_FUSE_GO(4, 0, 2) : SMM_FUSE_GO(4, 0, 4));
+			return launched;
+		}
 	}
-	return hp2 ? launchMarchKN<T, RV, 0, true, 2, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
-	           : launchMarchKN<T, RV, 0, true, 4, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz);
+	launched = kn5 ? (hp2 ? SMM_FUSE_GO(RF, 5, 2) : SMM_FUSE_GO(RF, 5, 4)) : (hp2 ? SMM_FUSE_GO(RF, 0, 2) : SMM_FUSE_GO(RF, 0, 4));
+#undef SMM_FUSE_GO
+	return launched;
 }
 template bool launchConstMarchFusedP<float>(const smm_hip_csr*, const float*, float*, float*, const int*, const CgFuseArgs<float>&, hipStream_t);
 template bool launchConstMarchFusedP<double>(const smm_hip_csr*, const double*, double*, double*, const int*, const CgFuseArgs<double>&, hipStream_t);

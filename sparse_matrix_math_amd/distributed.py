@@ -771,7 +771,7 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
         "max_rel_err_vs_x_true": float(err.item()),
         "rccl_ranks": comm_info["rccl_ranks"],  # the communicator's size as RCCL reports it (ncclCommCount); 0: not an RCCL communicator
         "distributed": {"driver": driver, "comm": comm_info["kind"], "comm_ranks": comm_info["world"],
-                        "kernels_per_iteration": 8 if driver == "native" else 13,  # (native: + a one-workgroup finishing launch with the collectives) "allreduces_per_iteration": 3, "halo_exchanges_per_iteration": 2},
+                        "kernels_per_iteration": 8 if driver == "native" else 13, "allreduces_per_iteration": 3, "halo_exchanges_per_iteration": 2},
         # the first thing to read in a multi-GPU line that scales worse than hoped: milliseconds per BiCGStab iteration (two exchanges) that
         # rank 0's A_rem waited for its halo AFTER A_loc had ended -- the exchange's share that no compute covered
         "exposed_comm_ms": exposed_ms / iters_measured,
