@@ -249,9 +249,9 @@ constexpr int SPMV_OP_DIV = 3;
 // row-partitioned SpMV with the Jacobi division folded in ("add, then divide").  Internal operation SPMV_OP_ADD_DIV.
 constexpr int SPMV_ADD_DIV = 0x1000;
 constexpr int SPMV_OP_ADD_DIV = 4;
-// launch-side: ConjugateGradient's SpMV (+ p.Ap) launches.  On the 2.5-D constant-diagonal kernel in fp32 with outputs beyond the caches they
-// take HALF the tile height (4 rows per lane instead of 8): the launch that forms the next direction inside the SpMV (MarchFuse) holds two
-// streams' request sets and fits three workgroups per CU only with half tiles (512^3: 0.95 -> 0.82 ms per iteration); the partial sums of
+// launch-side: ConjugateGradient's SpMV (+ p.Ap) launches.  On the 2.5-D constant-diagonal kernel with outputs beyond the caches they
+// take HALF the tile height (fp32 4 rows per lane instead of 8, fp64 2 instead of 4): the launch that forms the next direction inside the SpMV (MarchFuse) holds two
+// streams' request sets and fits three workgroups per CU only with half tiles (512^3 fp32: 0.95 -> 0.83 ms per iteration, fp64 1.71 -> 1.67); the partial sums of
 // p.Ap follow the tiles, so EVERY loop form of CG uses the same tiles and they stay bit for bit equal.  Other kernels ignore the flag.
 constexpr int SPMV_HALF_TILES = 0x2000;
 constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer

@@ -1219,16 +1219,16 @@ static bool launchMarch3(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	return true;
 }
 
-// ConjugateGradient's launches on the two-window kernel take half tiles in fp32 when the outputs are beyond the caches (the size at which
-// the direction is formed inside the SpMV: SPMV_HALF_TILES, smm_internal.h).  fp64: half tiles (2 rows per lane) gain 2 % in the fused
-// launch and would need the plain kernel at 2 rows per lane as well -- not done.  SMM_HIP_MARCH_FUSE_FULL_TILES=1: full tiles everywhere (A/B)
+// ConjugateGradient's launches on the two-window kernel take half tiles (fp32 4 rows per lane, fp64 2) when the outputs are beyond the caches
+// (the size at which the direction is formed inside the SpMV: SPMV_HALF_TILES, smm_internal.h).  SMM_HIP_MARCH_FUSE_FULL_TILES=1: full tiles
+// everywhere (A/B measurements)
 bool cgHalfTiles(const smm_hip_csr* m, size_t elemBytes) {
 	static const bool fullTiles = [] {
 		const char* env = getenv("SMM_HIP_MARCH_FUSE_FULL_TILES");
 		return env && atoi(env) != 0;
 	}();
 	static const bool rowsForced = getenv("SMM_HIP_MARCH_R") != nullptr;
-	return !fullTiles && !rowsForced && elemBytes == 4 && !m->march_clusters && (spmvOutFlags(m, elemBytes) & SPMV_NT_OUT) != 0;
+	return !fullTiles && !rowsForced && !m->march_clusters && (spmvOutFlags(m, elemBytes) & SPMV_NT_OUT) != 0;
 }
 
 // true: the launch went to the march kernel.  SMM_HIP_CONST_MARCH=0 keeps the gather kernel (A/B measurements).
@@ -1269,7 +1269,17 @@ bool launchPatConstMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	 : hp2     ? launchMarchKN<T, RV, KNV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)                 \
 	           : launchMarchKN<T, RV, KNV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s))
 #define SMM_MARCH_GO(KNV) (r4 ? SMM_MARCH_GO2(4, KNV) : SMM_MARCH_GO2(8, KNV))
-	const bool launched = nNear == 5 && m->d_pat_masks8 ? SMM_MARCH_GO(5) : SMM_MARCH_GO(0);  // (KN = 5 reads the byte masks)
+	bool launched;
+	if constexpr (sizeof(T) == 8) {
+		if (halfTiles && !forcedRows) {  // (fp64 half tiles: 2 rows per lane; only with non-temporal outputs, which cgHalfTiles implies)
+			launched = nNear == 5 && m->d_pat_masks8 ? (hp2 ? launchMarchKN<T, 2, 5, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)
+			                                                : launchMarchKN<T, 2, 5, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s))
+			                                         : (hp2 ? launchMarchKN<T, 2, 0, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)
+			                                                : launchMarchKN<T, 2, 0, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s));
+			return launched;
+		}
+	}
+	launched = nNear == 5 && m->d_pat_masks8 ? SMM_MARCH_GO(5) : SMM_MARCH_GO(0);  // (KN = 5 reads the byte masks)
 #undef SMM_MARCH_GO2
 #undef SMM_MARCH_GO
 	return launched;  // false: the windows do not fit the LDS a launch can be granted -- the gather kernel serves the matrix
@@ -1309,20 +1319,20 @@ bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* parti
 	fz.par = f.par;
 	fz.iter = f.iter;
 	const int nNear = m->pat_k - m->march_lo - m->march_hi;
-	// rows per lane: what ConjugateGradient's plain launches use for this matrix (cgHalfTiles: fp32 4 instead of 8 -- the fused launch holds
-	// two streams' request sets and fits three workgroups per CU at 143 VGPRs instead of two at 205: 512^3 fp32 0.95 -> 0.82 ms per CG
-	// iteration, profiles/r05/cg_fuse_half_tiles.txt); the partial sums of p.Ap follow the tiles, so all loop forms share them
+	// rows per lane: what ConjugateGradient's plain launches use for this matrix (cgHalfTiles: fp32 4 instead of 8, fp64 2 instead of 4 --
+	// the fused launch holds two streams' request sets and fits three workgroups per CU at 143-154 VGPRs instead of two at 195-205: 512^3
+	// fp32 0.95 -> 0.83 ms per CG iteration, fp64 1.71 -> 1.67, profiles/r05/cg_fuse_half_tiles.txt); the partial sums of p.Ap follow the
+	// tiles, so all loop forms share them
 	constexpr int RF = sizeof(T) == 8 ? 4 : 8;
 	const bool half = cgHalfTiles(m, sizeof(T));
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
 	const bool kn5 = nNear == 5 && m->d_pat_masks8;
 #define SMM_FUSE_GO(RV, KNV, HPV) launchMarchKN<T, RV, KNV, true, HPV, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
 	bool launched;
-	if constexpr (sizeof(T) == 4) {
-		if (half) {
-			launched = kn5 ? (hp2 ? SMM_FUSE_GO(4, 5, 2) : SMM_FUSE_GO(4, 5, 4)) : (hp2 ? SMM_FUSE_GO(4, 0, 2) : SMM_FUSE_GO(4, 0, 4));
-			return launched;
-		}
+	if (half) {
+		constexpr int RH = RF / 2;
+		launched = kn5 ? (hp2 ? SMM_FUSE_GO(RH, 5, 2) : SMM_FUSE_GO(RH, 5, 4)) : (hp2 ? SMM_FUSE_GO(RH, 0, 2) : SMM_FUSE_GO(RH, 0, 4));
+		return launched;
 	}
 	launched = kn5 ? (hp2 ? SMM_FUSE_GO(RF, 5, 2) : SMM_FUSE_GO(RF, 5, 4)) : (hp2 ? SMM_FUSE_GO(RF, 0, 2) : SMM_FUSE_GO(RF, 0, 4));
 #undef SMM_FUSE_GO
