@@ -164,7 +164,7 @@ int smm_hip_csr_pattern_info(const smm_hip_csr* m, int* encoding, int* offsets);
  * out.  Benchmarks price a kernel's launch time with THIS number, never with another layout's.  Diagnostics, like tile_info. */
 int smm_hip_csr_kernel_desc(const smm_hip_csr* m, char* name, int name_cap, long long* bytes_per_launch);
 /* From how many rows grid-shaped matrices are served by the 2.5-D kernels (csrc/smm_spmv_march.hip): constant diagonals (default
- * 2^21) and values read (default 12 x 2^20 fp64 / 2^26 fp32) -- below, the gather / wave kernels are as fast or faster
+ * 2^21) and values read (default 6 x 2^20 fp64 / 2^24 fp32) -- below, the gather / wave kernels are as fast or faster
  * (profiles/r04/march_threshold.txt).
  * -1 restores a default.  Applies to matrices analysed afterwards.  Tuning knob; the tests use it to run the kernels on small grids. */
 int smm_hip_set_march_min_rows(long long const_diagonals_rows, long long values_read_rows);

@@ -740,21 +740,22 @@ __global__ __launch_bounds__(TPB, SMM_MARCH_MIN_WAVES(T, R)) void spmvPatternCon
 // values[] keeps the wave kernel's route: the 64 consecutive rows of a wavefront own ONE contiguous run of values[], fetched with
 // coalesced loads a whole plane ahead (one register set per sub-step, re-issued as soon as its values sit in LDS), passed through a
 // wave-private LDS slice and read back by the row's
-// lane.  A tile is 1024 rows = 4 sub-steps of 256 (one row per lane and sub-step: 8-byte LDS reads at lane stride -- conflict-free).
+// lane.  A tile is 4 (fp64) or 2 (fp32) sub-steps of 256 rows (one row per lane and sub-step: LDS reads at lane stride -- conflict-free).
 // Row starts come from ONE start[] per 64 rows plus a prefix sum of the masks' popcounts across the wavefront: no start[] stream.
 // Bytes per fp64 row of the 7-point stencil: 56 (values) + 1 (mask; 4 until r05) + 8 (x) + 8 (out) = 73 against 84 in the wave kernel
 // (and the 104 that kernel really moves).  Same products in the same order: -P, the near offsets ascending, +P; value n of a row pairs with its
 // n-th set bit (ref:1484-1489): the reference's bits with one lane per row.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int MM_Q = 4;            // sub-steps per tile and plane
-constexpr int MM_B = MM_Q * TPB;   // rows of a tile
-
-template <typename T, int HP>
+// Q: sub-steps per tile and plane (a tile is Q x 256 rows).  4: tiles of 1024 rows, 229 VGPRs in fp64, two workgroups per CU; 2: 151 VGPRs
+// (fp32 117), three (four) per CU and twice the tiles per plane.  fp32 always takes 2 (512^3: 1.238 -> 1.120 ms, 384^3 0.548 -> 0.497); fp64
+// takes 2 below 10^8 rows (256^3 0.248 -> 0.234 ms, 320^3 0.538 -> 0.479, 384^3 0.862 -> 0.834, 448^3 1.373 -> 1.357) and 4 from there
+// (512^3: 1.872 against 2.023) (profiles/r05/masks_march_substeps.txt)
+template <typename T, int HP, int Q>
 struct MasksMarchSet {
-	T c[MM_Q];
+	T c[Q];
 	PackU<T> h[HP];
-	unsigned m[MM_Q];
-	int s0[MM_Q];  // start[] of the first row of the lane's wavefront in sub-step q
+	unsigned m[Q];
+	int s0[Q];  // start[] of the first row of the lane's wavefront in sub-step q
 };
 
 template <typename T, int KMAX>
@@ -763,16 +764,16 @@ struct MasksMarchVals {
 	int at;  // the lane's row begins here in the wavefront's run
 };
 
-template <typename T, int KMAX, bool NT, int HP>
+template <typename T, int KMAX, bool NT, int HP, int Q>
 __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 2)) void spmvPatternMasksMarchKernel(int rows, int cols, int P, int nPlanes, int nT, int zc, int nChunks, int xcdTiles, int H,
                                                                       int nOff, int hasLo, int hasHi, const int* __restrict__ offs, const int* __restrict__ start,
                                                                       const T* __restrict__ values, const unsigned char* __restrict__ masks8, int opFlags,
                                                                       const T* lhs, const T* __restrict__ divisor, const T* __restrict__ x, T* out, int dotMode,
                                                                       const T* __restrict__ w1, T* __restrict__ partials, const int* __restrict__ doneFlag) {
-	using Set = MasksMarchSet<T, HP>;
+	using Set = MasksMarchSet<T, HP, Q>;
 	using Vals = MasksMarchVals<T, KMAX>;
 	constexpr int VEC = 16 / sizeof(T);
-	const int winLen = MM_B + 2 * H;
+	const int winLen = (Q * TPB) + 2 * H;
 	T* sWin0 = reinterpret_cast<T*>(smmMarchLds);
 	T* sWin1 = sWin0 + winLen;
 	__shared__ T sVal[TPB / WAVE][WAVE * KMAX + KMAX];
@@ -809,14 +810,14 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 
 		const int tile = tLo + (u - chunk * tCount);
 		const int z0 = chunk * zc;
 		const int z1 = min(nPlanes, z0 + zc);
-		const int r0 = tile * MM_B;
-		const int bAct = min(MM_B, P - r0);
+		const int r0 = tile * (Q * TPB);
+		const int bAct = min((Q * TPB), P - r0);
 		auto haloWin = [&](int i) { return i < H / VEC ? i * VEC : H + bAct + (i - H / VEC) * VEC; };
 		auto issue = [&](Set& f, int z, bool wantCentre, bool wantWindow) {
 			const bool inside = z >= 0 && z < nPlanes;
 			const long long base = static_cast<long long>(z) * P + r0;
 #pragma unroll
-			for (int q = 0; q < MM_Q; ++q) {
+			for (int q = 0; q < Q; ++q) {
 				const int l = q * TPB + t;
 				const bool live = inside && l < bAct && base + l < rows;
 				f.c[q] = live && wantCentre ? x[base + l] : T(0);  // (cacheable: a neighbouring tile reads these lines as its halo)
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 
 		};
 		auto storeWindow = [&](T* win, const Set& f) {
 #pragma unroll
-			for (int q = 0; q < MM_Q; ++q) {
+			for (int q = 0; q < Q; ++q) {
 				if (q * TPB + t < bAct) win[H + q * TPB + t] = f.c[q];
 			}
 #pragma unroll
@@ -867,11 +868,11 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 
 			}
 		};
 
-		T xp[MM_Q];
-		unsigned mk[MM_Q];
-		int s0c[MM_Q];
+		T xp[Q];
+		unsigned mk[Q];
+		int s0c[Q];
 		Set fa, fb;
-		Vals vals[MM_Q];  // one request set per sub-step: re-issued for the NEXT plane as soon as its values sit in LDS (a whole plane ahead)
+		Vals vals[Q];  // one request set per sub-step: re-issued for the NEXT plane as soon as its values sit in LDS (a whole plane ahead)
 
 		auto subStep = [&](int z, int q, Vals& V, const Set& use, const T* win, bool more) {
 #pragma unroll
@@ -908,13 +909,13 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 
 			const bool more = z + 1 < z1;
 			if (more) issue(re, z + 2, z + 2 < z1 || hasHi, z + 2 < z1);
 #pragma unroll
-			for (int q = 0; q < MM_Q; ++q) subStep(z, q, vals[q], use, win, more);
+			for (int q = 0; q < Q; ++q) subStep(z, q, vals[q], use, win, more);
 			if (more) {
 #pragma unroll
-				for (int q = 0; q < MM_Q; ++q) xp[q] = win[H + q * TPB + t];
+				for (int q = 0; q < Q; ++q) xp[q] = win[H + q * TPB + t];
 				storeWindow(winNext, use);
 #pragma unroll
-				for (int q = 0; q < MM_Q; ++q) {
+				for (int q = 0; q < Q; ++q) {
 					mk[q] = use.m[q];
 					s0c[q] = use.s0[q];
 				}
@@ -924,19 +925,19 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 && KMAX <= 8 && HP <= 2 ? 3 : 
 
 		issue(fa, z0 - 1, hasLo != 0, false);
 #pragma unroll
-		for (int q = 0; q < MM_Q; ++q) xp[q] = fa.c[q];
+		for (int q = 0; q < Q; ++q) xp[q] = fa.c[q];
 		issue(fa, z0, true, true);
 		issue(fb, z0 + 1, z0 + 1 < z1 || hasHi, z0 + 1 < z1);
 		__syncthreads();  // (the previous unit's last window reads are over)
 		storeWindow(sWin0, fa);
 #pragma unroll
-		for (int q = 0; q < MM_Q; ++q) {
+		for (int q = 0; q < Q; ++q) {
 			mk[q] = fa.m[q];
 			s0c[q] = fa.s0[q];
 		}
 		__syncthreads();
 #pragma unroll
-		for (int q = 0; q < MM_Q; ++q) fetchVals(vals[q], mk[q], s0c[q]);
+		for (int q = 0; q < Q; ++q) fetchVals(vals[q], mk[q], s0c[q]);
 		for (int z = z0; z < z1; z += 2) {
 			step(z, fb, fa);
 			if (z + 1 < z1) step(z + 1, fa, fb);
@@ -976,9 +977,12 @@ void preloadMarchUnit() {
 //   fp64 constant: 96^3 8.0 / 8.0, 108^3 10.4 / 9.5, 128^3 16.2 / 12.4, 160^3 28.9 / 24.4, 256^3 143 / 70      -> from 2^21 rows (at 108^3 the
 //                  9 % of the bare SpMV do not survive inside BiCGStab: 24.4 against 23.4 ms for config 5's stand-in, Jacobi fold 26.2 / 24.1)
 //   fp32 constant: 108^3 8.5 / 9.0, 128^3 13.0 / 9.5, 144^3 17.1 / 17.6, 160^3 22.0 / 20.4, 256^3 86 / 55      -> from 2^21 rows
-//   fp64 values:   160^3 63.5 / 65.2, 200^3 122 / 124, 256^3 299 / 234, 512^3 2470 / 1840                       -> from 12 x 2^20 rows
-//   fp32 values:   200^3 72 / 109, 256^3 156 / 171, 512^3 1417 / 1261                                          -> from 2^26 rows
-// (below, a unit's few planes do not fill the chip's workgroup slots, and the masks march holds four value sets per lane).
+//   fp64 values:   160^3 63.5 / 65.2, 200^3 122 / 124, 256^3 299 / 234, 512^3 2470 / 1840                       -> r04: from 12 x 2^20 rows
+//   fp32 values:   200^3 72 / 109, 256^3 156 / 171, 512^3 1417 / 1261                                          -> r04: from 2^26 rows
+//   r05, two sub-steps per tile (profiles/r05/masks_march_thresholds.txt):
+//   fp64 values:   160^3 67.1 / 67.3, 200^3 131 / 112, 232^3 200 / 171                                          -> from 6 x 2^20 rows
+//   fp32 values:   200^3 68.5 / 71.7, 256^3 162 / 143, 320^3 342 / 282, 384^3 581 / 490                           -> from 2^24 rows
+// (below, a unit's few planes do not fill the chip's workgroup slots).
 // SMM_HIP_MARCH_MIN_ROWS (environment, all four) and smm_hip_set_march_min_rows (tests run the kernels on smaller grids) override them.
 static std::atomic<long long> g_marchMinRowsConst{-1}, g_marchMinRowsMasks{-1};
 
@@ -991,7 +995,7 @@ static long long marchMinRows(bool masksKernel, int dtype) {
 	}();
 	if (env >= 0) return env;
 	const bool f32 = dtype == SMM_DTYPE_F32;
-	if (masksKernel) return f32 ? 1LL << 26 : 12LL << 20;
+	if (masksKernel) return f32 ? 1LL << 24 : 6LL << 20;  // (r05, two sub-steps per tile: profiles/r05/masks_march_thresholds.txt; r04: 2^26 / 12 x 2^20)
 	return 1LL << 21;
 }
 
@@ -1341,17 +1345,17 @@ bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* parti
 template bool launchConstMarchFusedP<float>(const smm_hip_csr*, const float*, float*, float*, const int*, const CgFuseArgs<float>&, hipStream_t);
 template bool launchConstMarchFusedP<double>(const smm_hip_csr*, const double*, double*, double*, const int*, const CgFuseArgs<double>&, hipStream_t);
 
-template <typename T, int KMAX, bool NT, int HP>
+template <typename T, int KMAX, bool NT, int HP, int Q>
 static bool launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                               const int* doneFlag, hipStream_t s) {
 	const int P = m->march_P, H = m->march_H;
 	const int nPlanes = (m->rows + P - 1) / P;
-	const int nT = (P + MM_B - 1) / MM_B;
-	const size_t lds = 2 * static_cast<size_t>(MM_B + 2 * H) * sizeof(T);
+	const int nT = (P + (Q * TPB) - 1) / (Q * TPB);
+	const size_t lds = 2 * static_cast<size_t>((Q * TPB) + 2 * H) * sizeof(T);
 	static MarchLaunchState state;
 	int perCU = 0;
 	// (the kernel holds 8-17 KB of static LDS beside the windows: together they may pass the 64 KB default)
-	if (!marchPrepare(state, spmvPatternMasksMarchKernel<T, KMAX, NT, HP>, lds, (TPB / WAVE) * (WAVE * KMAX + KMAX) * sizeof(T) + 64 /* sVal[], red[] */, &perCU)) return false;
+	if (!marchPrepare(state, spmvPatternMasksMarchKernel<T, KMAX, NT, HP, Q>, lds, (TPB / WAVE) * (WAVE * KMAX + KMAX) * sizeof(T) + 64 /* sVal[], red[] */, &perCU)) return false;
 	const int cus = (op & SPMV_LEAVE_ROOM) ? std::max(8, numCUs() - 8) : numCUs();
 	op &= ~SPMV_LEAVE_ROOM;
 	const int resident = cus * perCU;
@@ -1366,7 +1370,7 @@ static bool launchMasksMarchK(const smm_hip_csr* m, int op, const T* lhs, const 
 	int grid = static_cast<int>(std::max<long long>(1, std::min<long long>(std::min<long long>(units, resident), NPART)));
 	const int xcdTiles = (nT % 8 == 0 || nT >= 64) && grid >= 8 ? 1 : 0;
 	if (xcdTiles) grid -= grid % 8;
-	spmvPatternMasksMarchKernel<T, KMAX, NT, HP><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
+	spmvPatternMasksMarchKernel<T, KMAX, NT, HP, Q><<<grid, TPB, lds, s>>>(m->rows, m->cols, P, nPlanes, nT, zc, nChunks, xcdTiles, H, m->pat_k, m->march_lo, m->march_hi,
 	                                                                  m->d_pat_off, m->d_start, static_cast<const T*>(m->d_values), m->d_pat_masks8, op, lhs, divisor, x,
 	                                                                  out, dotMode, w1, partials, doneFlag);
 	return true;
@@ -1394,12 +1398,17 @@ bool launchPatMasksMarch(const smm_hip_csr* m, int op, const T* lhs, const T* di
 	if (!enabled || !masksMarchApplies(m)) return false;
 	const bool nt = (spmvOutFlags(m, sizeof(T)) & SPMV_NT_OUT) != 0;
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
-#define SMM_MM_GO(KV)                                                                                                       \
-	(nt && hp2 ? launchMasksMarchK<T, KV, true, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)          \
-	 : nt      ? launchMasksMarchK<T, KV, true, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)          \
-	 : hp2     ? launchMasksMarchK<T, KV, false, 2>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)         \
-	           : launchMasksMarchK<T, KV, false, 4>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s))
-	const bool launched = SMM_MM_GO(8);
+#define SMM_MM_GO(KV, QV)                                                                                                   \
+	(nt && hp2 ? launchMasksMarchK<T, KV, true, 2, QV>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)      \
+	 : nt      ? launchMasksMarchK<T, KV, true, 4, QV>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)      \
+	 : hp2     ? launchMasksMarchK<T, KV, false, 2, QV>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s)     \
+	           : launchMasksMarchK<T, KV, false, 4, QV>(m, op, lhs, divisor, x, out, dotMode, w1, partials, doneFlag, s))
+	static const int forcedQ = [] {
+		const char* env = getenv("SMM_HIP_MASKS_MARCH_Q");  // 2 / 4: force the sub-steps per tile (A/B measurements)
+		return env ? atoi(env) : 0;
+	}();
+	const bool q2 = forcedQ == 2 || (forcedQ != 4 && (sizeof(T) == 4 || m->rows < 100000000LL));
+	const bool launched = q2 ? SMM_MM_GO(8, 2) : SMM_MM_GO(8, 4);
 #undef SMM_MM_GO
 	return launched;  // false: the wave kernel serves the matrix
 }

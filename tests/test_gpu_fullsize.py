@@ -122,7 +122,7 @@ def test_config4_laplacian_512_cg(smm):
 
 
 def test_config4_laplacian_512_fp32_masks_march(smm):
-    """spmvPatternMasksMarchKernel<float>: in production it serves grids from 2^26 rows only, and the parity tests reach it by lowering the
+    """spmvPatternMasksMarchKernel<float>: in production it serves grids from 2^24 rows only, and the parity tests reach it by lowering the
     threshold -- here the 512^3 stencil in fp32 at FULL size under the production thresholds, against the CSR stream at one lane per row
     (which the small-size tests pin to the reference bit for bit).  VERDICT r04 item 5c."""
     import torch

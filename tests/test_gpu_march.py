@@ -1,5 +1,5 @@
 """The 2.5-D form of the constant-diagonal SpMV (spmvPatternConstMarchKernel, csrc/smm_spmv_march.hip): grid-shaped matrices of at
-least 2^21 (values read: 12 x 2^20) rows march along the far direction with the plane's window of x in LDS.  Same products in the same order as the reference's
+least 2^21 (values read: 6 x 2^20) rows march along the far direction with the plane's window of x in LDS.  Same products in the same order as the reference's
 row loop (ref:1484-1499): every comparison below is bit for bit against the oracle."""
 import numpy as np
 import pytest
@@ -13,7 +13,7 @@ PATTERN, CONST = 3, 3
 
 @pytest.fixture(autouse=True)
 def _march_from_two_million_rows(smm):
-    """production serves grids from 2^21 rows (constant diagonals) and 12 x 2^20 / 2^26 rows (values read, fp64 / fp32) with these
+    """production serves grids from 2^21 rows (constant diagonals) and 6 x 2^20 / 2^24 rows (values read, fp64 / fp32) with these
     kernels -- where they start to win (profiles/r04/march_threshold.txt); the parity tests run all of them on grids of 2.1 M rows to keep the
     oracle's side cheap"""
     smm.host.set_march_min_rows(1 << 21, 1 << 21)
