@@ -295,3 +295,8 @@ def test_march_kernels_fuzz_below_the_production_threshold():
     assert "march fuzz: ALL OK" in r.stdout
     assert r.stdout.count("spmvPatternConstMarchKernel ok") >= 10 and r.stdout.count("spmvPatternMasksMarchKernel ok") >= 3, r.stdout[-3000:]
     assert r.stdout.count("spmvPatternConstMarch3Kernel ok") >= 4, r.stdout[-3000:]
+    # the masks march takes two sub-steps per tile at these sizes (fp64: below 1e8 rows); the four-sub-step form of the big fp64 grids, forced
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "march_fuzz.py"), "32"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SMM_HIP_MASKS_MARCH_Q="4"))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "march fuzz: ALL OK" in r.stdout and r.stdout.count("spmvPatternMasksMarchKernel ok") >= 2, r.stdout[-3000:]
