@@ -91,7 +91,10 @@ __device__ __forceinline__ bool p2pWaitGe(const unsigned long long* word, unsign
 		if ((spins & 63u) == 63u) {
 			if (p2pLoad(&hdr->err) != 0) return false;
 			if (wall_clock64() - t0 > ticks) {
-				p2pStore(&hdr->err, (static_cast<unsigned long long>(what) << 32) | (seq & 0xFFFFFFFFull));
+				// first writer wins: the word names the wait that expired FIRST -- the later ones are its consequences
+				unsigned long long none = 0ull;
+				(void)__hip_atomic_compare_exchange_strong(&hdr->err, &none, (static_cast<unsigned long long>(what) << 32) | (seq & 0xFFFFFFFFull), __ATOMIC_RELAXED,
+				                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				return false;
 			}
 		}

@@ -103,10 +103,14 @@ int numCUs() { return g_cus > 0 ? g_cus : 256; }
 // is kept in EPOCHS: when an allocation wants a quarantined size, the blocks freed so far are closed into an epoch and one event is
 // recorded on EVERY stream the library has ever been given work on (noteStream; a handful -- and never only the "recent" ones: a
 // `_dev` call notes its stream when it starts and frees its temporaries when it returns, with its kernels still queued); an epoch's
-// blocks become reusable once all its events have completed -- work enqueued BEFORE the free on any of those streams is then done.  Nothing
-// drains the device: other threads' streams and the communicator's side stream keep running (r02 called hipDeviceSynchronize here,
-// once per solve).  Only when the wanted size sits in an epoch that has not completed yet does the allocation wait -- for that epoch's
-// events alone; in the steady state of solve-after-solve a solve ends with a stream synchronise, so they have.
+// blocks become reusable once all its events have completed -- work enqueued BEFORE the free on any of those streams is then done.
+// r06: NO HOST THREAD EVER WAITS for an epoch.  An allocation whose size sits in an epoch that has not completed takes fresh memory
+// (hipMalloc) instead.  r03-r05 polled the epoch's events here, and those events sit on every noted stream of the PROCESS: with ranks
+// that are threads of one process and the peer-to-peer transport (smm_p2p.h), a rank entering a solve waited in devAlloc for an event
+// recorded behind a PEER's land kernel, which itself waited (on the device) for the push kernel this rank was about to enqueue -- a
+// cycle only the transport's bounded waits broke (the time-outs of gpurun_out/r05/p2p_thread.txt: the Jacobi solve's scratch vector,
+// allocated between the stand-alone SpMV and the solver's first exchange).  In the steady state of solve after
+// solve a solve ends with a synchronise of its stream, the epochs are complete when the next allocation looks, and nothing changes.
 static std::mutex g_allocMutex;
 static std::multimap<size_t, void*> g_free;  // safe to hand out
 static std::map<void*, size_t> g_live;
@@ -114,19 +118,20 @@ struct QuarantineEpoch {
 	unsigned long long id = 0;
 	std::multimap<size_t, void*> blocks;
 	std::vector<hipEvent_t> events;
-	bool drainInstead = false;  // an event could not be recorded (a stream destroyed meanwhile): fall back to a device drain
+	bool needIdle = false;  // an event could not be recorded (a stream its owner destroyed meanwhile): complete only once every noted stream is idle
 };
 static std::multimap<size_t, void*> g_open;       // freed since the last close
 static std::vector<QuarantineEpoch> g_epochs;     // closed, oldest first
 static std::vector<hipStream_t> g_recentStreams;  // every stream the library has been given work on (small: linear search)
-static std::vector<hipEvent_t> g_eventPool;
+static std::vector<hipEvent_t> g_eventPool;       // (under g_allocMutex)
 static std::mutex g_streamMutex;
 
 // The list is bounded: the most recently used MAX_NOTED_STREAMS caller streams, most recent last.  A stream that falls
-// off the end may still have work queued that reads a block freed later, and no event will be recorded on it any more: the next epoch
-// that is closed drains the device once instead (g_evictedSinceClose) -- rare (a process that cycles through more than 32 streams), safe.
+// off the end may still have work queued that reads a block freed later, and no epoch will record on it any more: an event is
+// recorded on it AS IT LEAVES the list and joins the next epoch that is closed (r03-r05 drained the device there instead).
 constexpr size_t MAX_NOTED_STREAMS = 32;
-static bool g_evictedSinceClose = false;
+static std::vector<hipEvent_t> g_strayEvents;  // of evicted streams, waiting for the next epoch (under g_streamMutex)
+static bool g_strayUnrecorded = false;         // an evicted stream could not be given an event: the next epoch needs every stream idle
 
 void noteStream(hipStream_t s) {
 	std::lock_guard<std::mutex> lock(g_streamMutex);
@@ -140,8 +145,22 @@ void noteStream(hipStream_t s) {
 		}
 	}
 	if (g_recentStreams.size() >= MAX_NOTED_STREAMS) {
+		hipStream_t old = g_recentStreams.front();
 		g_recentStreams.erase(g_recentStreams.begin());
-		g_evictedSinceClose = true;
+		hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+		const bool inCapture = hipStreamIsCapturing(old, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone;
+		(void)hipGetLastError();
+		if (!inCapture && hipStreamQuery(old) != hipSuccess) {
+			(void)hipGetLastError();
+			hipEvent_t ev = nullptr;
+			if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, old) == hipSuccess) {
+				g_strayEvents.push_back(ev);
+			} else {
+				(void)hipGetLastError();
+				if (ev) (void)hipEventDestroy(ev);
+				g_strayUnrecorded = true;
+			}
+		}
 	}
 	g_recentStreams.push_back(s);
 }
@@ -167,8 +186,9 @@ static void closeEpochLocked() {
 	{
 		std::lock_guard<std::mutex> lock(g_streamMutex);
 		streams = g_recentStreams;
-		if (g_evictedSinceClose) ep.drainInstead = true;
-		g_evictedSinceClose = false;
+		ep.events.swap(g_strayEvents);
+		ep.needIdle = g_strayUnrecorded;
+		g_strayUnrecorded = false;
 	}
 	bool haveLib = false;
 	for (hipStream_t k : streams) haveLib = haveLib || k == g_stream;
@@ -190,13 +210,14 @@ static void closeEpochLocked() {
 			ev = g_eventPool.back();
 			g_eventPool.pop_back();
 		} else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-			ep.drainInstead = true;
+			(void)hipGetLastError();
+			ep.needIdle = true;
 			continue;
 		}
-		if (hipEventRecord(ev, k) != hipSuccess) {  // a stream its owner has destroyed meanwhile: drain once, then forget it
+		if (hipEventRecord(ev, k) != hipSuccess) {  // a stream its owner has destroyed meanwhile: forget it
 			(void)hipGetLastError();
 			g_eventPool.push_back(ev);
-			ep.drainInstead = true;
+			ep.needIdle = true;
 			forgetStream(k);
 			continue;
 		}
@@ -205,52 +226,42 @@ static void closeEpochLocked() {
 	g_epochs.push_back(std::move(ep));
 }
 
-// moves the blocks of every completed epoch (oldest first, in order) to the free list; with `waitFor` != 0 it first waits for the
-// oldest epoch that holds a block of that size
-static void reapEpochsLocked(std::unique_lock<std::mutex>& lock, size_t waitFor) {
-	while (!g_epochs.empty()) {
-		QuarantineEpoch& ep = g_epochs.front();
-		bool done = !ep.drainInstead;
+static bool everyNotedStreamIdle() {
+	std::vector<hipStream_t> streams;
+	{
+		std::lock_guard<std::mutex> lock(g_streamMutex);
+		streams = g_recentStreams;
+	}
+	if (g_stream) streams.push_back(g_stream);
+	for (hipStream_t k : streams) {
+		if (hipStreamQuery(k) != hipSuccess) {
+			(void)hipGetLastError();
+			return false;
+		}
+	}
+	return true;
+}
+
+// moves the blocks of every COMPLETED epoch to the free list.  Never waits (see the note at the top): events are queried, not
+// synchronised; every epoch is looked at on its own (its events alone say that its blocks are safe), so one that stays open -- a
+// peer rank's kernel that spins until this very thread has enqueued more work -- holds back nothing but its own blocks.
+static void reapEpochsLocked() {
+	for (size_t i = 0; i < g_epochs.size();) {
+		QuarantineEpoch& ep = g_epochs[i];
+		bool done = true;
 		for (hipEvent_t ev : ep.events) {
 			if (!done) break;
 			done = hipEventQuery(ev) != hipErrorNotReady;  // (an error state does not come back: treat the event as over)
 		}
+		(void)hipGetLastError();
+		if (done && ep.needIdle) done = everyNotedStreamIdle();
 		if (!done) {
-			bool wanted = false;
-			if (waitFor) {
-				for (const auto& e : g_epochs) wanted = wanted || e.blocks.count(waitFor) != 0;
-			}
-			if (!wanted) return;
-			// Wait for the front epoch only, by POLLING its events under the lock with the lock released in between: another thread may
-			// reap this epoch meanwhile and hand its events back to the pool, where the next close records them again -- an event a
-			// thread is blocked on in hipEventSynchronize must not be re-recorded under it, so nobody blocks on one.
-			const unsigned long long id = ep.id;
-			if (ep.drainInstead) {
-				lock.unlock();
-				(void)hipDeviceSynchronize();
-				lock.lock();
-				if (g_epochs.empty() || g_epochs.front().id != id) continue;
-				g_epochs.front().drainInstead = false;
-			}
-			for (unsigned polls = 0;; ++polls) {
-				if (g_epochs.empty() || g_epochs.front().id != id) break;  // another thread reaped it meanwhile
-				bool all = true;
-				for (hipEvent_t ev : g_epochs.front().events) all = all && hipEventQuery(ev) != hipErrorNotReady;
-				if (all) break;
-				lock.unlock();
-				// (the first polls spin -- an epoch usually completes within microseconds --, then the thread sleeps between polls: another
-				// thread's whole solve may be what the events wait for, and a core must not burn for that long)
-				if (polls < 64) std::this_thread::yield();
-				else std::this_thread::sleep_for(std::chrono::microseconds(polls < 1024 ? 20 : 200));
-				lock.lock();
-			}
-			if (g_epochs.empty() || g_epochs.front().id != id) continue;
+			++i;
+			continue;
 		}
-		QuarantineEpoch finished = std::move(g_epochs.front());
-		g_epochs.erase(g_epochs.begin());
-		g_free.insert(finished.blocks.begin(), finished.blocks.end());
-		g_eventPool.insert(g_eventPool.end(), finished.events.begin(), finished.events.end());
-		if (waitFor && g_free.count(waitFor)) return;
+		g_free.insert(ep.blocks.begin(), ep.blocks.end());
+		g_eventPool.insert(g_eventPool.end(), ep.events.begin(), ep.events.end());
+		g_epochs.erase(g_epochs.begin() + static_cast<long>(i));
 	}
 }
 
@@ -278,10 +289,10 @@ int devAlloc(void** p, size_t bytes) {
 		std::unique_lock<std::mutex> lock(g_allocMutex);
 		auto it = g_free.find(bytes);
 		if (it == g_free.end() && quarantineHoldsLocked(bytes)) {
-			SetupTrace trace("allocator: close the epoch + wait for a quarantined block");
+			SetupTrace trace("allocator: close the epoch, take what has completed");
 			closeEpochLocked();
-			reapEpochsLocked(lock, bytes);
-			it = g_free.find(bytes);
+			reapEpochsLocked();
+			it = g_free.find(bytes);  // (still quarantined behind running work: fresh memory below -- never a wait)
 		}
 		if (it != g_free.end()) {
 			*p = it->second;
@@ -340,13 +351,35 @@ struct CopyStage {
 	hipEvent_t ev[SLOTS] = {};
 	bool busy[SLOTS] = {};
 	int next = 0;
-	int init() {
-		if (buf[0]) return SMM_HIP_OK;
+	bool ready = false, refused = false;
+	// true: every slot has its pinned chunk and its event.  A failure releases what was set up and is remembered (the thread's copies then
+	// take the caller's pointers, as with SMM_HIP_STAGED_COPIES=0): ADVICE r05 -- `buf[0] != nullptr` used to stand for "all four slots".
+	bool init() {
+		if (ready || refused) return ready;
 		for (int i = 0; i < SLOTS; ++i) {
-			SMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&buf[i]), CHUNK, hipHostMallocDefault));
-			SMM_HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+			if (hipHostMalloc(reinterpret_cast<void**>(&buf[i]), CHUNK, hipHostMallocDefault) != hipSuccess) buf[i] = nullptr;
+			if (!buf[i] || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+				(void)hipGetLastError();
+				release();
+				refused = true;
+				return false;
+			}
 		}
-		return SMM_HIP_OK;
+		ready = true;
+		return true;
+	}
+	void release() {
+		for (int i = 0; i < SLOTS; ++i) {
+			if (ev[i]) {
+				if (busy[i]) (void)hipEventSynchronize(ev[i]);
+				(void)hipEventDestroy(ev[i]);
+			}
+			if (buf[i]) (void)hipHostFree(buf[i]);
+			ev[i] = nullptr;
+			buf[i] = nullptr;
+			busy[i] = false;
+		}
+		ready = false;
 	}
 	int wait(int i) {
 		if (busy[i]) SMM_HIP_TRY(hipEventSynchronize(ev[i]));
@@ -354,13 +387,8 @@ struct CopyStage {
 		return SMM_HIP_OK;
 	}
 	~CopyStage() {
-		for (int i = 0; i < SLOTS; ++i) {
-			if (ev[i]) {
-				(void)hipEventSynchronize(ev[i]);
-				(void)hipEventDestroy(ev[i]);
-			}
-			if (buf[i]) (void)hipHostFree(buf[i]);
-		}
+		release();
+		(void)hipGetLastError();  // (a thread that outlives the HIP runtime: nothing left to release)
 	}
 };
 }  // namespace
@@ -385,7 +413,10 @@ int hostToDev(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
 		return SMM_HIP_OK;
 	}
 	CopyStage& st = copyStage();
-	SMM_TRY(st.init());
+	if (!st.init()) {
+		SMM_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+		return SMM_HIP_OK;
+	}
 	for (size_t at = 0; at < bytes; at += CopyStage::CHUNK) {
 		const size_t len = std::min(CopyStage::CHUNK, bytes - at);
 		const int i = st.next;
@@ -406,7 +437,11 @@ int devToHost(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
 		return SMM_HIP_OK;
 	}
 	CopyStage& st = copyStage();
-	SMM_TRY(st.init());
+	if (!st.init()) {
+		SMM_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+		SMM_HIP_TRY(hipStreamSynchronize(s));
+		return SMM_HIP_OK;
+	}
 	const size_t nChunks = (bytes + CopyStage::CHUNK - 1) / CopyStage::CHUNK;
 	int slotOf[CopyStage::SLOTS];
 	size_t issued = 0, drained = 0;

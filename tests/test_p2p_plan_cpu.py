@@ -35,6 +35,11 @@ def test_every_halo_element_arrives_exactly_once(world):
         for q in range(world):
             needs[2 * q] = max(0, bounds[q] - lo_reach)
             needs[2 * q + 1] = min(rows, bounds[q + 1] + hi_reach)
+        if trial == 5 and world >= 3:
+            # a decoupled last block: the last rank needs nothing but its own rows and nobody needs them -- yet it relays
+            needs[2 * (world - 1)], needs[2 * (world - 1) + 1] = bounds[world - 1], bounds[world]
+            for q in range(world - 1):
+                needs[2 * q + 1] = min(needs[2 * q + 1], bounds[world - 1])
         for relays in sorted({0, 1, max(0, world - 4), max(0, world - 2)}):
             relays = min(relays, max(0, world - 2))
             share = 4.0 / (relays + 4) if relays else 1.0
@@ -61,6 +66,11 @@ def test_every_halo_element_arrives_exactly_once(world):
                     land[dst][lpos:lpos + count] = stage[r][spos:spos + count]
                     writes_land[dst][lpos:lpos + count] += 1
             assert not staged  # every staged share was forwarded
+            if trial == 5 and world >= 3 and relays >= world - 2 and reach > 0:
+                last = plans[world - 1]
+                assert not len(last[last[:, 0] == 0]) and not len(last[last[:, 0] == 2])  # it sends and receives nothing ...
+                long_segments = any(rec[0] == 2 and rec[4] >= 64 * (relays + 1) for p2 in plans for rec in p2)
+                assert (len(last[last[:, 0] == 1]) > 0) == long_segments  # ... and relays every segment long enough to be split: a relay-only rank
             for r, p in enumerate(plans):  # stage 3: landing areas into the halos
                 cmin = needs[2 * r]
                 seen = 0
