@@ -468,6 +468,11 @@ int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks);
  *   halo_first   1: the rows of an updated vector that a peer receives are produced by a small launch of their own and the exchange is
  *                posted right behind it, before the bulk of the update runs (SMM_HIP_HALO_FIRST=0 turns it off); same bits either way. */
 int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, int* halo_first, double* direct_share);
+/* How many SpMVs with a halo this matrix has run so far as ONE launch (csrc/smm_spmv_split.hip: the local half of a workgroup's rows, a
+ * bounded wait for the word the exchange raises, the remote half; out[] written once) and how many as TWO (A_loc, then A_rem behind the
+ * exchange's event).  One launch is taken whenever both local blocks are in the row-mask encoding with values read at 1 / 2 / 4 lanes per
+ * row (what the solvers adopt from 2^20 entries); SMM_HIP_SPLIT_SPMV=0 keeps the two launches.  Same bits either way. */
+int smm_hip_dist_csr_matvec_forms(const smm_hip_dist_csr* D, long long* one_launch, long long* two_launches);
 /* The peer-to-peer plan of one rank as plain numbers: host arithmetic only (no device, no communicator), the same function the set-up uses.
  * needs[2 q], needs[2 q + 1] = the column range [cmin, cmax) rank q's rows touch; bounds[0 .. world] = the row partition.  Writes records of
  * 8 values into out (capacity in values; *out_count = records): push {0, dst, relay or -1, first global column, position at dst / relay,

@@ -361,7 +361,8 @@ __global__ void colRangeKernel(long long nnz, const int* __restrict__ positions,
 
 // counts[row] = entries of the row with an owned column; counts[nLocal + 1 + row] = the others.  Both arrays have nLocal + 1
 // slots so that an exclusive scan over nLocal + 1 elements ends with the total.
-__global__ void splitCountKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, int ownLo, int ownHi,
+// labWindow > 0 (measurements with ONE rank, smm_hip_dist_csr::labWindow): an owned column farther than that from the row counts as remote too
+__global__ void splitCountKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, int ownLo, int ownHi, int labWindow,
                                  int* __restrict__ cntLoc, int* __restrict__ cntRem) {
 	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row <= nLocal; row += gridDim.x * blockDim.x) {
 		int nl = 0, nr = 0;
@@ -369,7 +370,7 @@ __global__ void splitCountKernel(int nLocal, const int* __restrict__ start, cons
 			const int e = start[row + 1];
 			for (int k = start[row]; k < e; ++k) {
 				const int c = positions[k];
-				if (c >= ownLo && c < ownHi) ++nl;
+				if (c >= ownLo && c < ownHi && (labWindow <= 0 || abs(c - (ownLo + row)) < labWindow)) ++nl;
 				else ++nr;
 			}
 		}
@@ -380,7 +381,7 @@ __global__ void splitCountKernel(int nLocal, const int* __restrict__ start, cons
 
 template <typename T>
 __global__ void splitScatterKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ values, int ownLo,
-                                   int ownHi, int cmin, const int* __restrict__ startLoc, const int* __restrict__ startRem, int* __restrict__ posLoc,
+                                   int ownHi, int labWindow, int cmin, const int* __restrict__ startLoc, const int* __restrict__ startRem, int* __restrict__ posLoc,
                                    T* __restrict__ valLoc, int* __restrict__ posRem, T* __restrict__ valRem) {
 	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nLocal; row += gridDim.x * blockDim.x) {
 		int il = startLoc[row], ir = startRem[row];
@@ -388,7 +389,7 @@ __global__ void splitScatterKernel(int nLocal, const int* __restrict__ start, co
 		for (int k = start[row]; k < e; ++k) {  // order inside a row is preserved (columns stay ascending, ref:1247-1249)
 			const int c = positions[k];
 			const T v = values[k];
-			if (c >= ownLo && c < ownHi) {
+			if (c >= ownLo && c < ownHi && (labWindow <= 0 || abs(c - (ownLo + row)) < labWindow)) {
 				posLoc[il] = c - ownLo;
 				valLoc[il] = v;
 				++il;
@@ -550,11 +551,20 @@ struct smm_hip_dist_csr {
 		bool active = false;
 		int kind = 0;
 		unsigned long long seq = 0;
+		unsigned long long landSeq = 0;  // what splitSync[kind] will read once this exchange has landed (0: no word is raised for it)
 		hipEvent_t landed[smm::MAX_HALO_CHUNKS] = {};
 		int waitSlot[smm::MAX_HALO_CHUNKS] = {-1, -1, -1, -1};
 		bool async = false;
 	} pending;
 	smm::P2PState* p2p = nullptr;  // peer-to-peer data movement (smm_p2p.h); null: collectives of the communicator
+	// the SpMV in ONE launch (smm_spmv_split.hip): splitSync[kind] is raised -- on the stream the exchange ran on, behind it -- to the sequence
+	// number of the exchange whose halo has landed in the vector of that kind; splitSync[P2P_KINDS] is the error word of an expired wait
+	// (with the peer-to-peer transport the block's own error word is used instead: one word for the host to read)
+	unsigned long long* splitSync = nullptr;
+	unsigned long long landSeq[smm::P2P_KINDS] = {};
+	long long matvecsSplit = 0, matvecsTwo = 0;  // how many SpMVs with a halo ran in one launch / in two (smm_hip_dist_csr_matvec_forms)
+	bool splitAllowed = true;  // SMM_HIP_SPLIT_SPMV=0 at create time: this matrix keeps the two launches (A/B measurements, the bit-equality tests)
+	int labWindow = 0;  // measurements on ONE GPU (SMM_HIP_LAB_SELF_SPLIT, single-rank communicator only): entries |column - row| >= window count as "remote"
 };
 
 namespace smm {
@@ -575,7 +585,10 @@ static int distWorkspace(smm_hip_dist_csr* D) {
 	SMM_TRY(devAlloc(&D->partsB, PARTS_LEN * sizeof(T)));
 	SMM_TRY(devAlloc(&D->partsC, PARTS_LEN * sizeof(T)));
 	SMM_TRY(devAlloc(&D->sc, sizeof(DistScal<T>)));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&D->splitSync), (P2P_KINDS + 1) * sizeof(unsigned long long)));
+	preloadSplitUnit();  // (its code object is built for the device now, not inside the first iteration)
 	hipStream_t s = libStream();
+	SMM_HIP_TRY(hipMemsetAsync(D->splitSync, 0, (P2P_KINDS + 1) * sizeof(unsigned long long), s));
 	// halo slots outside every recv segment are never read by A_rem; zero keeps them finite.  Tickets start at 0.
 	SMM_HIP_TRY(hipMemsetAsync(D->pExt, 0, eb, s));
 	SMM_HIP_TRY(hipMemsetAsync(D->sExt, 0, eb, s));
@@ -1087,8 +1100,10 @@ static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int cou
 // the error word of the peer-to-peer path, read wherever the host reads `done` (stream `s` is synchronised by the caller afterwards)
 static int p2pPostErrRead(smm_hip_dist_csr* D, unsigned long long* err, hipStream_t s) {
 	*err = 0;
-	if (!D->p2p) return SMM_HIP_OK;
-	SMM_HIP_TRY(hipMemcpyAsync(err, &D->p2p->hdr()->err, sizeof(*err), hipMemcpyDeviceToHost, s));
+	// (without the peer-to-peer transport the one-launch SpMV's own word -- smm_hip_dist_csr::splitSync -- is the only bounded device-side wait)
+	const unsigned long long* word = D->p2p ? &D->p2p->hdr()->err : D->splitSync ? D->splitSync + P2P_KINDS : nullptr;
+	if (!word) return SMM_HIP_OK;
+	SMM_HIP_TRY(hipMemcpyAsync(err, word, sizeof(*err), hipMemcpyDeviceToHost, s));
 	return SMM_HIP_OK;
 }
 static int p2pFailIf(smm_hip_dist_csr* D, unsigned long long err) {
@@ -1096,9 +1111,10 @@ static int p2pFailIf(smm_hip_dist_csr* D, unsigned long long err) {
 	const unsigned what = static_cast<unsigned>(err >> 32);
 	static const char* const names[] = {"?", "a push for the destination's acknowledgement of the previous exchange (vector, destination rank)",
 	                                    "a forward for its staged share (vector, relay job)", "the land kernel for a part (vector, source rank, path)",
-	                                    "a reduction for a rank's slot (reduction point, rank)"};
-	setError("dist: rank %d waited longer than SMM_HIP_P2P_TIMEOUT_S for a peer (peer-to-peer path): %s = (%u, %u, %u), sequence number %llu; the communicator "
-	         "is unusable", D->comm->rank, names[std::min(4u, what >> 12)], (what >> 8) & 0xFu, (what >> 4) & 0xFu, what & 0xFu, err & 0xFFFFFFFFull);
+	                                    "a reduction for a rank's slot (reduction point, rank)", "the one-launch SpMV for the halo of its exchange"};
+	setError("dist: rank %d waited longer than SMM_HIP_P2P_TIMEOUT_S for a peer (%s): %s = (%u, %u, %u), sequence number %llu; the communicator "
+	         "is unusable", D->comm->rank, D->p2p ? "peer-to-peer path" : "collectives", names[std::min(5u, what >> 12)], (what >> 8) & 0xFu, (what >> 4) & 0xFu, what & 0xFu,
+	         err & 0xFFFFFFFFull);
 	fprintf(stderr, "libsmm_hip: %s\n", smm_hip_last_error());
 	D->comm->broken = true;
 	return SMM_HIP_ERR_COMM;
@@ -1193,7 +1209,15 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 	int* startLoc = cnt;
 	int* startRem = cnt + nLocal + 1;
 	const int grid = std::max(1, std::min(8192, (nLocal + 256) / 256));
-	splitCountKernel<<<grid, 256, 0, s>>>(nLocal, d_start, d_positions, D->rowBegin, D->rowEnd, startLoc, startRem);
+	{
+		const char* env = getenv("SMM_HIP_SPLIT_SPMV");  // (read at every create, like SMM_HIP_HALO_CHUNKS: a property of the matrix)
+		D->splitAllowed = env ? atoi(env) != 0 : true;
+	}
+	if (comm->kind == SMM_COMM_SELF) {
+		const char* env = getenv("SMM_HIP_LAB_SELF_SPLIT");  // (measurement hook: what a rank of a many-GPU run computes, on one GPU -- tools/lab/rank_loop_streams.py)
+		D->labWindow = env ? std::max(0, atoi(env)) : 0;
+	}
+	splitCountKernel<<<grid, 256, 0, s>>>(nLocal, d_start, d_positions, D->rowBegin, D->rowEnd, D->labWindow, startLoc, startRem);
 	SMM_HIP_TRY(hipGetLastError());
 	SMM_TRY(exclusiveScan(startLoc, nLocal + 1, s));
 	SMM_TRY(exclusiveScan(startRem, nLocal + 1, s));
@@ -1209,7 +1233,7 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 	SMM_TRY(devAlloc(&D->arrays[4], std::max<size_t>(1, totals[1]) * sizeof(int)));
 	SMM_TRY(devAlloc(&D->arrays[5], std::max<size_t>(1, totals[1]) * sizeof(T)));
 	if (nLocal > 0) {
-		splitScatterKernel<T><<<grid, 256, 0, s>>>(nLocal, d_start, d_positions, d_values, D->rowBegin, D->rowEnd, D->cmin, startLoc, startRem,
+		splitScatterKernel<T><<<grid, 256, 0, s>>>(nLocal, d_start, d_positions, d_values, D->rowBegin, D->rowEnd, D->labWindow, D->cmin, startLoc, startRem,
 		                                          static_cast<int*>(D->arrays[1]), static_cast<T*>(D->arrays[2]), static_cast<int*>(D->arrays[4]),
 		                                          static_cast<T*>(D->arrays[5]));
 		SMM_HIP_TRY(hipGetLastError());
@@ -1311,6 +1335,13 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 // distMatvecCompute: out = op(lhs, A ext) on the owned rows: the local block while the halo is in flight, then -- once it has landed --
 // the remote block(s), with the dot products of the freshly computed vector (dotMode / w1 / parts as in launchSpmv; parts a finishing
 // buffer) and the Jacobi division in the epilogue of the launch that completes a row.
+// the device word the one-launch SpMV polls, and where an expired wait of it is recorded
+static unsigned long long* splitErrWord(smm_hip_dist_csr* D) {
+	if (D->p2p) return &D->p2p->hdr()->err;
+	return D->splitSync ? D->splitSync + P2P_KINDS : nullptr;
+}
+static bool splitWordWanted(const smm_hip_dist_csr* D) { return D->splitAllowed && D->splitSync && !D->remEmpty && D->chunks == 1; }
+
 template <typename T>
 static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t s) {
 	smm_hip_comm* c = D->comm;
@@ -1326,6 +1357,24 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 		noteStream(cs);
 		return p2pHaloLaunch<T>(D, ext, kind, cs);
 	}
+	if (D->labWindow > 0 && !D->remEmpty) {
+		// one rank, "remote" entries by distance (measurements): nothing travels, but the word is raised from the communicator's stream behind
+		// the update -- the one-launch SpMV takes exactly the path it takes behind a real exchange
+		hipStream_t cs = c->stream;
+		noteStream(cs);
+		pend.active = true;
+		pend.kind = kind;
+		pend.async = true;
+		SMM_TRY(orderAfter(c, s, cs));
+		if (splitWordWanted(D)) {
+			pend.landSeq = ++D->landSeq[kind];
+			launchSplitSignal(D->splitSync + kind, pend.landSeq, cs);
+		}
+		pend.landed[0] = takeEvent(c);
+		SMM_HIP_TRY(hipEventRecord(pend.landed[0], cs));
+		pend.waitSlot[0] = profWaitAwaited(cs);
+		return SMM_HIP_OK;
+	}
 	if (!exchange) return SMM_HIP_OK;
 	pend.active = true;
 	pend.kind = kind;
@@ -1338,6 +1387,10 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 		// the land kernel (waits for every part of every segment, then landing area -> halo of `ext`) runs on the side stream as well, beside
 		// the local block: the solver's stream only waits for its event, as it waits for a collective exchange
 		SMM_TRY(p2pLandLaunch<T>(D, ext, kind, pend.seq, cs));
+		if (splitWordWanted(D)) {  // (behind the land kernel: its copies are complete -- and written back -- when this one-lane launch starts)
+			pend.landSeq = ++D->landSeq[kind];
+			launchSplitSignal(D->splitSync + kind, pend.landSeq, cs);
+		}
 		pend.landed[0] = takeEvent(c);
 		SMM_HIP_TRY(hipEventRecord(pend.landed[0], cs));
 		pend.waitSlot[0] = profWaitAwaited(cs);
@@ -1366,6 +1419,10 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 		return SMM_HIP_OK;
 	}
 	SMM_TRY(commExchange<T>(c, ext, D->sends, D->recvs, cs));
+	if (splitWordWanted(D)) {  // (behind the grouped receive / the staged copies, on the stream they ran on)
+		pend.landSeq = ++D->landSeq[kind];
+		launchSplitSignal(D->splitSync + kind, pend.landSeq, cs);
+	}
 	if (cs != s) {
 		pend.landed[0] = takeEvent(c);
 		SMM_HIP_TRY(hipEventRecord(pend.landed[0], cs));
@@ -1389,6 +1446,21 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 		if (jacobiDiag) return launchSpmv<T>(D->aLoc, op, jacobiDiag, own, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_DIV_LHS);
 		return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
 	}
+	// ONE launch for both halves where the blocks allow it (smm_spmv_split.hip; r06): the local half of the workgroup's rows, a bounded wait for the
+	// word this exchange raises, the remote half -- the arithmetic of the two launches below, bit for bit, without the second ramp and tail, the
+	// second pass over out[] and the kernel boundary behind the exchange
+	if (exchange && pend.landSeq != 0 && !D->remEmpty) {
+		SMM_TRY(ensureCsrReady(D->aLoc, s, true));
+		SMM_TRY(ensureCsrReady(D->aRem, s, true));
+		const int st = launchSpmvSplit<T>(D->aLoc, D->aRem, op, lhs, jacobiDiag, own, ext, out, dotMode, w1, parts, doneFlag, finish | (jacobiDiag ? SPMV_ADD_DIV : 0),
+		                                  D->splitSync + pend.kind, pend.landSeq, splitErrWord(D), p2pTicks(), s);
+		if (st == SMM_HIP_OK) {
+			++D->matvecsSplit;
+			return SMM_HIP_OK;  // (the kernel itself waited for the halo: `s` needs no event of the communicator's stream)
+		}
+		if (st < 0) return st;
+	}
+	if (exchange && !D->remEmpty) ++D->matvecsTwo;
 	// the local block runs while the halo is in flight; the exchange is itself a kernel (a few workgroups per peer), and the persistent
 	// SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
 	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, exchange && pend.async ? SPMV_LEAVE_ROOM : 0));
@@ -1832,6 +1904,10 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 	maxIterations = std::min(maxIterations, D->nGlobal);  // ref:2200
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2201-2203
 	// many SpMVs ahead: both local blocks may take the index-free family (each rank decides for its own blocks; no collective involved)
+	// (the blocks' own configuration first: a block nobody has multiplied with yet still carries the handle's initial word, and the adoption
+	// below only moves a block that is on the STREAM family -- r05: the FIRST solve of a distributed matrix ran on the CSR kernels)
+	if (D->aLoc) SMM_TRY(ensureCsrReady(D->aLoc, s, true));
+	if (D->aRem) SMM_TRY(ensureCsrReady(D->aRem, s, true));
 	if (D->aLoc) SMM_TRY(adoptPatternForSolver(D->aLoc, maxIterations, s));
 	if (D->aRem) SMM_TRY(adoptPatternForSolver(D->aRem, maxIterations, s));
 	for (smm_hip_csr* piece : D->aRemK) SMM_TRY(adoptPatternForSolver(piece, maxIterations, s));
@@ -1942,6 +2018,10 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		return SMM_HIP_ERR_INVALID;
 	}
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2345-2347 (no clamp otherwise)
+	// (the blocks' own configuration first: a block nobody has multiplied with yet still carries the handle's initial word, and the adoption
+	// below only moves a block that is on the STREAM family -- r05: the FIRST solve of a distributed matrix ran on the CSR kernels)
+	if (D->aLoc) SMM_TRY(ensureCsrReady(D->aLoc, s, true));
+	if (D->aRem) SMM_TRY(ensureCsrReady(D->aRem, s, true));
 	if (D->aLoc) SMM_TRY(adoptPatternForSolver(D->aLoc, maxIterations, s));
 	if (D->aRem) SMM_TRY(adoptPatternForSolver(D->aRem, maxIterations, s));
 	for (smm_hip_csr* piece : D->aRemK) SMM_TRY(adoptPatternForSolver(piece, maxIterations, s));
@@ -2293,6 +2373,7 @@ int smm_hip_dist_csr_destroy(smm_hip_dist_csr* D) {
 	for (void* p : D->chunkArrays) devFree(p);
 	for (void* p : D->arrays) devFree(p);
 	for (void* p : {D->r, D->r0, D->ap, D->as, D->scratch, D->pExt, D->sExt, D->xExt, D->partsA, D->partsB, D->partsC, D->sc}) devFree(p);
+	devFree(D->splitSync);
 	for (void* p : D->lazyExt) devFree(p);
 	delete D;
 	return SMM_HIP_OK;
@@ -2374,6 +2455,16 @@ int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, i
 	if (relays) *relays = D->p2p ? D->p2p->relays : 0;
 	if (halo_first) *halo_first = D->haloFirst ? 1 : 0;
 	if (direct_share) *direct_share = D->p2p ? D->p2p->directShare : 1.0;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_matvec_forms(const smm_hip_dist_csr* D, long long* one_launch, long long* two_launches) {
+	if (!D) {
+		setError("dist_csr_matvec_forms: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (one_launch) *one_launch = D->matvecsSplit;
+	if (two_launches) *two_launches = D->matvecsTwo;
 	return SMM_HIP_OK;
 }
 

@@ -193,6 +193,9 @@ struct smm_hip_csr {
 	int pat_nnz_cap = 0;
 	int pat_max_rows = 0;
 	int pat_chunk_tiles = 0;
+	// one-launch form of the row-partitioned SpMV (smm_spmv_split.hip): the most entries any run of 256 / 128 / 64 consecutive rows (cut at
+	// multiples of that) holds -- its fixed row tiles are staged whole, so their LDS is sized from this; -1: not counted yet (under tileMutex)
+	int split_tile_max[3] = {-1, -1, -1};
 };
 
 struct smm_hip_precond {
@@ -346,6 +349,17 @@ template <typename T>
 int launchSpmvPattern(const smm_hip_csr* m, int lanes, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                       const int* doneFlag, hipStream_t s);
 void chooseSpmvConfig(smm_hip_csr* m);
+// The row-partitioned SpMV in ONE launch (smm_spmv_split.hip): out = op(lhs, A_loc own) (+|-) A_rem ext [/ divisor], the local half while the
+// halo is in flight, the remote half once `landed` (a device word, raised on the exchange's stream by launchSplitSignal) has reached `seq`
+// (null: the halo is already in place); bounded by `ticks` (100 MHz), an expired wait leaves a code in *err.  op / extraFlags as the two-launch
+// form passes them to its FIRST launch plus SPMV_ADD_DIV when the Jacobi division rides in the epilogue (`divisor`).  Returns SMM_HIP_OK
+// (launched), 1 (this form does not serve the pair of blocks: nothing was enqueued, run the two launches) or an error.
+template <typename T>
+int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, const T* lhs, const T* divisor, const T* own, const T* ext, T* out, int dotMode,
+                    const T* w1, T* partials, const int* doneFlag, int extraFlags, const unsigned long long* landed, unsigned long long seq, unsigned long long* err,
+                    long long ticks, hipStream_t s);
+void launchSplitSignal(unsigned long long* landed, unsigned long long seq, hipStream_t s);
+void preloadSplitUnit();
 // ConjugateGradient's next direction formed in the SpMV's load phase (smm_spmv_march.hip, MarchFuse): Ap = A (beta pOld + r), the new
 // direction written to pNew, p.Ap into `partials`; `sc` is the solver's Scal<T>.  constMarchFusable: the matrix is served by the 2.5-D
 // constant-diagonal kernel in the form this exists for; the launch returns false when it could not be made (the caller must not have

@@ -625,9 +625,18 @@ __global__ __launch_bounds__(TPB) void spmvTileKernel(int nTiles, int cap, int c
 			// one of the last tiles of the matrix: one lane per row, left to right, straight from HBM
 			if (t < nrows) {
 				const int row = r0 + t;
-				const int e = start[row + 1];
+				// (in the PIECE structure of the staged path -- L chains added left to right: the same bits whatever the tile cut; r02-r05 walked
+				// these rows as one chain)
+				const int b = start[row], e = start[row + 1];
+				const int piecelen = (e - b + L - 1) / L;
 				T dot = T(0);
-				for (int k = start[row]; k < e; ++k) dot = smmFma(values[k], x[positions[k]], dot);
+#pragma unroll
+				for (int q = 0; q < L; ++q) {
+					const int kb = b + q * piecelen, ke = min(e, kb + piecelen);
+					T pd = T(0);
+					for (int k = kb; k < ke; ++k) pd = smmFma(values[k], x[positions[k]], pd);
+					dot = q == 0 ? pd : dot + pd;
+				}
 				const T o = applyOp(op, lhs, divisor, row, dot);
 				out[row] = o;
 				if (dotMode == 2) acc0 += o * o;

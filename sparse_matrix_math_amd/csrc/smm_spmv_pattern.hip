@@ -32,57 +32,9 @@
 
 #include "smm_device.h"
 #include "smm_internal.h"
+#include "smm_pattern_dev.h"
 
 namespace smm {
-
-constexpr int TPB = 256;
-constexpr int MAXOFF = 64;
-
-typedef float pf32x4 __attribute__((ext_vector_type(4)));
-typedef double pf64x2 __attribute__((ext_vector_type(2)));
-
-template <typename T>
-struct PatCfg {
-	static constexpr int PIECE = 4 * TPB;                  // values staged per pass: one 16-byte load per lane (fp32)
-	static constexpr int NVMAX = sizeof(T) == 4 ? 8 : 4;   // passes held in registers one tile ahead (32 VGPRs)
-	static constexpr int PAD = 16;
-};
-
-template <typename T>
-__device__ __forceinline__ T patApplyOp(int op, const T* __restrict__ lhs, const T* __restrict__ divisor, int row, T dot) {
-	if (op == SMM_OP_ASSIGN) return dot;
-	if (op == SPMV_OP_DIV) return dot / divisor[row];  // the Jacobi apply folded into the row (smm_spmv.hip, applyOp)
-	const T l = lhs[row];
-	if (op == SPMV_OP_ADD_DIV) return (l + dot) / divisor[row];
-	return op == SMM_OP_ADD ? l + dot : l - dot;
-}
-
-template <typename T>
-__device__ __forceinline__ T patGather(const T* __restrict__ x, unsigned byteOffset) {
-	return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + byteOffset);
-}
-
-// index of the k-th (0-based) set bit of m; k < popcount(m)
-__device__ __forceinline__ int selectBit(unsigned long long m, int k) {
-	int pos = 0;
-	unsigned v = static_cast<unsigned>(m);
-	int c = __popc(v);
-	if (k >= c) {
-		k -= c;
-		pos = 32;
-		v = static_cast<unsigned>(m >> 32);
-	}
-	c = __popc(v & 0xFFFFu);
-	if (k >= c) { k -= c; pos += 16; v >>= 16; }
-	c = __popc(v & 0xFFu);
-	if (k >= c) { k -= c; pos += 8; v >>= 8; }
-	c = __popc(v & 0xFu);
-	if (k >= c) { k -= c; pos += 4; v >>= 4; }
-	c = __popc(v & 0x3u);
-	if (k >= c) { k -= c; pos += 2; v >>= 2; }
-	if (k >= static_cast<int>(v & 1u)) pos += 1;
-	return pos;
-}
 
 // ---- analysis: row masks + verification of every entry ----------------------------------------------------------------------
 // One WAVEFRONT per 64 consecutive rows: their entries are one contiguous range of positions[], read coalesced (r02 gave every lane a
@@ -542,9 +494,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap
 			// over-long rows and the last tiles of the matrix: one lane per row, left to right, straight from HBM (with positions[])
 			for (int rr = t; rr < nrows; rr += TPB) {
 				const int row = r0 + rr;
-				const int e = start[row + 1];
-				T dot = T(0);
-				for (int k = start[row]; k < e; ++k) dot = smmFma(values[k], x[positions[k]], dot);
+				const T dot = patRowDirect<T, L>(start[row], start[row + 1], values, positions, x);  // (the staged path's pieces: the same bits)
 				const T o = patApplyOp(op, lhs, divisor, row, dot);
 				out[row] = o;
 				if (dotMode == 2) acc0 += o * o;

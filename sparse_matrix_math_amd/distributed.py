@@ -572,6 +572,12 @@ class NativeDistMatrix:
         self.options = {"p2p": bool(p2p.value), "relays": relays.value, "halo_first": bool(first.value), "direct_share": share.value}
         self._M = None
 
+    def matvec_forms(self):
+        """(SpMVs with a halo run as ONE launch, as TWO launches) so far -- csrc/smm_spmv_split.hip"""
+        one, two = ctypes.c_longlong(), ctypes.c_longlong()
+        self.check(self.lib.smm_hip_dist_csr_matvec_forms(self._h, ctypes.byref(one), ctypes.byref(two)))
+        return one.value, two.value
+
     def local_blocks(self):
         a, r = ctypes.c_void_p(), ctypes.c_void_p()
         self.check(self.lib.smm_hip_dist_csr_local_block(self._h, ctypes.byref(a), ctypes.byref(r)))

@@ -9,7 +9,7 @@ Matrices:
   decoupled  -- a block-diagonal matrix of two such bands whose SECOND block is exactly the last rank's rows: that rank neither sends
                 nor receives, and in a world >= 3 with relays it is picked as a relay (planRelays goes by ring distance alone) -- the
                 relay-only rank of ADVICE r05
-usage: p2p_proc_worker.py MATRIX DTYPE  (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT from the environment)"""
+usage: p2p_proc_worker.py MATRIX DTYPE [pattern]  (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT from the environment)"""
 import json
 import os
 import sys
@@ -66,6 +66,12 @@ def main():
     d_pos = torch.from_numpy(pos[start[lo]:start[hi]].copy()).to(dev)
     d_val = torch.from_numpy(val[start[lo]:start[hi]].copy()).to(dev)
     A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, dtype)
+    if len(sys.argv) > 3 and sys.argv[3] == "pattern":
+        # both local blocks in the row-mask encoding (what the solvers adopt for blocks of >= 2^20 entries): SpMVs with a halo then run as ONE
+        # launch (csrc/smm_spmv_split.hip) -- here with the exchange's word raised by another PROCESS's pushes landing
+        for blk, lanes in zip(A.local_blocks(), (2, 1)):
+            if blk.nnz > 0:
+                blk.set_kernel(3, lanes)
     b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
     results = {}
@@ -94,7 +100,7 @@ def main():
         assert all(e == every[0] for e in every), every  # every rank reports the same status / iterations / residual
         results[name] = {"res": every[0], "x": gather(x)}
     options = [None] * world
-    dist.all_gather_object(options, dict(A.options, halo_elements=A.halo_elements, nnz_rem=A.nnz_rem))
+    dist.all_gather_object(options, dict(A.options, halo_elements=A.halo_elements, nnz_rem=A.nnz_rem, matvec_forms=list(A.matvec_forms())))
     A.set_precond(None)
     A.close()
     comm.close()

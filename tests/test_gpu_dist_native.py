@@ -509,6 +509,88 @@ def p2p_thread_rank_cases():
     print("P2P_REPORT " + json.dumps(report, default=str))
 
 
+def _solve_forms(smm, csr, b_full, world, dtype, lanes, split):
+    """SpMV (three ops), BiCGStab with / without Jacobi and CG on thread ranks with both local blocks forced to the PATTERN family at `lanes` =
+    (A_loc, A_rem) pieces per row; `split` = SMM_HIP_SPLIT_SPMV at create time.  Returns the assembled bytes and the counts of matvec forms."""
+    import torch
+
+    from sparse_matrix_math_amd.distributed import NativeDistMatrix, partition_rows_by_nnz
+
+    dev = torch.device("cuda:0")
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    start, pos, val = csr
+    n = len(start) - 1
+    bounds = partition_rows_by_nnz(lambda i: int(start[i]), n, world)
+    os.environ["SMM_HIP_SPLIT_SPMV"] = "1" if split else "0"
+
+    def rank_main(rank, shared):
+        lo, hi = bounds[rank], bounds[rank + 1]
+        comm = _host_comm(shared, rank)
+        d_start = torch.from_numpy((start[lo:hi + 1] - start[lo]).astype(np.int32)).to(dev)
+        d_pos = torch.from_numpy(pos[start[lo]:start[hi]].copy()).to(dev)
+        d_val = torch.from_numpy(val[start[lo]:start[hi]].copy()).to(dev)
+        A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, dtype)
+        for blk, L in zip(A.local_blocks(), lanes):
+            blk.set_kernel(3, L)  # SMM_SPMV_PATTERN: the analysis runs now, on the block's own arrays
+        b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
+        out = []
+        for op in (0, 1, 2):  # assign / add / sub (ref:1458-1515), lhs = b
+            y = torch.empty(hi - lo, dtype=tdt, device=dev)
+            A.spmv(op, b if op else None, b, y)
+            torch.cuda.synchronize()
+            out.append(y.cpu().numpy())
+        for solver, precond, max_it in (("bicgstab", None, 7), ("bicgstab", smm.SolverPreconditioner.JACOBI, 7), ("cg", None, 9)):
+            A.set_precond(precond)
+            x = torch.zeros(hi - lo, dtype=tdt, device=dev)
+            res = A.cg(b, x, x, max_it, 1e-30) if solver == "cg" else A.bicgstab(b, x, max_it, 1e-30)
+            torch.cuda.synchronize()
+            out.append(x.cpu().numpy())
+            out.append(np.array(res, dtype=np.float64))
+        forms = A.matvec_forms()
+        A.set_precond(None)
+        A.close()
+        comm.close()
+        return out, forms
+
+    try:
+        got = _run_ranks(world, rank_main)
+    finally:
+        os.environ.pop("SMM_HIP_SPLIT_SPMV", None)
+    pieces = [np.concatenate([g[0][i] for g in got]).tobytes() if got[0][0][i].shape != (3,) else got[0][0][i].tobytes() for i in range(len(got[0][0]))]
+    return pieces, [g[1] for g in got]
+
+
+@pytest.mark.parametrize("world,dtype,lanes", [(2, np.float32, (2, 1)), (3, np.float64, (2, 2)), (2, np.float64, (1, 1)), (3, np.float32, (4, 2)), (2, np.float32, (1, 4))])
+def test_one_launch_spmv_is_the_two_launches_bit_for_bit(smm, oracle, world, dtype, lanes):
+    """csrc/smm_spmv_split.hip (r06): the row-partitioned SpMV as ONE launch -- the local half of a workgroup's rows, the
+    wait for the exchange's word, the remote half, out[] written once -- against the two launches (A_loc, then A_rem behind the exchange):
+    every SpMV op, BiCGStab with and without the Jacobi division in the epilogue, CG, fp32 / fp64, every pairing of pieces per row the
+    blocks can have -- the same bytes; and against the oracle within the piece forms' bound."""
+    csr = gen.banded_random_spd(60000, k=12, seed=4, max_offset=9000, dtype=dtype)
+    n = len(csr[0]) - 1
+    x_true = np.random.default_rng(3).uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, 0, None, x_true)
+    one, forms_one = _solve_forms(smm, csr, b, world, dtype, lanes, split=True)
+    two, forms_two = _solve_forms(smm, csr, b, world, dtype, lanes, split=False)
+    assert all(f[0] > 0 and f[1] == 0 for f in forms_one), forms_one  # every SpMV with a halo ran as one launch ...
+    assert all(f[0] == 0 and f[1] > 0 for f in forms_two), forms_two  # ... / as two
+    # the SpMV itself: the same bytes, every op.  The solvers' dot products ride in the epilogue as per-WORKGROUP partial sums, and the two forms
+    # deal the rows to workgroups differently: their scalars agree to rounding, x to the solvers' tolerance
+    assert [a == b_ for a, b_ in zip(one[:3], two[:3])] == [True] * 3
+    tol = 3e-4 if dtype == np.float32 else 1e-10
+    for i in (3, 5, 7):
+        xa, xb = np.frombuffer(one[i], dtype=dtype), np.frombuffer(two[i], dtype=dtype)
+        assert float(np.max(np.abs(xa - xb))) <= tol * float(np.max(np.abs(xb))), i
+        ra, rb = np.frombuffer(one[i + 1], dtype=np.float64), np.frombuffer(two[i + 1], dtype=np.float64)
+        assert tuple(ra[:2]) == tuple(rb[:2]) and abs(ra[2] - rb[2]) <= 50 * tol * max(abs(rb[2]), 1e-30), (ra, rb)
+    y = np.frombuffer(one[0], dtype=dtype)
+    y_ref = oracle.spmv(csr, 0, None, b)
+    assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
+    st_ref, x_ref, it_ref, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 7, 1e-30)
+    x = np.frombuffer(one[3], dtype=dtype)
+    assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref)))
+
+
 def test_peer_to_peer_thread_ranks():
     """csrc/smm_p2p.h with 2 / 3 ranks as threads of ONE process (host-callback communicator for the set-up; the halo and the scalars go
     peer to peer through the ranks' fine-grained blocks, raw pointers instead of hipIpcMemHandles inside one process), with and without a
@@ -528,7 +610,7 @@ def test_peer_to_peer_thread_ranks():
         assert all(case["bit_equal"]), case
 
 
-def _run_worker_processes(world, matrix, dtype, env_extra):
+def _run_worker_processes(world, matrix, dtype, env_extra, extra_args=()):
     """tests/p2p_proc_worker.py as `world` processes sharing the GPU (gloo for the set-up collectives); returns rank 0's report"""
     import socket
 
@@ -540,7 +622,7 @@ def _run_worker_processes(world, matrix, dtype, env_extra):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "p2p_proc_worker.py"), matrix, np.dtype(dtype).name], cwd=root, env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "p2p_proc_worker.py"), matrix, np.dtype(dtype).name, *extra_args], cwd=root, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     try:
@@ -674,3 +756,14 @@ def test_bench_self_launch_rehearsal(ranks):
     assert line["exposed_comm_ms"] >= 0 and line["exposed_comm"]["exchanges"] >= 0 and line["halo_chunks"] == 1
     assert line["dist_options"] == {"p2p": False, "relays": 0, "halo_first": True, "direct_share": 1.0}  # (peer to peer is asked for with SMM_HIP_P2P=1)
     assert "spmvTileKernel" in line["roofline"]["kernel"] or "spmvStreamKernel" in line["roofline"]["kernel"] or "Pattern" in line["roofline"]["kernel"]
+
+
+@pytest.mark.parametrize("world,relays,dtype", [(2, 0, np.float32), (3, 1, np.float64)])
+def test_one_launch_spmv_between_processes(smm, oracle, world, relays, dtype):
+    """The one-launch SpMV behind the peer-to-peer transport between PROCESSES: the word a rank's SpMV kernel polls is raised behind ITS land
+    kernel, which waits for pushes of other processes -- the kernel sits on the GPU with its local half done while they arrive.  Both local
+    blocks forced to the row-mask encoding; SpMVs back to back, BiCGStab +- Jacobi, CG; against the oracle."""
+    rep = _run_worker_processes(world, "banded", dtype, {"SMM_HIP_P2P": "1", "SMM_HIP_P2P_RELAYS": str(relays), "SMM_HIP_P2P_TIMEOUT_S": "20"}, extra_args=("pattern",))
+    for o in rep["options"]:
+        assert o["p2p"] is True and o["matvec_forms"][0] > 0 and o["matvec_forms"][1] == 0, rep["options"]
+    _check_worker_report(oracle, smm, rep, dtype)
