@@ -84,7 +84,7 @@ def spmv_kernel_source_sha():
 
 def pattern_kernel_source_sha():
     """the PATTERN family's kernels"""
-    return _source_sha(("smm_spmv_pattern.hip", "smm_device.h"))
+    return _source_sha(("smm_spmv_pattern.hip", "smm_pattern_dev.h", "smm_device.h"))
 
 
 def load_traffic(args, kernel):

@@ -873,12 +873,7 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 		}
 	}
 	// ---- every rank learns every rank's handle, process, address and layout
-	constexpr int WORDS = 8 + 2 + 2 * P2P_KINDS + 2;  // handle | pid, address | landing, staging offsets | ok | device
-	int myDevice = -1;
-	if (hipGetDevice(&myDevice) != hipSuccess) {
-		(void)hipGetLastError();
-		ok = false;
-	}
+	constexpr int WORDS = 8 + 2 + 2 * P2P_KINDS + 1;  // handle | pid, address | landing, staging offsets | ok
 	std::vector<long long> table(static_cast<size_t>(world) * WORDS, 0);
 	long long* me = table.data() + static_cast<size_t>(rank) * WORDS;
 	hipIpcMemHandle_t handle{};
@@ -895,7 +890,6 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 		me[10 + P2P_KINDS + k] = static_cast<long long>(P->stageOff[k]);
 	}
 	me[10 + 2 * P2P_KINDS] = ok ? 1 : 0;
-	me[WORDS - 1] = myDevice;
 	SMM_TRY(commAllreduceI64(c, table.data(), world * WORDS));
 	for (int q = 0; q < world; ++q) ok = ok && table[static_cast<size_t>(q) * WORDS + 10 + 2 * P2P_KINDS] == 1;
 	P->peer.assign(static_cast<size_t>(world), nullptr);
@@ -906,11 +900,13 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 			if (q == rank) {
 				P->peer[static_cast<size_t>(q)] = static_cast<char*>(P->block);
 			} else if (row[8] == static_cast<long long>(getpid())) {
-				// a rank of this very process (the thread-rank tests): its block is already mapped here -- as long as both ranks run on ONE device.
-				// Thread ranks on different GPUs would need peer access enabled; nothing here has run that way, so they vote for the collectives
-				// instead of faulting in the self-test
-				if (row[WORDS - 1] != myDevice) ok = false;
-				else P->peer[static_cast<size_t>(q)] = reinterpret_cast<char*>(static_cast<uintptr_t>(row[9]));
+				// A rank of this very process (ranks as threads: the tests).  REFUSED since r06: this transport makes kernels of one rank wait for
+				// kernels of another, and inside ONE process HIP gives no control over which hardware queue a stream's dispatches take -- a kernel
+				// trace of the thread-rank test under GPU_MAX_HW_QUEUES=32 shows 15 of 59 streams dispatched on more than one queue and the side
+				// streams of two live ranks on the same one (profiles/r06/p2p_thread_rank_queues.txt): a waiting kernel then sits in front of the
+				// kernel it waits for until its bound expires (the intermittent time-outs of r05 / r06).  Ranks in separate processes -- one per
+				// GPU, the deployment -- have queues of their own.  Every rank sees the same table, so every rank votes alike: the collectives.
+				ok = false;
 			} else {
 				hipIpcMemHandle_t h{};
 				memcpy(&h, row, 64);

@@ -5,8 +5,10 @@
 // RCCL exchange costs ~15 us of launch and completion on top of 4.2 MB over ONE link per neighbour (~70 us) and an RCCL all-reduce of 8-16
 // bytes ~10-12 us plus two cross-stream event hops -- the r04 estimate was 4-4.6 x.  Here
 //   * every rank owns a SYMMETRIC BLOCK of fine-grained device memory (coherent without kernel boundaries: remote writes are seen by
-//     system-scope loads), exported once with hipIpcGetMemHandle and mapped by every peer (threads of one process -- the tests -- use the
-//     raw pointers): flags, reduction slots, a LANDING area per halo-extended vector and a STAGING area for data this rank relays;
+//     system-scope loads), exported once with hipIpcGetMemHandle and mapped by every peer (ranks must be separate PROCESSES: between threads
+//     of one process the set-up votes for the collectives -- HIP may put two streams of a process on one hardware queue, and a kernel that
+//     waits for a peer's kernel would then sit in front of it; smm_dist.hip, p2pSetup): flags, reduction slots, a LANDING area per
+//     halo-extended vector and a STAGING area for data this rank relays;
 //   * halo: a push kernel on the communicator's side stream copies the boundary slices of the freshly updated vector into the
 //     neighbours' landing areas, one share DIRECTLY and the other shares through RELAY ranks (rank g -> r -> g + 1 uses the links
 //     g -> r and r -> g + 1, which a nearest-neighbour exchange leaves idle: 5 of 7 per GPU); a relay's forward kernel, enqueued ahead on

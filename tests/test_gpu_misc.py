@@ -384,3 +384,54 @@ def test_sweeps_with_long_dependent_rows(smm, oracle):
         M.apply_dev(d_rhs, d_x, torch.cuda.current_stream().cuda_stream)
         M.take_error(torch.cuda.current_stream().cuda_stream)  # raises if a sweep tripped its bound
         np.testing.assert_array_equal(d_x.cpu().numpy(), want)
+
+
+def test_an_allocation_never_waits_for_queued_work(smm):
+    """csrc/smm_runtime.hip, r06: a freed block is reusable once the work queued before the free has ended (event epochs) -- and an allocation
+    that finds its size still quarantined takes FRESH memory instead of waiting for those events.  r03-r05 polled them: with ranks as
+    threads of one process and the peer-to-peer transport, a rank entering a solve waited in the allocator for an event recorded behind a
+    peer's kernel that was itself waiting (on the device) for a kernel this rank had yet to enqueue.  Here: ~0.3 s of SpMVs
+    are queued on a stream, a handle is destroyed behind them, and a handle of the same sizes is created at once: the create must return
+    while the stream is still busy."""
+    import time
+
+    import torch
+
+    from sparse_matrix_math_amd import host
+
+    dev = torch.device("cuda:0")
+    rows = 4_000_000
+    nnz = host.gen_banded_nnz(rows, 25, 0x5EED, 1 << 18)
+    own = torch.cuda.Stream(device=dev)
+    st = own.cuda_stream
+    ds = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+    dp = torch.empty(nnz, dtype=torch.int32, device=dev)
+    dv = torch.empty(nnz, dtype=torch.float32, device=dev)
+    host.gen_banded_dev(rows, 25, 0x5EED, 1 << 18, ds, dp, dv, np.float32, st, diag_shift=1.0)
+    big = smm.CSRMatrix.from_device(rows, rows, ds, dp, dv, np.float32)
+    x = torch.rand(rows, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    small = gen.poisson2d(300, dtype=np.float64)
+    n_small = len(small[0]) - 1
+    for _ in range(3):
+        big.spmv_dev(0, None, x, y, st)
+    torch.cuda.synchronize()
+    h1 = smm.CSRMatrix(n_small, n_small, *small)  # owns device copies of its three arrays
+    t0 = time.perf_counter()
+    for _ in range(1500):  # ~0.2 ms each: some tenths of a second of queued work behind which ...
+        big.spmv_dev(0, None, x, y, st)
+    enqueue_s = time.perf_counter() - t0
+    h1.close()  # ... the handle's arrays are freed (quarantined: an event on the busy stream guards them)
+    t1 = time.perf_counter()
+    h2 = smm.CSRMatrix(n_small, n_small, *small)  # the same three sizes, at once
+    create_s = time.perf_counter() - t1
+    still_busy = not own.query()
+    torch.cuda.synchronize()
+    total_s = time.perf_counter() - t0
+    assert still_busy, (enqueue_s, create_s, total_s)  # the queued work outlived the create ...
+    assert create_s < 0.5 * (total_s - enqueue_s), (enqueue_s, create_s, total_s)  # ... which did not wait for it
+    yv = np.zeros(n_small)
+    h2.rMult(np.ones(n_small), yv)
+    assert np.isfinite(yv).all()
+    h2.close()
+    big.close()
