@@ -460,9 +460,12 @@ int smm_hip_dist_csr_halo_chunks(const smm_hip_dist_csr* D, int* chunks);
  *   p2p          1: peer to peer (csrc/smm_p2p.h) -- every rank maps every rank's block of fine-grained device memory (hipIpcMemHandle; over
  *                xGMI between GPUs), pushes the boundary slices of a vector straight into the neighbours' landing areas and completes the
  *                dot products by one single-workgroup kernel that writes into / reads from per-rank slots: no collective is launched inside
- *                the loop.  Asked for with SMM_HIP_P2P=1 on EVERY rank; stays 0 (the communicator's grouped send / receive and all-reduce)
- *                unless every rank could map every peer and passed a self-test through every path.  Results: the halo is pure data
- *                movement (same bits); the scalars are added in rank order on every rank (deterministic, identical on all ranks).
+ *                the loop.  r06: the DEFAULT between processes -- taken whenever every rank could map every peer and passed the self-test
+ *                through every path at create time; SMM_HIP_P2P=0 on any rank keeps every rank with the communicator's collectives (0).
+ *                2: the hybrid -- the scalars through the slots, the halo through the communicator's grouped send / receive (the halo part of
+ *                the self-test failed on some rank, or SMM_HIP_P2P_HALO=0).  Ranks that are threads of ONE process always get 0.
+ *                Results: the halo is pure data movement (same bits); the scalars are added in rank order on every rank (deterministic,
+ *                identical on all ranks).
  *   relays       relay ranks per halo segment (SMM_HIP_P2P_RELAYS; default world - 4, i.e. 4 at 8 ranks): the segment's direct_share goes
  *                over the link src -> dst, the rest in equal shares src -> relay -> dst over links a nearest-neighbour exchange leaves idle.
  *   halo_first   1: the rows of an updated vector that a peer receives are produced by a small launch of their own and the exchange is

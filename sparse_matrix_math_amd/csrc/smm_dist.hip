@@ -490,6 +490,7 @@ struct RowRanges {
 
 struct P2PState {
 	int world = 1, rank = 0;
+	bool haloOn = true;      // false: the halo stays with the communicator's grouped send / receive, only the scalars go through the slots (the hybrid)
 	int relays = 0;          // relay ranks per segment (0: the direct path only)
 	double directShare = 1;  // share of a segment that takes the direct path
 	void* block = nullptr;   // this rank's symmetric block (fine-grained device memory)
@@ -815,9 +816,11 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 	smm_hip_comm* c = D->comm;
 	const int world = c->world, rank = c->rank;
 	if (world < 2 || world > P2P_MAX_WORLD) return SMM_HIP_OK;
-	const char* env = getenv("SMM_HIP_P2P");  // (read at every create, like SMM_HIP_HALO_CHUNKS)
+	// r06: ON unless a rank says SMM_HIP_P2P=0 -- the transport is taken whenever EVERY rank can allocate, export and map the blocks and passes
+	// the self-test below; anything less leaves all ranks with the communicator's collectives (read at every create, like SMM_HIP_HALO_CHUNKS)
+	const char* env = getenv("SMM_HIP_P2P");
 	bool all = false;
-	SMM_TRY(p2pAllAgree(c, env && atoi(env) != 0 && D->chunks == 1, &all));
+	SMM_TRY(p2pAllAgree(c, !(env && atoi(env) == 0) && D->chunks == 1, &all));
 	if (!all) return SMM_HIP_OK;
 	std::unique_ptr<P2PState> owner(new P2PState());
 	P2PState* P = owner.get();
@@ -1006,53 +1009,87 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 		p2pTeardown(D);
 		return SMM_HIP_OK;
 	}
-	// ---- self-test through every path: x's halo-extended vector carries the global column number of every owned element; after one
-	// exchange every halo element of every rank must hold ITS column number; one reduction must give world (world + 1) / 2
-	// (no early return between the two votes -- ADVICE r05: a rank that left here would tear its block down in p2pTeardown, whose "meet"
-	// all-reduces would pair with the peers' vote below and could even be counted as a pass; every failure is a `pass = false`)
+	// ---- self-test, in two parts with a vote each (no early return between votes -- ADVICE r05: a rank that left would tear its block down in
+	// p2pTeardown, whose "meet" all-reduces would pair with the peers' votes; every failure is a `pass = false`).
+	// (on the communicator's own stream: kernels of this rank WAIT for kernels of its peers)
+	hipStream_t s = c->stream;
+	noteStream(s);
+	// Part 1, the scalars: every reduction point once -- rank + 1 and 2 (rank + 1) through the slots must give world (world + 1) / 2 and twice that
+	// on every rank.  A failure here leaves every rank with the collectives for everything.
 	bool pass = true;
 	{
-		// (on the communicator's own stream: kernels of this rank WAIT for kernels of its peers, and ranks that are threads of one process
-		// share the library's stream -- a waiting kernel there would sit in front of the very kernel it waits for)
-		hipStream_t s = c->stream;
-		noteStream(s);
-		T* xExt = static_cast<T*>(D->xExt);
-		std::vector<T> host(static_cast<size_t>(D->extLen), T(-1));
-		for (int i = 0; i < D->nLocal; ++i) host[static_cast<size_t>(D->ownOffset + i)] = static_cast<T>((D->rowBegin + i) % 8191);
 		DevBuf<T> tot;
-		const T mineTot[2] = {static_cast<T>(rank + 1), static_cast<T>(2 * (rank + 1))};
-		T got[2] = {T(0), T(0)};
+		T mineTot[2 * P2P_RED_POINTS], got[2 * P2P_RED_POINTS] = {};
+		for (int k = 0; k < P2P_RED_POINTS; ++k) {
+			mineTot[2 * k] = static_cast<T>(rank + 1 + k);
+			mineTot[2 * k + 1] = static_cast<T>(2 * (rank + 1 + k));
+		}
 		unsigned long long err = 0;
-		// whatever fails on the host, the three launches go out if they can at all: the peers' kernels are waiting for this rank's parts and slots
-		bool okHost = tot.alloc(2) == SMM_HIP_OK;
-		okHost = hipMemcpyAsync(xExt, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess && okHost;
-		int rc = p2pHaloLaunch<T>(D, xExt, 2, s);
-		if (rc == SMM_HIP_OK) rc = p2pLandLaunch<T>(D, xExt, 2, D->p2p->haloSeq[2], s);
+		bool okHost = tot.alloc(2 * P2P_RED_POINTS) == SMM_HIP_OK;
 		if (okHost) okHost = hipMemcpyAsync(tot, mineTot, sizeof(mineTot), hipMemcpyHostToDevice, s) == hipSuccess;
-		if (rc == SMM_HIP_OK && okHost) rc = p2pAllreduceLaunch<T>(D, P2P_RED_POINTS - 1, tot.p, 2, nullptr, s);
-		okHost = hipMemcpyAsync(host.data(), xExt, host.size() * sizeof(T), hipMemcpyDeviceToHost, s) == hipSuccess && okHost;
+		int rc = SMM_HIP_OK;
+		for (int k = 0; k < P2P_RED_POINTS && okHost && rc == SMM_HIP_OK; ++k) rc = p2pAllreduceLaunch<T>(D, k, tot.p + 2 * k, 2, nullptr, s);
 		if (okHost) okHost = hipMemcpyAsync(got, tot, sizeof(got), hipMemcpyDeviceToHost, s) == hipSuccess;
-		okHost = hipMemcpyAsync(&err, &D->p2p->hdr()->err, sizeof(err), hipMemcpyDeviceToHost, s) == hipSuccess && okHost;
+		okHost = hipMemcpyAsync(&err, &P->hdr()->err, sizeof(err), hipMemcpyDeviceToHost, s) == hipSuccess && okHost;
 		okHost = hipStreamSynchronize(s) == hipSuccess && okHost;
 		if (!okHost) (void)hipGetLastError();
 		pass = okHost && rc == SMM_HIP_OK && err == 0;
-		for (const PlanSeg& g : mine) {
-			for (int i = 0; i < g.count && pass; ++i) {
-				const long long col = D->cmin + g.extOff + i;
-				pass = host[static_cast<size_t>(g.extOff + i)] == static_cast<T>(col % 8191);
-			}
-		}
-		const T want = static_cast<T>(0.5 * world * (world + 1));
-		pass = pass && got[0] == want && got[1] == 2 * want;
-		if (hipMemsetAsync(xExt, 0, host.size() * sizeof(T), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-			(void)hipGetLastError();
-			pass = false;
+		for (int k = 0; k < P2P_RED_POINTS && pass; ++k) {
+			const T want = static_cast<T>(0.5 * world * (world + 1) + static_cast<double>(k) * world);
+			pass = got[2 * k] == want && got[2 * k + 1] == 2 * want;
 		}
 	}
 	SMM_TRY(p2pAllAgree(c, pass, &all));
 	if (!all) {
-		if (!pass) fprintf(stderr, "libsmm_hip: rank %d: the peer-to-peer self-test failed; every rank stays with the communicator's collectives\n", rank);
+		if (!pass) fprintf(stderr, "libsmm_hip: rank %d: the peer-to-peer self-test (scalars) failed; every rank stays with the communicator's collectives\n", rank);
 		p2pTeardown(D);
+		return SMM_HIP_OK;
+	}
+	// Part 2, the halo: the halo-extended vector carries (global column + 7 round) mod 8191 in every owned element; after an exchange every halo
+	// element of every rank must hold ITS column's number -- once through the areas of each vector kind, then twice more back to back through
+	// the last kind's (a push then waits for the acknowledgement of the exchange before).  A failure here leaves the HALO with the
+	// communicator's grouped send / receive and keeps the scalars in the slots (the hybrid: a reduction point costs ~3 us instead of ~23).
+	const char* haloEnv = getenv("SMM_HIP_P2P_HALO");  // 0: do not try (tests of the hybrid)
+	pass = !(haloEnv && atoi(haloEnv) == 0);
+	{
+		T* xExt = static_cast<T*>(D->xExt);
+		std::vector<T> host(static_cast<size_t>(D->extLen), T(-1));
+		unsigned long long err = 0;
+		const int kinds[5] = {0, 1, 2, 2, 2};
+		for (int round = 0; round < 5 && pass; ++round) {
+			std::fill(host.begin(), host.end(), T(-1));
+			for (int i = 0; i < D->nLocal; ++i) host[static_cast<size_t>(D->ownOffset + i)] = static_cast<T>((D->rowBegin + i + 7LL * round) % 8191);
+			bool okHost = hipMemcpyAsync(xExt, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess;
+			// (whatever fails on the host, the launches go out if they can at all: the peers' kernels are waiting for this rank's parts)
+			int rc = p2pHaloLaunch<T>(D, xExt, kinds[round], s);
+			if (rc == SMM_HIP_OK) rc = p2pLandLaunch<T>(D, xExt, kinds[round], P->haloSeq[kinds[round]], s);
+			okHost = hipMemcpyAsync(host.data(), xExt, host.size() * sizeof(T), hipMemcpyDeviceToHost, s) == hipSuccess && okHost;
+			okHost = hipMemcpyAsync(&err, &P->hdr()->err, sizeof(err), hipMemcpyDeviceToHost, s) == hipSuccess && okHost;
+			okHost = hipStreamSynchronize(s) == hipSuccess && okHost;
+			if (!okHost) (void)hipGetLastError();
+			pass = okHost && rc == SMM_HIP_OK && err == 0;
+			for (const PlanSeg& g : mine) {
+				for (int i = 0; i < g.count && pass; ++i) {
+					const long long col = D->cmin + g.extOff + i;
+					pass = host[static_cast<size_t>(g.extOff + i)] == static_cast<T>((col + 7LL * round) % 8191);
+				}
+			}
+		}
+		if (hipMemsetAsync(xExt, 0, host.size() * sizeof(T), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) (void)hipGetLastError();
+	}
+	SMM_TRY(p2pAllAgree(c, pass, &all));
+	if (!all) {
+		if (!pass && !(haloEnv && atoi(haloEnv) == 0)) {
+			fprintf(stderr, "libsmm_hip: rank %d: the peer-to-peer self-test (halo) failed; the halo stays with the communicator's send / receive on every rank\n", rank);
+		}
+		// every rank is past its own waits (each synchronised its stream above, and the vote was a collective): the error words of the halo part
+		// are history, the slots go on
+		P->haloOn = false;
+		P->relays = 0;
+		P->directShare = 1.0;
+		if (hipMemset(&P->hdr()->err, 0, sizeof(unsigned long long)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+		bool cleared = false;
+		SMM_TRY(p2pAllAgree(c, true, &cleared));  // (nobody enters a reduction before every rank has cleared its word)
 	}
 	return SMM_HIP_OK;
 }
@@ -1331,6 +1368,8 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 // distMatvecCompute: out = op(lhs, A ext) on the owned rows: the local block while the halo is in flight, then -- once it has landed --
 // the remote block(s), with the dot products of the freshly computed vector (dotMode / w1 / parts as in launchSpmv; parts a finishing
 // buffer) and the Jacobi division in the epilogue of the launch that completes a row.
+static bool p2pHaloOn(const smm_hip_dist_csr* D) { return D->p2p && D->p2p->haloOn; }
+
 // the device word the one-launch SpMV polls, and where an expired wait of it is recorded
 static unsigned long long* splitErrWord(smm_hip_dist_csr* D) {
 	if (D->p2p) return &D->p2p->hdr()->err;
@@ -1344,7 +1383,7 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 	auto& pend = D->pending;
 	pend = smm_hip_dist_csr::Pending{};
 	const bool exchange = !D->sends.empty() || !D->recvs.empty();
-	if (D->p2p && !exchange) {
+	if (p2pHaloOn(D) && !exchange) {
 		// A rank that neither sends nor receives may still RELAY (planRelays picks by ring distance alone: a decoupled diagonal block in a
 		// world >= 3): its forwards must run, and its sequence numbers must advance, with every exchange of the peers -- r05 returned here
 		// before looking at nFwd, and every solve of such a world expired.  Nothing of `ext` is read or written: no ordering
@@ -1374,7 +1413,7 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 	if (!exchange) return SMM_HIP_OK;
 	pend.active = true;
 	pend.kind = kind;
-	if (D->p2p) {
+	if (p2pHaloOn(D)) {
 		hipStream_t cs = c->stream;
 		noteStream(cs);
 		SMM_TRY(orderAfter(c, s, cs));
@@ -2447,7 +2486,7 @@ int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, i
 		setError("dist_csr_options: null handle");
 		return SMM_HIP_ERR_INVALID;
 	}
-	if (p2p) *p2p = D->p2p ? 1 : 0;
+	if (p2p) *p2p = D->p2p ? (D->p2p->haloOn ? 1 : 2) : 0;
 	if (relays) *relays = D->p2p ? D->p2p->relays : 0;
 	if (halo_first) *halo_first = D->haloFirst ? 1 : 0;
 	if (direct_share) *direct_share = D->p2p ? D->p2p->directShare : 1.0;

@@ -569,7 +569,9 @@ class NativeDistMatrix:
         p2p, relays, first, share = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
         self.check(self.lib.smm_hip_dist_csr_options(self._h, ctypes.byref(p2p), ctypes.byref(relays), ctypes.byref(first), ctypes.byref(share)))
         # how the halo and the scalars travel (smm_hip.h, smm_hip_dist_csr_options): agreed by all ranks when the matrix was created
-        self.options = {"p2p": bool(p2p.value), "relays": relays.value, "halo_first": bool(first.value), "direct_share": share.value}
+        # p2p: the halo travels peer to peer; p2p_scalars: the dot products go through the per-rank slots (also true in the hybrid, where the halo stays
+        # with the communicator's send / receive)
+        self.options = {"p2p": p2p.value == 1, "p2p_scalars": p2p.value != 0, "relays": relays.value, "halo_first": bool(first.value), "direct_share": share.value}
         self._M = None
 
     def matvec_forms(self):
@@ -700,8 +702,20 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
             last = resnorm
         return done, last
 
-    if args.warmup > 0:
-        run(args.warmup)
+    def failed(e):
+        # a communication failure in the N > 1 leg (a bounded wait expired, a collective failed): this rank leaves with a status of its own, at once
+        # and without tearing anything down (the peers run into THEIR bounded waits); never a re-exec of a process that has touched the GPU
+        import os
+        import sys
+
+        print(f"rank {rank}: the row-partitioned solve failed: {e}", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    try:
+        if args.warmup > 0:
+            run(args.warmup)
+    except Exception as e:  # noqa: BLE001
+        failed(e)
     # THE timed region (`value`, `ms_per_step`): K iterations between two barriers, no instrumentation inside.  The live SpMV timing -- HIP
     # events around every SpMV launch -- is not free in this loop: measured on one rank's share of the benchmark matrix (1.25 M rows,
     # profiles/r05/rank_loop_gaps.txt) every instrumented launch has ~6 us of idle stream on either side, 316 us per iteration against
@@ -710,7 +724,10 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    iters, resnorm = run(args.steps)
+    try:
+        iters, resnorm = run(args.steps)
+    except Exception as e:  # noqa: BLE001
+        failed(e)
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -719,8 +736,12 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
     host.profile_read_waits(reset=True)
     dist.barrier()
     torch.cuda.synchronize()
+    forms_before = A.matvec_forms() if driver == "native" else (0, 0)
     t1 = time.perf_counter()
-    iters2, _ = run(args.steps)
+    try:
+        iters2, _ = run(args.steps)
+    except Exception as e:  # noqa: BLE001
+        failed(e)
     torch.cuda.synchronize()
     dist.barrier()
     elapsed_instrumented = time.perf_counter() - t1
@@ -758,14 +779,27 @@ def bench_bicgstab(args, rank, world, dev, np_dtype, t_dtype):
             else:
                 b_true += nnz_blk * (s_bytes + 4) + (hi - lo + 1) * 4
     per_matvec = 1 if one_launch else 2
-    matvec_s = spmv_ms * 1e-3 / max(spmv_launches // per_matvec, 1)
+    matvecs = max(spmv_launches // per_matvec, 1)
+    split_forms = None
+    if driver == "native" and not one_launch:
+        # SpMVs with a halo run as ONE launch (csrc/smm_spmv_split.hip: local half, wait for the exchange's word, remote half) or as two
+        forms_after = A.matvec_forms()
+        d_one, d_two = forms_after[0] - forms_before[0], forms_after[1] - forms_before[1]
+        split_forms = {"one_launch": d_one, "two_launches": d_two}
+        if d_one + d_two > 0:
+            matvecs = d_one + d_two
+            per_matvec = 1 if d_two == 0 else 2
+        if d_one > 0 and d_two == 0:
+            kernels = ["spmvPatternSplitKernel"]
+    matvec_s = spmv_ms * 1e-3 / matvecs
     achieved = b_true / matvec_s / 1e9
     return {
         # the same definition as the one-GPU line's `roofline`: the kernels the timed region runs, priced with the bytes THEIR layouts move
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "kernel": " + ".join(kernels) + " (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")"),
+                     "kernel": " + ".join(kernels) + (" (one matvec of rank 0 = ONE launch over A_loc and A_rem)" if kernels == ["spmvPatternSplitKernel"] else
+                                                    " (one matvec of rank 0 = its A_loc launch" + (" + its A_rem launch)" if per_matvec == 2 else ")")),
                      "algorithmic_bytes_per_launch": b_true, "csr_bytes_per_launch": b_local, "avg_launch_ms": matvec_s * 1e3,
-                     "launches": spmv_launches // per_matvec, "families": families,
+                     "launches": matvecs, "matvec_forms": split_forms, "families": families,
                      "measured_in": "a second pass of the same K iterations right behind the timed region (the events cost this loop ~12 us per SpMV launch: kept out of `value`)",  # (family, lanes per row, PATTERN encoding) of each block
                      "note": "bytes = what the kernels that ran really move per matvec of rank 0 (a block AUTO moved to the PATTERN family has no positions[]); "
                              "csr_bytes_per_launch is the SURVEY 8d formula; the CSR kernel's own fraction is the one-GPU line's roofline_csr"},

@@ -580,7 +580,7 @@ def test_peer_to_peer_between_processes(ranks, relays):
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     line = json.loads(lines[0])
-    assert line["dist_options"] == {"p2p": True, "relays": relays, "halo_first": True, "direct_share": 4.0 / (relays + 4) if relays else 1.0}, line["dist_options"]
+    assert line["dist_options"] == {"p2p": True, "p2p_scalars": True, "relays": relays, "halo_first": True, "direct_share": 4.0 / (relays + 4) if relays else 1.0}, line["dist_options"]
     assert line["n_gpus"] == ranks and line["value"] > 0 and line["max_rel_err_vs_x_true"] < 1e-3
     if ranks == 2:
         # two ranks: a + b in either order is the same sum, so the collectives' result must come out bit for bit (pure data movement)
@@ -629,7 +629,9 @@ def test_bench_self_launch_rehearsal(ranks):
     # what a multi-GPU line that scales worse than hoped is read by first: the exchanges' share that A_loc did not cover (events on the
     # solver's and the communicator's stream; the rehearsal's host-staged exchanges run on the solver's own stream: no pairs, 0 ms)
     assert line["exposed_comm_ms"] >= 0 and line["exposed_comm"]["exchanges"] >= 0 and line["halo_chunks"] == 1
-    assert line["dist_options"] == {"p2p": False, "relays": 0, "halo_first": True, "direct_share": 1.0}  # (peer to peer is asked for with SMM_HIP_P2P=1)
+    # r06: between processes the peer-to-peer transport is the default (taken because every rank passed its create-time self-test; 2 and 4 ranks:
+    # world - 4 <= 0 relays); SMM_HIP_P2P=0 would keep the collectives
+    assert line["dist_options"] == {"p2p": True, "p2p_scalars": True, "relays": 0, "halo_first": True, "direct_share": 1.0}, line["dist_options"]
     assert "spmvTileKernel" in line["roofline"]["kernel"] or "spmvStreamKernel" in line["roofline"]["kernel"] or "Pattern" in line["roofline"]["kernel"]
 
 
@@ -652,7 +654,8 @@ def test_peer_to_peer_equals_the_collectives_between_processes(smm, oracle, worl
     tolerance (gloo's all-reduce adds in its own order, the slot reduction in rank order) -- and both match the oracle."""
     on = _run_worker_processes(world, "banded", dtype, {"SMM_HIP_P2P": "1", "SMM_HIP_P2P_RELAYS": str(relays), "SMM_HIP_P2P_TIMEOUT_S": "20"})
     off = _run_worker_processes(world, "banded", dtype, {"SMM_HIP_P2P": "0"})
-    assert all(o["p2p"] is True and o["relays"] == relays for o in on["options"]) and not any(o["p2p"] for o in off["options"])
+    assert all(o["p2p"] is True and o["p2p_scalars"] is True and o["relays"] == relays for o in on["options"])
+    assert not any(o["p2p"] or o["p2p_scalars"] for o in off["options"])
     assert on["results"]["y"] == off["results"]["y"]
     tol = 3e-4 if dtype == np.float32 else 1e-10
     for name in ("bicgstab7", "jacobi7", "cg9"):
@@ -664,3 +667,14 @@ def test_peer_to_peer_equals_the_collectives_between_processes(smm, oracle, worl
             xa, xb = (np.frombuffer(bytes.fromhex(r["x"]), dtype=dtype) for r in (a, b_))
             assert float(np.max(np.abs(xa - xb))) <= tol * float(np.max(np.abs(xb))), name
     _check_worker_report(oracle, smm, on, dtype)
+
+
+def test_hybrid_transport_between_processes(smm, oracle):
+    """The hybrid (r06): the halo through the communicator's grouped send / receive, the scalars through the per-rank slots -- what every rank
+    falls back to when the halo part of the create-time self-test fails somewhere (here: SMM_HIP_P2P_HALO=0 makes every rank vote so).
+    Three processes, the default transport otherwise; against the oracle."""
+    dtype = np.float64
+    rep = _run_worker_processes(3, "banded", dtype, {"SMM_HIP_P2P_HALO": "0", "SMM_HIP_P2P_TIMEOUT_S": "20"})
+    for o in rep["options"]:
+        assert o["p2p"] is False and o["p2p_scalars"] is True and o["relays"] == 0, rep["options"]
+    _check_worker_report(oracle, smm, rep, dtype)
