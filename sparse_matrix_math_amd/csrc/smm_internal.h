@@ -257,6 +257,8 @@ constexpr int SPMV_OP_ADD_DIV = 4;
 // streams' request sets and fits three workgroups per CU only with half tiles (512^3 fp32: 0.95 -> 0.83 ms per iteration, fp64 1.71 -> 1.67); the partial sums of
 // p.Ap follow the tiles, so EVERY loop form of CG uses the same tiles and they stay bit for bit equal.  Other kernels ignore the flag.
 constexpr int SPMV_HALF_TILES = 0x2000;
+// kernel-side (spmvPatternTileKernel): no fast path for wavefronts whose rows all hold every offset (SMM_HIP_FULL_ROWS=0, measurements)
+constexpr int SPMV_NO_FULL_ROWS = 0x4000;
 constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer
 constexpr int PARTS_TICKETS = 16;             // sub-counters of the "last workgroup" ticket (lastBlockSums, smm_device.h)
 constexpr int PARTS_LEN = 2 * NPART + 2 + 2 * (PARTS_TICKETS + 1);  // elements of a finishing buffer: 2 x NPART partials, 2 totals, the ticket words

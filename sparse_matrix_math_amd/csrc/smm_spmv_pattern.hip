@@ -419,6 +419,9 @@ __global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap
 	const int piece = wave % L;
 	const int rl = (wave / L) * 64 + lane;
 	const int nv = (cap + Cfg::PIECE - 1) / Cfg::PIECE;
+	// (0: the fast path for full rows is off -- SPMV_NO_FULL_ROWS, measurements)
+	const unsigned long long fullMask = (opFlags & SPMV_NO_FULL_ROWS) ? 0ULL : nOff >= 64 ? ~0ULL : (1ULL << nOff) - 1ULL;
+	const int offLane = lane < nOff ? offs[lane] : 0;  // (offset j in lane j of every wavefront: the full-row path reads it with v_readlane)
 	T acc0 = T(0), acc1 = T(0);
 	for (int i = t; i < cap + Cfg::PAD; i += TPB) sVal[i] = T(0);
 	if (t < MAXOFF) sOff[t] = t < nOff ? offs[t] : 0;
@@ -512,28 +515,56 @@ __global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap
 				kb = b + piece * piecelen;
 				ke = min(e, kb + piecelen);
 				mm = sMask[rl];
-				// this piece starts at the (kb - b)-th entry of the row = the (kb - b)-th set bit of the mask
-				if (piece > 0 && kb < ke) mm &= ~0ULL << selectBit(mm, kb - b);
 			}
-			for (int k = kb; k < ke; k += G) {
-				unsigned off[G];
-				T xv[G], vv[G];
+			// FULL rows (r06): when every row of this wavefront holds every offset -- the interior of a band: four rows in five of the benchmark
+			// matrix -- entry e of a row IS offset e, for every lane alike.  The column of an entry then needs no bit scan, no clamp and no
+			// per-lane address arithmetic: the offset is a wave-uniform number (a scalar load of offs[]), the gather a load at
+			// (x + offset) [scalar base] + 4 row [one vector register, formed once per tile].  The general path below spends ~15 vector
+			// instructions per entry on exactly that.  Same products in the same order: the same bits.
+			const bool fullWave = fullMask != 0ULL && __builtin_amdgcn_ballot_w64(!(rl < nrows && mm == fullMask)) == 0ULL;
+			if (fullWave) {
+				const int pu = __builtin_amdgcn_readfirstlane(piece);
+				const int pl = (nOff + L - 1) / L;
+				const int e0 = pu * pl, e1 = min(nOff, e0 + pl);
+				const unsigned rowBytes = static_cast<unsigned>(row) * static_cast<unsigned>(sizeof(T));
+				for (int e = e0; e < e1; e += G) {
+					T xv[G], vv[G];
+					const int nvalid = e1 - e;  // (wave-uniform)
 #pragma unroll
-				for (int u = 0; u < G; ++u) {
-					const int jj = mm ? __builtin_ctzll(mm) : 0;
-					mm &= mm - 1;
-					// entries past the end of the piece get a clamped, valid column; their products are discarded
-					const int col = min(max(row + sOff[jj], 0), cols - 1);
-					off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
-					vv[u] = sVal[k + u];
+					for (int u = 0; u < G; ++u) {
+						// entries past the end of the piece repeat its last (valid) column; their products are discarded
+						const int o = __builtin_amdgcn_readlane(offLane, min(e + u, e1 - 1));
+						xv[u] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x + o) + rowBytes);
+						vv[u] = sVal[kb + (e - e0) + u];
+					}
+#pragma unroll
+					for (int u = 0; u < G; ++u) {
+						if (u < nvalid) dot = smmFma(vv[u], xv[u], dot);
+					}
 				}
+			} else {
+				// this piece starts at the (kb - b)-th entry of the row = the (kb - b)-th set bit of the mask
+				if (rl < nrows && piece > 0 && kb < ke) mm &= ~0ULL << selectBit(mm, kb - sStart[rl]);
+				for (int k = kb; k < ke; k += G) {
+					unsigned off[G];
+					T xv[G], vv[G];
 #pragma unroll
-				for (int u = 0; u < G; ++u) xv[u] = patGather<T>(x, off[u]);
-				const int nvalid = ke - k;
+					for (int u = 0; u < G; ++u) {
+						const int jj = mm ? __builtin_ctzll(mm) : 0;
+						mm &= mm - 1;
+						// entries past the end of the piece get a clamped, valid column; their products are discarded
+						const int col = min(max(row + sOff[jj], 0), cols - 1);
+						off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
+						vv[u] = sVal[k + u];
+					}
 #pragma unroll
-				for (int u = 0; u < G; ++u) {
-					const T next = smmFma(vv[u], xv[u], dot);
-					dot = u < nvalid ? next : dot;
+					for (int u = 0; u < G; ++u) xv[u] = patGather<T>(x, off[u]);
+					const int nvalid = ke - k;
+#pragma unroll
+					for (int u = 0; u < G; ++u) {
+						const T next = smmFma(vv[u], xv[u], dot);
+						dot = u < nvalid ? next : dot;
+					}
 				}
 			}
 			// pieces of a row meet in LDS and are added left to right: ((p0 + p1) + p2) + p3
@@ -1452,6 +1483,15 @@ static int patBatch(const smm_hip_csr* m, int lanes) {
 	return g <= 8 ? 8 : g <= 13 ? 13 : 16;
 }
 
+// SMM_HIP_FULL_ROWS=0: the tile kernel's general path for every row (A/B measurements of the full-row fast path).  Read once.
+static int noFullRowsFlag() {
+	static const int flag = [] {
+		const char* env = getenv("SMM_HIP_FULL_ROWS");
+		return env && atoi(env) == 0 ? SPMV_NO_FULL_ROWS : 0;
+	}();
+	return flag;
+}
+
 template <typename T, int L, int G>
 static void launchPatTileG(const smm_hip_csr* m, int op, const T* lhs, const T* divisor, const T* x, T* out, int dotMode, const T* w1, T* partials,
                            const int* doneFlag, hipStream_t s) {
@@ -1468,8 +1508,8 @@ static void launchPatTileG(const smm_hip_csr* m, int op, const T* lhs, const T* 
 	const int chunkTiles = m->pat_chunk_tiles > 0 ? m->pat_chunk_tiles : (m->pat_n_rowblocks + nGroups - 1) / nGroups;
 	spmvPatternTileKernel<T, L, G><<<grid, TPB, lds, s>>>(m->pat_n_rowblocks, cap, chunkTiles, m->cols, m->pat_k, m->d_pat_off,
 	                                                     reinterpret_cast<const int2*>(m->d_pat_rowblocks), m->d_start, m->d_pat_masks, m->d_positions,
-	                                                     static_cast<const T*>(m->d_values), (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)), lhs, divisor, x, out,
-	                                                     dotMode, w1, partials, doneFlag);
+	                                                     static_cast<const T*>(m->d_values), (op & ~SPMV_LEAVE_ROOM) | spmvOutFlags(m, sizeof(T)) | noFullRowsFlag(), lhs,
+	                                                     divisor, x, out, dotMode, w1, partials, doneFlag);
 }
 
 template <typename T, int L>
