@@ -72,8 +72,9 @@ __device__ __forceinline__ T blockSum256(T v, T* lds4) {
 // Lane 0 of every workgroup must be the one that stored partials[k * npart + blockIdx.x]; workgroups have 256 threads; all of them must
 // call this (it contains barriers).
 // ---------------------------------------------------------------------------------------------------------
+// Returns (to every thread of the workgroup alike) whether THIS workgroup was the last one and formed the totals.
 template <typename T>
-__device__ __forceinline__ void lastBlockSums(T* partials, int npart, int nsets, T* totals, unsigned* ticket) {
+__device__ __forceinline__ bool lastBlockSums(T* partials, int npart, int nsets, T* totals, unsigned* ticket) {
 	__shared__ int sIsLast;
 	__shared__ T sRed[4];
 	if (threadIdx.x == 0) {
@@ -107,7 +108,7 @@ __device__ __forceinline__ void lastBlockSums(T* partials, int npart, int nsets,
 		sIsLast = last;
 	}
 	__syncthreads();
-	if (!sIsLast) return;
+	if (!sIsLast) return false;
 	for (int k = 0; k < nsets; ++k) {
 		T acc = T(0);
 		for (int i = threadIdx.x; i < npart; i += 256) {
@@ -117,6 +118,7 @@ __device__ __forceinline__ void lastBlockSums(T* partials, int npart, int nsets,
 		if (threadIdx.x == 0) totals[k] = s;
 	}
 	if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return true;
 }
 
 // out[] of an SpMV row with a RUN-TIME choice of the cache policy.  `if (nt) __builtin_nontemporal_store(...) else out[row] = ...` does

@@ -565,6 +565,7 @@ struct smm_hip_dist_csr {
 	unsigned long long landSeq[smm::P2P_KINDS] = {};
 	long long matvecsSplit = 0, matvecsTwo = 0;  // how many SpMVs with a halo ran in one launch / in two (smm_hip_dist_csr_matvec_forms)
 	bool splitAllowed = true;  // SMM_HIP_SPLIT_SPMV=0 at create time: this matrix keeps the two launches (A/B measurements, the bit-equality tests)
+	bool reducedInKernel = false;  // the SpMV just launched ran its reduction point itself (the one-launch form with the slots): allreduceTotals has nothing to do
 	int labWindow = 0;  // measurements on ONE GPU (SMM_HIP_LAB_SELF_SPLIT, single-rank communicator only): entries |column - row| >= window count as "remote"
 };
 
@@ -815,7 +816,10 @@ template <typename T>
 static int p2pSetup(smm_hip_dist_csr* D) {
 	smm_hip_comm* c = D->comm;
 	const int world = c->world, rank = c->rank;
-	if (world < 2 || world > P2P_MAX_WORLD) return SMM_HIP_OK;
+	// (SMM_HIP_LAB_SELF_P2P=1, single-rank communicator: the slots with ONE rank -- what a rank of a many-GPU run launches per iteration in this
+	// transport, measured on one GPU; tools/lab/rank_loop_streams.py)
+	const bool labSelf = world == 1 && c->kind == SMM_COMM_SELF && getenv("SMM_HIP_LAB_SELF_P2P") && atoi(getenv("SMM_HIP_LAB_SELF_P2P")) != 0;
+	if ((world < 2 && !labSelf) || world > P2P_MAX_WORLD) return SMM_HIP_OK;
 	// r06: ON unless a rank says SMM_HIP_P2P=0 -- the transport is taken whenever EVERY rank can allocate, export and map the blocks and passes
 	// the self-test below; anything less leaves all ranks with the communicator's collectives (read at every create, like SMM_HIP_HALO_CHUNKS)
 	const char* env = getenv("SMM_HIP_P2P");
@@ -1383,15 +1387,6 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 	auto& pend = D->pending;
 	pend = smm_hip_dist_csr::Pending{};
 	const bool exchange = !D->sends.empty() || !D->recvs.empty();
-	if (p2pHaloOn(D) && !exchange) {
-		// A rank that neither sends nor receives may still RELAY (planRelays picks by ring distance alone: a decoupled diagonal block in a
-		// world >= 3): its forwards must run, and its sequence numbers must advance, with every exchange of the peers -- r05 returned here
-		// before looking at nFwd, and every solve of such a world expired (ADVICE r05).  Nothing of `ext` is read or written: no ordering
-		// against `s`, no event for `s` to wait for, nothing pending.
-		hipStream_t cs = c->stream;
-		noteStream(cs);
-		return p2pHaloLaunch<T>(D, ext, kind, cs);
-	}
 	if (D->labWindow > 0 && !D->remEmpty) {
 		// one rank, "remote" entries by distance (measurements): nothing travels, but the word is raised from the communicator's stream behind
 		// the update -- the one-launch SpMV takes exactly the path it takes behind a real exchange
@@ -1409,6 +1404,15 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 		SMM_HIP_TRY(hipEventRecord(pend.landed[0], cs));
 		pend.waitSlot[0] = profWaitAwaited(cs);
 		return SMM_HIP_OK;
+	}
+	if (p2pHaloOn(D) && !exchange) {
+		// A rank that neither sends nor receives may still RELAY (planRelays picks by ring distance alone: a decoupled diagonal block in a
+		// world >= 3): its forwards must run, and its sequence numbers must advance, with every exchange of the peers -- r05 returned here
+		// before looking at nFwd, and every solve of such a world expired (ADVICE r05).  Nothing of `ext` is read or written: no ordering
+		// against `s`, no event for `s` to wait for, nothing pending.
+		hipStream_t cs = c->stream;
+		noteStream(cs);
+		return p2pHaloLaunch<T>(D, ext, kind, cs);
 	}
 	if (!exchange) return SMM_HIP_OK;
 	pend.active = true;
@@ -1468,7 +1472,7 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 
 template <typename T>
 static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s,
-                             const T* jacobiDiag = nullptr) {
+                             const T* jacobiDiag = nullptr, int slotPoint = -1) {
 	const T* own = ext + D->ownOffset;
 	auto& pend = D->pending;
 	const bool exchange = pend.active;
@@ -1487,9 +1491,27 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 	if (exchange && pend.landSeq != 0 && !D->remEmpty) {
 		SMM_TRY(ensureCsrReady(D->aLoc, s, true));
 		SMM_TRY(ensureCsrReady(D->aRem, s, true));
-		const int st = launchSpmvSplit<T>(D->aLoc, D->aRem, op, lhs, jacobiDiag, own, ext, out, dotMode, w1, parts, doneFlag, finish | (jacobiDiag ? SPMV_ADD_DIV : 0),
-		                                  D->splitSync + pend.kind, pend.landSeq, splitErrWord(D), p2pTicks(), s);
+		// peer-to-peer scalars: the launch finishes its dot products and runs their reduction point in its last workgroup (slotPoint: which one)
+		P2PSlotArgs slots{};
+		const bool fuseSlots = D->p2p && dotMode && slotPoint >= 0;
+		if (fuseSlots) {
+			P2PState* P = D->p2p;
+			slots.peers = P->peers;
+			slots.world = P->world;
+			slots.me = P->rank;
+			slots.point = slotPoint;
+			slots.count = dotMode == 2 ? 2 : 1;
+			slots.seq = P->redSeq[slotPoint] + 1;
+			slots.ticks = P->ticks;
+		}
+		const int st = launchSpmvSplit<T>(D->aLoc, D->aRem, op, lhs, jacobiDiag, own, ext, out, dotMode, w1, parts, doneFlag,
+		                                  (fuseSlots ? SPMV_FINISH : finish) | (jacobiDiag ? SPMV_ADD_DIV : 0), D->splitSync + pend.kind, pend.landSeq, splitErrWord(D),
+		                                  p2pTicks(), s, fuseSlots ? &slots : nullptr);
 		if (st == SMM_HIP_OK) {
+			if (fuseSlots) {
+				++D->p2p->redSeq[slotPoint];
+				D->reducedInKernel = true;
+			}
 			++D->matvecsSplit;
 			return SMM_HIP_OK;  // (the kernel itself waited for the halo: `s` needs no event of the communicator's stream)
 		}
@@ -1541,7 +1563,11 @@ template <typename T>
 static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t s, hipEvent_t* joined, int point = 0, const int* doneFlag = nullptr) {
 	smm_hip_comm* c = D->comm;
 	*joined = nullptr;
-	if (c->kind == SMM_COMM_SELF) return SMM_HIP_OK;
+	if (D->reducedInKernel) {  // (the one-launch SpMV in front ran this point in its last workgroup)
+		D->reducedInKernel = false;
+		return SMM_HIP_OK;
+	}
+	if (c->kind == SMM_COMM_SELF && !D->p2p) return SMM_HIP_OK;  // (one rank with the slots: the lab's SMM_HIP_LAB_SELF_P2P)
 	T* totals = parts + PARTS_TOTALS;
 	// peer to peer: ONE single-workgroup kernel on the solver's own stream writes this rank's totals into every rank's slot, waits for all
 	// slots of this sequence number and adds them in rank order (smm_p2p.h) -- no collective launch, no cross-stream events
@@ -1654,6 +1680,35 @@ __global__ __launch_bounds__(TPB) void distBicgR(int n, DistScal<T>* sc, const T
 	streamMap<T, false, 3, 1>(n, in, out, [&](const T(&v)[3], T(&o)[1]) {
 		const T ri = smmFma(-omega, v[1], v[0]);
 		o[0] = ri;
+		acc0 += ri * ri;
+		acc1 += ri * v[2];
+	});
+	const T s0 = blockSum256(acc0, red);
+	const T s1 = blockSum256(acc1, red);
+	if (threadIdx.x == 0) {
+		partsC[blockIdx.x] = s0;
+		partsC[NPART + blockIdx.x] = s1;
+	}
+}
+
+// The same with x = alpha p + (omega s + x) (ref:2264) folded in -- the single-GPU loop's bicgFusedXR: s is read once for both, one launch
+// instead of two.  Taken when the scalars go through the per-rank slots (the reduction behind this kernel is then a single-workgroup launch on
+// the solver's own stream: there is no side-stream collective for a separate x update to run beside).  Same expressions: same bits.
+template <typename T>
+__global__ __launch_bounds__(TPB) void distBicgRX(int n, DistScal<T>* sc, const T* __restrict__ totalsB, const T* sv, const T* as, const T* r0, const T* p, T* r,
+                                                  T* x, T* partsC) {
+	__shared__ T red[4];
+	if (sc->done) return;
+	const T omega = totalsB[1] / totalsB[0];
+	const T alpha = sc->alpha;
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->omega = omega;
+	T acc0 = T(0), acc1 = T(0);
+	const T* const in[5] = {sv, as, r0, p, x};
+	T* const out[2] = {r, x};
+	streamMap<T, false, 5, 2>(n, in, out, [&](const T(&v)[5], T(&o)[2]) {
+		const T ri = smmFma(-omega, v[1], v[0]);
+		o[0] = ri;
+		o[1] = smmFma(alpha, v[3], smmFma(omega, v[0], v[4]));
 		acc0 += ri * ri;
 		acc1 += ri * v[2];
 	});
@@ -1985,14 +2040,14 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 		const int par = i & 1;
 		// ap = [M^-1] A p ; ap.r0 (ref:2233-2243) -- the exchange of p was posted behind its update
 		if (jacobiDiag) {
-			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s, jacobiDiag));
+			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s, jacobiDiag, 0));
 		} else if (pre) {
 			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, ap, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, ap, r0, nullptr, 1, partsA, doneFlag);
 			if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsA, 1, partsA + PARTS_TOTALS, doneFlag);
 		} else {
-			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s));
+			SMM_TRY(distMatvecCompute<T>(D, pExt, SMM_OP_ASSIGN, nullptr, ap, 1, r0, partsA, doneFlag, s, nullptr, 0));
 		}
 		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
 		SMM_TRY(join(s, ev));
@@ -2001,21 +2056,26 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 		})));
 		// as = [M^-1] A s ; as.as, as.s (ref:2249-2261)
 		if (jacobiDiag) {
-			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s, jacobiDiag));
+			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s, jacobiDiag, 1));
 		} else if (pre) {
 			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, scratch, 0, nullptr, nullptr, doneFlag, s));
 			SMM_TRY(precondApplyDev<T>(M, scratch, as, doneFlag, s));
 			distDots<T><<<NPART, TPB, 0, s>>>(n, as, as, sv, 2, partsB, doneFlag);
 			if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsB, 2, partsB + PARTS_TOTALS, doneFlag);
 		} else {
-			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s));
+			SMM_TRY(distMatvecCompute<T>(D, sExt, SMM_OP_ASSIGN, nullptr, as, 2, sv, partsB, doneFlag, s, nullptr, 1));
 		}
 		SMM_TRY(allreduceTotals<T>(D, partsB, 2, s, &ev, 1, doneFlag));
 		SMM_TRY(join(s, ev));
-		distBicgR<T><<<NPART, TPB, 0, s>>>(n, sc, partsB + PARTS_TOTALS, sv, as, r0, r, partsC);
-		if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 2, partsC + PARTS_TOTALS, doneFlag);
-		SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev, 2, doneFlag));  // (the communicator's collectives: on the side stream ...
-		distBicgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, sv, x);         // ... while x is updated)
+		if (D->p2p) {
+			distBicgRX<T><<<NPART, TPB, 0, s>>>(n, sc, partsB + PARTS_TOTALS, sv, as, r0, p, r, x, partsC);  // (r and x in one pass over s)
+			SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev, 2, doneFlag));
+		} else {
+			distBicgR<T><<<NPART, TPB, 0, s>>>(n, sc, partsB + PARTS_TOTALS, sv, as, r0, r, partsC);
+			distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 2, partsC + PARTS_TOTALS, doneFlag);
+			SMM_TRY(allreduceTotals<T>(D, partsC, 2, s, &ev, 2, doneFlag));  // (the communicator's collectives: on the side stream ...
+			distBicgX<T><<<gridFor(n), TPB, 0, s>>>(n, sc, p, sv, x);         // ... while x is updated)
+		}
 		SMM_TRY(join(s, ev));
 		if (i + 1 < planned) {
 			SMM_TRY((updateThenExchange<T>(D, pExt, 0, s, [&](const RowRanges& rg, int book) {
@@ -2109,7 +2169,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		T* const curExt = ringExt[cur];
 		T* const pc = ring.p[cur];
 		if (i == 0) SMM_TRY(distExchangeBegin<T>(D, curExt, 0, s));  // (later passes: posted behind the update of p)
-		SMM_TRY(distMatvecCompute<T>(D, curExt, SMM_OP_ASSIGN, nullptr, ap, 1, pc, partsA, doneFlag, s));  // Ap = A p ; p.Ap, ref:2353-2354
+		SMM_TRY(distMatvecCompute<T>(D, curExt, SMM_OP_ASSIGN, nullptr, ap, 1, pc, partsA, doneFlag, s, nullptr, 0));  // Ap = A p ; p.Ap, ref:2353-2354
 		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
 		SMM_TRY(join(s, ev));
 		SMM_DIST_UPDATE(distCgR, nt3, NPART, s, n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC, i % LAZY_M);

@@ -257,7 +257,7 @@ constexpr int SPMV_OP_ADD_DIV = 4;
 // streams' request sets and fits three workgroups per CU only with half tiles (512^3 fp32: 0.95 -> 0.83 ms per iteration, fp64 1.71 -> 1.67); the partial sums of
 // p.Ap follow the tiles, so EVERY loop form of CG uses the same tiles and they stay bit for bit equal.  Other kernels ignore the flag.
 constexpr int SPMV_HALF_TILES = 0x2000;
-// kernel-side (spmvPatternTileKernel): no fast path for wavefronts whose rows all hold every offset (SMM_HIP_FULL_ROWS=0, measurements)
+// kernel-side (spmvPatternTileKernel): no fast path for wavefronts whose 64 rows all hold the same offsets (SMM_HIP_FULL_ROWS=0, measurements)
 constexpr int SPMV_NO_FULL_ROWS = 0x4000;
 constexpr int PARTS_TOTALS = 2 * NPART;    // index of the two totals inside a finishing buffer
 constexpr int PARTS_TICKETS = 16;             // sub-counters of the "last workgroup" ticket (lastBlockSums, smm_device.h)
@@ -359,7 +359,7 @@ void chooseSpmvConfig(smm_hip_csr* m);
 template <typename T>
 int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, const T* lhs, const T* divisor, const T* own, const T* ext, T* out, int dotMode,
                     const T* w1, T* partials, const int* doneFlag, int extraFlags, const unsigned long long* landed, unsigned long long seq, unsigned long long* err,
-                    long long ticks, hipStream_t s);
+                    long long ticks, hipStream_t s, const struct P2PSlotArgs* slots = nullptr);  // slots (smm_p2p.h): the launch runs the reduction point of its dot products itself
 void launchSplitSignal(unsigned long long* landed, unsigned long long seq, hipStream_t s);
 void preloadSplitUnit();
 // ConjugateGradient's next direction formed in the SpMV's load phase (smm_spmv_march.hip, MarchFuse): Ap = A (beta pOld + r), the new

@@ -181,37 +181,31 @@ __global__ __launch_bounds__(P2P_TPB) void p2pLandKernel(const P2PLandSeg* __res
 struct P2PPeers {
 	P2PHeader* hdr[P2P_MAX_WORLD];
 };
-// parts != nullptr: the rank's own totals are first formed HERE from the npart partials per quantity the producing kernel left behind --
-// in the order of lastBlockSums / distFinishSums (i = t, t + 256, ...; then blockSum256): the same bits -- so that in the peer-to-peer
-// transport neither the SpMV kernels finish their sums nor a finishing launch runs (r05: ~12 us per BiCGStab iteration).
+
+// what a kernel needs to run a reduction point itself (world == 0: it does not)
+struct P2PSlotArgs {
+	P2PPeers peers;
+	int world, me, point, count;
+	unsigned long long seq;
+	long long ticks;
+};
+
+// The exchange itself, by ALL P2P_TPB threads of ONE workgroup: mine[0 .. count) (shared or global memory, complete and visible to the
+// workgroup) goes into this rank's slot in EVERY rank's block with the sequence number; every rank's slot of that number is awaited
+// (bounded) and the values are added in rank order -- the same order, hence the same bits, on every rank -- into totals[0 .. count).
 template <typename T>
-__global__ __launch_bounds__(P2P_TPB) void p2pAllreduceKernel(P2PPeers peers, int world, int me, int point, unsigned long long seq, int count, T* totals,
-                                                             const T* __restrict__ parts, int npart, long long ticks, const int* __restrict__ doneFlag) {
+__device__ __forceinline__ void p2pSlotExchange(const P2PPeers& peers, int world, int me, int point, unsigned long long seq, int count, const T* mine, T* totals,
+                                                long long ticks) {
 	__shared__ unsigned long long sBits[P2P_MAX_WORLD][2];
 	__shared__ int sOk;
-	__shared__ T sRed[4];
-	__shared__ T sMine[2];
-	// (no early return on `done`: every rank must publish for every reduction the others may still be waiting in; the totals of a finished
-	// solve are simply not used)
-	(void)doneFlag;
 	const int t = threadIdx.x;
 	const int par = static_cast<int>(seq & 1ull);
 	if (t == 0) sOk = 1;
-	for (int k = 0; k < count; ++k) {
-		if (parts) {
-			T acc = T(0);
-			for (int i = t; i < npart; i += P2P_TPB) acc += parts[k * npart + i];
-			const T sum = blockSum256(acc, sRed);
-			if (t == 0) sMine[k] = sum;
-		} else if (t == 0) {
-			sMine[k] = totals[k];
-		}
-	}
 	__syncthreads();
 	if (t < world) {
 		unsigned long long b[2] = {0ull, 0ull};
 		for (int k = 0; k < count; ++k) {
-			T v = sMine[k];
+			T v = mine[k];
 			__builtin_memcpy(&b[k], &v, sizeof(T));
 		}
 		P2PSlot* slot = &peers.hdr[t]->slot[point][par][me];
@@ -221,9 +215,9 @@ __global__ __launch_bounds__(P2P_TPB) void p2pAllreduceKernel(P2PPeers peers, in
 		p2pStore(&slot->seq, seq);
 	}
 	if (t < world) {
-		P2PHeader* mine = peers.hdr[me];
-		P2PSlot* slot = &mine->slot[point][par][t];
-		if (!p2pWaitGe(&slot->seq, seq, mine, ticks, 0x4000u | (point << 8) | t)) sOk = 0;
+		P2PHeader* own = peers.hdr[me];
+		P2PSlot* slot = &own->slot[point][par][t];
+		if (!p2pWaitGe(&slot->seq, seq, own, ticks, 0x4000u | (point << 8) | t)) sOk = 0;
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 		sBits[t][0] = p2pLoad(&slot->bits[0]);
 		sBits[t][1] = p2pLoad(&slot->bits[1]);
@@ -238,6 +232,34 @@ __global__ __launch_bounds__(P2P_TPB) void p2pAllreduceKernel(P2PPeers peers, in
 		}
 		totals[t] = acc;
 	}
+}
+
+// parts != nullptr: the rank's own totals are first formed HERE from the npart partials per quantity the producing kernel left behind --
+// in the order of lastBlockSums / distFinishSums (i = t, t + 256, ...; then blockSum256): the same bits -- so that in the peer-to-peer
+// transport neither the update kernels finish their sums nor a finishing launch runs (r05: ~12 us per BiCGStab iteration).  (r06: the
+// one-launch SpMV finishes its sums AND runs this exchange in its last workgroup -- P2PSlotArgs --, so two of BiCGStab's three points are no
+// launch at all.)
+template <typename T>
+__global__ __launch_bounds__(P2P_TPB) void p2pAllreduceKernel(P2PPeers peers, int world, int me, int point, unsigned long long seq, int count, T* totals,
+                                                             const T* __restrict__ parts, int npart, long long ticks, const int* __restrict__ doneFlag) {
+	__shared__ T sRed[4];
+	__shared__ T sMine[2];
+	// (no early return on `done`: every rank must publish for every reduction the others may still be waiting in; the totals of a finished
+	// solve are simply not used)
+	(void)doneFlag;
+	const int t = threadIdx.x;
+	for (int k = 0; k < count; ++k) {
+		if (parts) {
+			T acc = T(0);
+			for (int i = t; i < npart; i += P2P_TPB) acc += parts[k * npart + i];
+			const T sum = blockSum256(acc, sRed);
+			if (t == 0) sMine[k] = sum;
+		} else if (t == 0) {
+			sMine[k] = totals[k];
+		}
+	}
+	__syncthreads();
+	p2pSlotExchange<T>(peers, world, me, point, seq, count, sMine, totals, ticks);
 }
 
 }  // namespace smm

@@ -57,6 +57,13 @@ __device__ __forceinline__ int selectBit(unsigned long long m, int k) {
 	return pos;
 }
 
+// lane 0's value of a 64-bit quantity, as a wave-uniform (scalar) number
+__device__ __forceinline__ unsigned long long patUniform64(unsigned long long v) {
+	const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+	const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+	return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 // A row straight from HBM (tiles that are not staged: the last ones of a matrix, rows longer than a tile), in the PIECE structure of the
 // staged path: L chains over ceil(len / L) consecutive entries each, added left to right -- the bits of the tile kernels' lanes whatever
 // the tile cut (r06: r02-r05 walked such rows as ONE chain, so the last ~cap entries of a matrix had the one-lane bits at every L, and two

@@ -419,9 +419,6 @@ __global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap
 	const int piece = wave % L;
 	const int rl = (wave / L) * 64 + lane;
 	const int nv = (cap + Cfg::PIECE - 1) / Cfg::PIECE;
-	// (0: the fast path for full rows is off -- SPMV_NO_FULL_ROWS, measurements)
-	const unsigned long long fullMask = (opFlags & SPMV_NO_FULL_ROWS) ? 0ULL : nOff >= 64 ? ~0ULL : (1ULL << nOff) - 1ULL;
-	const int offLane = lane < nOff ? offs[lane] : 0;  // (offset j in lane j of every wavefront: the full-row path reads it with v_readlane)
 	T acc0 = T(0), acc1 = T(0);
 	for (int i = t; i < cap + Cfg::PAD; i += TPB) sVal[i] = T(0);
 	if (t < MAXOFF) sOff[t] = t < nOff ? offs[t] : 0;
@@ -516,26 +513,30 @@ __global__ __launch_bounds__(TPB) void spmvPatternTileKernel(int nTiles, int cap
 				ke = min(e, kb + piecelen);
 				mm = sMask[rl];
 			}
-			// FULL rows (r06): when every row of this wavefront holds every offset -- the interior of a band: four rows in five of the benchmark
-			// matrix -- entry e of a row IS offset e, for every lane alike.  The column of an entry then needs no bit scan, no clamp and no
-			// per-lane address arithmetic: the offset is a wave-uniform number (a scalar load of offs[]), the gather a load at
-			// (x + offset) [scalar base] + 4 row [one vector register, formed once per tile].  The general path below spends ~15 vector
-			// instructions per entry on exactly that.  Same products in the same order: the same bits.
-			const bool fullWave = fullMask != 0ULL && __builtin_amdgcn_ballot_w64(!(rl < nrows && mm == fullMask)) == 0ULL;
-			if (fullWave) {
+			// UNIFORM rows (r06): when the 64 rows of this wavefront all hold the SAME offsets -- everywhere in a band except where a diagonal
+			// enters or leaves the matrix (or a rank's column range) -- entry e of a row is the same offset for every lane.  The column of an
+			// entry then needs no per-lane bit scan, clamp or address arithmetic: the piece's offsets are looked up ONCE per tile (lane u: the u-th),
+			// an entry's offset comes out of that vector register with v_readlane, the gather is a load at (x + offset) + 4 row [one 64-bit add].
+			// The general path below spends ~15 vector instructions per entry on exactly that.  Same products in the same order: the same bits.
+			const unsigned long long lead = patUniform64(mm);
+			const bool uniform = !(opFlags & SPMV_NO_FULL_ROWS) && __builtin_amdgcn_ballot_w64(!(rl < nrows && mm == lead)) == 0ULL;
+			if (uniform) {
+				const int len = __builtin_popcountll(lead);
+				const int pl = (len + L - 1) / L;
 				const int pu = __builtin_amdgcn_readfirstlane(piece);
-				const int pl = (nOff + L - 1) / L;
-				const int e0 = pu * pl, e1 = min(nOff, e0 + pl);
-				const unsigned rowBytes = static_cast<unsigned>(row) * static_cast<unsigned>(sizeof(T));
-				for (int e = e0; e < e1; e += G) {
+				const int e0 = pu * pl, cnt = max(0, min(len, e0 + pl) - e0);
+				// lane u of the wavefront looks up the offset of the piece's u-th entry ONCE per tile (a piece has at most 64 entries); the loop below
+				// then reads it with v_readlane at a wave-uniform index: no per-entry bit scan at all
+				const int offPiece = sOff[lane < cnt ? selectBit(lead, e0 + lane) : 0];
+				const T* const xr = x + row;
+				for (int e = 0; e < cnt; e += G) {
 					T xv[G], vv[G];
-					const int nvalid = e1 - e;  // (wave-uniform)
+					const int nvalid = cnt - e;  // (wave-uniform)
 #pragma unroll
 					for (int u = 0; u < G; ++u) {
 						// entries past the end of the piece repeat its last (valid) column; their products are discarded
-						const int o = __builtin_amdgcn_readlane(offLane, min(e + u, e1 - 1));
-						xv[u] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x + o) + rowBytes);
-						vv[u] = sVal[kb + (e - e0) + u];
+						xv[u] = xr[__builtin_amdgcn_readlane(offPiece, min(e + u, cnt - 1))];
+						vv[u] = sVal[kb + e + u];
 					}
 #pragma unroll
 					for (int u = 0; u < G; ++u) {
@@ -1483,7 +1484,7 @@ static int patBatch(const smm_hip_csr* m, int lanes) {
 	return g <= 8 ? 8 : g <= 13 ? 13 : 16;
 }
 
-// SMM_HIP_FULL_ROWS=0: the tile kernel's general path for every row (A/B measurements of the full-row fast path).  Read once.
+// SMM_HIP_FULL_ROWS=0: the tile kernel's general path for every row (A/B measurements of the fast path for wavefronts of uniform rows).  Read once.
 static int noFullRowsFlag() {
 	static const int flag = [] {
 		const char* env = getenv("SMM_HIP_FULL_ROWS");

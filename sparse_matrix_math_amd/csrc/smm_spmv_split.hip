@@ -29,6 +29,7 @@
 
 #include "smm_device.h"
 #include "smm_internal.h"
+#include "smm_p2p.h"
 #include "smm_pattern_dev.h"
 
 namespace smm {
@@ -63,6 +64,7 @@ struct SplitArgs {
 	unsigned long long seq;
 	unsigned long long* err;
 	long long ticks;
+	P2PSlotArgs slots;  // world != 0 (peer-to-peer scalars, dotMode != 0, SPMV_FINISH): the last workgroup runs the reduction point itself
 };
 
 template <typename T>
@@ -203,28 +205,57 @@ __device__ __forceinline__ void splitPhase(const SplitSide<T>& M, int rows, int 
 				kb = b + piece * piecelen;
 				ke = min(e, kb + piecelen);
 				mm = sMask[rl];
-				// this piece starts at the (kb - b)-th entry of the row = the (kb - b)-th set bit of the mask
-				if (piece > 0 && kb < ke) mm &= ~0ULL << selectBit(mm, kb - b);
 			}
-			for (int k = kb; k < ke; k += G) {
-				unsigned off[G];
-				T xv[G], vv[G];
+			const unsigned long long rowMask = mm;
+			// wavefronts whose 64 rows all hold the SAME offsets (everywhere but where a diagonal enters or leaves the rank's column range):
+			// spmvPatternTileKernel's fast path
+			const unsigned long long lead = patUniform64(rowMask);
+			if (__builtin_amdgcn_ballot_w64(!(rl < cnrows && rowMask == lead)) == 0ULL) {
+				const int len = __builtin_popcountll(lead);
+				const int pl = (len + L - 1) / L;
+				const int pu = __builtin_amdgcn_readfirstlane(piece);
+				const int e0 = pu * pl, cnt = max(0, min(len, e0 + pl) - e0);
+				// lane u of the wavefront looks up the offset of the piece's u-th entry ONCE per tile (a piece has at most 64 entries); the loop below
+				// then reads it with v_readlane at a wave-uniform index: no per-entry bit scan at all
+				const int offPiece = sOff[lane < cnt ? selectBit(lead, e0 + lane) : 0];
+				const unsigned rowBytes = static_cast<unsigned>(row) * static_cast<unsigned>(sizeof(T));
+				for (int e = 0; e < cnt; e += G) {
+					T xv[G], vv[G];
+					const int nvalid = cnt - e;  // (wave-uniform)
 #pragma unroll
-				for (int u = 0; u < G; ++u) {
-					const int jj = mm ? __builtin_ctzll(mm) : 0;
-					mm &= mm - 1;
-					// entries past the end of the piece get a clamped, valid column; their products are discarded
-					const int col = min(max(row + sOff[jj], 0), M.cols - 1);
-					off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
-					vv[u] = sVal[k + u];
+					for (int u = 0; u < G; ++u) {
+						// entries past the end of the piece repeat its last (valid) column; their products are discarded
+						xv[u] = splitGather<T>(x + __builtin_amdgcn_readlane(offPiece, min(e + u, cnt - 1)), rowBytes, REMOTE);
+						vv[u] = sVal[kb + e + u];
+					}
+#pragma unroll
+					for (int u = 0; u < G; ++u) {
+						if (u < nvalid) dot = smmFma(vv[u], xv[u], dot);
+					}
 				}
+			} else {
+				// this piece starts at the (kb - b)-th entry of the row = the (kb - b)-th set bit of the mask
+				if (rl < cnrows && piece > 0 && kb < ke) mm &= ~0ULL << selectBit(mm, kb - sStart[rl]);
+				for (int k = kb; k < ke; k += G) {
+					unsigned off[G];
+					T xv[G], vv[G];
 #pragma unroll
-				for (int u = 0; u < G; ++u) xv[u] = splitGather<T>(x, off[u], REMOTE);
-				const int nvalid = ke - k;
+					for (int u = 0; u < G; ++u) {
+						const int jj = mm ? __builtin_ctzll(mm) : 0;
+						mm &= mm - 1;
+						// entries past the end of the piece get a clamped, valid column; their products are discarded
+						const int col = min(max(row + sOff[jj], 0), M.cols - 1);
+						off[u] = static_cast<unsigned>(col) * static_cast<unsigned>(sizeof(T));
+						vv[u] = sVal[k + u];
+					}
 #pragma unroll
-				for (int u = 0; u < G; ++u) {
-					const T next = smmFma(vv[u], xv[u], dot);
-					dot = u < nvalid ? next : dot;
+					for (int u = 0; u < G; ++u) xv[u] = splitGather<T>(x, off[u], REMOTE);
+					const int nvalid = ke - k;
+#pragma unroll
+					for (int u = 0; u < G; ++u) {
+						const T next = smmFma(vv[u], xv[u], dot);
+						dot = u < nvalid ? next : dot;
+					}
 				}
 			}
 			if constexpr (L > 1) {
@@ -280,7 +311,15 @@ __global__ __launch_bounds__(TPB) void spmvPatternSplitKernel(const SplitArgs<T>
 	T* sLoc = sPart + ((PARTS + 1) & ~1);
 	T* red = sLoc + static_cast<size_t>(A.K) * SUPER;
 	int* sGo = reinterpret_cast<int*>(red + 4);
-	if (A.doneFlag && *A.doneFlag) return;
+	if (A.doneFlag && *A.doneFlag) {
+		// (a finished solve's launches are no-ops -- except the reduction point this launch carries: every rank publishes for every point, the slots
+		// are double-buffered by the parity of a sequence number that must not skip; the values are never used)
+		if (A.slots.world && blockIdx.x == 0) {
+			p2pSlotExchange<T>(A.slots.peers, A.slots.world, A.slots.me, A.slots.point, A.slots.seq, A.slots.count, A.partials + PARTS_TOTALS, A.partials + PARTS_TOTALS,
+			                   A.slots.ticks);
+		}
+		return;
+	}
 
 	const int t = threadIdx.x;
 	for (int i = t; i < capMax + Cfg::PAD; i += TPB) sVal[i] = T(0);
@@ -323,7 +362,13 @@ __global__ __launch_bounds__(TPB) void spmvPatternSplitKernel(const SplitArgs<T>
 			*sGo = go;
 		}
 		__syncthreads();
-		if (!*sGo) return;  // (the host finds the error word where it reads `done`: the solve fails with SMM_HIP_ERR_COMM)
+		if (!*sGo) {  // (the host finds the error word where it reads `done`: the solve fails with SMM_HIP_ERR_COMM; the peers' waits are released all the same)
+			if (A.slots.world && blockIdx.x == 0) {
+				p2pSlotExchange<T>(A.slots.peers, A.slots.world, A.slots.me, A.slots.point, A.slots.seq, A.slots.count, A.partials + PARTS_TOTALS,
+				                   A.partials + PARTS_TOTALS, A.slots.ticks);
+			}
+			return;
+		}
 	}
 	// ---- phase 2: the remote block; out[] is written once, the solver's dot products ride along
 	T acc0 = T(0), acc1 = T(0);
@@ -344,7 +389,15 @@ __global__ __launch_bounds__(TPB) void spmvPatternSplitKernel(const SplitArgs<T>
 			A.partials[i] = T(0);
 			if (A.dotMode == 2) A.partials[NPART + i] = T(0);
 		}
-		if (A.opFlags & SPMV_FINISH) lastBlockSums<T>(A.partials, NPART, A.dotMode == 2 ? 2 : 1, A.partials + PARTS_TOTALS, partsTicket(A.partials));
+		if (A.opFlags & SPMV_FINISH) {
+			const bool last = lastBlockSums<T>(A.partials, NPART, A.dotMode == 2 ? 2 : 1, A.partials + PARTS_TOTALS, partsTicket(A.partials));
+			// the peer-to-peer transport's reduction point, by the workgroup that has just formed this rank's totals: no launch of its own
+			if (last && A.slots.world) {
+				__syncthreads();
+				p2pSlotExchange<T>(A.slots.peers, A.slots.world, A.slots.me, A.slots.point, A.slots.seq, A.slots.count, A.partials + PARTS_TOTALS,
+				                   A.partials + PARTS_TOTALS, A.slots.ticks);
+			}
+		}
 	}
 }
 
@@ -489,7 +542,7 @@ static int launchSplitL(const SplitArgs<T>& base, int cus, hipStream_t s) {
 template <typename T>
 int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, const T* lhs, const T* divisor, const T* own, const T* ext, T* out, int dotMode,
                     const T* w1, T* partials, const int* doneFlag, int extraFlags, const unsigned long long* landed, unsigned long long seq, unsigned long long* err,
-                    long long ticks, hipStream_t s) {
+                    long long ticks, hipStream_t s, const P2PSlotArgs* slots) {
 	const int LA = splitLanes(aLoc), LB = splitLanes(aRem);
 	if (!LA || !LB || aLoc->rows != aRem->rows) return 1;
 	if (aLoc->dtype != dtypeOf<T>() || aRem->dtype != dtypeOf<T>()) return 1;
@@ -529,6 +582,7 @@ int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, co
 	a.seq = seq;
 	a.err = err;
 	a.ticks = ticks;
+	if (slots && dotMode && (extraFlags & SPMV_FINISH)) a.slots = *slots;
 	// the exchange is itself a few workgroups (the land kernel, the peers' pushes, an RCCL kernel) that must find room beside this grid while it
 	// waits for them: one CU per XCD's worth of slots stays free
 	const int cus = landed ? std::max(8, numCUs() - 8) : numCUs();
@@ -546,9 +600,9 @@ int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, co
 }
 
 template int launchSpmvSplit<float>(const smm_hip_csr*, const smm_hip_csr*, int, const float*, const float*, const float*, const float*, float*, int, const float*, float*,
-                                    const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t);
+                                    const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*);
 template int launchSpmvSplit<double>(const smm_hip_csr*, const smm_hip_csr*, int, const double*, const double*, const double*, const double*, double*, int, const double*,
-                                     double*, const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t);
+                                     double*, const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*);
 
 void preloadSplitUnit() {
 	hipFuncAttributes attr;

@@ -34,7 +34,8 @@ torch.cuda.synchronize()
 own = torch.cuda.Stream(device=dev)
 
 
-def dist_matrix(win, split):
+def dist_matrix(win, split, slots=False):
+    os.environ["SMM_HIP_LAB_SELF_P2P"] = "1" if slots else "0"  # the scalars through the (one-rank) slots: the peer-to-peer transport's launches
     os.environ["SMM_HIP_LAB_SELF_SPLIT"] = str(win)
     os.environ["SMM_HIP_SPLIT_SPMV"] = "1" if split else "0"
     D = NativeDistMatrix(comm, n, [0, n], ds, dp, dv, np.float32)
@@ -50,6 +51,7 @@ legs = [("row-partitioned, unsplit", dist_matrix(0, True))]
 if window > 0:
     legs.append(("row-partitioned, A_loc / A_rem in ONE launch", dist_matrix(window, True)))
     legs.append(("row-partitioned, A_loc / A_rem in TWO launches", dist_matrix(window, False)))
+    legs.append(("row-partitioned, ONE launch, scalars through the slots (the peer-to-peer transport's launches)", dist_matrix(window, True, slots=True)))
 legs.append(("single-GPU", None))
 results = {}
 for name, st in (("own stream", own.cuda_stream),) if window > 0 else (("NULL stream", s0), ("own stream", own.cuda_stream)):
@@ -67,7 +69,7 @@ for name, st in (("own stream", own.cuda_stream),) if window > 0 else (("NULL st
         extra = ""
         if D is not None:
             one, two = D.matvec_forms()
-            extra = f"; nnz A_loc {D.nnz_loc} ({100.0 * D.nnz_loc / max(1, D.nnz_loc + D.nnz_rem):.0f} %), A_rem {D.nnz_rem}; SpMVs in one launch {one}, in two {two}"
+            extra = f"; options {D.options['p2p_scalars']}; nnz A_loc {D.nnz_loc} ({100.0 * D.nnz_loc / max(1, D.nnz_loc + D.nnz_rem):.0f} %), A_rem {D.nnz_rem}; SpMVs in one launch {one}, in two {two}"
         print(f"{name}, {kind}: {best / 20 * 1e6:.1f} us per iteration (solves of 20 iterations, best of 8){extra}", flush=True)
 if window > 0:
     a, c = results["row-partitioned, A_loc / A_rem in ONE launch"], results["row-partitioned, A_loc / A_rem in TWO launches"]
