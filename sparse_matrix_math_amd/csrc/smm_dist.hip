@@ -806,7 +806,7 @@ static int p2pAllAgree(smm_hip_comm* c, bool mine, bool* all) {
 template <typename T>
 static int p2pHaloLaunch(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t cs);
 template <typename T>
-static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long long seq, hipStream_t s);
+static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long long seq, hipStream_t s, unsigned long long* word = nullptr, unsigned long long wordSeq = 0);
 template <typename T>
 static int p2pAllreduceLaunch(smm_hip_dist_csr* D, int point, T* totals, int count, const int* doneFlag, hipStream_t s, const T* parts = nullptr);
 
@@ -999,7 +999,7 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 		};
 		// (a failure here must not return: the other ranks are about to vote, and a rank that left would leave them alone in the collective)
 		void* cnt = nullptr;
-		const size_t nCounters = static_cast<size_t>(std::max(1, P->nPush + P->nFwd + P->nLand));
+		const size_t nCounters = static_cast<size_t>(P->nPush + P->nFwd + P->nLand + 1);  // (+ 1: finished segments of a land launch)
 		if (upload(push, &P->d_push) != SMM_HIP_OK || upload(fwd, &P->d_fwd) != SMM_HIP_OK || upload(land, &P->d_land) != SMM_HIP_OK ||
 		    devAlloc(&cnt, nCounters * sizeof(unsigned)) != SMM_HIP_OK || hipMemset(cnt, 0, nCounters * sizeof(unsigned)) != hipSuccess) {
 			(void)hipGetLastError();
@@ -1116,11 +1116,15 @@ static int p2pHaloLaunch(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t cs) 
 }
 
 template <typename T>
-static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long long seq, hipStream_t s) {
+static int p2pLandLaunch(smm_hip_dist_csr* D, T* ext, int kind, unsigned long long seq, hipStream_t s, unsigned long long* word, unsigned long long wordSeq) {
 	P2PState* P = D->p2p;
-	if (P->nLand == 0) return SMM_HIP_OK;
+	if (P->nLand == 0) {
+		if (word) launchSplitSignal(word, wordSeq, s);  // (nothing lands here, yet a launch is waiting for the word)
+		return SMM_HIP_OK;
+	}
 	const T* landing = reinterpret_cast<const T*>(static_cast<char*>(P->block) + P->landOff[kind]);
-	p2pLandKernel<T><<<dim3(16, static_cast<unsigned>(P->nLand)), P2P_TPB, 0, s>>>(P->d_land, P->d_counters + P->nPush + P->nFwd, landing, ext, kind, seq, P->hdr(), P->ticks);
+	p2pLandKernel<T><<<dim3(16, static_cast<unsigned>(P->nLand)), P2P_TPB, 0, s>>>(P->d_land, P->d_counters + P->nPush + P->nFwd, landing, ext, kind, seq, P->hdr(), P->ticks,
+	                                                                               word, wordSeq, P->d_counters + P->nPush + P->nFwd + P->nLand);
 	SMM_HIP_TRY(hipGetLastError());
 	return SMM_HIP_OK;
 }
@@ -1425,11 +1429,9 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 		pend.seq = D->p2p->haloSeq[kind];
 		// the land kernel (waits for every part of every segment, then landing area -> halo of `ext`) runs on the side stream as well, beside
 		// the local block: the solver's stream only waits for its event, as it waits for a collective exchange
-		SMM_TRY(p2pLandLaunch<T>(D, ext, kind, pend.seq, cs));
-		if (splitWordWanted(D)) {  // (behind the land kernel: its copies are complete -- and written back -- when this one-lane launch starts)
-			pend.landSeq = ++D->landSeq[kind];
-			launchSplitSignal(D->splitSync + kind, pend.landSeq, cs);
-		}
+		// (r06: the land kernel raises the word the one-launch SpMV polls itself -- write-through stores, drained, then the word: no launch behind it)
+		if (splitWordWanted(D)) pend.landSeq = ++D->landSeq[kind];
+		SMM_TRY(p2pLandLaunch<T>(D, ext, kind, pend.seq, cs, pend.landSeq ? D->splitSync + kind : nullptr, pend.landSeq));
 		pend.landed[0] = takeEvent(c);
 		SMM_HIP_TRY(hipEventRecord(pend.landed[0], cs));
 		pend.waitSlot[0] = profWaitAwaited(cs);

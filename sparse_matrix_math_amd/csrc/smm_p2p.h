@@ -105,7 +105,11 @@ __device__ __forceinline__ bool p2pWaitGe(const unsigned long long* word, unsign
 
 // ---- copies: grid (P2P_BLOCKS_PER_JOB, jobs); the last workgroup of a job to finish publishes the job's flag -----------------------------
 // (16-byte accesses at element alignment on both sides: gfx950 global accesses may be unaligned; the pieces are a few MB)
-template <typename T>
+// WT (the land kernel): the destination -- the halo of the cached vector -- is stored WRITE-THROUGH (sc1: the bytes leave this XCD's L2 at once),
+// because the land kernel itself raises the word the one-launch SpMV polls, in the same launch: that kernel's workgroups, on every XCD, read the
+// halo with sc1 loads as soon as they see the word (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores, every storing wave drained,
+// then the flag).  16-byte accesses at element alignment either way.
+template <typename T, bool WT = false>
 __device__ __forceinline__ void p2pCopyPiece(const T* __restrict__ src, T* __restrict__ dst, int count, int part, int parts, bool coherentLoads) {
 	constexpr int VEC = 16 / sizeof(T);
 	typedef T V __attribute__((ext_vector_type(VEC)));
@@ -118,9 +122,18 @@ __device__ __forceinline__ void p2pCopyPiece(const T* __restrict__ src, T* __res
 		// (staging / landing areas are fine-grained memory written by another device and read once: streamed past the caches)
 		if (coherentLoads) v = __builtin_nontemporal_load(sp);
 		else v = *sp;
-		*reinterpret_cast<U*>(dst + lo + i * VEC) = v;
+		if constexpr (WT) {
+			const V w = v;
+			asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + lo + i * VEC), "v"(w) : "memory");
+		} else {
+			*reinterpret_cast<U*>(dst + lo + i * VEC) = v;
+		}
 	}
-	for (long long i = lo + nvec * VEC + threadIdx.x; i < hi; i += blockDim.x) dst[i] = coherentLoads ? __builtin_nontemporal_load(src + i) : src[i];
+	for (long long i = lo + nvec * VEC + threadIdx.x; i < hi; i += blockDim.x) {
+		const T v = coherentLoads ? __builtin_nontemporal_load(src + i) : src[i];
+		if constexpr (WT) __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else dst[i] = v;
+	}
 }
 
 // kind: which vector; seq: this exchange's sequence number.  jobs[blockIdx.y]; counters[blockIdx.y] counts finished workgroups (left at 0).
@@ -152,9 +165,12 @@ __global__ __launch_bounds__(P2P_TPB) void p2pCopyKernel(const P2PJob* __restric
 }
 
 // the destination: wait for every part of every segment, then landing area -> halo of the cached vector.  grid (blocks, segments)
+// word != nullptr (the one-launch SpMV is waiting, smm_spmv_split.hip): the workgroup that ends the LAST segment raises *word to wordSeq --
+// `total` counts finished segments (left at 0) -- so the halo path has no further launch behind this one.
 template <typename T>
 __global__ __launch_bounds__(P2P_TPB) void p2pLandKernel(const P2PLandSeg* __restrict__ segs, unsigned* counters, const T* landing, T* ext, int kind,
-                                                        unsigned long long seq, P2PHeader* hdr, long long ticks) {
+                                                        unsigned long long seq, P2PHeader* hdr, long long ticks, unsigned long long* word, unsigned long long wordSeq,
+                                                        unsigned* total) {
 	__shared__ int sGo;
 	const P2PLandSeg g = segs[blockIdx.y];
 	if (threadIdx.x == 0) sGo = 1;
@@ -165,13 +181,20 @@ __global__ __launch_bounds__(P2P_TPB) void p2pLandKernel(const P2PLandSeg* __res
 	__syncthreads();
 	if (!sGo) return;
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-	p2pCopyPiece<T>(landing + g.landOff, ext + g.extOff, g.count, blockIdx.x, gridDim.x, true);
+	p2pCopyPiece<T, true>(landing + g.landOff, ext + g.extOff, g.count, blockIdx.x, gridDim.x, true);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every storing wave drains its write-through stores before anything is signalled)
 	__syncthreads();  // (every lane's loads of the landing area have returned: the values were stored)
 	if (threadIdx.x == 0) {
 		const unsigned before = __hip_atomic_fetch_add(&counters[blockIdx.y], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 		if (before + 1 == gridDim.x) {
 			__hip_atomic_store(&counters[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			p2pStore(g.ack[kind], seq);  // the source may overwrite this segment of the landing area
+			if (word) {
+				if (__hip_atomic_fetch_add(total, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 == gridDim.y) {
+					__hip_atomic_store(total, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(word, wordSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
 		}
 	}
 }

@@ -33,6 +33,6 @@ for rows, k, maxoff, lanes in ((10_000_000, 25, 1 << 20, 2), (10_000_000, 25, 1 
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 50.0)
     name, nbytes = A.kernel_desc()
-    print(f"rows {rows} k {k} offsets < 2^{maxoff.bit_length() - 1} lanes {lanes}: {nnz} entries ({nnz / rows:.1f} per row), {name}: {best:.1f} us per launch = {best * 1e3 / nnz:.3f} ns per 1000 entries, "
+    print(f"rows {rows} k {k} offsets < 2^{maxoff.bit_length() - 1} lanes {lanes}: {nnz} entries ({nnz / rows:.1f} per row), {name}: {best:.1f} us per launch = {best * 1e6 / nnz:.3f} ns per 1000 entries, "
           f"{nbytes / best / 1e6:.2f} TB/s on its own {nbytes / 1e9:.3f} GB", flush=True)
     del A, ds, dp, dv, x, y
