@@ -463,6 +463,130 @@ def test_partition_rows_by_nnz_native_matches_python(smm):
         assert list(out) == partition_rows_by_nnz(lambda i: int(start[i]), len(start) - 1, world)
 
 
+def _solve_forms(smm, csr, b_full, world, dtype, lanes, split):
+    """SpMV (three ops), BiCGStab with / without Jacobi and CG on thread ranks with both local blocks forced to the PATTERN family at `lanes` =
+    (A_loc, A_rem) pieces per row; `split` = SMM_HIP_SPLIT_SPMV at create time.  Returns the assembled bytes and the counts of matvec forms."""
+    import torch
+
+    from sparse_matrix_math_amd.distributed import NativeDistMatrix, partition_rows_by_nnz
+
+    dev = torch.device("cuda:0")
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    start, pos, val = csr
+    n = len(start) - 1
+    bounds = partition_rows_by_nnz(lambda i: int(start[i]), n, world)
+    os.environ["SMM_HIP_SPLIT_SPMV"] = "1" if split else "0"
+
+    def rank_main(rank, shared):
+        lo, hi = bounds[rank], bounds[rank + 1]
+        comm = _host_comm(shared, rank)
+        d_start = torch.from_numpy((start[lo:hi + 1] - start[lo]).astype(np.int32)).to(dev)
+        d_pos = torch.from_numpy(pos[start[lo]:start[hi]].copy()).to(dev)
+        d_val = torch.from_numpy(val[start[lo]:start[hi]].copy()).to(dev)
+        A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, dtype)
+        for blk, L in zip(A.local_blocks(), lanes):
+            blk.set_kernel(3, L)  # SMM_SPMV_PATTERN: the analysis runs now, on the block's own arrays
+        b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
+        out = []
+        for op in (0, 1, 2):  # assign / add / sub (ref:1458-1515), lhs = b
+            y = torch.empty(hi - lo, dtype=tdt, device=dev)
+            A.spmv(op, b if op else None, b, y)
+            torch.cuda.synchronize()
+            out.append(y.cpu().numpy())
+        for solver, precond, max_it in (("bicgstab", None, 7), ("bicgstab", smm.SolverPreconditioner.JACOBI, 7), ("cg", None, 9)):
+            A.set_precond(precond)
+            x = torch.zeros(hi - lo, dtype=tdt, device=dev)
+            res = A.cg(b, x, x, max_it, 1e-30) if solver == "cg" else A.bicgstab(b, x, max_it, 1e-30)
+            torch.cuda.synchronize()
+            out.append(x.cpu().numpy())
+            out.append(np.array(res, dtype=np.float64))
+        forms = A.matvec_forms()
+        A.set_precond(None)
+        A.close()
+        comm.close()
+        return out, forms
+
+    try:
+        got = _run_ranks(world, rank_main)
+    finally:
+        os.environ.pop("SMM_HIP_SPLIT_SPMV", None)
+    pieces = [np.concatenate([g[0][i] for g in got]).tobytes() if got[0][0][i].shape != (3,) else got[0][0][i].tobytes() for i in range(len(got[0][0]))]
+    return pieces, [g[1] for g in got]
+
+
+@pytest.mark.parametrize("world,dtype,lanes", [(2, np.float32, (2, 1)), (3, np.float64, (2, 2)), (2, np.float64, (1, 1)), (3, np.float32, (4, 2)), (2, np.float32, (1, 4))])
+def test_one_launch_spmv_is_the_two_launches_bit_for_bit(smm, oracle, world, dtype, lanes):
+    """csrc/smm_spmv_split.hip (r06): the row-partitioned SpMV as ONE launch -- the local half of a workgroup's rows, the
+    wait for the exchange's word, the remote half, out[] written once -- against the two launches (A_loc, then A_rem behind the exchange):
+    every SpMV op, BiCGStab with and without the Jacobi division in the epilogue, CG, fp32 / fp64, every pairing of pieces per row the
+    blocks can have -- the same bytes; and against the oracle within the piece forms' bound."""
+    csr = gen.banded_random_spd(60000, k=12, seed=4, max_offset=9000, dtype=dtype)
+    n = len(csr[0]) - 1
+    x_true = np.random.default_rng(3).uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, 0, None, x_true)
+    one, forms_one = _solve_forms(smm, csr, b, world, dtype, lanes, split=True)
+    two, forms_two = _solve_forms(smm, csr, b, world, dtype, lanes, split=False)
+    assert all(f[0] > 0 and f[1] == 0 for f in forms_one), forms_one  # every SpMV with a halo ran as one launch ...
+    assert all(f[0] == 0 and f[1] > 0 for f in forms_two), forms_two  # ... / as two
+    # the SpMV itself: the same bytes, every op.  The solvers' dot products ride in the epilogue as per-WORKGROUP partial sums, and the two forms
+    # deal the rows to workgroups differently: their scalars agree to rounding, x to the solvers' tolerance
+    assert [a == b_ for a, b_ in zip(one[:3], two[:3])] == [True] * 3
+    tol = 3e-4 if dtype == np.float32 else 1e-10
+    for i in (3, 5, 7):
+        xa, xb = np.frombuffer(one[i], dtype=dtype), np.frombuffer(two[i], dtype=dtype)
+        assert float(np.max(np.abs(xa - xb))) <= tol * float(np.max(np.abs(xb))), i
+        ra, rb = np.frombuffer(one[i + 1], dtype=np.float64), np.frombuffer(two[i + 1], dtype=np.float64)
+        assert tuple(ra[:2]) == tuple(rb[:2]) and abs(ra[2] - rb[2]) <= 50 * tol * max(abs(rb[2]), 1e-30), (ra, rb)
+    y = np.frombuffer(one[0], dtype=dtype)
+    y_ref = oracle.spmv(csr, 0, None, b)
+    assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
+    st_ref, x_ref, it_ref, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 7, 1e-30)
+    x = np.frombuffer(one[3], dtype=dtype)
+    assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref)))
+
+
+def _ragged(csr, seed, drop=0.3):
+    """the band with holes: every off-diagonal entry dropped with probability `drop`, a run of rows reduced to their diagonal, a run of rows
+    that keep only entries LEFT of the diagonal and one that keeps only entries far to the RIGHT (rows without a local / without a remote
+    part for some partition); diagonally dominant as before"""
+    start, pos, val = csr
+    n = len(start) - 1
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n), np.diff(start))
+    keep = (pos == rows) | (rng.random(len(pos)) >= drop)
+    keep &= ~((rows >= n // 5) & (rows < n // 5 + 300) & (pos != rows))
+    keep &= ~((rows >= n // 2) & (rows < n // 2 + 500) & (pos > rows))
+    keep &= ~((rows >= n // 3) & (rows < n // 3 + 500) & (pos != rows) & (pos < rows + 2000))
+    new_start = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(new_start, rows[keep] + 1, 1)
+    return np.cumsum(new_start).astype(np.int32), pos[keep].copy(), val[keep].copy()
+
+
+@pytest.mark.parametrize("world,dtype,lanes,seed", [(2, np.float32, (2, 1), 1), (3, np.float64, (1, 1), 2), (3, np.float32, (4, 2), 3), (2, np.float64, (2, 4), 4),
+                                                    (4, np.float32, (1, 2), 5)])
+def test_one_launch_spmv_on_ragged_matrices(smm, oracle, world, dtype, lanes, seed):
+    """the one-launch SpMV on bands with HOLES: rows of every length, rows without a local or without a remote part, runs of diagonal-only rows
+    (wavefronts whose rows differ take the general path beside wavefronts that take the uniform one), partial tiles at the end -- the two
+    launches' bytes for every op, the oracle's numbers within the piece forms' bound"""
+    csr = _ragged(gen.banded_random_spd(50000 + 137 * seed, k=14, seed=seed, max_offset=8000, dtype=dtype), seed)
+    n = len(csr[0]) - 1
+    x_true = np.random.default_rng(3).uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, 0, None, x_true)
+    one, forms_one = _solve_forms(smm, csr, b, world, dtype, lanes, split=True)
+    two, forms_two = _solve_forms(smm, csr, b, world, dtype, lanes, split=False)
+    assert all(f[0] > 0 and f[1] == 0 for f in forms_one), forms_one
+    assert all(f[0] == 0 and f[1] > 0 for f in forms_two), forms_two
+    assert [a == b_ for a, b_ in zip(one[:3], two[:3])] == [True] * 3
+    y_ref = oracle.spmv(csr, 0, None, b)
+    for op, ref in ((0, y_ref), (1, b + y_ref), (2, b - y_ref)):
+        y = np.frombuffer(one[op], dtype=dtype)
+        assert float(np.max(np.abs(y - ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8, op
+    tol = 3e-4 if dtype == np.float32 else 1e-10
+    st_ref, x_ref, it_ref, _ = oracle.bicgstab(csr, b, np.zeros(n, dtype=dtype), 7, 1e-30)
+    x = np.frombuffer(one[3], dtype=dtype)
+    assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref)))
+
+
 def test_peer_to_peer_is_refused_between_ranks_of_one_process(smm, oracle, monkeypatch):
     """Ranks that are THREADS of one process asking for the peer-to-peer transport stay with the communicator's collectives (r06): the
     transport makes kernels of one rank wait for kernels of another, and inside one process HIP gives no control over which hardware queue
