@@ -1993,6 +1993,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 		setError("dist_bicgstab: preconditioner must be JACOBI / ILU0 / SGS / BLOCK_ILU0 / BLOCK_SGS of the local diagonal block (smm_hip_dist_csr_local_block)");
 		return SMM_HIP_ERR_INVALID;
 	}
+	D->reducedInKernel = false;  // (a call that failed between an SpMV and its reduction point must not leave the mark behind)
 	maxIterations = std::min(maxIterations, D->nGlobal);  // ref:2200
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2201-2203
 	// many SpMVs ahead: both local blocks may take the index-free family (each rank decides for its own blocks; no collective involved)
@@ -2114,6 +2115,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		setError("dist_cg: null vector");
 		return SMM_HIP_ERR_INVALID;
 	}
+	D->reducedInKernel = false;
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2345-2347 (no clamp otherwise)
 	// (the blocks' own configuration first: a block nobody has multiplied with yet still carries the handle's initial word, and the adoption
 	// below only moves a block that is on the STREAM family -- r05: the FIRST solve of a distributed matrix ran on the CSR kernels)
