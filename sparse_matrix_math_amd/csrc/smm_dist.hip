@@ -361,7 +361,15 @@ __global__ void colRangeKernel(long long nnz, const int* __restrict__ positions,
 
 // counts[row] = entries of the row with an owned column; counts[nLocal + 1 + row] = the others.  Both arrays have nLocal + 1
 // slots so that an exclusive scan over nLocal + 1 elements ends with the total.
-// labWindow > 0 (measurements with ONE rank, smm_hip_dist_csr::labWindow): an owned column farther than that from the row counts as remote too
+// labWindow (measurements with ONE rank, smm_hip_dist_csr::labWindow).  > 0: an owned column farther than that from its row counts as remote too
+// (every row gets a remote part: a rank of MANY); < 0: the last |labWindow| columns of the range count as remote (only rows near that end get a
+// remote part: a rank of a FEW)
+__device__ __forceinline__ bool labLocal(int c, int row, int ownLo, int ownHi, int labWindow) {
+	if (labWindow == 0) return true;
+	if (labWindow > 0) return abs(c - row) < labWindow;
+	return c < ownHi + labWindow;  // (the last |labWindow| columns are "the neighbour's": the first rank of two)
+}
+
 __global__ void splitCountKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, int ownLo, int ownHi, int labWindow,
                                  int* __restrict__ cntLoc, int* __restrict__ cntRem) {
 	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row <= nLocal; row += gridDim.x * blockDim.x) {
@@ -370,7 +378,7 @@ __global__ void splitCountKernel(int nLocal, const int* __restrict__ start, cons
 			const int e = start[row + 1];
 			for (int k = start[row]; k < e; ++k) {
 				const int c = positions[k];
-				if (c >= ownLo && c < ownHi && (labWindow <= 0 || abs(c - (ownLo + row)) < labWindow)) ++nl;
+				if (c >= ownLo && c < ownHi && labLocal(c, ownLo + row, ownLo, ownHi, labWindow)) ++nl;
 				else ++nr;
 			}
 		}
@@ -389,7 +397,7 @@ __global__ void splitScatterKernel(int nLocal, const int* __restrict__ start, co
 		for (int k = start[row]; k < e; ++k) {  // order inside a row is preserved (columns stay ascending, ref:1247-1249)
 			const int c = positions[k];
 			const T v = values[k];
-			if (c >= ownLo && c < ownHi && (labWindow <= 0 || abs(c - (ownLo + row)) < labWindow)) {
+			if (c >= ownLo && c < ownHi && labLocal(c, ownLo + row, ownLo, ownHi, labWindow)) {
 				posLoc[il] = c - ownLo;
 				valLoc[il] = v;
 				++il;
@@ -564,6 +572,7 @@ struct smm_hip_dist_csr {
 	unsigned long long* splitSync = nullptr;
 	unsigned long long landSeq[smm::P2P_KINDS] = {};
 	long long matvecsSplit = 0, matvecsTwo = 0;  // how many SpMVs with a halo ran in one launch / in two (smm_hip_dist_csr_matvec_forms)
+	int splitSumsLdsMax = 16384;  // SMM_HIP_SPLIT_SUMS_LDS at create time: bytes of LDS the one-launch SpMV's row sums may take (0: always through out[]; tests)
 	bool splitAllowed = true;  // SMM_HIP_SPLIT_SPMV=0 at create time: this matrix keeps the two launches (A/B measurements, the bit-equality tests)
 	bool reducedInKernel = false;  // the SpMV just launched ran its reduction point itself (the one-launch form with the slots): allreduceTotals has nothing to do
 	int labWindow = 0;  // measurements on ONE GPU (SMM_HIP_LAB_SELF_SPLIT, single-rank communicator only): entries |column - row| >= window count as "remote"
@@ -1253,10 +1262,12 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 	{
 		const char* env = getenv("SMM_HIP_SPLIT_SPMV");  // (read at every create, like SMM_HIP_HALO_CHUNKS: a property of the matrix)
 		D->splitAllowed = env ? atoi(env) != 0 : true;
+		const char* lds = getenv("SMM_HIP_SPLIT_SUMS_LDS");
+		if (lds) D->splitSumsLdsMax = std::max(0, atoi(lds));
 	}
 	if (comm->kind == SMM_COMM_SELF) {
 		const char* env = getenv("SMM_HIP_LAB_SELF_SPLIT");  // (measurement hook: what a rank of a many-GPU run computes, on one GPU -- tools/lab/rank_loop_streams.py)
-		D->labWindow = env ? std::max(0, atoi(env)) : 0;
+		D->labWindow = env ? atoi(env) : 0;
 	}
 	splitCountKernel<<<grid, 256, 0, s>>>(nLocal, d_start, d_positions, D->rowBegin, D->rowEnd, D->labWindow, startLoc, startRem);
 	SMM_HIP_TRY(hipGetLastError());
@@ -1391,7 +1402,7 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 	auto& pend = D->pending;
 	pend = smm_hip_dist_csr::Pending{};
 	const bool exchange = !D->sends.empty() || !D->recvs.empty();
-	if (D->labWindow > 0 && !D->remEmpty) {
+	if (D->labWindow != 0 && !D->remEmpty) {
 		// one rank, "remote" entries by distance (measurements): nothing travels, but the word is raised from the communicator's stream behind
 		// the update -- the one-launch SpMV takes exactly the path it takes behind a real exchange
 		hipStream_t cs = c->stream;
@@ -1508,7 +1519,7 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 		}
 		const int st = launchSpmvSplit<T>(D->aLoc, D->aRem, op, lhs, jacobiDiag, own, ext, out, dotMode, w1, parts, doneFlag,
 		                                  (fuseSlots ? SPMV_FINISH : finish) | (jacobiDiag ? SPMV_ADD_DIV : 0), D->splitSync + pend.kind, pend.landSeq, splitErrWord(D),
-		                                  p2pTicks(), s, fuseSlots ? &slots : nullptr);
+		                                  p2pTicks(), s, fuseSlots ? &slots : nullptr, D->splitSumsLdsMax);
 		if (st == SMM_HIP_OK) {
 			if (fuseSlots) {
 				++D->p2p->redSeq[slotPoint];

@@ -7,7 +7,7 @@
 //
 // Here ONE persistent grid does both halves.  The rows are cut into SUPER TILES of 256 consecutive rows (no table: row r belongs to super
 // tile r / 256), dealt to the workgroups once -- XCD group g owns a contiguous eighth, its workgroups interleave inside it, as in the tile
-// kernels.  A workgroup
+// kernels (r06, second form: in chunks of 64 super tiles dealt round-robin to the groups -- SplitMap).  A workgroup
 //   phase 1: walks the A_loc part of each of its K super tiles and keeps the row sums in LDS (K x 256 values: a few KB);
 //   waits  : one lane polls the word the communicator's stream raises once the halo of THIS exchange has landed in `ext`
 //            (splitSignalKernel behind the land kernel / the grouped receive; bounded: an expired wait leaves a code in the error word);
@@ -38,6 +38,23 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smmSplitLds[];
 
 constexpr int SUPER = TPB;  // rows per super tile
 
+// Which super tiles a workgroup walks.  Workgroups b, b + 8, ... share an XCD (group g = b % 8).  Two deals, chosen per pair of blocks:
+//   chunk == 0: group g owns the contiguous eighth [g * perGroup, (g + 1) * perGroup) -- neighbouring tiles share x lines, one L2 serves them:
+//               the deal of the tile kernels, best whenever the work is spread evenly over the rows (a rank of eight: 198 against 222 us per iteration);
+//   chunk > 0 : the tiles are dealt in chunks of `chunk` consecutive ones, chunk c to group c % 8 -- a rank of two or four has its remote
+//               entries in the rows near one end, and contiguous eighths leave that half of the work to three of the eight groups (795 against 758 us).
+// Inside a group the workgroups interleave.
+constexpr int SPLIT_CHUNK = 64;
+struct SplitMap {
+	int nSupers, nGroups, group, slot, groupSlots, chunk, perGroup;
+	__device__ __forceinline__ int superOf(int k) const {  // the k-th super tile of this workgroup; >= nSupers: none left
+		const int i = slot + k * groupSlots;  // index in the group's list of tiles
+		if (chunk == 0) return i < perGroup ? group * perGroup + i : nSupers;
+		const int c = i / chunk;
+		return (c * nGroups + group) * chunk + (i - c * chunk);
+	}
+};
+
 template <typename T>
 struct SplitSide {
 	const int* offs;
@@ -52,7 +69,9 @@ struct SplitSide {
 template <typename T>
 struct SplitArgs {
 	SplitSide<T> a, b;
-	int rows, nSupers, perGroup, K;
+	int rows, nSupers, chunk, perGroup, K;
+	int sumsInLds;  // 1: the local half's row sums stay in LDS (K x 256 values); 0: K is too large for that (few ranks, many rows) and they travel
+	                // through out[] -- written as the two-launch form's first launch wrote it, read back by the same workgroup
 	int opFlags, dotMode;
 	const T* lhs;
 	const T* divisor;
@@ -81,7 +100,7 @@ __device__ __forceinline__ T splitGather(const T* __restrict__ x, unsigned byteO
 // sub tile is a chain of 4-5 dependent trips to memory (row bounds, values, two gather batches) and a CU holds five workgroups.
 // done(row, index in the workgroup's row sums, dot) is called by the lane that holds a row's sum.
 template <typename T, int L, int G, typename Done>
-__device__ __forceinline__ void splitPhase(const SplitSide<T>& M, int rows, int spFirst, int spStep, int spEnd, int K, bool REMOTE, T* sVal, unsigned long long* sMask,
+__device__ __forceinline__ void splitPhase(const SplitSide<T>& M, int rows, const SplitMap& map, int K, bool REMOTE, T* sVal, unsigned long long* sMask,
                                            int* sStart, const int* sOff, T* sPart, Done&& done) {
 	const T* __restrict__ x = M.x;
 	using Cfg = PatCfg<T>;
@@ -102,9 +121,9 @@ __device__ __forceinline__ void splitPhase(const SplitSide<T>& M, int rows, int 
 	bool direct = false, valid = false;
 	auto subTile = [&](int j, int& rr0) {  // first row of sub tile j of this workgroup, false past its last one
 		const int k = j / L, q = j - k * L;
-		const int sp = spFirst + k * spStep;
+		const int sp = map.superOf(k);
 		rr0 = sp * SUPER + q * RT;
-		return k < K && sp < spEnd && rr0 < rows;
+		return k < K && sp < map.nSupers && rr0 < rows;
 	};
 	auto request = [&](int j) {
 		valid = subTile(j, r0);
@@ -115,7 +134,7 @@ __device__ __forceinline__ void splitPhase(const SplitSide<T>& M, int rows, int 
 		n1 = M.start[r1];
 		a0 = n0 & ~3;
 		direct = n1 - n0 > M.cap - 3 || a0 > M.stageLimit;
-		if (direct) return;
+		if (direct || n1 == n0) return;  // (nothing is staged for a sub tile without entries: the interior rows of a rank have no remote part)
 		ps = 0;
 		pm = 0ULL;
 		if (t < nrows) {
@@ -141,7 +160,14 @@ __device__ __forceinline__ void splitPhase(const SplitSide<T>& M, int rows, int 
 		// this sub tile's geometry (the request set is about to be re-issued)
 		const int cr0 = r0, cnrows = nrows, cn1 = n1, ca0 = a0;
 		const bool cdirect = direct;
+		const bool cempty = n1 == n0;
 		const int base = (j / L) * SUPER + (j % L) * RT;  // where this sub tile's rows sit among the workgroup's row sums
+		if (cempty) {
+			// no entry in these rows of this half: every row's sum is +0 (what its empty pieces add up to) -- no staging, no barrier
+			request(j + 1);
+			for (int rr = t; rr < cnrows; rr += TPB) done(cr0 + rr, base + rr, T(0));
+			continue;
+		}
 		if (!cdirect) {
 #pragma unroll
 			for (int v = 0; v < NVP; ++v) {
@@ -277,11 +303,11 @@ __device__ __forceinline__ void splitPhase(const SplitSide<T>& M, int rows, int 
 
 // the gather batch is a run-time property of a block (fitted to its rows, patBatch): three compiled sizes per half
 template <typename T, int L, typename Done>
-__device__ __forceinline__ void splitPhaseG(const SplitSide<T>& M, int rows, int spFirst, int spStep, int spEnd, int K, bool REMOTE, T* sVal, unsigned long long* sMask,
+__device__ __forceinline__ void splitPhaseG(const SplitSide<T>& M, int rows, const SplitMap& map, int K, bool REMOTE, T* sVal, unsigned long long* sMask,
                                             int* sStart, const int* sOff, T* sPart, Done&& done) {
-	if (M.batch <= 8) splitPhase<T, L, 8>(M, rows, spFirst, spStep, spEnd, K, REMOTE, sVal, sMask, sStart, sOff, sPart, done);
-	else if (M.batch <= 13) splitPhase<T, L, 13>(M, rows, spFirst, spStep, spEnd, K, REMOTE, sVal, sMask, sStart, sOff, sPart, done);
-	else splitPhase<T, L, 16>(M, rows, spFirst, spStep, spEnd, K, REMOTE, sVal, sMask, sStart, sOff, sPart, done);
+	if (M.batch <= 8) splitPhase<T, L, 8>(M, rows, map, K, REMOTE, sVal, sMask, sStart, sOff, sPart, done);
+	else if (M.batch <= 13) splitPhase<T, L, 13>(M, rows, map, K, REMOTE, sVal, sMask, sStart, sOff, sPart, done);
+	else splitPhase<T, L, 16>(M, rows, map, K, REMOTE, sVal, sMask, sStart, sOff, sPart, done);
 }
 
 // what the second launch of the two-launch form did with the first one's out[row]
@@ -291,6 +317,19 @@ __device__ __forceinline__ T splitCombine(int op, const T* __restrict__ lhs, con
 	if (op == SMM_OP_ASSIGN) return loc + rem;                      // out = A_loc x; out = out + A_rem x
 	const T l = lhs[row];
 	return op == SMM_OP_ADD ? (l + loc) + rem : (l - loc) - rem;    // out = lhs +|- A_loc x; out = out +|- A_rem x
+}
+
+// the same in two steps, for row sums that travel through out[]: out = op(lhs, loc) as the first launch left it, then out (+|-) rem [/ diag]
+template <typename T>
+__device__ __forceinline__ T splitFirst(int op, const T* __restrict__ lhs, int row, T loc) {
+	if (op == SPMV_OP_ADD_DIV || op == SMM_OP_ASSIGN) return loc;
+	const T l = lhs[row];
+	return op == SMM_OP_ADD ? l + loc : l - loc;
+}
+template <typename T>
+__device__ __forceinline__ T splitSecond(int op, const T* __restrict__ divisor, int row, T first, T rem) {
+	if (op == SPMV_OP_ADD_DIV) return (first + rem) / divisor[row];
+	return op == SMM_OP_SUB ? first - rem : first + rem;
 }
 
 template <typename T, int LA, int LB>
@@ -309,7 +348,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternSplitKernel(const SplitArgs<T>
 	int* sOffB = sOffA + MAXOFF;
 	T* sPart = reinterpret_cast<T*>(sOffB + MAXOFF);
 	T* sLoc = sPart + ((PARTS + 1) & ~1);
-	T* red = sLoc + static_cast<size_t>(A.K) * SUPER;
+	T* red = sLoc + (A.sumsInLds ? static_cast<size_t>(A.K) * SUPER : 0);
 	int* sGo = reinterpret_cast<int*>(red + 4);
 	if (A.doneFlag && *A.doneFlag) {
 		// (a finished solve's launches are no-ops -- except the reduction point this launch carries: every rank publishes for every point, the slots
@@ -327,17 +366,20 @@ __global__ __launch_bounds__(TPB) void spmvPatternSplitKernel(const SplitArgs<T>
 		sOffA[t] = t < A.a.nOff ? A.a.offs[t] : 0;
 		sOffB[t] = t < A.b.nOff ? A.b.offs[t] : 0;
 	}
-	// workgroups b, b + 8, ... share an XCD: group g owns the super tiles [g * perGroup, (g + 1) * perGroup), its workgroups interleave
+	// workgroups b, b + 8, ... share an XCD: which super tiles this one walks -- SplitMap
 	const int nGroups = min(8, static_cast<int>(gridDim.x));
 	const int group = blockIdx.x % nGroups;
 	const int slot = blockIdx.x / nGroups;
 	const int groupSlots = (static_cast<int>(gridDim.x) - group + nGroups - 1) / nGroups;
-	const int first = group * A.perGroup;
-	const int last = min(A.nSupers, first + A.perGroup);
+	const SplitMap map{A.nSupers, nGroups, group, slot, groupSlots, A.chunk, A.perGroup};
 	__syncthreads();
 
 	// ---- phase 1: the local block; row sums stay in LDS
-	splitPhaseG<T, LA>(A.a, A.rows, first + slot, groupSlots, last, A.K, false, sVal, sMask, sStart, sOffA, sPart, [&](int, int at, T dot) { sLoc[at] = dot; });
+	splitPhaseG<T, LA>(A.a, A.rows, map, A.K, false, sVal, sMask, sStart, sOffA, sPart, [&](int row, int at, T dot) {
+		if (A.sumsInLds) sLoc[at] = dot;
+		else A.out[row] = splitFirst<T>(op, A.lhs, row, dot);  // (what the first of two launches left in out[]; out may alias lhs: element by element)
+	});
+	if (!A.sumsInLds) __syncthreads();  // (every lane's stores of out[] have completed -- the barrier's fence waits for them -- before a lane of phase 2 reads one back)
 	// ---- the halo of this exchange must have landed (the word is raised on the communicator's stream, behind the land kernel / the receive)
 	if (A.landed) {
 		if (t == 0) {
@@ -372,8 +414,10 @@ __global__ __launch_bounds__(TPB) void spmvPatternSplitKernel(const SplitArgs<T>
 	}
 	// ---- phase 2: the remote block; out[] is written once, the solver's dot products ride along
 	T acc0 = T(0), acc1 = T(0);
-	splitPhaseG<T, LB>(A.b, A.rows, first + slot, groupSlots, last, A.K, true, sVal, sMask, sStart, sOffB, sPart, [&](int row, int at, T dot) {
-		const T o = splitCombine<T>(op, A.lhs, A.divisor, row, sLoc[at], dot);
+	splitPhaseG<T, LB>(A.b, A.rows, map, A.K, true, sVal, sMask, sStart, sOffB, sPart, [&](int row, int at, T dot) {
+		// (sums through out[]: written by a lane of this workgroup before the barriers of phase 1's end; read past this CU's L1)
+		const T o = A.sumsInLds ? splitCombine<T>(op, A.lhs, A.divisor, row, sLoc[at], dot)
+		                        : splitSecond<T>(op, A.divisor, row, __hip_atomic_load(A.out + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), dot);
 		storeOut(A.out + row, o, ntOut);
 		if (A.dotMode == 2) acc0 += o * o;
 		if (A.dotMode) acc1 += o * A.w1[row];
@@ -417,8 +461,10 @@ static int splitLanes(const smm_hip_csr* m) {
 	return L == 1 || L == 2 || L == 4 ? L : 0;
 }
 
-// the most entries a run of `rt` consecutive rows (cut at multiples of rt) holds
+// the most entries a run of `rt` consecutive rows (cut at multiples of rt) holds; out[1 .. 9] = start[] at the borders of the eight contiguous
+// eighths of the rows (how evenly the block's entries are spread over them decides the deal of the tiles: SplitMap)
 __global__ void splitTileMaxKernel(int rows, const int* __restrict__ start, int rt, int* out) {
+	if (blockIdx.x == 0 && threadIdx.x < 9) out[1 + threadIdx.x] = start[static_cast<long long>(rows) * threadIdx.x / 8];
 	int mx = 0;
 	const int nTiles = (rows + rt - 1) / rt;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nTiles; i += gridDim.x * blockDim.x) {
@@ -446,17 +492,20 @@ static int splitCap(const smm_hip_csr* cm, int L, hipStream_t s) {
 		std::lock_guard<std::mutex> lock(m->tileMutex);
 		if (m->split_tile_max[slot] < 0) {
 			DevBuf<int> d;
-			if (d.alloc(1) != SMM_HIP_OK) return 0;
-			int h = 0;
-			if (hipMemsetAsync(d.p, 0, sizeof(int), s) != hipSuccess) return 0;
+			if (d.alloc(10) != SMM_HIP_OK) return 0;
+			int h[10] = {};
+			if (hipMemsetAsync(d.p, 0, sizeof(h), s) != hipSuccess) return 0;
 			const int rt = SUPER / L;
 			const int nTiles = (m->rows + rt - 1) / rt;
 			splitTileMaxKernel<<<std::max(1, std::min(1024, (nTiles + 255) / 256)), 256, 0, s>>>(m->rows, m->d_start, rt, d.p);
-			if (hipMemcpyAsync(&h, d.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+			if (hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
 				(void)hipGetLastError();
 				return 0;
 			}
-			m->split_tile_max[slot] = h;
+			m->split_tile_max[slot] = h[0];
+			long long most = 0;
+			for (int k = 0; k < 8; ++k) most = std::max<long long>(most, h[2 + k] - h[1 + k]);
+			m->split_uneven = static_cast<long long>(h[9] - h[1]) > 0 && most * 8 > (static_cast<long long>(h[9] - h[1]) * 3) / 2;  // an eighth holds > 1.5 x its share
 		}
 		mx = m->split_tile_max[slot];
 	}
@@ -479,14 +528,14 @@ static int splitBatch(const smm_hip_csr* m, int L) {  // (patBatch of smm_spmv_p
 // grid, super tiles per workgroup and LDS of a launch: the grid decides K, K the LDS, the LDS how many workgroups a CU holds -- a fixed point
 // found once per (instantiation, matrix shape) and kept (the occupancy query costs 10+ us of host time; the solvers launch this every ~90 us)
 struct SplitPlan {
-	int nSupers = 0, capMax = 0, cus = 0;
-	int grid = 0, K = 0, perGroup = 0;
+	int nSupers = 0, capMax = 0, cus = 0, sumsLdsMax = 0, chunked = 0;
+	int grid = 0, K = 0, chunk = 0, perGroup = 0, sumsInLds = 1;
 	size_t lds = 0;
 	bool ok = false;
 };
 
 template <typename T, int LA, int LB>
-static int launchSplitL(const SplitArgs<T>& base, int cus, hipStream_t s) {
+static int launchSplitL(const SplitArgs<T>& base, int cus, int sumsLdsMax, int chunked, hipStream_t s) {
 	SplitArgs<T> a = base;
 	const int capMax = std::max(a.a.cap, a.b.cap);
 	constexpr int LMAX = LA > LB ? LA : LB;
@@ -498,7 +547,7 @@ static int launchSplitL(const SplitArgs<T>& base, int cus, hipStream_t s) {
 	{
 		std::lock_guard<std::mutex> lock(planMutex);
 		for (const SplitPlan& p : plans) {
-			if (p.nSupers == a.nSupers && p.capMax == capMax && p.cus == cus) plan = p;
+			if (p.nSupers == a.nSupers && p.capMax == capMax && p.cus == cus && p.sumsLdsMax == sumsLdsMax && p.chunked == chunked) plan = p;
 		}
 		if (!plan.nSupers) {
 			const size_t fixed = static_cast<size_t>((capMax + PatCfg<T>::PAD + 1) & ~1) * sizeof(T) + SUPER * 8 + (SUPER + 4) * 4 + 2 * MAXOFF * 4 +
@@ -506,15 +555,27 @@ static int launchSplitL(const SplitArgs<T>& base, int cus, hipStream_t s) {
 			plan.nSupers = a.nSupers;
 			plan.capMax = capMax;
 			plan.cus = cus;
+			plan.sumsLdsMax = sumsLdsMax;
+			plan.chunked = chunked;
 			int perCU = forcedWgsPerCU() > 0 ? forcedWgsPerCU() : 8;
 			for (int pass = 0; pass < 8 && !plan.ok; ++pass) {
 				plan.grid = std::max(1, std::min(std::min(a.nSupers, cus * perCU), NPART));
 				const int nGroups = std::min(8, plan.grid);
-				plan.perGroup = (a.nSupers + nGroups - 1) / nGroups;
+				int perGroup = (a.nSupers + nGroups - 1) / nGroups;  // contiguous eighths ...
+				plan.chunk = 0;
+				if (chunked) {  // ... or chunks dealt round-robin (at least eight per group): the most tiles a group's list can hold
+					plan.chunk = std::max(1, std::min(SPLIT_CHUNK, a.nSupers / 64));
+					const int nChunks = (a.nSupers + plan.chunk - 1) / plan.chunk;
+					perGroup = ((nChunks + nGroups - 1) / nGroups) * plan.chunk;
+				}
+				plan.perGroup = perGroup;
 				const int slotsMin = std::max(1, plan.grid / nGroups);  // (the groups with the fewest workgroups)
-				plan.K = (plan.perGroup + slotsMin - 1) / slotsMin;
-				plan.lds = fixed + static_cast<size_t>(plan.K) * SUPER * sizeof(T);
-				if (plan.lds > 150 * 1024 || static_cast<size_t>(plan.K) * SUPER * sizeof(T) > 48 * 1024) break;  // (the row sums do not fit: the two launches)
+				plan.K = (perGroup + slotsMin - 1) / slotsMin;
+				// the local half's row sums: in LDS while that costs no workgroup per CU worth having (<= 16 KB); beyond -- few ranks, many rows per
+				// workgroup -- through out[] (two small passes more, the same arithmetic)
+				plan.sumsInLds = static_cast<size_t>(plan.K) * SUPER * sizeof(T) <= static_cast<size_t>(sumsLdsMax) ? 1 : 0;
+				plan.lds = fixed + (plan.sumsInLds ? static_cast<size_t>(plan.K) * SUPER * sizeof(T) : 0);
+				if (plan.lds > 150 * 1024) break;
 				if (!ensureDynamicLds(granted, spmvPatternSplitKernel<T, LA, LB>, plan.lds)) break;
 				int fit = 0;
 				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, spmvPatternSplitKernel<T, LA, LB>, TPB, plan.lds) != hipSuccess || fit < 1) {
@@ -530,6 +591,8 @@ static int launchSplitL(const SplitArgs<T>& base, int cus, hipStream_t s) {
 	}
 	if (!plan.ok) return 1;
 	a.K = plan.K;
+	a.sumsInLds = plan.sumsInLds;
+	a.chunk = plan.chunk;
 	a.perGroup = plan.perGroup;
 	const int profSlot = profBegin(s);  // (smm_hip_profile_*: one SpMV launch)
 	spmvPatternSplitKernel<T, LA, LB><<<plan.grid, TPB, plan.lds, s>>>(a);
@@ -542,7 +605,7 @@ static int launchSplitL(const SplitArgs<T>& base, int cus, hipStream_t s) {
 template <typename T>
 int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, const T* lhs, const T* divisor, const T* own, const T* ext, T* out, int dotMode,
                     const T* w1, T* partials, const int* doneFlag, int extraFlags, const unsigned long long* landed, unsigned long long seq, unsigned long long* err,
-                    long long ticks, hipStream_t s, const P2PSlotArgs* slots) {
+                    long long ticks, hipStream_t s, const P2PSlotArgs* slots, int sumsLdsMax) {
 	const int LA = splitLanes(aLoc), LB = splitLanes(aRem);
 	if (!LA || !LB || aLoc->rows != aRem->rows) return 1;
 	if (aLoc->dtype != dtypeOf<T>() || aRem->dtype != dtypeOf<T>()) return 1;
@@ -586,23 +649,24 @@ int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, co
 	// the exchange is itself a few workgroups (the land kernel, the peers' pushes, an RCCL kernel) that must find room beside this grid while it
 	// waits for them: one CU per XCD's worth of slots stays free
 	const int cus = landed ? std::max(8, numCUs() - 8) : numCUs();
+	const int chunked = (aLoc->split_uneven || aRem->split_uneven) ? 1 : 0;
 	switch (LA * 8 + LB) {
-	case 1 * 8 + 1: return launchSplitL<T, 1, 1>(a, cus, s);
-	case 1 * 8 + 2: return launchSplitL<T, 1, 2>(a, cus, s);
-	case 1 * 8 + 4: return launchSplitL<T, 1, 4>(a, cus, s);
-	case 2 * 8 + 1: return launchSplitL<T, 2, 1>(a, cus, s);
-	case 2 * 8 + 2: return launchSplitL<T, 2, 2>(a, cus, s);
-	case 2 * 8 + 4: return launchSplitL<T, 2, 4>(a, cus, s);
-	case 4 * 8 + 1: return launchSplitL<T, 4, 1>(a, cus, s);
-	case 4 * 8 + 2: return launchSplitL<T, 4, 2>(a, cus, s);
-	default: return launchSplitL<T, 4, 4>(a, cus, s);
+	case 1 * 8 + 1: return launchSplitL<T, 1, 1>(a, cus, sumsLdsMax, chunked, s);
+	case 1 * 8 + 2: return launchSplitL<T, 1, 2>(a, cus, sumsLdsMax, chunked, s);
+	case 1 * 8 + 4: return launchSplitL<T, 1, 4>(a, cus, sumsLdsMax, chunked, s);
+	case 2 * 8 + 1: return launchSplitL<T, 2, 1>(a, cus, sumsLdsMax, chunked, s);
+	case 2 * 8 + 2: return launchSplitL<T, 2, 2>(a, cus, sumsLdsMax, chunked, s);
+	case 2 * 8 + 4: return launchSplitL<T, 2, 4>(a, cus, sumsLdsMax, chunked, s);
+	case 4 * 8 + 1: return launchSplitL<T, 4, 1>(a, cus, sumsLdsMax, chunked, s);
+	case 4 * 8 + 2: return launchSplitL<T, 4, 2>(a, cus, sumsLdsMax, chunked, s);
+	default: return launchSplitL<T, 4, 4>(a, cus, sumsLdsMax, chunked, s);
 	}
 }
 
 template int launchSpmvSplit<float>(const smm_hip_csr*, const smm_hip_csr*, int, const float*, const float*, const float*, const float*, float*, int, const float*, float*,
-                                    const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*);
+                                    const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*, int);
 template int launchSpmvSplit<double>(const smm_hip_csr*, const smm_hip_csr*, int, const double*, const double*, const double*, const double*, double*, int, const double*,
-                                     double*, const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*);
+                                     double*, const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*, int);
 
 void preloadSplitUnit() {
 	hipFuncAttributes attr;

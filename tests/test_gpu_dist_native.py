@@ -463,7 +463,7 @@ def test_partition_rows_by_nnz_native_matches_python(smm):
         assert list(out) == partition_rows_by_nnz(lambda i: int(start[i]), len(start) - 1, world)
 
 
-def _solve_forms(smm, csr, b_full, world, dtype, lanes, split):
+def _solve_forms(smm, csr, b_full, world, dtype, lanes, split, sums_lds=None):
     """SpMV (three ops), BiCGStab with / without Jacobi and CG on thread ranks with both local blocks forced to the PATTERN family at `lanes` =
     (A_loc, A_rem) pieces per row; `split` = SMM_HIP_SPLIT_SPMV at create time.  Returns the assembled bytes and the counts of matvec forms."""
     import torch
@@ -476,6 +476,8 @@ def _solve_forms(smm, csr, b_full, world, dtype, lanes, split):
     n = len(start) - 1
     bounds = partition_rows_by_nnz(lambda i: int(start[i]), n, world)
     os.environ["SMM_HIP_SPLIT_SPMV"] = "1" if split else "0"
+    if sums_lds is not None:
+        os.environ["SMM_HIP_SPLIT_SUMS_LDS"] = str(sums_lds)  # 0: the local half's row sums travel through out[] (what many rows per workgroup get)
 
     def rank_main(rank, shared):
         lo, hi = bounds[rank], bounds[rank + 1]
@@ -510,6 +512,7 @@ def _solve_forms(smm, csr, b_full, world, dtype, lanes, split):
         got = _run_ranks(world, rank_main)
     finally:
         os.environ.pop("SMM_HIP_SPLIT_SPMV", None)
+        os.environ.pop("SMM_HIP_SPLIT_SUMS_LDS", None)
     pieces = [np.concatenate([g[0][i] for g in got]).tobytes() if got[0][0][i].shape != (3,) else got[0][0][i].tobytes() for i in range(len(got[0][0]))]
     return pieces, [g[1] for g in got]
 
@@ -577,6 +580,10 @@ def test_one_launch_spmv_on_ragged_matrices(smm, oracle, world, dtype, lanes, se
     assert all(f[0] > 0 and f[1] == 0 for f in forms_one), forms_one
     assert all(f[0] == 0 and f[1] > 0 for f in forms_two), forms_two
     assert [a == b_ for a, b_ in zip(one[:3], two[:3])] == [True] * 3
+    # ... and with the local half's row sums travelling through out[] instead of LDS (the form many rows per workgroup get: few ranks of a big matrix)
+    via_out, forms_out = _solve_forms(smm, csr, b, world, dtype, lanes, split=True, sums_lds=0)
+    assert all(f[0] > 0 and f[1] == 0 for f in forms_out), forms_out
+    assert via_out[:3] == one[:3] and via_out[3:] == one[3:]  # (the same rows in the same workgroups: the solves are the same bytes too)
     y_ref = oracle.spmv(csr, 0, None, b)
     for op, ref in ((0, y_ref), (1, b + y_ref), (2, b - y_ref)):
         y = np.frombuffer(one[op], dtype=dtype)

@@ -39,7 +39,7 @@ def dist_matrix(win, split, slots=False):
     os.environ["SMM_HIP_LAB_SELF_SPLIT"] = str(win)
     os.environ["SMM_HIP_SPLIT_SPMV"] = "1" if split else "0"
     D = NativeDistMatrix(comm, n, [0, n], ds, dp, dv, np.float32)
-    if win > 0 and os.environ.get("LAB_LANES"):  # e.g. LAB_LANES=2,2: pieces per row of A_loc, A_rem (PATTERN family forced)
+    if win != 0 and os.environ.get("LAB_LANES"):  # e.g. LAB_LANES=2,2: pieces per row of A_loc, A_rem (PATTERN family forced)
         for blk, L in zip(D.local_blocks(), os.environ["LAB_LANES"].split(",")):
             blk.set_kernel(3, int(L))
     os.environ.pop("SMM_HIP_LAB_SELF_SPLIT")
@@ -48,13 +48,13 @@ def dist_matrix(win, split, slots=False):
 
 
 legs = [("row-partitioned, unsplit", dist_matrix(0, True))]
-if window > 0:
+if window != 0:
     legs.append(("row-partitioned, A_loc / A_rem in ONE launch", dist_matrix(window, True)))
     legs.append(("row-partitioned, A_loc / A_rem in TWO launches", dist_matrix(window, False)))
     legs.append(("row-partitioned, ONE launch, scalars through the slots (the peer-to-peer transport's launches)", dist_matrix(window, True, slots=True)))
 legs.append(("single-GPU", None))
 results = {}
-for name, st in (("own stream", own.cuda_stream),) if window > 0 else (("NULL stream", s0), ("own stream", own.cuda_stream)):
+for name, st in (("own stream", own.cuda_stream),) if window != 0 else (("NULL stream", s0), ("own stream", own.cuda_stream)):
     for kind, D in legs:
         def solve(it):
             x = torch.zeros_like(xt); torch.cuda.synchronize()
@@ -71,6 +71,6 @@ for name, st in (("own stream", own.cuda_stream),) if window > 0 else (("NULL st
             one, two = D.matvec_forms()
             extra = f"; options {D.options['p2p_scalars']}; nnz A_loc {D.nnz_loc} ({100.0 * D.nnz_loc / max(1, D.nnz_loc + D.nnz_rem):.0f} %), A_rem {D.nnz_rem}; SpMVs in one launch {one}, in two {two}"
         print(f"{name}, {kind}: {best / 20 * 1e6:.1f} us per iteration (solves of 20 iterations, best of 8){extra}", flush=True)
-if window > 0:
+if window != 0:
     a, c = results["row-partitioned, A_loc / A_rem in ONE launch"], results["row-partitioned, A_loc / A_rem in TWO launches"]
     print("x after 20 iterations, one launch == two launches bit for bit:", a == c)
