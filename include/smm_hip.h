@@ -476,6 +476,10 @@ int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, i
  * exchange's event).  One launch is taken whenever both local blocks are in the row-mask encoding with values read at 1 / 2 / 4 lanes per
  * row (what the solvers adopt from 2^20 entries); SMM_HIP_SPLIT_SPMV=0 keeps the two launches.  Same bits either way. */
 int smm_hip_dist_csr_matvec_forms(const smm_hip_dist_csr* D, long long* one_launch, long long* two_launches);
+/* Milliseconds that workgroup 0 of this matrix's one-launch SpMVs has spent, in total, waiting for the word its halo exchange raises after
+ * finishing the local half of its rows (100 MHz device clock): what the exchanges cost beyond the compute that ran beside them -- the one-launch
+ * form's counterpart of smm_hip_profile_read_waits (`exposed_comm_ms` of `bench.py --gpus N`).  Synchronises the device; reset != 0 clears it. */
+int smm_hip_dist_csr_split_wait(smm_hip_dist_csr* D, double* waited_ms, int reset);
 /* The peer-to-peer plan of one rank as plain numbers: host arithmetic only (no device, no communicator), the same function the set-up uses.
  * needs[2 q], needs[2 q + 1] = the column range [cmin, cmax) rank q's rows touch; bounds[0 .. world] = the row partition.  Writes records of
  * 8 values into out (capacity in values; *out_count = records): push {0, dst, relay or -1, first global column, position at dst / relay,

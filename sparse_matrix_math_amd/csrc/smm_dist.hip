@@ -568,11 +568,14 @@ struct smm_hip_dist_csr {
 	smm::P2PState* p2p = nullptr;  // peer-to-peer data movement (smm_p2p.h); null: collectives of the communicator
 	// the SpMV in ONE launch (smm_spmv_split.hip): splitSync[kind] is raised -- on the stream the exchange ran on, behind it -- to the sequence
 	// number of the exchange whose halo has landed in the vector of that kind; splitSync[P2P_KINDS] is the error word of an expired wait
-	// (with the peer-to-peer transport the block's own error word is used instead: one word for the host to read)
+	// (with the peer-to-peer transport the block's own error word is used instead: one word for the host to read); splitSync[P2P_KINDS + 1]
+	// accumulates the ticks workgroup 0 of every one-launch SpMV waited for its word (smm_hip_dist_csr_split_wait)
 	unsigned long long* splitSync = nullptr;
 	unsigned long long landSeq[smm::P2P_KINDS] = {};
 	long long matvecsSplit = 0, matvecsTwo = 0;  // how many SpMVs with a halo ran in one launch / in two (smm_hip_dist_csr_matvec_forms)
 	int splitSumsLdsMax = 16384;  // SMM_HIP_SPLIT_SUMS_LDS at create time: bytes of LDS the one-launch SpMV's row sums may take (0: always through out[]; tests)
+	bool splitForced = false;
+	bool sharedGpu = false;  // two ranks of the communicator run on one card (seen in the peer-to-peer set-up's table)
 	bool splitAllowed = true;  // SMM_HIP_SPLIT_SPMV=0 at create time: this matrix keeps the two launches (A/B measurements, the bit-equality tests)
 	bool reducedInKernel = false;  // the SpMV just launched ran its reduction point itself (the one-launch form with the slots): allreduceTotals has nothing to do
 	int labWindow = 0;  // measurements on ONE GPU (SMM_HIP_LAB_SELF_SPLIT, single-rank communicator only): entries |column - row| >= window count as "remote"
@@ -596,10 +599,10 @@ static int distWorkspace(smm_hip_dist_csr* D) {
 	SMM_TRY(devAlloc(&D->partsB, PARTS_LEN * sizeof(T)));
 	SMM_TRY(devAlloc(&D->partsC, PARTS_LEN * sizeof(T)));
 	SMM_TRY(devAlloc(&D->sc, sizeof(DistScal<T>)));
-	SMM_TRY(devAlloc(reinterpret_cast<void**>(&D->splitSync), (P2P_KINDS + 1) * sizeof(unsigned long long)));
+	SMM_TRY(devAlloc(reinterpret_cast<void**>(&D->splitSync), (P2P_KINDS + 2) * sizeof(unsigned long long)));
 	preloadSplitUnit();  // (its code object is built for the device now, not inside the first iteration)
 	hipStream_t s = libStream();
-	SMM_HIP_TRY(hipMemsetAsync(D->splitSync, 0, (P2P_KINDS + 1) * sizeof(unsigned long long), s));
+	SMM_HIP_TRY(hipMemsetAsync(D->splitSync, 0, (P2P_KINDS + 2) * sizeof(unsigned long long), s));
 	// halo slots outside every recv segment are never read by A_rem; zero keeps them finite.  Tickets start at 0.
 	SMM_HIP_TRY(hipMemsetAsync(D->pExt, 0, eb, s));
 	SMM_HIP_TRY(hipMemsetAsync(D->sExt, 0, eb, s));
@@ -889,7 +892,19 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 		}
 	}
 	// ---- every rank learns every rank's handle, process, address and layout
-	constexpr int WORDS = 8 + 2 + 2 * P2P_KINDS + 1;  // handle | pid, address | landing, staging offsets | ok
+	constexpr int WORDS = 8 + 2 + 2 * P2P_KINDS + 2;  // handle | pid, address | landing, staging offsets | ok | which GPU (a hash of its PCI bus id)
+	long long myGpu = 0;
+	{
+		int dev = 0;
+		char bus[64] = {};
+		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bus, sizeof(bus), dev) == hipSuccess) {
+			unsigned long long hsh = 1469598103934665603ull;  // FNV-1a
+			for (const char* ch = bus; *ch; ++ch) hsh = (hsh ^ static_cast<unsigned char>(*ch)) * 1099511628211ull;
+			myGpu = static_cast<long long>(hsh >> 1) | 1;
+		} else {
+			(void)hipGetLastError();
+		}
+	}
 	std::vector<long long> table(static_cast<size_t>(world) * WORDS, 0);
 	long long* me = table.data() + static_cast<size_t>(rank) * WORDS;
 	hipIpcMemHandle_t handle{};
@@ -906,8 +921,19 @@ static int p2pSetup(smm_hip_dist_csr* D) {
 		me[10 + P2P_KINDS + k] = static_cast<long long>(P->stageOff[k]);
 	}
 	me[10 + 2 * P2P_KINDS] = ok ? 1 : 0;
+	me[WORDS - 1] = myGpu;
 	SMM_TRY(commAllreduceI64(c, table.data(), world * WORDS));
 	for (int q = 0; q < world; ++q) ok = ok && table[static_cast<size_t>(q) * WORDS + 10 + 2 * P2P_KINDS] == 1;
+	// Ranks that SHARE a GPU (a rehearsal of several ranks on one card) keep the two-launch SpMV: the one-launch form waits inside a grid that fills
+	// the chip but for one CU per XCD's worth of slots, and on a shared card a peer's grid takes exactly those slots -- the land and push kernels
+	// the grids are waiting for then find no room until the bounded wait expires (seen with 2 x 2.5 M rows on one MI355X, r06).  One rank per
+	// GPU -- the deployment -- leaves the room to the rank's own copy kernels.  Every rank sees the same table: every rank decides alike.
+	for (int q = 0; q < world; ++q) {
+		for (int r2 = q + 1; r2 < world; ++r2) {
+			const long long a = table[static_cast<size_t>(q) * WORDS + WORDS - 1], b = table[static_cast<size_t>(r2) * WORDS + WORDS - 1];
+			if (a == 0 || b == 0 || a == b) D->sharedGpu = true;
+		}
+	}
 	P->peer.assign(static_cast<size_t>(world), nullptr);
 	P->opened.assign(static_cast<size_t>(world), false);
 	if (ok) {
@@ -1262,6 +1288,7 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 	{
 		const char* env = getenv("SMM_HIP_SPLIT_SPMV");  // (read at every create, like SMM_HIP_HALO_CHUNKS: a property of the matrix)
 		D->splitAllowed = env ? atoi(env) != 0 : true;
+		D->splitForced = env && atoi(env) == 2;  // (2: also between ranks that share a GPU -- the tests, whose matrices leave the card half empty)
 		const char* lds = getenv("SMM_HIP_SPLIT_SUMS_LDS");
 		if (lds) D->splitSumsLdsMax = std::max(0, atoi(lds));
 	}
@@ -1394,7 +1421,15 @@ static unsigned long long* splitErrWord(smm_hip_dist_csr* D) {
 	if (D->p2p) return &D->p2p->hdr()->err;
 	return D->splitSync ? D->splitSync + P2P_KINDS : nullptr;
 }
-static bool splitWordWanted(const smm_hip_dist_csr* D) { return D->splitAllowed && D->splitSync && !D->remEmpty && D->chunks == 1; }
+// The one-launch SpMV is taken behind the peer-to-peer halo (the kernels it waits for are this library's own few workgroups, for which its grid
+// leaves room) and wherever the exchange has completed before the launch is enqueued (the host-callback communicator: same stream).  Behind an
+// RCCL exchange (the collectives, the hybrid) the two launches stay: a grid that waits inside the kernel must not depend on a library kernel
+// whose resource needs are not ours to know finding room beside it.
+static bool splitWordWanted(const smm_hip_dist_csr* D) {
+	if (!D->splitAllowed || !D->splitSync || D->remEmpty || D->chunks != 1) return false;
+	if (D->p2p && D->p2p->haloOn) return !D->sharedGpu || D->splitForced;  // (ranks that share a card: the two launches, see p2pSetup)
+	return D->labWindow != 0 || D->comm->kind != SMM_COMM_RCCL;
+}
 
 template <typename T>
 static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t s) {
@@ -1519,7 +1554,7 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 		}
 		const int st = launchSpmvSplit<T>(D->aLoc, D->aRem, op, lhs, jacobiDiag, own, ext, out, dotMode, w1, parts, doneFlag,
 		                                  (fuseSlots ? SPMV_FINISH : finish) | (jacobiDiag ? SPMV_ADD_DIV : 0), D->splitSync + pend.kind, pend.landSeq, splitErrWord(D),
-		                                  p2pTicks(), s, fuseSlots ? &slots : nullptr, D->splitSumsLdsMax);
+		                                  p2pTicks(), s, fuseSlots ? &slots : nullptr, D->splitSumsLdsMax, D->splitSync + P2P_KINDS + 1);
 		if (st == SMM_HIP_OK) {
 			if (fuseSlots) {
 				++D->p2p->redSeq[slotPoint];
@@ -2575,6 +2610,21 @@ int smm_hip_dist_csr_matvec_forms(const smm_hip_dist_csr* D, long long* one_laun
 	}
 	if (one_launch) *one_launch = D->matvecsSplit;
 	if (two_launches) *two_launches = D->matvecsTwo;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_split_wait(smm_hip_dist_csr* D, double* waited_ms, int reset) {
+	if (!D || !waited_ms) {
+		setError("dist_csr_split_wait: null argument");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*waited_ms = 0.0;
+	if (!D->splitSync) return SMM_HIP_OK;
+	unsigned long long ticks = 0;
+	SMM_HIP_TRY(hipDeviceSynchronize());
+	SMM_HIP_TRY(hipMemcpy(&ticks, D->splitSync + P2P_KINDS + 1, sizeof(ticks), hipMemcpyDeviceToHost));
+	if (reset) SMM_HIP_TRY(hipMemset(D->splitSync + P2P_KINDS + 1, 0, sizeof(ticks)));
+	*waited_ms = static_cast<double>(ticks) * 1.0e-5;  // (wall_clock64 counts at 100 MHz on gfx9)
 	return SMM_HIP_OK;
 }
 

@@ -360,7 +360,7 @@ void chooseSpmvConfig(smm_hip_csr* m);
 template <typename T>
 int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, const T* lhs, const T* divisor, const T* own, const T* ext, T* out, int dotMode,
                     const T* w1, T* partials, const int* doneFlag, int extraFlags, const unsigned long long* landed, unsigned long long seq, unsigned long long* err,
-                    long long ticks, hipStream_t s, const struct P2PSlotArgs* slots = nullptr, int sumsLdsMax = 16384);  // slots (smm_p2p.h): the launch runs the reduction point of its dot products itself; sumsLdsMax: bytes of LDS the local half's row sums may take (more: they travel through out[])
+                    long long ticks, hipStream_t s, const struct P2PSlotArgs* slots = nullptr, int sumsLdsMax = 16384, unsigned long long* waited = nullptr);  // slots (smm_p2p.h): the launch runs the reduction point of its dot products itself; sumsLdsMax: bytes of LDS the local half's row sums may take (more: they travel through out[])
 void launchSplitSignal(unsigned long long* landed, unsigned long long seq, hipStream_t s);
 void preloadSplitUnit();
 // ConjugateGradient's next direction formed in the SpMV's load phase (smm_spmv_march.hip, MarchFuse): Ap = A (beta pOld + r), the new

@@ -83,6 +83,7 @@ struct SplitArgs {
 	unsigned long long seq;
 	unsigned long long* err;
 	long long ticks;
+	unsigned long long* waited;  // workgroup 0 adds the ticks (100 MHz) it spent waiting for the word: what the exchange cost beyond the local half
 	P2PSlotArgs slots;  // world != 0 (peer-to-peer scalars, dotMode != 0, SPMV_FINISH): the last workgroup runs the reduction point itself
 };
 
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(TPB) void spmvPatternSplitKernel(const SplitArgs<T>
 				}
 			}
 			*sGo = go;
+			if (blockIdx.x == 0 && A.waited) atomicAdd(A.waited, static_cast<unsigned long long>(wall_clock64() - t0));
 		}
 		__syncthreads();
 		if (!*sGo) {  // (the host finds the error word where it reads `done`: the solve fails with SMM_HIP_ERR_COMM; the peers' waits are released all the same)
@@ -605,7 +607,7 @@ static int launchSplitL(const SplitArgs<T>& base, int cus, int sumsLdsMax, int c
 template <typename T>
 int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, const T* lhs, const T* divisor, const T* own, const T* ext, T* out, int dotMode,
                     const T* w1, T* partials, const int* doneFlag, int extraFlags, const unsigned long long* landed, unsigned long long seq, unsigned long long* err,
-                    long long ticks, hipStream_t s, const P2PSlotArgs* slots, int sumsLdsMax) {
+                    long long ticks, hipStream_t s, const P2PSlotArgs* slots, int sumsLdsMax, unsigned long long* waited) {
 	const int LA = splitLanes(aLoc), LB = splitLanes(aRem);
 	if (!LA || !LB || aLoc->rows != aRem->rows) return 1;
 	if (aLoc->dtype != dtypeOf<T>() || aRem->dtype != dtypeOf<T>()) return 1;
@@ -645,10 +647,12 @@ int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, co
 	a.seq = seq;
 	a.err = err;
 	a.ticks = ticks;
+	a.waited = waited;
 	if (slots && dotMode && (extraFlags & SPMV_FINISH)) a.slots = *slots;
 	// the exchange is itself a few workgroups (the land kernel, the peers' pushes, an RCCL kernel) that must find room beside this grid while it
-	// waits for them: one CU per XCD's worth of slots stays free
-	const int cus = landed ? std::max(8, numCUs() - 8) : numCUs();
+	// waits for them
+	// (16 CUs' worth of slots -- two per XCD -- stay free: ~80 of the 256 CUs then hold four workgroups instead of five and have registers to spare)
+	const int cus = landed ? std::max(8, numCUs() - 16) : numCUs();
 	const int chunked = (aLoc->split_uneven || aRem->split_uneven) ? 1 : 0;
 	switch (LA * 8 + LB) {
 	case 1 * 8 + 1: return launchSplitL<T, 1, 1>(a, cus, sumsLdsMax, chunked, s);
@@ -664,9 +668,9 @@ int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, co
 }
 
 template int launchSpmvSplit<float>(const smm_hip_csr*, const smm_hip_csr*, int, const float*, const float*, const float*, const float*, float*, int, const float*, float*,
-                                    const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*, int);
+                                    const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*, int, unsigned long long*);
 template int launchSpmvSplit<double>(const smm_hip_csr*, const smm_hip_csr*, int, const double*, const double*, const double*, const double*, double*, int, const double*,
-                                     double*, const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*, int);
+                                     double*, const int*, int, const unsigned long long*, unsigned long long, unsigned long long*, long long, hipStream_t, const P2PSlotArgs*, int, unsigned long long*);
 
 void preloadSplitUnit() {
 	hipFuncAttributes attr;

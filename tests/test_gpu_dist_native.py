@@ -771,7 +771,10 @@ def test_one_launch_spmv_between_processes(smm, oracle, world, relays, dtype):
     """The one-launch SpMV behind the peer-to-peer transport between PROCESSES: the word a rank's SpMV kernel polls is raised behind ITS land
     kernel, which waits for pushes of other processes -- the kernel sits on the GPU with its local half done while they arrive.  Both local
     blocks forced to the row-mask encoding; SpMVs back to back, BiCGStab +- Jacobi, CG; against the oracle."""
-    rep = _run_worker_processes(world, "banded", dtype, {"SMM_HIP_P2P": "1", "SMM_HIP_P2P_RELAYS": str(relays), "SMM_HIP_P2P_TIMEOUT_S": "20"}, extra_args=("pattern",))
+    # (SMM_HIP_SPLIT_SPMV=2: ranks that share a GPU normally keep the two launches -- on a card that two full-size grids fill, the copy kernels the
+    # grids wait for find no room; these matrices leave it half empty)
+    rep = _run_worker_processes(world, "banded", dtype, {"SMM_HIP_P2P": "1", "SMM_HIP_P2P_RELAYS": str(relays), "SMM_HIP_P2P_TIMEOUT_S": "20", "SMM_HIP_SPLIT_SPMV": "2"},
+                                extra_args=("pattern",))
     for o in rep["options"]:
         assert o["p2p"] is True and o["matvec_forms"][0] > 0 and o["matvec_forms"][1] == 0, rep["options"]
     _check_worker_report(oracle, smm, rep, dtype)
@@ -808,4 +811,15 @@ def test_hybrid_transport_between_processes(smm, oracle):
     rep = _run_worker_processes(3, "banded", dtype, {"SMM_HIP_P2P_HALO": "0", "SMM_HIP_P2P_TIMEOUT_S": "20"})
     for o in rep["options"]:
         assert o["p2p"] is False and o["p2p_scalars"] is True and o["relays"] == 0, rep["options"]
+    _check_worker_report(oracle, smm, rep, dtype)
+
+
+def test_ranks_that_share_a_gpu_keep_the_two_launch_spmv(smm, oracle):
+    """r06: the one-launch SpMV waits inside a grid that fills the chip but for a few workgroup slots; ranks of a rehearsal that share ONE card
+    would take each other's spare slots and starve the copy kernels both are waiting for (seen with 2 x 2.5 M rows: both ranks' bounded waits
+    expired).  The peer-to-peer set-up sees every rank's GPU and keeps the two launches when two ranks share one -- the transport itself stays."""
+    dtype = np.float64
+    rep = _run_worker_processes(2, "banded", dtype, {"SMM_HIP_P2P_TIMEOUT_S": "20"}, extra_args=("pattern",))
+    for o in rep["options"]:
+        assert o["p2p"] is True and o["matvec_forms"][0] == 0 and o["matvec_forms"][1] > 0, rep["options"]
     _check_worker_report(oracle, smm, rep, dtype)
