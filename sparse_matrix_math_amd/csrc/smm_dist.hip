@@ -17,6 +17,10 @@
 //     8 kernels per BiCGStab iteration (4 SpMV launches, s, r, x, p updates) + 1 finishing launch, 6 + 1 per CG iteration.  The x update does not depend
 //     on the last all-reduce of an iteration (||r||^2, r.r0) and runs beside it.
 //   * nothing in the loop synchronises with the host; the `done` flag is polled through a pinned mailbox (DonePoller).
+//   * r05 / r06: between processes the halo and the scalars travel PEER TO PEER by default (smm_p2p.h: pushes into IPC-mapped landing areas with
+//     relay ranks, slot reductions -- no collective inside the loop), and a rank's SpMV runs as ONE launch over A_loc and A_rem
+//     (smm_spmv_split.hip: local half, a bounded wait for the word the land kernel raises, remote half).  The collectives above are the
+//     fall-back (SMM_HIP_P2P=0, a failed self-test, ranks that are threads of one process).
 //
 // Communicators: RCCL (librccl resolved with dlopen at run time, so single-GPU users need no RCCL), or host callbacks (the
 // caller moves the bytes: used by the tests to run several ranks on one GPU, where RCCL cannot, and by the gloo rehearsal of

@@ -22,8 +22,10 @@
 //     the place the RCCL all-reduce would have left them: the update kernels are unchanged;
 //   * every wait is bounded (SMM_HIP_P2P_TIMEOUT_S, default 20 s): an expired wait raises the block's error word, every later wait of the
 //     rank returns at once, and the host -- which reads the word wherever it reads `done` -- fails the call with SMM_HIP_ERR_COMM.
-// RCCL stays the fall-back (and the default until a multi-GPU run has confirmed this path: SMM_HIP_P2P=1 asks for it; every rank must
-// succeed in mapping every peer and in a self-test through every path, else all ranks agree to stay with RCCL).
+// r06: the DEFAULT between processes (SMM_HIP_P2P=0 on any rank turns it off): taken when every rank succeeds in mapping every peer and in
+// the create-time self-test -- every reduction point through the slots, five halo exchanges through every path --; the halo part failing
+// leaves the scalars in the slots and the halo with the communicator (the hybrid), the scalar part failing leaves everything with the
+// communicator's collectives (smm_dist.hip, p2pSetup).
 #pragma once
 #include <hip/hip_runtime.h>
 

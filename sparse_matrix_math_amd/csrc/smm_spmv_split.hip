@@ -651,8 +651,10 @@ int launchSpmvSplit(const smm_hip_csr* aLoc, const smm_hip_csr* aRem, int op, co
 	if (slots && dotMode && (extraFlags & SPMV_FINISH)) a.slots = *slots;
 	// the exchange is itself a few workgroups (the land kernel, the peers' pushes, an RCCL kernel) that must find room beside this grid while it
 	// waits for them
-	// (16 CUs' worth of slots -- two per XCD -- stay free: ~80 of the 256 CUs then hold four workgroups instead of five and have registers to spare)
-	const int cus = landed ? std::max(8, numCUs() - 16) : numCUs();
+	// (8 CUs' worth of slots -- one per XCD -- stay free: ~40 of the 256 CUs then hold four workgroups instead of five and have registers and wave
+	// slots to spare; the push, forward and land kernels of an exchange run one after the other on the communicator's stream, so one of them at a
+	// time needs room.  16 CUs' worth cost the SpMV 2-3 us and bought nothing measurable)
+	const int cus = landed ? std::max(8, numCUs() - 8) : numCUs();
 	const int chunked = (aLoc->split_uneven || aRem->split_uneven) ? 1 : 0;
 	switch (LA * 8 + LB) {
 	case 1 * 8 + 1: return launchSplitL<T, 1, 1>(a, cus, sumsLdsMax, chunked, s);
