@@ -594,6 +594,44 @@ def test_one_launch_spmv_on_ragged_matrices(smm, oracle, world, dtype, lanes, se
     assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref)))
 
 
+@pytest.mark.parametrize("seed", list(range(10, 22)))
+def test_one_launch_spmv_fuzz(smm, oracle, seed):
+    """random bands with holes, random worlds (2-4), lanes pairings, dtypes and forms of the row sums (LDS / through out[]), among them matrices
+    whose entries sit in the rows near one end (the chunked deal of the super tiles) and rows no rank shares: the one-launch SpMV's bytes are
+    the two launches' for every op, and the oracle's numbers within the piece forms' bound"""
+    rng = np.random.default_rng(seed)
+    dtype = (np.float32, np.float64)[seed % 2]
+    world = int(rng.integers(2, 5))
+    lanes = ((1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 4), (2, 4))[int(rng.integers(0, 7))]
+    n = int(rng.integers(30000, 90000))
+    csr = _ragged(gen.banded_random_spd(n, k=int(rng.integers(3, 20)), seed=seed, max_offset=int(rng.integers(200, 12000)), dtype=dtype), seed,
+                  drop=float(rng.uniform(0.0, 0.6)))
+    if seed % 3 == 0:
+        # everything beyond the diagonal dropped from the first 60 % of the rows: what is left of the off-diagonal entries sits near the end
+        start, pos, val = csr
+        rows = np.repeat(np.arange(n), np.diff(start))
+        keep = (pos == rows) | (rows >= int(0.6 * n))
+        new_start = np.zeros(n + 1, dtype=np.int32)
+        np.add.at(new_start, rows[keep] + 1, 1)
+        csr = (np.cumsum(new_start).astype(np.int32), pos[keep].copy(), val[keep].copy())
+    b = np.random.default_rng(seed + 100).uniform(0.5, 1.5, n).astype(dtype)
+    sums = None if seed % 2 else 0
+    one, forms_one = _solve_forms(smm, csr, b, world, dtype, lanes, split=True, sums_lds=sums)
+    two, forms_two = _solve_forms(smm, csr, b, world, dtype, lanes, split=False)
+    # (a rank without a halo has nothing to count; long rows at one lane per row in fp64 do not fit the 64 KB a tile may stage: those pairs of
+    # blocks keep the two launches -- by design, and then both runs are the same form)
+    nnz_row = (csr[0][-1] / n)
+    fits = all(256 // L * nnz_row * 1.25 + 3 <= 65536 // np.dtype(dtype).itemsize for L in lanes)
+    if fits:
+        assert sum(f[0] for f in forms_one) > 0 and all(f[1] == 0 for f in forms_one), forms_one
+    assert all(f[0] == 0 or f[1] == 0 for f in forms_one), forms_one
+    assert all(f[0] == 0 for f in forms_two), forms_two
+    assert [a == b_ for a, b_ in zip(one[:3], two[:3])] == [True] * 3
+    y_ref = oracle.spmv(csr, 0, None, b)
+    y = np.frombuffer(one[0], dtype=dtype)
+    assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
+
+
 def test_peer_to_peer_is_refused_between_ranks_of_one_process(smm, oracle, monkeypatch):
     """Ranks that are THREADS of one process asking for the peer-to-peer transport stay with the communicator's collectives (r06): the
     transport makes kernels of one rank wait for kernels of another, and inside one process HIP gives no control over which hardware queue
