@@ -476,6 +476,20 @@ int smm_hip_dist_csr_options(const smm_hip_dist_csr* D, int* p2p, int* relays, i
  * exchange's event).  One launch is taken whenever both local blocks are in the row-mask encoding with values read at 1 / 2 / 4 lanes per
  * row (what the solvers adopt from 2^20 entries); SMM_HIP_SPLIT_SPMV=0 keeps the two launches.  Same bits either way. */
 int smm_hip_dist_csr_matvec_forms(const smm_hip_dist_csr* D, long long* one_launch, long long* two_launches);
+/* A THIN remote block: when at most an eighth of this rank's rows hold an entry in another rank's columns (the slabs of a 3-D grid: the two
+ * boundary planes) those rows are listed at creation (*rows; 0: the block is not thin) and the second half of an SpMV is a launch over the
+ * listed rows only -- out[row] (+|-)= A_rem[row] . halo, the row's entries in order -- instead of a pass over all of out[]; the dot products
+ * ride in the local launch and the thin one adds what its rows change (o . w = a . w + d . w,  o . o = a . a + d (a + o)).  *matvecs: SpMVs
+ * run in this form so far (they are not counted by smm_hip_dist_csr_matvec_forms).  Taken when the remote block's kernel reads one lane per
+ * row and no Jacobi division rides in the epilogue; out[] has the bits of the general form, the dot products differ in the order of their
+ * additions.  SMM_HIP_THIN_REMOTE=0 at creation keeps the general second launch. */
+int smm_hip_dist_csr_thin_remote(const smm_hip_dist_csr* D, int* rows, long long* matvecs);
+/* SpMVs of smm_hip_dist_cg_* on this matrix that formed the next direction themselves (p = beta p_old + r in the load phase of the 2.5-D
+ * constant-diagonal kernel, csrc/smm_spmv_march.hip): taken when x is deferred (vectors beyond the caches), the local block is served by that
+ * kernel with non-temporal outputs and the remote block is empty or thin; the halo of r then travels instead of the direction's and every rank
+ * forms the halo of the new direction itself -- the owner's expression on the owner's operands.  Same bits as the loop that forms p in a
+ * launch of its own (smm_hip_set_cg_fuse_p(0)). */
+int smm_hip_dist_csr_cg_fused(const smm_hip_dist_csr* D, long long* matvecs);
 /* Milliseconds that workgroup 0 of this matrix's one-launch SpMVs has spent, in total, waiting for the word its halo exchange raises after
  * finishing the local half of its rows (100 MHz device clock): what the exchanges cost beyond the compute that ran beside them -- the one-launch
  * form's counterpart of smm_hip_profile_read_waits (`exposed_comm_ms` of `bench.py --gpus N`).  Synchronises the device; reset != 0 clears it. */

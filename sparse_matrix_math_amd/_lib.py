@@ -138,6 +138,8 @@ _PLAIN = {
     "smm_hip_dist_csr_halo_chunks": (c_int, [_P, POINTER(c_int)]),
     "smm_hip_dist_csr_options": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(ctypes.c_double)]),
     "smm_hip_dist_csr_matvec_forms": (c_int, [_P, POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong)]),
+    "smm_hip_dist_csr_thin_remote": (c_int, [_P, POINTER(c_int), POINTER(ctypes.c_longlong)]),
+    "smm_hip_dist_csr_cg_fused": (c_int, [_P, POINTER(ctypes.c_longlong)]),
     "smm_hip_dist_csr_split_wait": (c_int, [_P, POINTER(ctypes.c_double), c_int]),
     "smm_hip_dist_p2p_plan": (c_int, [c_int, c_int, POINTER(c_longlong), POINTER(c_int), c_int, c_double, POINTER(c_longlong), c_int, POINTER(c_int)]),
 }

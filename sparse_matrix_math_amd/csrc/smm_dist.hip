@@ -391,6 +391,19 @@ __global__ void splitCountKernel(int nLocal, const int* __restrict__ start, cons
 	}
 }
 
+constexpr int THIN_SHARE = 8;  // a remote block is thin when rows with a remote entry x THIN_SHARE <= rows
+// rows that hold a remote entry: a 0 / 1 flag per row (scanned into the row's index in the list), then the list
+__global__ void thinFlagKernel(int nLocal, const int* __restrict__ startRem, int* __restrict__ flag) {
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row <= nLocal; row += gridDim.x * blockDim.x) {
+		flag[row] = row < nLocal && startRem[row + 1] > startRem[row] ? 1 : 0;
+	}
+}
+__global__ void thinListKernel(int nLocal, const int* __restrict__ startRem, const int* __restrict__ index, int* __restrict__ rows) {
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nLocal; row += gridDim.x * blockDim.x) {
+		if (startRem[row + 1] > startRem[row]) rows[index[row]] = row;
+	}
+}
+
 template <typename T>
 __global__ void splitScatterKernel(int nLocal, const int* __restrict__ start, const int* __restrict__ positions, const T* __restrict__ values, int ownLo,
                                    int ownHi, int labWindow, int cmin, const int* __restrict__ startLoc, const int* __restrict__ startRem, int* __restrict__ posLoc,
@@ -485,8 +498,9 @@ template <typename T>
 struct DistScal {
 	T rrPing[2];  // BiCGStab: rr0 / CG: ||r||^2, double-buffered by iteration parity (workgroup 0 writes the next while others read)
 	T alpha, omega, res;
-	int done, iters, status, pad;
+	int done, iters, status, pad;  // pad: `done` as distCgR found it (what the launches behind it test: workgroup 0 of one of them may set `done` while others still start)
 	T alphaRing[LAZY_M];  // CG with the deferred x update (distCgLazyP): alpha of the last LAZY_M iterations
+	int flushIter, pad2;  // CG with the direction formed inside the SpMV: the iteration whose SpMV launch found its predecessor converged (-1: none)
 };
 
 // up to four [lo, hi) runs of rows, passed to the update kernels by value
@@ -550,6 +564,8 @@ struct smm_hip_dist_csr {
 	void *r = nullptr, *r0 = nullptr, *ap = nullptr, *as = nullptr, *scratch = nullptr;
 	void *pExt = nullptr, *sExt = nullptr, *xExt = nullptr;
 	void* lazyExt[smm::LAZY_M] = {};  // CG with the deferred x update: LAZY_M more halo-extended direction vectors (allocated by the first such solve)
+	void* rExt = nullptr;  // CG with the direction formed inside the SpMV: the residual, halo-extended (its halo travels instead of the direction's)
+	long long cgFused = 0;  // SpMVs of ConjugateGradient that formed the direction themselves (smm_hip_dist_csr_thin_remote reports it)
 	void *partsA = nullptr, *partsB = nullptr, *partsC = nullptr;  // finishing buffers (PARTS_LEN): totals are all-reduced in place
 	void* sc = nullptr;
 	// every rank's column range [cmin, cmaxExcl) and the row bounds (global knowledge: any rank can derive any rank's halo plan)
@@ -583,6 +599,13 @@ struct smm_hip_dist_csr {
 	bool splitAllowed = true;  // SMM_HIP_SPLIT_SPMV=0 at create time: this matrix keeps the two launches (A/B measurements, the bit-equality tests)
 	bool reducedInKernel = false;  // the SpMV just launched ran its reduction point itself (the one-launch form with the slots): allreduceTotals has nothing to do
 	int labWindow = 0;  // measurements on ONE GPU (SMM_HIP_LAB_SELF_SPLIT, single-rank communicator only): entries |column - row| >= window count as "remote"
+	// a THIN remote block (r06): at most an eighth of the rows hold a remote entry (the slabs of a 3-D grid: two planes) -- thinRows lists them, and
+	// the second half of the SpMV is a launch over those rows only (thinRemoteKernel) instead of a pass over every row of `out`
+	int* thinRows = nullptr;
+	int nThin = 0;
+	void* partsThin = nullptr;  // finishing buffer of that launch's share of the dot products
+	bool totalsFinal = false;   // the SpMV just launched left the rank's TOTALS in the finishing buffer (the thin form): the slot kernel must not add partials again
+	long long matvecsThin = 0;
 };
 
 namespace smm {
@@ -1329,6 +1352,30 @@ static int distCreate(smm_hip_comm* comm, int nGlobal, const int* bounds, const 
 		SMM_TRY(smm_hip_csr_create_dev_f64(nLocal, nLocal, startLoc, static_cast<int*>(D->arrays[1]), static_cast<double*>(D->arrays[2]), &D->aLoc));
 		SMM_TRY(smm_hip_csr_create_dev_f64(nLocal, D->extLen, startRem, static_cast<int*>(D->arrays[4]), static_cast<double*>(D->arrays[5]), &D->aRem));
 	}
+	// ---- a thin remote block: the rows with a remote entry, listed (each rank for itself: nothing collective depends on it)
+	{
+		const char* env = getenv("SMM_HIP_THIN_REMOTE");  // (read at every create: a property of the matrix; 0: the general second launch)
+		const bool allowed = env ? atoi(env) != 0 : true;
+		if (allowed && nLocal > 0 && totals[1] > 0) {
+			DevBuf<int> flag;
+			SMM_TRY(flag.alloc(static_cast<size_t>(nLocal) + 1));
+			thinFlagKernel<<<grid, 256, 0, s>>>(nLocal, startRem, flag);
+			SMM_HIP_TRY(hipGetLastError());
+			SMM_TRY(exclusiveScan(flag, nLocal + 1, s));
+			int nThin = 0;
+			SMM_HIP_TRY(hipMemcpyAsync(&nThin, flag.p + nLocal, sizeof(int), hipMemcpyDeviceToHost, s));
+			SMM_HIP_TRY(hipStreamSynchronize(s));
+			if (nThin > 0 && static_cast<long long>(nThin) * THIN_SHARE <= nLocal) {
+				SMM_TRY(devAlloc(reinterpret_cast<void**>(&D->thinRows), static_cast<size_t>(nThin) * sizeof(int)));
+				thinListKernel<<<grid, 256, 0, s>>>(nLocal, startRem, flag, D->thinRows);
+				SMM_HIP_TRY(hipGetLastError());
+				SMM_TRY(devAlloc(&D->partsThin, PARTS_LEN * sizeof(T)));
+				SMM_HIP_TRY(hipMemsetAsync(D->partsThin, 0, PARTS_LEN * sizeof(T), s));
+				SMM_HIP_TRY(hipStreamSynchronize(s));
+				D->nThin = nThin;
+			}
+		}
+	}
 	// ---- the halo in pieces (opt-in): every rank must cut alike, so the ranks agree on the smallest request
 	{
 		const char* env = getenv("SMM_HIP_HALO_CHUNKS");  // (read at every create: a property of the matrix, not of the process)
@@ -1522,9 +1569,81 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 	return SMM_HIP_OK;
 }
 
+// The second half of a row-partitioned SpMV whose remote block is THIN (smm_hip_dist_csr::thinRows): out[row] (+|-)= A_rem[row] . ext for the
+// listed rows only -- one lane per row, the row's entries in order: the sum the one-lane kernels form -- where the general form passes over
+// every row of out[] to add nothing to most of them and to read them for the dot products.  The dot products were taken by the LOCAL
+// launch over the half-finished vector (its totals are in `totals`); this launch adds what its rows change: with o = a + d,
+//   o . w = a . w + d . w          o . o = a . a + d (a + o)
+// (the same numbers up to the order of the additions: the partial sums of a rank are not the reference's in any form).  The workgroups'
+// shares go through a buffer of their own; thinFinishKernel adds them to `totals` in a fixed order.
+constexpr int THIN_MAX_GRID = NPART;
+template <typename T>
+__global__ __launch_bounds__(TPB) void thinRemoteKernel(int nThin, const int* __restrict__ rowsList, const int* __restrict__ start, const int* __restrict__ positions,
+                                                        const T* __restrict__ values, const T* __restrict__ ext, int subtract, T* out, int dotMode,
+                                                        const T* __restrict__ w1, T* __restrict__ partsThin, const int* __restrict__ doneFlag) {
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	T acc0 = T(0), acc1 = T(0);
+	for (int k = blockIdx.x * TPB + threadIdx.x; k < nThin; k += gridDim.x * TPB) {
+		const int row = rowsList[k];
+		const int e = start[row + 1];
+		T sum = T(0);
+		for (int j = start[row]; j < e; ++j) sum = smmFma(values[j], ext[positions[j]], sum);
+		const T a = out[row];
+		const T o = subtract ? a - sum : a + sum;
+		out[row] = o;
+		if (dotMode) {
+			const T dlt = subtract ? -sum : sum;
+			if (dotMode == 2) acc0 += dlt * (a + o);
+			acc1 += dlt * w1[row];
+		}
+	}
+	if (!dotMode) return;
+	if (dotMode == 2) {
+		const T s0 = blockSum256(acc0, red);
+		if (threadIdx.x == 0) partsThin[blockIdx.x] = s0;
+	}
+	const T s1 = blockSum256(acc1, red);
+	if (threadIdx.x == 0) partsThin[(dotMode == 2 ? NPART : 0) + blockIdx.x] = s1;
+}
+// (a launch of its own, started without a gap, instead of a ticket taken by every workgroup of a kernel that lasts microseconds: as distFinishSums)
+template <typename T>
+__global__ __launch_bounds__(TPB) void thinFinishKernel(const T* __restrict__ partsThin, int groups, int nsets, T* totals, const int* __restrict__ doneFlag) {
+	__shared__ T red[4];
+	if (doneFlag && *doneFlag) return;
+	for (int k = 0; k < nsets; ++k) {
+		T acc = T(0);
+		for (int i = threadIdx.x; i < groups; i += TPB) acc += partsThin[(nsets == 2 ? k * NPART : 0) + i];
+		const T s = blockSum256(acc, red);
+		if (threadIdx.x == 0) totals[k] += s;
+	}
+}
+
+// whether the thin form serves this matrix now (the remote block's kernel configuration is settled first: it decides the lanes per row)
+static int thinUsable(smm_hip_dist_csr* D, hipStream_t s, bool* usable) {
+	*usable = false;
+	if (D->nThin <= 0 || D->chunks != 1) return SMM_HIP_OK;
+	SMM_TRY(ensureCsrReady(D->aRem, s, true));
+	*usable = D->aRem->lanes() == 1;
+	return SMM_HIP_OK;
+}
+// out[listed rows] (+|-)= A_rem . ext, the launch's share of the dot products added to the totals the local launch left in `parts`
+template <typename T>
+static int launchThinRemote(smm_hip_dist_csr* D, const T* ext, bool subtract, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s) {
+	const int g = std::max(1, std::min(THIN_MAX_GRID, (D->nThin + TPB - 1) / TPB));
+	thinRemoteKernel<T><<<g, TPB, 0, s>>>(D->nThin, D->thinRows, static_cast<const int*>(D->arrays[0]) + D->nLocal + 1 /* startRem */, static_cast<const int*>(D->arrays[4]),
+	                                     static_cast<const T*>(D->arrays[5]), ext, subtract ? 1 : 0, out, dotMode, w1, static_cast<T*>(D->partsThin), doneFlag);
+	if (dotMode) thinFinishKernel<T><<<1, TPB, 0, s>>>(static_cast<const T*>(D->partsThin), g, dotMode == 2 ? 2 : 1, parts + PARTS_TOTALS, doneFlag);
+	SMM_HIP_TRY(hipGetLastError());
+	D->totalsFinal = dotMode != 0;
+	++D->matvecsThin;
+	return SMM_HIP_OK;
+}
+
+// locFlags: flags of the LOCAL block's launch beyond those formed here (SPMV_HALF_TILES: ConjugateGradient's launches, smm_internal.h)
 template <typename T>
 static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s,
-                             const T* jacobiDiag = nullptr, int slotPoint = -1) {
+                             const T* jacobiDiag = nullptr, int slotPoint = -1, int locFlags = 0) {
 	const T* own = ext + D->ownOffset;
 	auto& pend = D->pending;
 	const bool exchange = pend.active;
@@ -1534,8 +1653,8 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 	// local block's when nothing is remote, else the remote block's epilogue ("add, then divide"): the loop then has the kernel count
 	// of the unpreconditioned one, and the dot products of the divided vector ride in the same epilogue
 	if (D->remEmpty && !exchange) {
-		if (jacobiDiag) return launchSpmv<T>(D->aLoc, op, jacobiDiag, own, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_DIV_LHS);
-		return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish);
+		if (jacobiDiag) return launchSpmv<T>(D->aLoc, op, jacobiDiag, own, out, dotMode, w1, parts, doneFlag, s, finish | SPMV_DIV_LHS | locFlags);
+		return launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s, finish | locFlags);
 	}
 	// ONE launch for both halves where the blocks allow it (smm_spmv_split.hip; r06): the local half of the workgroup's rows, a bounded wait for the
 	// word this exchange raises, the remote half -- the arithmetic of the two launches below, bit for bit, without the second ramp and tail, the
@@ -1569,10 +1688,23 @@ static int distMatvecCompute(smm_hip_dist_csr* D, T* ext, int op, const T* lhs, 
 		}
 		if (st < 0) return st;
 	}
+	// a THIN remote block (at most an eighth of the rows hold a remote entry; one lane per row; no Jacobi division in the epilogue): the local
+	// launch takes the dot products and finishes them, the remote half is a launch over the listed rows that adds its share to the totals
+	bool thin = false;
+	if (!jacobiDiag) SMM_TRY(thinUsable(D, s, &thin));
+	if (thin) {
+		SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, dotMode, w1, parts, doneFlag, s,
+		                      (dotMode ? SPMV_FINISH : 0) | (exchange && pend.async ? SPMV_LEAVE_ROOM : 0) | locFlags));
+		if (exchange && pend.landed[0]) {
+			profWaitWaiting(pend.waitSlot[0], s);
+			SMM_HIP_TRY(hipStreamWaitEvent(s, pend.landed[0], 0));
+		}
+		return launchThinRemote<T>(D, ext, op == SMM_OP_SUB, out, dotMode, w1, parts, doneFlag, s);
+	}
 	if (exchange && !D->remEmpty) ++D->matvecsTwo;
 	// the local block runs while the halo is in flight; the exchange is itself a kernel (a few workgroups per peer), and the persistent
 	// SpMV grid would otherwise take every workgroup slot of the chip until it ends: it leaves one CU per XCD's worth free
-	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, exchange && pend.async ? SPMV_LEAVE_ROOM : 0));
+	SMM_TRY(launchSpmv<T>(D->aLoc, op, lhs, own, out, 0, nullptr, nullptr, doneFlag, s, (exchange && pend.async ? SPMV_LEAVE_ROOM : 0) | locFlags));
 	const int remOp = op == SMM_OP_SUB ? SMM_OP_SUB : SMM_OP_ADD;
 	if (exchange && D->chunks > 1 && !D->p2p) {
 		// part k of A_rem reads only piece k and starts as soon as THAT piece has landed: out = ((A_loc x + A_rem,0 x) + A_rem,1 x) + ... -- each
@@ -1615,6 +1747,8 @@ template <typename T>
 static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t s, hipEvent_t* joined, int point = 0, const int* doneFlag = nullptr) {
 	smm_hip_comm* c = D->comm;
 	*joined = nullptr;
+	const bool finished = D->totalsFinal;  // (the thin form: the rank's totals are in place)
+	D->totalsFinal = false;
 	if (D->reducedInKernel) {  // (the one-launch SpMV in front ran this point in its last workgroup)
 		D->reducedInKernel = false;
 		return SMM_HIP_OK;
@@ -1623,7 +1757,7 @@ static int allreduceTotals(smm_hip_dist_csr* D, T* parts, int count, hipStream_t
 	T* totals = parts + PARTS_TOTALS;
 	// peer to peer: ONE single-workgroup kernel on the solver's own stream writes this rank's totals into every rank's slot, waits for all
 	// slots of this sequence number and adds them in rank order (smm_p2p.h) -- no collective launch, no cross-stream events
-	if (D->p2p) return p2pAllreduceLaunch<T>(D, point, totals, count, doneFlag, s, parts);  // (it adds the rank's partials itself: nobody finished them)
+	if (D->p2p) return p2pAllreduceLaunch<T>(D, point, totals, count, doneFlag, s, finished ? nullptr : parts);  // (else it adds the rank's partials itself: nobody finished them)
 	if (c->kind == SMM_COMM_HOST) return commAllreduce<T>(c, totals, count, s);
 	noteStream(c->stream);
 	SMM_TRY(orderAfter(c, s, c->stream));
@@ -1812,10 +1946,12 @@ __global__ void distCgInit(const T* __restrict__ totals, DistScal<T>* sc, T eps)
 	sc->iters = 0;
 	sc->done = 0;
 	sc->status = SMM_SOLVER_MAX_ITERATIONS_REACHED;
+	sc->flushIter = -1;
 	if (eps * eps > rr) {  // ref:2342-2344: x stays untouched
 		sc->done = 1;
 		sc->status = SMM_SOLVER_SUCCESS;
 	}
+	sc->pad = sc->done;
 }
 
 // alpha = rr / (Ap.p) ; r = -alpha Ap + r ; local ||r||^2   (ref:2354-2375)
@@ -1823,7 +1959,9 @@ __global__ void distCgInit(const T* __restrict__ totals, DistScal<T>* sc, T eps)
 template <typename T, bool NT>
 __global__ __launch_bounds__(TPB) void distCgR(int n, DistScal<T>* sc, int par, const T* __restrict__ totalsA, const T* Ap, T* r, T* partsC, int alphaSlot) {
 	__shared__ T red[4];
-	if (sc->done) return;
+	const int done = sc->done;
+	if (blockIdx.x == 0 && threadIdx.x == 0) sc->pad = done;
+	if (done) return;
 	const T alpha = sc->rrPing[par] / totalsA[0];
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		sc->alpha = alpha;
@@ -1907,7 +2045,7 @@ __device__ __forceinline__ void distLazyFlush(const RowRanges& rg, const DistRin
 template <typename T, bool NT>
 __global__ __launch_bounds__(TPB) void distCgLazyP(RowRanges rg, int book, DistScal<T>* sc, int par, const T* __restrict__ totalsC, T eps, DistRing<T> ring, int cur,
                                                    int pending, int flush, int alphaSlot, const T* r, const T* xcur, T* x) {
-	if (sc->done) return;
+	if (sc->pad) return;  // (`done` as distCgR found it: workgroup 0 of THIS launch may be setting it while others start -- and their rows still need the flush)
 	const T rrNew = totalsC[0];
 	const T rrOld = sc->rrPing[par];
 	const bool converged = eps * eps > rrNew;
@@ -1949,6 +2087,51 @@ __global__ __launch_bounds__(TPB) void distCgLazyP(RowRanges rg, int book, DistS
 	default: break;
 	}
 #undef SMM_DIST_LAZY_CASE
+}
+
+// ---- the direction formed inside the SpMV (smm_spmv_march.hip, MarchFuse) ----------------------------------------
+// The local block's launch reads the previous direction and r and forms p = beta p_old + r for every element it touches; what it cannot
+// form is the HALO of the new direction -- so the halo of r travels instead of p's (posted right behind distCgR, while ||r||^2 is reduced)
+// and this launch forms the halo of p from it: the owner's expression on the owner's operands -- beta from the same all-reduced total
+// and the same rrPing on every rank -- hence the owner's bits.  Runs behind the fused launch (whose workgroup 0 did iteration i - 1's
+// bookkeeping: rrPing[par] is untouched, `done` is final).
+struct HaloSegs {
+	int n = 0;
+	int off[P2P_MAX_WORLD] = {}, cnt[P2P_MAX_WORLD] = {};
+};
+template <typename T>
+__global__ __launch_bounds__(TPB) void distCgHaloP(HaloSegs segs, const DistScal<T>* __restrict__ sc, int par, const T* __restrict__ totalsC, const T* __restrict__ pOldExt,
+                                                   const T* __restrict__ rExt, T* __restrict__ pNewExt) {
+	if (sc->done) return;
+	const T beta = totalsC[0] / sc->rrPing[par];
+	for (int g = 0; g < segs.n; ++g) {
+		const int base = segs.off[g];
+		for (int i = blockIdx.x * TPB + threadIdx.x; i < segs.cnt[g]; i += gridDim.x * TPB) pNewExt[base + i] = smmFma(beta, pOldExt[base + i], rExt[base + i]);
+	}
+}
+
+// what is left of distCgLazyP once the direction is formed in the SpMV: x, brought up to date when scheduled (every LAZY_M-th iteration)
+// or when the SpMV launch in front found its predecessor converged (flushIter == iter) -- cgLazyFlushOnly of smm_solvers.hip
+template <typename T, bool NT>
+__global__ __launch_bounds__(TPB) void distCgFlushOnly(RowRanges rg, const DistScal<T>* __restrict__ sc, DistRing<T> ring, int cur, int pending, int scheduled, int iter,
+                                                       int alphaSlot, const T* xcur, T* x) {
+	const bool converged = sc->flushIter == iter;
+	if (!converged && (!scheduled || sc->done)) return;
+	T alpha[LAZY_M];
+#pragma unroll
+	for (int k = 0; k < LAZY_M; ++k) alpha[LAZY_M - 1 - k] = sc->alphaRing[(alphaSlot + LAZY_M - k) % LAZY_M];
+	static_assert(LAZY_M == 8, "the cases below");
+	switch (pending) {
+	case 1: distLazyFlush<T, NT, 1, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 2: distLazyFlush<T, NT, 2, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 3: distLazyFlush<T, NT, 3, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 4: distLazyFlush<T, NT, 4, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 5: distLazyFlush<T, NT, 5, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 6: distLazyFlush<T, NT, 6, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 7: distLazyFlush<T, NT, 7, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	case 8: distLazyFlush<T, NT, 8, false>(rg, ring, cur, alpha, T(0), nullptr, xcur, x); break;
+	default: break;
+	}
 }
 
 #define SMM_DIST_UPDATE(KERNEL, NTFLAG, GRID, STREAM, ...)                       \
@@ -2044,6 +2227,7 @@ static int distBicgstab(smm_hip_dist_csr* D, const T* b, T* x, int maxIterations
 		return SMM_HIP_ERR_INVALID;
 	}
 	D->reducedInKernel = false;  // (a call that failed between an SpMV and its reduction point must not leave the mark behind)
+	D->totalsFinal = false;
 	maxIterations = std::min(maxIterations, D->nGlobal);  // ref:2200
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2201-2203
 	// many SpMVs ahead: both local blocks may take the index-free family (each rank decides for its own blocks; no collective involved)
@@ -2166,6 +2350,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		return SMM_HIP_ERR_INVALID;
 	}
 	D->reducedInKernel = false;
+	D->totalsFinal = false;
 	if (maxIterations == -1) maxIterations = D->nGlobal;  // ref:2345-2347 (no clamp otherwise)
 	// (the blocks' own configuration first: a block nobody has multiplied with yet still carries the handle's initial word, and the adoption
 	// below only moves a block that is on the STREAM family -- r05: the FIRST solve of a distributed matrix ran on the CSR kernels)
@@ -2180,15 +2365,6 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 	T *partsA = static_cast<T*>(D->partsA), *partsC = static_cast<T*>(D->partsC);
 	auto* sc = static_cast<DistScal<T>*>(D->sc);
 	hipEvent_t ev = nullptr;
-	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x0, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
-	SMM_TRY(distMatvec<T>(D, xExt, 2, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
-	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));                                           // p = r, ref:2340
-	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);
-	if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
-	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
-	SMM_TRY(join(s, ev));
-	distCgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc, eps);
-	const int* doneFlag = &sc->done;
 	// vectors beyond the caches: x deferred through a ring of LAZY_M more direction vectors (distCgLazyP); when they cannot be had, the eager loop
 	bool lazy = n > 0 && static_cast<long long>(n) * static_cast<long long>(sizeof(T)) >= cgLazyMinBytes();
 	T* ringExt[LAZY_M + 1] = {pExt};
@@ -2210,8 +2386,63 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 			ring.p[k + 1] = ringExt[k + 1] + D->ownOffset;
 		}
 	}
+	// ... and the next direction formed inside the local block's SpMV where that block is served by the 2.5-D constant-diagonal kernel and the
+	// remote one is empty or thin (the slabs of a grid): the halo of r travels instead of p's, in a halo-extended r.  What travels differs from
+	// the other loop forms, so the ranks must AGREE: decided once per solve by a vote (one small all-reduce; nothing is in flight yet)
+	bool fuse = false;
+	if (lazy && D->aLoc && constMarchFusable(D->aLoc, sizeof(T)) && D->recvs.size() <= static_cast<size_t>(P2P_MAX_WORLD) && D->chunks == 1) {
+		bool thin = false;
+		if (!D->remEmpty) SMM_TRY(thinUsable(D, s, &thin));
+		fuse = D->remEmpty || thin;
+	}
+	if (fuse && !D->rExt) {
+		const size_t eb = static_cast<size_t>(std::max(1, D->extLen)) * sizeof(T);
+		if (devAlloc(&D->rExt, eb) != SMM_HIP_OK) {
+			(void)hipGetLastError();
+			D->rExt = nullptr;
+			fuse = false;
+		} else {
+			SMM_HIP_TRY(hipMemsetAsync(D->rExt, 0, eb, s));
+		}
+	}
+	if (getenv("SMM_HIP_DIST_DEBUG")) {
+		const smm_hip_csr* m = D->aLoc;
+		fprintf(stderr, "libsmm_hip: dist_cg rank %d: lazy %d, local block fusable %d (family %d lanes %d state %d encoding %d const %d const_off %d clusters %d), remote empty %d thin rows %d, candidate %d\n",
+		        D->comm->rank, lazy ? 1 : 0, m && constMarchFusable(m, sizeof(T)) ? 1 : 0, m ? m->family() : -1, m ? m->lanes() : -1, m ? static_cast<int>(m->pat_state.load()) : -1,
+		        m ? m->pat_encoding : -1, m ? static_cast<int>(m->pat_const) : -1, m ? static_cast<int>(m->pat_const_off) : -1, m ? static_cast<int>(m->march_clusters) : -1,
+		        D->remEmpty ? 1 : 0, D->nThin, fuse ? 1 : 0);
+	}
+	if (D->comm->world > 1) {
+		long long votes = fuse ? 1 : 0;
+		SMM_TRY(commAllreduceI64(D->comm, &votes, 1));
+		fuse = votes == D->comm->world;
+	}
+	T* rExt = nullptr;
+	if (fuse) {
+		rExt = static_cast<T*>(D->rExt);
+		r = rExt + D->ownOffset;
+	}
+	if (n > 0) SMM_HIP_TRY(hipMemcpyAsync(xExt + D->ownOffset, x0, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
+	SMM_TRY(distMatvec<T>(D, xExt, 2, SMM_OP_SUB, b, r, 0, nullptr, nullptr, nullptr, s));  // r = b - A x0, ref:2337
+	SMM_TRY(launchCopy2<T>(n, r, p, nullptr, s));                                           // p = r, ref:2340
+	distDots<T><<<NPART, TPB, 0, s>>>(n, r, r, nullptr, 1, partsC, nullptr);
+	if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, nullptr);
+	SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2));
+	SMM_TRY(join(s, ev));
+	distCgInit<T><<<1, 1, 0, s>>>(partsC + PARTS_TOTALS, sc, eps);
+	const int* doneFlag = &sc->done;
 	T* lastExt = pExt;  // the vector the last posted exchange fills
 	const bool nt3 = updateNT(n, sizeof(T), 3);
+	HaloSegs segs{};
+	for (const Seg& g : D->recvs) {
+		if (segs.n < P2P_MAX_WORLD) {
+			segs.off[segs.n] = g.offset;
+			segs.cnt[segs.n++] = g.count;
+		}
+	}
+	RowRanges allRows{};
+	allRows.n = 1;
+	allRows.hi[0] = n;
 	for (int i = 0; i < maxIterations; ++i) {
 		if (i % CHECK_EVERY == 0) {  // i == 0: the early exit of ref:2342-2344 costs nothing more than this read
 			int seen = 0;
@@ -2222,8 +2453,59 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		const int cur = lazy ? i % (LAZY_M + 1) : 0, next = lazy ? (cur + 1) % (LAZY_M + 1) : 0;
 		T* const curExt = ringExt[cur];
 		T* const pc = ring.p[cur];
+		if (fuse) {
+			// the loop of smm_solvers.hip's cgDev with the direction formed INSIDE the SpMV: SpMV' (iteration i - 1's bookkeeping, p_i, A_loc p_i, the local
+			// share of p.Ap) while r's halo is in flight, the halo of p_i and the thin remote block behind it, the flush of x (scheduled every LAZY_M-th
+			// iteration, or because SpMV' found iteration i - 1 converged), the r update -- and r's halo on its way while ||r||^2 is reduced
+			if (i == 0) {
+				SMM_TRY(distExchangeBegin<T>(D, curExt, 0, s));
+				SMM_TRY(distMatvecCompute<T>(D, curExt, SMM_OP_ASSIGN, nullptr, ap, 1, pc, partsA, doneFlag, s, nullptr, 0, SPMV_HALF_TILES));
+			} else {
+				const int prev = (i - 1) % (LAZY_M + 1);
+				auto& pend = D->pending;
+				const bool exchange = pend.active;
+				pend.active = false;
+				const CgFuseBook<T> bk{&sc->pad, sc->rrPing, &sc->res, &sc->iters, &sc->done, &sc->status, &sc->flushIter};
+				CgFuseArgs<T> f{r, pc, bk, nullptr, eps, (i - 1) & 1, i};
+				f.totalsC = partsC + PARTS_TOTALS;
+				f.extraFlags = SPMV_FINISH | (exchange && pend.async ? SPMV_LEAVE_ROOM : 0);
+				if (!launchConstMarchFusedP<T>(D->aLoc, ring.p[prev], ap, partsA, doneFlag, f, s)) {
+					setError("dist_cg: the fused SpMV could not be launched");
+					return SMM_HIP_ERR_HIP;
+				}
+				++D->cgFused;
+				if (exchange && pend.landed[0]) {  // (also a rank that only sends: r's boundary rows must not be rewritten before they have left)
+					profWaitWaiting(pend.waitSlot[0], s);
+					SMM_HIP_TRY(hipStreamWaitEvent(s, pend.landed[0], 0));
+				}
+				D->totalsFinal = true;
+				if (!D->remEmpty) {
+					const int g = std::max(1, std::min(256, (D->haloElements + TPB - 1) / TPB));
+					distCgHaloP<T><<<g, TPB, 0, s>>>(segs, sc, (i - 1) & 1, partsC + PARTS_TOTALS, ringExt[prev], rExt, curExt);
+					SMM_TRY(launchThinRemote<T>(D, curExt, false, ap, 1, pc, partsA, doneFlag, s));
+				}
+				SMM_DIST_UPDATE(distCgFlushOnly, updateNT(n, sizeof(T), 5), gridFor(n), s, allRows, sc, ring, prev, (i - 1) % LAZY_M + 1, i % LAZY_M == 0 ? 1 : 0, i,
+				                (i - 1) % LAZY_M, i <= LAZY_M ? x0 : x, x);
+			}
+			SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
+			SMM_TRY(join(s, ev));
+			SMM_DIST_UPDATE(distCgR, nt3, NPART, s, n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC, i % LAZY_M);
+			if (!D->p2p) distFinishSums<T><<<1, TPB, 0, s>>>(partsC, 1, partsC + PARTS_TOTALS, doneFlag);
+			SMM_TRY(allreduceTotals<T>(D, partsC, 1, s, &ev, 2, doneFlag));
+			const bool lastPass = i + 1 >= maxIterations;
+			if (!lastPass) {
+				SMM_TRY(distExchangeBegin<T>(D, rExt, 1, s));  // r's halo travels behind the reduction of ||r||^2 and beside the next SpMV'
+				lastExt = rExt;
+			}
+			SMM_TRY(join(s, ev));
+			if (lastPass) {  // the last planned iteration has no SpMV' behind it: its bookkeeping and the rest of x
+				SMM_DIST_UPDATE(distCgLazyP, nt3, gridFor(n), s, allRows, 1, sc, par, partsC + PARTS_TOTALS, eps, ring, cur, i % LAZY_M + 1, 1, i % LAZY_M, r,
+				                i < LAZY_M ? x0 : x, x);
+			}
+			continue;
+		}
 		if (i == 0) SMM_TRY(distExchangeBegin<T>(D, curExt, 0, s));  // (later passes: posted behind the update of p)
-		SMM_TRY(distMatvecCompute<T>(D, curExt, SMM_OP_ASSIGN, nullptr, ap, 1, pc, partsA, doneFlag, s, nullptr, 0));  // Ap = A p ; p.Ap, ref:2353-2354
+		SMM_TRY(distMatvecCompute<T>(D, curExt, SMM_OP_ASSIGN, nullptr, ap, 1, pc, partsA, doneFlag, s, nullptr, 0, SPMV_HALF_TILES));  // Ap = A p ; p.Ap, ref:2353-2354
 		SMM_TRY(allreduceTotals<T>(D, partsA, 1, s, &ev, 0, doneFlag));
 		SMM_TRY(join(s, ev));
 		SMM_DIST_UPDATE(distCgR, nt3, NPART, s, n, sc, par, partsA + PARTS_TOTALS, ap, r, partsC, i % LAZY_M);
@@ -2523,6 +2805,9 @@ int smm_hip_dist_csr_destroy(smm_hip_dist_csr* D) {
 	for (void* p : D->arrays) devFree(p);
 	for (void* p : {D->r, D->r0, D->ap, D->as, D->scratch, D->pExt, D->sExt, D->xExt, D->partsA, D->partsB, D->partsC, D->sc}) devFree(p);
 	devFree(D->splitSync);
+	devFree(D->thinRows);
+	devFree(D->partsThin);
+	devFree(D->rExt);
 	for (void* p : D->lazyExt) devFree(p);
 	delete D;
 	return SMM_HIP_OK;
@@ -2614,6 +2899,25 @@ int smm_hip_dist_csr_matvec_forms(const smm_hip_dist_csr* D, long long* one_laun
 	}
 	if (one_launch) *one_launch = D->matvecsSplit;
 	if (two_launches) *two_launches = D->matvecsTwo;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_thin_remote(const smm_hip_dist_csr* D, int* rows, long long* matvecs) {
+	if (!D) {
+		setError("dist_csr_thin_remote: null matrix");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (rows) *rows = D->nThin;
+	if (matvecs) *matvecs = D->matvecsThin;
+	return SMM_HIP_OK;
+}
+
+int smm_hip_dist_csr_cg_fused(const smm_hip_dist_csr* D, long long* matvecs) {
+	if (!D || !matvecs) {
+		setError("dist_csr_cg_fused: null argument");
+		return SMM_HIP_ERR_INVALID;
+	}
+	*matvecs = D->cgFused;
 	return SMM_HIP_OK;
 }
 

@@ -367,14 +367,24 @@ void preloadSplitUnit();
 // direction written to pNew, p.Ap into `partials`; `sc` is the solver's Scal<T>.  constMarchFusable: the matrix is served by the 2.5-D
 // constant-diagonal kernel in the form this exists for; the launch returns false when it could not be made (the caller must not have
 // relied on it: ask constMarchFusable first).
+// the words of the solver's scalar block the fused launch does its bookkeeping in (Scal<T> on one GPU, DistScal<T> in smm_dist.hip)
+template <typename T>
+struct CgFuseBook {
+	const int* pad = nullptr;  // the done flag as the update before found it
+	T* rrPing = nullptr;
+	T* res = nullptr;
+	int *iters = nullptr, *done = nullptr, *status = nullptr, *flushIter = nullptr;
+};
 template <typename T>
 struct CgFuseArgs {
 	const T* r;
 	T* pNew;
-	void* sc;
-	const T* partsC;
+	CgFuseBook<T> bk;
+	const T* partsC;   // ||r||^2: NPART partial sums (summed by every workgroup in the fixed order) ...
 	T eps;
 	int par, iter;
+	const T* totalsC = nullptr;  // ... or, when set, the finished (all-reduced) total
+	int extraFlags = 0;          // SPMV_FINISH / SPMV_LEAVE_ROOM of the launch (the row-partitioned loop)
 };
 bool constMarchFusable(const smm_hip_csr* m, size_t elemBytes);
 template <typename T>

@@ -612,7 +612,8 @@ int cgDev(const smm_hip_csr* a, const T* b, const T* x0, T* x, int maxIterations
 				SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, ring.p[0], Ap, 1, ring.p[0], parts, doneFlag, s, SPMV_HALF_TILES));
 			} else {
 				const int prev = (i - 1) % (LAZY_M + 1);
-				const CgFuseArgs<T> f{r, ring.p[cur], sc.p, parts2, eps, (i - 1) & 1, i};
+				const CgFuseBook<T> bk{&sc.p->pad, sc.p->rrPing, &sc.p->res, &sc.p->iters, &sc.p->done, &sc.p->status, &sc.p->flushIter};
+				const CgFuseArgs<T> f{r, ring.p[cur], bk, parts2, eps, (i - 1) & 1, i};
 				if (!launchConstMarchFusedP<T>(a, ring.p[prev], Ap, parts, doneFlag, f, s)) {
 					setError("cg: the fused SpMV could not be launched");
 					return SMM_HIP_ERR_HIP;

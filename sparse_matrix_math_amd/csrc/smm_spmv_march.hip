@@ -119,8 +119,9 @@ template <typename T>
 struct MarchFuse {
 	const T* r = nullptr;
 	T* pNew = nullptr;
-	Scal<T>* sc = nullptr;
-	const T* partsC = nullptr;
+	CgFuseBook<T> bk{};
+	const T* partsC = nullptr;   // ||r||^2 as NPART partial sums (one GPU) ...
+	const T* totalsC = nullptr;  // ... or as the all-reduced total (the row-partitioned loop, smm_dist.hip)
 	T eps = T(0);
 	int par = 0;
 	int iter = 0;
@@ -187,19 +188,19 @@ __global__ __launch_bounds__(TPB, FUSE ? SMM_MARCH_FUSE_MIN_WAVES : SMM_MARCH_MI
 	T beta = T(0);
 	if constexpr (FUSE) {
 		__shared__ T redF[5];
-		if (fz.sc->pad) return;  // (the done flag as the update before found it)
-		const T rrNew = sumPartsAll(fz.partsC, redF);
-		const T rrOld = fz.sc->rrPing[fz.par];
+		if (*fz.bk.pad) return;  // (the done flag as the update before found it)
+		const T rrNew = fz.totalsC ? fz.totalsC[0] : sumPartsAll(fz.partsC, redF);
+		const T rrOld = fz.bk.rrPing[fz.par];
 		const bool converged = fz.eps * fz.eps > rrNew;
 		if (blockIdx.x == 0 && t == 0) {  // ref:2377-2382
-			fz.sc->iters += 1;
-			fz.sc->res = rrNew;
+			*fz.bk.iters += 1;
+			*fz.bk.res = rrNew;
 			if (converged) {
-				fz.sc->done = 1;
-				fz.sc->status = SMM_SOLVER_SUCCESS;
-				fz.sc->flushIter = fz.iter;
+				*fz.bk.done = 1;
+				*fz.bk.status = SMM_SOLVER_SUCCESS;
+				*fz.bk.flushIter = fz.iter;
 			} else {
-				fz.sc->rrPing[fz.par ^ 1] = rrNew;
+				fz.bk.rrPing[fz.par ^ 1] = rrNew;
 			}
 		}
 		if (converged) return;
@@ -1317,8 +1318,9 @@ bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* parti
 	MarchFuse<T> fz;
 	fz.r = f.r;
 	fz.pNew = f.pNew;
-	fz.sc = static_cast<Scal<T>*>(f.sc);
+	fz.bk = f.bk;
 	fz.partsC = f.partsC;
+	fz.totalsC = f.totalsC;
 	fz.eps = f.eps;
 	fz.par = f.par;
 	fz.iter = f.iter;
@@ -1331,7 +1333,7 @@ bool launchConstMarchFusedP(const smm_hip_csr* m, const T* pOld, T* Ap, T* parti
 	const bool half = cgHalfTiles(m, sizeof(T));
 	const bool hp2 = 2 * m->march_H / (16 / static_cast<int>(sizeof(T))) <= 2 * TPB;
 	const bool kn5 = nNear == 5 && m->d_pat_masks8;
-#define SMM_FUSE_GO(RV, KNV, HPV) launchMarchKN<T, RV, KNV, true, HPV, true>(m, SMM_OP_ASSIGN, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
+#define SMM_FUSE_GO(RV, KNV, HPV) launchMarchKN<T, RV, KNV, true, HPV, true>(m, SMM_OP_ASSIGN | f.extraFlags, nullptr, nullptr, pOld, Ap, 1, nullptr, partials, doneFlag, s, fz)
 	bool launched;
 	if (half) {
 		constexpr int RH = RF / 2;

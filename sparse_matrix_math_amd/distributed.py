@@ -580,6 +580,18 @@ class NativeDistMatrix:
         self.check(self.lib.smm_hip_dist_csr_matvec_forms(self._h, ctypes.byref(one), ctypes.byref(two)))
         return one.value, two.value
 
+    def thin_remote(self):
+        """(rows listed as holding a remote entry -- 0: the remote block is not thin --, SpMVs whose second half ran over those rows only)"""
+        rows, count = ctypes.c_int(), ctypes.c_longlong()
+        self.check(self.lib.smm_hip_dist_csr_thin_remote(self._h, ctypes.byref(rows), ctypes.byref(count)))
+        return rows.value, count.value
+
+    def cg_fused(self):
+        """SpMVs of cg() that formed the next direction themselves (MarchFuse in the row-partitioned loop)"""
+        count = ctypes.c_longlong()
+        self.check(self.lib.smm_hip_dist_csr_cg_fused(self._h, ctypes.byref(count)))
+        return count.value
+
     def split_wait_ms(self, reset=True):
         """total milliseconds workgroup 0 of the one-launch SpMVs waited for the halo's word after its local half (device clock)"""
         ms = ctypes.c_double()

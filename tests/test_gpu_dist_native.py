@@ -81,7 +81,7 @@ def _run_ranks(world, fn):
 
 
 def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", precond=None, x0_full=None, families=None, chunks_seen=None, options_seen=None,
-           own_streams=False):
+           own_streams=False, forms_seen=None, lanes=None, bounds=None):
     import torch
 
     from sparse_matrix_math_amd.distributed import NativeDistMatrix, partition_rows_by_nnz
@@ -90,7 +90,7 @@ def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", preco
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     start, pos, val = csr
     n = len(start) - 1
-    bounds = partition_rows_by_nnz(lambda i: int(start[i]), n, world)
+    bounds = bounds or partition_rows_by_nnz(lambda i: int(start[i]), n, world)
 
     def rank_main(rank, shared):
         lo, hi = bounds[rank], bounds[rank + 1]
@@ -102,6 +102,8 @@ def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", preco
         A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, dtype)
         assert A.n_local == hi - lo and A.nnz_loc + A.nnz_rem == int(start[hi] - start[lo])
         A.set_precond(precond)
+        for blk, L in zip(A.local_blocks(), lanes or ()):
+            blk.set_kernel(3, L)  # SMM_SPMV_PATTERN at L pieces per row, whatever the solvers' adoption would have decided
         b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
         x = torch.zeros(hi - lo, dtype=tdt, device=dev) if x0_full is None else torch.from_numpy(x0_full[lo:hi].copy()).to(dev)
         # y = A x through the distributed SpMV as well
@@ -130,6 +132,8 @@ def _solve(smm, csr, b_full, world, dtype, max_it, eps, solver="bicgstab", preco
             chunks_seen[rank] = A.halo_chunks
         if options_seen is not None:
             options_seen[rank] = dict(A.options)
+        if forms_seen is not None:  # (rows listed as holding a remote entry, SpMVs over those rows only, SpMVs of cg() that formed the direction themselves)
+            forms_seen[rank] = A.thin_remote() + (A.cg_fused(),)
         r = (res, lo, hi, x.cpu().numpy(), y.cpu().numpy(), A.halo_elements)
         A.close()
         comm.close()
@@ -463,7 +467,7 @@ def test_partition_rows_by_nnz_native_matches_python(smm):
         assert list(out) == partition_rows_by_nnz(lambda i: int(start[i]), len(start) - 1, world)
 
 
-def _solve_forms(smm, csr, b_full, world, dtype, lanes, split, sums_lds=None):
+def _solve_forms(smm, csr, b_full, world, dtype, lanes, split, sums_lds=None, thin=None):
     """SpMV (three ops), BiCGStab with / without Jacobi and CG on thread ranks with both local blocks forced to the PATTERN family at `lanes` =
     (A_loc, A_rem) pieces per row; `split` = SMM_HIP_SPLIT_SPMV at create time.  Returns the assembled bytes and the counts of matvec forms."""
     import torch
@@ -478,6 +482,8 @@ def _solve_forms(smm, csr, b_full, world, dtype, lanes, split, sums_lds=None):
     os.environ["SMM_HIP_SPLIT_SPMV"] = "1" if split else "0"
     if sums_lds is not None:
         os.environ["SMM_HIP_SPLIT_SUMS_LDS"] = str(sums_lds)  # 0: the local half's row sums travel through out[] (what many rows per workgroup get)
+    if thin is not None:
+        os.environ["SMM_HIP_THIN_REMOTE"] = "1" if thin else "0"  # (0: the general second launch also where few rows hold a remote entry)
 
     def rank_main(rank, shared):
         lo, hi = bounds[rank], bounds[rank + 1]
@@ -486,7 +492,7 @@ def _solve_forms(smm, csr, b_full, world, dtype, lanes, split, sums_lds=None):
         d_pos = torch.from_numpy(pos[start[lo]:start[hi]].copy()).to(dev)
         d_val = torch.from_numpy(val[start[lo]:start[hi]].copy()).to(dev)
         A = NativeDistMatrix(comm, n, bounds, d_start, d_pos, d_val, dtype)
-        for blk, L in zip(A.local_blocks(), lanes):
+        for blk, L in zip(A.local_blocks(), lanes or ()):
             blk.set_kernel(3, L)  # SMM_SPMV_PATTERN: the analysis runs now, on the block's own arrays
         b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
         out = []
@@ -502,7 +508,7 @@ def _solve_forms(smm, csr, b_full, world, dtype, lanes, split, sums_lds=None):
             torch.cuda.synchronize()
             out.append(x.cpu().numpy())
             out.append(np.array(res, dtype=np.float64))
-        forms = A.matvec_forms()
+        forms = A.matvec_forms() + A.thin_remote()
         A.set_precond(None)
         A.close()
         comm.close()
@@ -513,6 +519,7 @@ def _solve_forms(smm, csr, b_full, world, dtype, lanes, split, sums_lds=None):
     finally:
         os.environ.pop("SMM_HIP_SPLIT_SPMV", None)
         os.environ.pop("SMM_HIP_SPLIT_SUMS_LDS", None)
+        os.environ.pop("SMM_HIP_THIN_REMOTE", None)
     pieces = [np.concatenate([g[0][i] for g in got]).tobytes() if got[0][0][i].shape != (3,) else got[0][0][i].tobytes() for i in range(len(got[0][0]))]
     return pieces, [g[1] for g in got]
 
@@ -630,6 +637,49 @@ def test_one_launch_spmv_fuzz(smm, oracle, seed):
     y_ref = oracle.spmv(csr, 0, None, b)
     y = np.frombuffer(one[0], dtype=dtype)
     assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
+
+
+@pytest.mark.parametrize("world,dtype,matrix", [(2, np.float64, "band"), (3, np.float32, "band"), (3, np.float64, "grid"), (2, np.float32, "ragged"), (4, np.float64, "ragged")])
+def test_thin_remote_block(smm, oracle, world, dtype, matrix):
+    """csrc/smm_dist.hip thinRemoteKernel (r06): when at most an eighth of a rank's rows hold a remote entry (a narrow band, the slabs of a
+    grid) the second half of the row-partitioned SpMV runs over the listed rows only and the dot products ride in the local launch --
+    against the general second launch (SMM_HIP_THIN_REMOTE=0): every SpMV op the same bytes; BiCGStab and CG the same iteration counts, x
+    and residual to the solvers' tolerance (the dot products add the same terms in another order); and against the oracle."""
+    if matrix == "grid":
+        csr = gen.stencil3d(24, 24, 60, dtype=dtype)
+    else:
+        csr = gen.banded_random_spd(60000, k=10, seed=8, max_offset=1200, dtype=dtype)
+        if matrix == "ragged":
+            csr = _ragged(csr, 5)
+    n = len(csr[0]) - 1
+    x_true = np.random.default_rng(5).uniform(0.5, 1.5, n).astype(dtype)
+    b = oracle.spmv(csr, 0, None, x_true)
+    lanes = None if matrix == "grid" else (1, 1)  # (the grid: whatever AUTO and the solvers' adoption choose -- seven entries per row are one lane)
+    thin, forms_thin = _solve_forms(smm, csr, b, world, dtype, lanes, split=False, thin=True)
+    wide, forms_wide = _solve_forms(smm, csr, b, world, dtype, lanes, split=False, thin=False)
+    assert all(f[2] > 0 and f[3] > 0 and f[2] * 8 <= n for f in forms_thin), forms_thin  # rows listed, SpMVs run over them
+    assert all(f[2] == 0 and f[3] == 0 and f[1] > 0 for f in forms_wide), forms_wide
+    assert [a == b_ for a, b_ in zip(thin[:3], wide[:3])] == [True] * 3
+    tol = 3e-4 if dtype == np.float32 else 1e-10
+    for i in (3, 5, 7):
+        xa, xb = np.frombuffer(thin[i], dtype=dtype), np.frombuffer(wide[i], dtype=dtype)
+        assert float(np.max(np.abs(xa - xb))) <= tol * float(np.max(np.abs(xb))), i
+        ra, rb = np.frombuffer(thin[i + 1], dtype=np.float64), np.frombuffer(wide[i + 1], dtype=np.float64)
+        assert tuple(ra[:2]) == tuple(rb[:2]) and abs(ra[2] - rb[2]) <= 50 * tol * max(abs(rb[2]), 1e-30), (ra, rb)
+    np.testing.assert_array_equal(np.frombuffer(thin[0], dtype=dtype), oracle.spmv(csr, 0, None, b))  # one lane per row everywhere: the reference's bits
+    st_ref, x_ref, it_ref, _ = oracle.cg(csr, b, np.zeros(n, dtype=dtype), 9, 1e-30)
+    x = np.frombuffer(thin[7], dtype=dtype)
+    assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref)))
+
+
+def test_cg_direction_formed_inside_the_spmv_across_ranks():
+    """tests/dist_cg_fuse_check.py in a process of its own: the row-partitioned ConjugateGradient with p = beta p_old + r formed in the load
+    phase of the local block's 2.5-D SpMV kernel -- r's halo travels, each rank forms the halo of p itself, the thin
+    remote block follows -- against the deferred-x loop and the eager loop, bit for bit, 1 / 2 / 3 slabs, fp32 / fp64, and against the oracle"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_cg_fuse_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "dist cg fuse check: ALL OK" in r.stdout and r.stdout.count("fused == deferred == eager") == 10
 
 
 def test_peer_to_peer_is_refused_between_ranks_of_one_process(smm, oracle, monkeypatch):
