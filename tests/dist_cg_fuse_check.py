@@ -25,7 +25,7 @@ bad = 0
 for dtype in (np.float64, np.float32):
     # (worlds: a slab's remote block is thin -- and the ranks vote for the fused form -- from 16 planes per rank; three ranks: whole planes each,
     # because the 2.5-D kernel wants a multiple of 16 bytes of rows and the partition by stored entries does not always give one)
-    for name, csr, worlds in (("stencil 96x112x33", gen.stencil3d(96, 112, 33, dtype=dtype), (1, 2)), ("stencil 48x40x66", gen.stencil3d(48, 40, 66, dtype=dtype), (1, 2, 3))):
+    for name, csr, worlds in (("stencil 96x112x33", gen.stencil3d(96, 112, 33, dtype=dtype), (1, 2)), ("stencil 96x88x54", gen.stencil3d(96, 88, 54, dtype=dtype), (1, 2, 3))):
         start, pos, val = csr
         n = len(start) - 1
         b = gen.row_sums(start, val).astype(dtype)
@@ -39,7 +39,7 @@ for dtype in (np.float64, np.float32):
                     host.set_cg_lazy_x_min_bytes(1 << 60 if mode == "eager" else 0)
                     host.set_cg_fuse_p(mode == "fused")
                     seen = {}
-                    (st, it, res), x, _, _ = _solve(smm, csr, b, world, dtype, maxit, dtype(eps), solver="cg", x0_full=x0s, forms_seen=seen, lanes=(1,), bounds=[k * 22 * 48 * 40 for k in range(4)] if world == 3 else None)
+                    (st, it, res), x, _, _ = _solve(smm, csr, b, world, dtype, maxit, dtype(eps), solver="cg", x0_full=x0s, forms_seen=seen, lanes=(1,), bounds=[k * 18 * 96 * 88 for k in range(4)] if world == 3 else None)
                     got[mode] = (int(st), int(it), x.copy(), seen)
                 ok = got["fused"][:2] == got["lazy"][:2] == got["eager"][:2] and np.array_equal(got["fused"][2], got["eager"][2]) and np.array_equal(got["lazy"][2], got["eager"][2])
                 counts = [got["fused"][3][r][2] for r in range(world)]

