@@ -39,15 +39,17 @@ for leg, (name, win, thin, fuse) in enumerate((("nothing remote, p formed in a l
     os.environ.pop("SMM_HIP_LAB_SELF_SPLIT"); os.environ.pop("SMM_HIP_THIN_REMOTE")
     if b is None:
         b = torch.empty_like(ones); A.spmv(0, None, ones, b)
-    x = torch.zeros_like(ones); A.cg(b, x, x, 10, 0.0)
+    bicg = os.environ.get("LAB_SOLVER") == "bicgstab"  # (LAB_SOLVER=bicgstab: the same slab through the row-partitioned BiCGStab loop, two SpMVs per iteration)
+    solve = (lambda its: A.bicgstab(b, x, its, 0.0)) if bicg else (lambda its: A.cg(b, x, x, its, 0.0))
+    x = torch.zeros_like(ones); solve(10)
     best = 1e9
     for _ in range(3):
         x.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        st, it, r2 = A.cg(b, x, x, 100, 0.0); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        st, it, r2 = solve(100); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     res[name] = x.clone()
     blocks = A.local_blocks()
     desc = " / ".join(blk.kernel_desc()[0] for blk in blocks)
-    print(f"slab {nx}x{ny}x{nz} {np.dtype(dtype).name}, {name}: {best / it * 1e6:.0f} us per iteration (100 iterations, best of 3); nnz A_loc {A.nnz_loc}, A_rem {A.nnz_rem}; kernels {desc}; SpMV forms (one launch, two) {A.matvec_forms()}, thin (rows, SpMVs) {A.thin_remote()}, SpMVs that formed p {A.cg_fused()}", flush=True)
+    print(f"slab {nx}x{ny}x{nz} {np.dtype(dtype).name}{' BiCGStab' if bicg else ''}, {name}: {best / it * 1e6:.0f} us per iteration (100 iterations, best of 3); nnz A_loc {A.nnz_loc}, A_rem {A.nnz_rem}; kernels {desc}; SpMV forms (one launch, two) {A.matvec_forms()}, thin (rows, SpMVs) {A.thin_remote()}, SpMVs that formed p {A.cg_fused()}", flush=True)
     A.close()
 keys = list(res)
 for k in keys[1:]:
