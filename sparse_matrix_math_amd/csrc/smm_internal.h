@@ -271,7 +271,9 @@ inline int spmvOutFlags(const smm_hip_csr* m, size_t elemBytes) {
 		return env ? atoi(env) : -1;
 	}();
 	if (forced >= 0) return forced ? SPMV_NT_OUT : 0;
-	return static_cast<double>(m->rows) * static_cast<double>(elemBytes) > 64.0 * 1024 * 1024 ? SPMV_NT_OUT : 0;
+	// (from 64 MiB per vector, inclusive: config 4's fp32 slab at 8 GPUs is exactly that -- CG there 139 -> 124 us per iteration with the non-temporal
+	// policy and the fused direction it brings, profiles/r06/dist_cg_timing_nt.txt)
+	return static_cast<double>(m->rows) * static_cast<double>(elemBytes) >= 64.0 * 1024 * 1024 ? SPMV_NT_OUT : 0;
 }
 
 int buildRowBlocks(smm_hip_csr* m, int capNnz, int maxRows, hipStream_t s);
