@@ -1577,18 +1577,55 @@ static int distExchangeBegin(smm_hip_dist_csr* D, T* ext, int kind, hipStream_t 
 // (the same numbers up to the order of the additions: the partial sums of a rank are not the reference's in any form).  The workgroups'
 // shares go through a buffer of their own; thinFinishKernel adds them to `totals` in a fixed order.
 constexpr int THIN_MAX_GRID = NPART;
+// FORM (ConjugateGradient with the direction formed inside the SpMV, smm_spmv_march.hip MarchFuse): the local block's
+// launch reads the previous direction and r and forms p = beta p_old + r for every element it touches; what it cannot form is the HALO of
+// the new direction -- so the halo of r travels instead of p's (posted right behind distCgR, while ||r||^2 is reduced) and THIS launch forms
+// the halo of p from it, twice: the entries it gathers are formed on the fly, and the halo is stored for the next iteration (no lane reads
+// what another stores) -- fma(beta, p_old, r), the owner's expression on the owner's operands, beta from the same all-reduced total and the
+// same rrPing on every rank: the owner's bits.  Runs behind the fused launch (whose workgroup 0 did iteration i - 1's bookkeeping: rrPing[par]
+// is untouched, `done` is final).
+struct HaloSegs {
+	int n = 0;
+	int off[P2P_MAX_WORLD] = {}, cnt[P2P_MAX_WORLD] = {};
+};
 template <typename T>
+struct ThinForm {
+	const T* pOldExt = nullptr;
+	const T* rExt = nullptr;
+	T* pNewExt = nullptr;
+	const DistScal<T>* sc = nullptr;
+	const T* totalsC = nullptr;
+	int par = 0;
+	HaloSegs segs{};
+};
+template <typename T, bool FORM>
 __global__ __launch_bounds__(TPB) void thinRemoteKernel(int nThin, const int* __restrict__ rowsList, const int* __restrict__ start, const int* __restrict__ positions,
                                                         const T* __restrict__ values, const T* __restrict__ ext, int subtract, T* out, int dotMode,
-                                                        const T* __restrict__ w1, T* __restrict__ partsThin, const int* __restrict__ doneFlag) {
+                                                        const T* __restrict__ w1, T* __restrict__ partsThin, const int* __restrict__ doneFlag, ThinForm<T> fm) {
 	__shared__ T red[4];
 	if (doneFlag && *doneFlag) return;
+	T beta = T(0);
+	if constexpr (FORM) {
+		beta = fm.totalsC[0] / fm.sc->rrPing[fm.par];
+		for (int g = 0; g < fm.segs.n; ++g) {
+			const int base = fm.segs.off[g];
+			for (int i = blockIdx.x * TPB + threadIdx.x; i < fm.segs.cnt[g]; i += gridDim.x * TPB) {
+				fm.pNewExt[base + i] = smmFma(beta, fm.pOldExt[base + i], fm.rExt[base + i]);
+			}
+		}
+	}
 	T acc0 = T(0), acc1 = T(0);
 	for (int k = blockIdx.x * TPB + threadIdx.x; k < nThin; k += gridDim.x * TPB) {
 		const int row = rowsList[k];
 		const int e = start[row + 1];
 		T sum = T(0);
-		for (int j = start[row]; j < e; ++j) sum = smmFma(values[j], ext[positions[j]], sum);
+		for (int j = start[row]; j < e; ++j) {
+			const int c = positions[j];
+			T xv;
+			if constexpr (FORM) xv = smmFma(beta, fm.pOldExt[c], fm.rExt[c]);
+			else xv = ext[c];
+			sum = smmFma(values[j], xv, sum);
+		}
 		const T a = out[row];
 		const T o = subtract ? a - sum : a + sum;
 		out[row] = o;
@@ -1627,12 +1664,20 @@ static int thinUsable(smm_hip_dist_csr* D, hipStream_t s, bool* usable) {
 	*usable = D->aRem->lanes() == 1;
 	return SMM_HIP_OK;
 }
-// out[listed rows] (+|-)= A_rem . ext, the launch's share of the dot products added to the totals the local launch left in `parts`
+// out[listed rows] (+|-)= A_rem . ext, the launch's share of the dot products added to the totals the local launch left in `parts`; form: the
+// halo of `ext` is formed here (fused ConjugateGradient), not read
 template <typename T>
-static int launchThinRemote(smm_hip_dist_csr* D, const T* ext, bool subtract, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s) {
+static int launchThinRemote(smm_hip_dist_csr* D, const T* ext, bool subtract, T* out, int dotMode, const T* w1, T* parts, const int* doneFlag, hipStream_t s,
+                            const ThinForm<T>* form = nullptr) {
 	const int g = std::max(1, std::min(THIN_MAX_GRID, (D->nThin + TPB - 1) / TPB));
-	thinRemoteKernel<T><<<g, TPB, 0, s>>>(D->nThin, D->thinRows, static_cast<const int*>(D->arrays[0]) + D->nLocal + 1 /* startRem */, static_cast<const int*>(D->arrays[4]),
-	                                     static_cast<const T*>(D->arrays[5]), ext, subtract ? 1 : 0, out, dotMode, w1, static_cast<T*>(D->partsThin), doneFlag);
+	const int* startRem = static_cast<const int*>(D->arrays[0]) + D->nLocal + 1;
+	if (form) {
+		thinRemoteKernel<T, true><<<g, TPB, 0, s>>>(D->nThin, D->thinRows, startRem, static_cast<const int*>(D->arrays[4]), static_cast<const T*>(D->arrays[5]), ext,
+		                                           subtract ? 1 : 0, out, dotMode, w1, static_cast<T*>(D->partsThin), doneFlag, *form);
+	} else {
+		thinRemoteKernel<T, false><<<g, TPB, 0, s>>>(D->nThin, D->thinRows, startRem, static_cast<const int*>(D->arrays[4]), static_cast<const T*>(D->arrays[5]), ext,
+		                                            subtract ? 1 : 0, out, dotMode, w1, static_cast<T*>(D->partsThin), doneFlag, ThinForm<T>{});
+	}
 	if (dotMode) thinFinishKernel<T><<<1, TPB, 0, s>>>(static_cast<const T*>(D->partsThin), g, dotMode == 2 ? 2 : 1, parts + PARTS_TOTALS, doneFlag);
 	SMM_HIP_TRY(hipGetLastError());
 	D->totalsFinal = dotMode != 0;
@@ -2089,27 +2134,6 @@ __global__ __launch_bounds__(TPB) void distCgLazyP(RowRanges rg, int book, DistS
 #undef SMM_DIST_LAZY_CASE
 }
 
-// ---- the direction formed inside the SpMV (smm_spmv_march.hip, MarchFuse) ----------------------------------------
-// The local block's launch reads the previous direction and r and forms p = beta p_old + r for every element it touches; what it cannot
-// form is the HALO of the new direction -- so the halo of r travels instead of p's (posted right behind distCgR, while ||r||^2 is reduced)
-// and this launch forms the halo of p from it: the owner's expression on the owner's operands -- beta from the same all-reduced total
-// and the same rrPing on every rank -- hence the owner's bits.  Runs behind the fused launch (whose workgroup 0 did iteration i - 1's
-// bookkeeping: rrPing[par] is untouched, `done` is final).
-struct HaloSegs {
-	int n = 0;
-	int off[P2P_MAX_WORLD] = {}, cnt[P2P_MAX_WORLD] = {};
-};
-template <typename T>
-__global__ __launch_bounds__(TPB) void distCgHaloP(HaloSegs segs, const DistScal<T>* __restrict__ sc, int par, const T* __restrict__ totalsC, const T* __restrict__ pOldExt,
-                                                   const T* __restrict__ rExt, T* __restrict__ pNewExt) {
-	if (sc->done) return;
-	const T beta = totalsC[0] / sc->rrPing[par];
-	for (int g = 0; g < segs.n; ++g) {
-		const int base = segs.off[g];
-		for (int i = blockIdx.x * TPB + threadIdx.x; i < segs.cnt[g]; i += gridDim.x * TPB) pNewExt[base + i] = smmFma(beta, pOldExt[base + i], rExt[base + i]);
-	}
-}
-
 // what is left of distCgLazyP once the direction is formed in the SpMV: x, brought up to date when scheduled (every LAZY_M-th iteration)
 // or when the SpMV launch in front found its predecessor converged (flushIter == iter) -- cgLazyFlushOnly of smm_solvers.hip
 template <typename T, bool NT>
@@ -2455,7 +2479,7 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 		T* const pc = ring.p[cur];
 		if (fuse) {
 			// the loop of smm_solvers.hip's cgDev with the direction formed INSIDE the SpMV: SpMV' (iteration i - 1's bookkeeping, p_i, A_loc p_i, the local
-			// share of p.Ap) while r's halo is in flight, the halo of p_i and the thin remote block behind it, the flush of x (scheduled every LAZY_M-th
+			// share of p.Ap) while r's halo is in flight, the thin remote block -- which forms the halo of p_i -- behind it, the flush of x (scheduled every LAZY_M-th
 			// iteration, or because SpMV' found iteration i - 1 converged), the r update -- and r's halo on its way while ||r||^2 is reduced
 			if (i == 0) {
 				SMM_TRY(distExchangeBegin<T>(D, curExt, 0, s));
@@ -2479,10 +2503,16 @@ static int distCg(smm_hip_dist_csr* D, const T* b, const T* x0, T* x, int maxIte
 					SMM_HIP_TRY(hipStreamWaitEvent(s, pend.landed[0], 0));
 				}
 				D->totalsFinal = true;
-				if (!D->remEmpty) {
-					const int g = std::max(1, std::min(256, (D->haloElements + TPB - 1) / TPB));
-					distCgHaloP<T><<<g, TPB, 0, s>>>(segs, sc, (i - 1) & 1, partsC + PARTS_TOTALS, ringExt[prev], rExt, curExt);
-					SMM_TRY(launchThinRemote<T>(D, curExt, false, ap, 1, pc, partsA, doneFlag, s));
+				if (!D->remEmpty) {  // the thin remote block, forming the halo of p_i as it goes (and storing it for iteration i + 1)
+					ThinForm<T> fm;
+					fm.pOldExt = ringExt[prev];
+					fm.rExt = rExt;
+					fm.pNewExt = curExt;
+					fm.sc = sc;
+					fm.totalsC = partsC + PARTS_TOTALS;
+					fm.par = (i - 1) & 1;
+					fm.segs = segs;
+					SMM_TRY(launchThinRemote<T>(D, curExt, false, ap, 1, pc, partsA, doneFlag, s, &fm));
 				}
 				SMM_DIST_UPDATE(distCgFlushOnly, updateNT(n, sizeof(T), 5), gridFor(n), s, allRows, sc, ring, prev, (i - 1) % LAZY_M + 1, i % LAZY_M == 0 ? 1 : 0, i,
 				                (i - 1) % LAZY_M, i <= LAZY_M ? x0 : x, x);
