@@ -463,6 +463,51 @@ def extra_spmv_legs(args, smm, host, torch, np, dev, stream):
     except Exception as e:  # noqa: BLE001
         out["bicgstab_convdiff108_f64"] = {"skipped": str(e)[:200]}
     torch.cuda.empty_cache()
+    # (d) what ONE RANK of BASELINE config 4 at 8 GPUs computes per ConjugateGradient iteration: a 512 x 512 x 64 slab of the Laplacian through the
+    # row-partitioned loop (csrc/smm_dist.hip distCg) on a single-rank communicator -- with nothing remote, and with the last plane's columns counted
+    # as another rank's (SMM_HIP_LAB_SELF_SPLIT: A_rem holds what a neighbouring slab would own; nothing travels).  DESIGN.md section 4's config-4 table.
+    try:
+        from sparse_matrix_math_amd.distributed import NativeComm, NativeDistMatrix
+
+        nx, ny, nz = 512, 512, 64
+        n, nnz = nx * ny * nz, host.gen_stencil3d_nnz(nx, ny, nz)
+        d_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        d_pos = torch.empty(nnz, dtype=torch.int32, device=dev)
+        d_val = torch.empty(nnz, dtype=torch.float64, device=dev)
+        host.gen_stencil3d_dev(nx, ny, nz, 6.0, -1.0, -1.0, d_start, d_pos, d_val, np.float64, stream)
+        torch.cuda.synchronize()
+        comm = NativeComm.single()
+        leg = {"rows": n, "dtype": "f64", "note": "microseconds per CG iteration of one rank's slab (100 iterations, best of 3); not the headline"}
+        ones = torch.ones(n, dtype=torch.float64, device=dev)
+        b = None
+        for name, window in (("nothing_remote", 0), ("a_remote_plane", -nx * ny)):
+            os.environ["SMM_HIP_LAB_SELF_SPLIT"] = str(window)
+            try:
+                A = NativeDistMatrix(comm, n, [0, n], d_start, d_pos, d_val, np.float64)
+            finally:
+                os.environ.pop("SMM_HIP_LAB_SELF_SPLIT")
+            if b is None:
+                b = torch.empty_like(ones)
+                A.spmv(0, None, ones, b)
+            x = torch.zeros_like(ones)
+            A.cg(b, x, x, 10, 0.0)
+            best = None
+            for _ in range(3):
+                x.zero_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, iters, _ = A.cg(b, x, x, 100, 0.0)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / max(1, iters) * 1e6
+                best = dt if best is None else min(best, dt)
+            leg[name] = {"us_per_iteration": best, "nnz_remote": A.nnz_rem, "thin_remote_rows": A.thin_remote()[0], "spmvs_that_formed_p": A.cg_fused()}
+            A.close()
+        comm.close()
+        out["dist_cg_slab512x512x64_f64"] = leg
+        del d_start, d_pos, d_val, ones, b, x
+    except Exception as e:  # noqa: BLE001
+        out["dist_cg_slab512x512x64_f64"] = {"skipped": str(e)[:200]}
+    torch.cuda.empty_cache()
     return out
 
 
