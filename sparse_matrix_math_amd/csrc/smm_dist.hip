@@ -565,7 +565,7 @@ struct smm_hip_dist_csr {
 	void *pExt = nullptr, *sExt = nullptr, *xExt = nullptr;
 	void* lazyExt[smm::LAZY_M] = {};  // CG with the deferred x update: LAZY_M more halo-extended direction vectors (allocated by the first such solve)
 	void* rExt = nullptr;  // CG with the direction formed inside the SpMV: the residual, halo-extended (its halo travels instead of the direction's)
-	long long cgFused = 0;  // SpMVs of ConjugateGradient that formed the direction themselves (smm_hip_dist_csr_thin_remote reports it)
+	long long cgFused = 0;  // SpMVs of ConjugateGradient that formed the direction themselves (smm_hip_dist_csr_cg_fused)
 	void *partsA = nullptr, *partsB = nullptr, *partsC = nullptr;  // finishing buffers (PARTS_LEN): totals are all-reduced in place
 	void* sc = nullptr;
 	// every rank's column range [cmin, cmaxExcl) and the row bounds (global knowledge: any rank can derive any rank's halo plan)
