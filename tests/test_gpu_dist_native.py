@@ -639,7 +639,8 @@ def test_one_launch_spmv_fuzz(smm, oracle, seed):
     assert float(np.max(np.abs(y - y_ref))) <= 64 * np.finfo(dtype).eps * float(np.max(np.abs(y_ref))) * 8
 
 
-@pytest.mark.parametrize("world,dtype,matrix", [(2, np.float64, "band"), (3, np.float32, "band"), (3, np.float64, "grid"), (2, np.float32, "ragged"), (4, np.float64, "ragged")])
+@pytest.mark.parametrize("world,dtype,matrix", [(2, np.float64, "band"), (3, np.float32, "band"), (3, np.float64, "grid"), (2, np.float32, "grid"), (2, np.float32, "ragged"),
+                                                (4, np.float64, "ragged"), (3, np.float64, "ragged7"), (2, np.float64, "ragged9"), (4, np.float32, "ragged11")])
 def test_thin_remote_block(smm, oracle, world, dtype, matrix):
     """csrc/smm_dist.hip thinRemoteKernel (r06): when at most an eighth of a rank's rows hold a remote entry (a narrow band, the slabs of a
     grid) the second half of the row-partitioned SpMV runs over the listed rows only and the dot products ride in the local launch --
@@ -649,8 +650,8 @@ def test_thin_remote_block(smm, oracle, world, dtype, matrix):
         csr = gen.stencil3d(24, 24, 60, dtype=dtype)
     else:
         csr = gen.banded_random_spd(60000, k=10, seed=8, max_offset=1200, dtype=dtype)
-        if matrix == "ragged":
-            csr = _ragged(csr, 5)
+        if matrix.startswith("ragged"):
+            csr = _ragged(csr, int(matrix[6:] or 5))
     n = len(csr[0]) - 1
     x_true = np.random.default_rng(5).uniform(0.5, 1.5, n).astype(dtype)
     b = oracle.spmv(csr, 0, None, x_true)
