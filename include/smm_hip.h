@@ -323,6 +323,14 @@ int smm_hip_precond_apply_f32(const smm_hip_precond* M, const float* rhs, float*
 int smm_hip_precond_apply_f64(const smm_hip_precond* M, const double* rhs, double* x);
 int smm_hip_precond_apply_dev_f32(const smm_hip_precond* M, const float* d_rhs, float* d_x, smm_hip_stream stream);
 int smm_hip_precond_apply_dev_f64(const smm_hip_precond* M, const double* d_rhs, double* d_x, smm_hip_stream stream);
+/* x = M^-1 (A v), A being the matrix M was created for: the operator a preconditioned loop applies twice per pass (ref:2234-2235,
+ * 2250-2251).  BLOCK_ILU0 / BLOCK_SGS form A v inside the apply's launch, each row summed in the order of its stored entries (the
+ * reference's rMult, ref:1484-1489) -- no SpMV launch, A v never travels through memory; every other kind runs the SpMV and then the
+ * apply.  v must not alias x. */
+int smm_hip_precond_apply_spmv_f32(const smm_hip_precond* M, const float* v, float* x);
+int smm_hip_precond_apply_spmv_f64(const smm_hip_precond* M, const double* v, double* x);
+int smm_hip_precond_apply_spmv_dev_f32(const smm_hip_precond* M, const float* d_v, float* d_x, smm_hip_stream stream);
+int smm_hip_precond_apply_spmv_dev_f64(const smm_hip_precond* M, const double* d_v, double* d_x, smm_hip_stream stream);
 /* The asynchronous apply cannot report a triangular sweep that failed to finish (the escape bound of the synchronisation-free sweeps:
  * it then publishes NaN and raises a sticky flag).  This call synchronises `stream`, returns SMM_HIP_ERR_HIP when a sweep applied on it
  * since the last call tripped the bound, and clears the flag.  The solver entry points call it themselves before they return. */

@@ -55,6 +55,8 @@ _TYPED = {
     "smm_hip_bicgsymmetric": (c_int, [_P, _P, _P, c_int, "T", POINTER(c_int), POINTER(c_int)]),
     "smm_hip_precond_apply": (c_int, [_P, _P, _P]),
     "smm_hip_precond_apply_dev": (c_int, [_P, _P, _P, _P]),
+    "smm_hip_precond_apply_spmv": (c_int, [_P, _P, _P]),
+    "smm_hip_precond_apply_spmv_dev": (c_int, [_P, _P, _P, _P]),
     "smm_hip_precond_values": (c_int, [_P, _P, c_size_t]),
     "smm_hip_gen_poisson2d_dev": (c_int, [c_int, c_int, _P, _P, _P, _P]),
     "smm_hip_gen_stencil3d_dev": (c_int, [c_int, c_int, c_int, "T", "T", "T", _P, _P, _P, _P]),

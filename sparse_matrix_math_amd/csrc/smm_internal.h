@@ -497,6 +497,9 @@ int blockCreateTyped(const smm_hip_csr* a, int kind, int blockRows, int levelCap
 // x = M^-1 rhs; dotMode / w1 / partials: dot products of x fused into the epilogue, as in launchSpmv (partials: 2 * NPART elements)
 template <typename T>
 int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s);
+template <typename T>
+int blockApplySpmvDev(const smm_hip_precond* M, const T* v, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s);
+bool blockFuseSpmv(const smm_hip_precond* M, bool asked);
 void blockDestroy(struct smm_precond_block* B);
 void blockLevels(const struct smm_precond_block* B, int* lo, int* up);
 int blockDefaultRows();

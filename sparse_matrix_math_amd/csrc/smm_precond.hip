@@ -1009,6 +1009,50 @@ static int applyHost(const smm_hip_precond* M, const T* rhs, T* x) {
 	return precondTakeError(M, s);
 }
 
+// x = M^-1 (A v), A = the matrix M was created for: what a preconditioned Krylov loop asks for twice per pass (ref:2234-2235,
+// 2250-2251).  The block kinds form A v inside the apply's launch (smm_precond_block.hip); the others run the SpMV and then the apply.
+template <typename T>
+static int applySpmvDev(const smm_hip_precond* M, const T* v, T* x, hipStream_t s) {
+	if (!M || M->dtype != dtypeOf<T>()) {
+		setError("precond_apply_spmv: null handle / dtype mismatch");
+		return SMM_HIP_ERR_INVALID;
+	}
+	const int n = M->a->rows;
+	if (n > 0 && (!v || !x || v == x)) {
+		setError("precond_apply_spmv: null vector or v aliases x");
+		return SMM_HIP_ERR_INVALID;
+	}
+	if (n == 0 || M->kind == SMM_PRECOND_NONE) return launchSpmv<T>(M->a, SMM_OP_ASSIGN, nullptr, v, x, 0, nullptr, nullptr, nullptr, s);
+	SMM_TRY(ensureCsrReady(M->a, s, true));
+	if (isBlockKind(M->kind) && M->a->nnz > 0 && blockFuseSpmv(M, true)) return blockApplySpmvDev<T>(M, v, x, 0, nullptr, nullptr, nullptr, s);
+	DevBuf<T> t;
+	SMM_TRY(t.alloc(n));
+	SMM_TRY(launchSpmv<T>(M->a, SMM_OP_ASSIGN, nullptr, v, t, 0, nullptr, nullptr, nullptr, s));
+	return precondApplyDev<T>(M, t, x, nullptr, s);
+}
+
+template <typename T>
+static int applySpmvHost(const smm_hip_precond* M, const T* v, T* x) {
+	if (!M) {
+		setError("precond_apply_spmv: null handle");
+		return SMM_HIP_ERR_INVALID;
+	}
+	SMM_TRY(ensureInit());
+	const int n = M->a->rows;
+	if (n > 0 && (!v || !x || v == x)) {
+		setError("precond_apply_spmv: null vector or v aliases x");
+		return SMM_HIP_ERR_INVALID;
+	}
+	hipStream_t s = libStream();
+	DevBuf<T> dv, dx;
+	SMM_TRY(dv.alloc(n));
+	SMM_TRY(dx.alloc(n));
+	SMM_TRY(hostToDev(dv, v, sizeof(T) * n, s));
+	SMM_TRY(applySpmvDev<T>(M, dv, dx, s));
+	SMM_TRY(devToHost(x, dx, sizeof(T) * n, s));
+	return precondTakeError(M, s);
+}
+
 template <typename T>
 static int valuesHost(const smm_hip_precond* M, T* out, size_t count) {
 	if (!M || M->dtype != dtypeOf<T>() || !out) {
@@ -1166,6 +1210,16 @@ int smm_hip_precond_apply_dev_f32(const smm_hip_precond* M, const float* d_rhs, 
 int smm_hip_precond_apply_dev_f64(const smm_hip_precond* M, const double* d_rhs, double* d_x, smm_hip_stream stream) {
 	SMM_TRY(ensureInit());
 	return precondApplyDev<double>(M, d_rhs, d_x, nullptr, pickStream(stream));
+}
+int smm_hip_precond_apply_spmv_f32(const smm_hip_precond* M, const float* v, float* x) { return applySpmvHost<float>(M, v, x); }
+int smm_hip_precond_apply_spmv_f64(const smm_hip_precond* M, const double* v, double* x) { return applySpmvHost<double>(M, v, x); }
+int smm_hip_precond_apply_spmv_dev_f32(const smm_hip_precond* M, const float* d_v, float* d_x, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return applySpmvDev<float>(M, d_v, d_x, pickStream(stream));
+}
+int smm_hip_precond_apply_spmv_dev_f64(const smm_hip_precond* M, const double* d_v, double* d_x, smm_hip_stream stream) {
+	SMM_TRY(ensureInit());
+	return applySpmvDev<double>(M, d_v, d_x, pickStream(stream));
 }
 int smm_hip_precond_values_f32(const smm_hip_precond* M, float* out, size_t count) { return valuesHost<float>(M, out, count); }
 int smm_hip_precond_values_f64(const smm_hip_precond* M, double* out, size_t count) { return valuesHost<double>(M, out, count); }

@@ -120,6 +120,11 @@ struct BlkApplyArgs {
 	const T* ovValUp;
 	const T* rhs;
 	T* x;
+	// SPMV form (blkApplyKernel<..., true>): rhs = A v is formed row by row on the way into LDS -- the three CSR arrays and v
+	const int* aStart;
+	const int* aPos;
+	const T* aVal;
+	const T* spmvX;
 	int dotMode;  // 0 none; 1: x.w1 -> partials[0..NPART); 2: x.x -> partials[0..NPART), x.w1 -> partials[NPART..2 NPART)
 	const T* w1;
 	T* partials;
@@ -253,11 +258,71 @@ __device__ __forceinline__ void blkSweep(SweepRing<T, MODE, KREG, D>& sr, long l
 	(void)LOWER;
 }
 
-template <typename T, int KIND, int KREG, bool OV, int D>
-__global__ __launch_bounds__(WAVE) void blkApplyKernel(const BlkApplyArgs<T> a) {
+// SPMV form: the rows of A v that make up a block's right-hand side, summed in the order of the stored entries from 0 (ref:1484-1489:
+// the sum the SpMV kernels form at one lane per row), by BLK_SPMV_TPB lanes -- four wavefronts instead of the one that sweeps, since
+// a row costs three dependent trips to memory (row -> start[] -> positions[] / values[] -> v[]) and only independent rows hide them.
+// RB rows per lane and pass, the first KU entries of each requested together (every load unconditional, clamped to the row's last
+// entry; the multiply-add is what is predicated), longer rows finish in a loop.
+constexpr int BLK_SPMV_TPB = 256;
+template <typename T>
+__device__ __forceinline__ void blkSpmvRows(const BlkApplyArgs<T>& a, int r0, int nb, T* xs) {
+	constexpr int RB = sizeof(T) == 4 ? 4 : 2, KU = 8;  // (registers: the launch keeps as many of these workgroups on a CU as it has blocks there)
+	const int* __restrict__ start = a.aStart;
+	const int* __restrict__ pos = a.aPos;
+	const T* __restrict__ val = a.aVal;
+	const T* __restrict__ v = a.spmvX;
+	for (int i0 = threadIdx.x; i0 < nb; i0 += BLK_SPMV_TPB * RB) {
+		int g[RB], kb[RB], kn[RB];
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+			const int i = i0 + j * BLK_SPMV_TPB;
+			g[j] = -1;
+			if (i < nb) g[j] = a.rowOrder ? a.rowOrder[r0 + i] : r0 + i;
+		}
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+			kb[j] = g[j] >= 0 ? start[g[j]] : 0;
+			kn[j] = g[j] >= 0 ? start[g[j] + 1] - kb[j] : 0;
+		}
+		int c[RB][KU];
+		T av[RB][KU], xv[RB][KU];
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+			const int last = max(kb[j] + kn[j] - 1, 0);
+#pragma unroll
+			for (int u = 0; u < KU; ++u) {
+				const int k = min(kb[j] + u, last);
+				c[j][u] = pos[k];
+				av[j][u] = val[k];
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+#pragma unroll
+			for (int u = 0; u < KU; ++u) xv[j][u] = v[c[j][u]];
+		}
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+			T dot = T(0);
+#pragma unroll
+			for (int u = 0; u < KU; ++u) {
+				const T next = smmFma(av[j][u], xv[j][u], dot);
+				dot = u < kn[j] ? next : dot;
+			}
+			for (int k = kb[j] + KU; k < kb[j] + kn[j]; ++k) dot = smmFma(val[k], v[pos[k]], dot);
+			const int i = i0 + j * BLK_SPMV_TPB;
+			if (i < nb) xs[i] = dot;
+		}
+	}
+}
+
+template <typename T, int KIND, int KREG, bool OV, int D, bool SPMV = false>
+__global__ __launch_bounds__(SPMV ? BLK_SPMV_TPB : WAVE) void blkApplyKernel(const BlkApplyArgs<T> a) {
 	extern __shared__ __align__(16) unsigned char blkLds[];
 	T* xs = reinterpret_cast<T*>(blkLds);
 	if (a.doneFlag && *a.doneFlag) return;
+	// SPMV form: wavefront 0 sweeps (the sweeps lean on ONE wavefront's in-order LDS queue), all four form the right-hand side
+	const bool sweeper = !SPMV || threadIdx.x < WAVE;
 	constexpr int LO = KIND == SMM_PRECOND_BLOCK_ILU0 ? B_ILU_LO : B_SGS_LO;
 	constexpr int UP = KIND == SMM_PRECOND_BLOCK_ILU0 ? B_ILU_UP : B_SGS_UP;
 	using LL = RecLayout<T, LO != B_ILU_LO, KREG>;
@@ -271,9 +336,23 @@ __global__ __launch_bounds__(WAVE) void blkApplyKernel(const BlkApplyArgs<T> a) 
 		const long long rec0 = static_cast<long long>(a.chunk0[b]) * WAVE;
 		SweepRing<T, LO, KREG, D> ringLo;
 		SweepRing<T, UP, KREG, D> ringUp;
-		ringLo.prologue(a.recLo + rec0 * LL::DW, nc);
-		ringUp.prologue(a.recUp + rec0 * LU::DW, nc);  // (in flight across the whole lower sweep)
-		for (int i = lane; i < nb; i += WAVE) xs[i] = a.rhs[a.rowOrder ? a.rowOrder[r0 + i] : r0 + i];
+		if (!SPMV) {
+			ringLo.prologue(a.recLo + rec0 * LL::DW, nc);
+			ringUp.prologue(a.recUp + rec0 * LU::DW, nc);  // (in flight across the whole lower sweep)
+		}
+		if (SPMV) {
+			blkSpmvRows<T>(a, r0, nb, xs);
+			__syncthreads();
+			// the launch has one workgroup per block (launchBlkApply): the three helper wavefronts are done and give their registers back --
+			// a sweep is a chain of LDS round trips, and what a sweep costs is how many blocks of a CU sweep at the same time
+			if (!sweeper) return;
+			// (the first records are requested only now: in flight across the SpMV they would cost every wavefront of the launch their
+			// registers, and the registers decide how many workgroups start at once)
+			ringLo.prologue(a.recLo + rec0 * LL::DW, nc);
+			ringUp.prologue(a.recUp + rec0 * LU::DW, nc);
+		} else {
+			for (int i = lane; i < nb; i += WAVE) xs[i] = a.rhs[a.rowOrder ? a.rowOrder[r0 + i] : r0 + i];
+		}
 		blkSweep<T, LO, KREG, OV, D>(ringLo, rec0, nc, xs, a.ovPtrLo, a.ovColLo, a.ovValLo);
 		blkSweep<T, UP, KREG, OV, D>(ringUp, rec0, nc, xs, a.ovPtrUp, a.ovColUp, a.ovValUp);
 		if (a.dotMode == 0) {
@@ -1125,6 +1204,15 @@ static int launchBlkApply(const smm_hip_precond* M, const BlkApplyArgs<T>& args,
 	}();
 	const int grid = std::min(B->nBlocks, NPART);
 	const size_t lds = static_cast<size_t>(B->blockRows) * sizeof(T);
+	if (args.spmvX) {
+		if (B->nBlocks > NPART) {
+			setError("precond_apply: the fused SpMV serves at most %d blocks", NPART);
+			return SMM_HIP_ERR_INVALID;
+		}
+		blkApplyKernel<T, KIND, KREG, OV, 2, true><<<grid, BLK_SPMV_TPB, lds, s>>>(args);
+		SMM_HIP_TRY(hipGetLastError());
+		return SMM_HIP_OK;
+	}
 	if constexpr (KREG <= 2) {
 		switch (depth) {
 		case 1: blkApplyKernel<T, KIND, KREG, OV, 1><<<grid, WAVE, lds, s>>>(args); break;
@@ -1152,9 +1240,11 @@ static int launchBlkApplyKind(const smm_hip_precond* M, const BlkApplyArgs<T>& a
 	}
 }
 
-// x = M^-1 rhs with the dot products of x fused into the epilogue (dotMode as in launchSpmv; partials: 2 * NPART elements)
+// x = M^-1 rhs with the dot products of x fused into the epilogue (dotMode as in launchSpmv; partials: 2 * NPART elements).
+// spmvOf != nullptr: rhs is not read -- the right-hand side is A spmvOf (A = the matrix M was created for), formed inside the launch
+// (ref:2234-2235 and ref:2250-2251 in one launch each: no SpMV launch, no pass of A p / A s through memory)
 template <typename T>
-int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s) {
+static int blockApplyAny(const smm_hip_precond* M, const T* rhs, const T* spmvOf, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s) {
 	const smm_precond_block* B = M->blk;
 	if (!B) {
 		setError("precond_apply: block preconditioner without its tables");
@@ -1176,6 +1266,10 @@ int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, con
 	args.ovValUp = static_cast<const T*>(B->d_ovValUp);
 	args.rhs = rhs;
 	args.x = x;
+	args.aStart = spmvOf ? M->a->d_start : nullptr;
+	args.aPos = spmvOf ? M->a->d_positions : nullptr;
+	args.aVal = spmvOf ? static_cast<const T*>(M->a->d_values) : nullptr;
+	args.spmvX = spmvOf;
 	args.dotMode = dotMode;
 	args.w1 = w1;
 	args.partials = partials;
@@ -1184,6 +1278,37 @@ int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, con
 	return launchBlkApplyKind<T, SMM_PRECOND_BLOCK_SGS>(M, args, s);
 }
 
+template <typename T>
+int blockApplyDev(const smm_hip_precond* M, const T* rhs, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s) {
+	return blockApplyAny<T>(M, rhs, nullptr, x, dotMode, w1, partials, doneFlag, s);
+}
+
+// x = M^-1 (A v) in one launch; v and x must not overlap (other blocks read v while this one writes x)
+template <typename T>
+int blockApplySpmvDev(const smm_hip_precond* M, const T* v, T* x, int dotMode, const T* w1, T* partials, const int* doneFlag, hipStream_t s) {
+	if (!M->a || !M->a->d_start || !M->a->d_positions || !M->a->d_values || M->a->nnz <= 0 || !v) {
+		setError("precond_apply: the fused SpMV needs the matrix the block preconditioner was created for");
+		return SMM_HIP_ERR_INVALID;
+	}
+	return blockApplyAny<T>(M, nullptr, v, x, dotMode, w1, partials, doneFlag, s);
+}
+
+// Whether x = M^-1 (A v) runs as ONE launch.  asked = true: the caller asked for exactly that operator (smm_hip_precond_apply_spmv):
+// yes wherever the launch exists.  asked = false: a solver loop choosing between one launch and SpMV + apply -- measured
+// (profiles/r06/block_spmv_inside_apply.txt, fp64): one launch wins where every block of a CU starts at once (2-D Poisson 1000^2, 1024
+// blocks = 4 per CU: 122 against 129 us per BiCGStab pass) and loses where they start in turns (108^3, 1372 blocks = 5.4 per CU: 187
+// against 153 -- the four wavefronts a workgroup needs for its SpMV find room only as the helpers of earlier workgroups leave, and every
+// turn adds the SpMV's three trips to memory in front of a 33 us sweep).  SMM_HIP_BLOCK_FUSE_SPMV=0 / 1 (read per call) forces either.
+bool blockFuseSpmv(const smm_hip_precond* M, bool asked) {
+	if (!M || !M->blk || M->blk->nBlocks > NPART) return false;  // (one workgroup per block: the helper wavefronts leave early)
+	const char* env = getenv("SMM_HIP_BLOCK_FUSE_SPMV");
+	if (env && env[0] == '0') return false;
+	if (asked || (env && env[0] == '1')) return true;
+	return M->blk->nBlocks <= 4 * numCUs();
+}
+
+template int blockApplySpmvDev<float>(const smm_hip_precond*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
+template int blockApplySpmvDev<double>(const smm_hip_precond*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 template int blockApplyDev<float>(const smm_hip_precond*, const float*, float*, int, const float*, float*, const int*, hipStream_t);
 template int blockApplyDev<double>(const smm_hip_precond*, const double*, double*, int, const double*, double*, const int*, hipStream_t);
 

@@ -727,6 +727,8 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 	}
 	SetupTrace traceLoop("bicgstab loop:   enqueue + run + read back");
 	const int g = NPART;  // update kernels that write partials use the full partial grid
+	// block preconditioner of THIS matrix: A p and A s are formed inside the apply's launch, row by row in the order of the stored entries
+	const bool fuseBlk = blockM && blockM->a == a && blockFuseSpmv(blockM, false);
 
 	if (precondition) {
 		SMM_TRY(launchSpmv<T>(a, SMM_OP_SUB, b, x, scratch, 0, nullptr, nullptr, nullptr, s));  // ref:2215
@@ -760,8 +762,12 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 		if (jacobiDiag) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, jacobiDiag, p, ap, 1, r0, parts, doneFlag, s, SPMV_DIV_LHS));  // ref:2234-2235 + 2243 fused
 		} else if (blockM) {
-			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
-			SMM_TRY(blockApplyDev<T>(blockM, scratch, ap, 1, r0, parts, doneFlag, s));                         // ref:2235 + 2243 fused
+			if (fuseBlk) {
+				SMM_TRY(blockApplySpmvDev<T>(blockM, p, ap, 1, r0, parts, doneFlag, s));  // ref:2234 + 2235 + 2243 in one launch
+			} else {
+				SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
+				SMM_TRY(blockApplyDev<T>(blockM, scratch, ap, 1, r0, parts, doneFlag, s));                         // ref:2235 + 2243 fused
+			}
 		} else if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, p, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2234
 			SMM_TRY(apply(scratch, ap, doneFlag, s));                                                          // ref:2235
@@ -774,8 +780,12 @@ static int bicgstabLoop(const smm_hip_csr* a, const T* b, T* x, int maxIteration
 		if (jacobiDiag) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, jacobiDiag, sv, as, 2, sv, parts, doneFlag, s, SPMV_DIV_LHS));  // ref:2250-2251 + 2256-2261 fused
 		} else if (blockM) {
-			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
-			SMM_TRY(blockApplyDev<T>(blockM, scratch, as, 2, sv, parts, doneFlag, s));                          // ref:2251 + 2259, 2261 fused
+			if (fuseBlk) {
+				SMM_TRY(blockApplySpmvDev<T>(blockM, sv, as, 2, sv, parts, doneFlag, s));  // ref:2250 + 2251 + 2259, 2261 in one launch
+			} else {
+				SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
+				SMM_TRY(blockApplyDev<T>(blockM, scratch, as, 2, sv, parts, doneFlag, s));                          // ref:2251 + 2259, 2261 fused
+			}
 		} else if (precondition) {
 			SMM_TRY(launchSpmv<T>(a, SMM_OP_ASSIGN, nullptr, sv, scratch, 0, nullptr, nullptr, doneFlag, s));  // ref:2250
 			SMM_TRY(apply(scratch, as, doneFlag, s));                                                           // ref:2251

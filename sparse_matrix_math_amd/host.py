@@ -182,6 +182,16 @@ class Preconditioner:
     def apply_dev(self, d_rhs, d_x, stream=None):
         check(_fn("smm_hip_precond_apply_dev", self.matrix._suf)(self._h, _dptr(d_rhs), _dptr(d_x), _dptr(stream)))
 
+    def apply_spmv(self, v, x):
+        """x = M^-1 (A v) (ref:2234-2235); the BLOCK_ kinds form A v inside the apply's launch"""
+        suf = self.matrix._suf
+        n = self.matrix.rows
+        check(_fn("smm_hip_precond_apply_spmv", suf)(self._h, _host(v, self.matrix.dtype, "v", n), _host(x, self.matrix.dtype, "x", n, True)))
+        return 0
+
+    def apply_spmv_dev(self, d_v, d_x, stream=None):
+        check(_fn("smm_hip_precond_apply_spmv_dev", self.matrix._suf)(self._h, _dptr(d_v), _dptr(d_x), _dptr(stream)))
+
     def take_error(self, stream=None):
         """synchronises `stream`; raises when a triangular sweep applied on it failed to finish (apply_dev cannot report it)"""
         check(_lib.load().smm_hip_precond_take_error(self._h, _dptr(stream)))

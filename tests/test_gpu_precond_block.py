@@ -107,6 +107,78 @@ def test_block_apply_and_factor_bit_identical_to_oracle(smm, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_spmv_inside_the_apply_bit_identical_to_oracle(smm, oracle, dtype):
+    """x = M^-1 (A v) in ONE launch (smm_hip_precond_apply_spmv: what BiCGStab's loop asks for twice per pass, ref:2234-2235,
+    2250-2251): every row of A v summed in the order of its stored entries (the oracle's rMult, ref:1484-1489), then the oracle's
+    sweeps -- bit for bit, on bricks and contiguous blocks, rows shorter and longer than the 8 entries requested at once, an empty row
+    at the end, and the kinds that have no fused form (the SpMV at one lane per row, then the apply)"""
+    P = smm.SolverPreconditioner
+    long_rows = gen.random_rows(900, 900, 2, 25, seed=9, dtype=dtype, diag_dominant=True)
+    cases = [
+        (gen.convdiff3d(24, 0.3, dtype=dtype), None, None),
+        (gen.convdiff3d(24, 0.3, dtype=dtype), 64, CONTIGUOUS),
+        (gen.convdiff3d(14, 0.3, dtype=dtype), 2048, None),  # one block of 2048 rows: eight rows per lane
+        (gen.poisson2d(70, dtype=dtype), 256, None),
+        (gen.banded_random_spd(4000, k=12, seed=11, max_offset=90, dtype=dtype), None, None),  # 25-entry rows: the tail loop
+        (long_rows, 300, None),
+        (gen.poisson2d(5, dtype=dtype), None, None),
+    ]
+    for csr, block_rows, partition in cases:
+        rows = len(csr[0]) - 1
+        A = make(smm, csr)
+        A.set_kernel(smm.SPMV_VECTOR, 1)  # (only the unfused kinds below run an SpMV kernel)
+        v = np.random.default_rng(17).uniform(-1, 1, rows).astype(dtype)
+        av = oracle.spmv(csr, 0, None, v)
+        for kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
+            M = A.getPreconditioner(kind, block_rows, None, partition)
+            bounds, order = M.block_bounds(), M.block_rows()[0]
+            mcsr = oracle.level_cut_matrix(permuted(csr, order)[0], bounds, M.level_cap())[0]
+            x = np.zeros(rows, dtype=dtype)
+            assert M.apply_spmv(v, x) == 0
+            if kind == P.BLOCK_ILU0:
+                want = oracle.block_ilu0_apply(mcsr, bounds, oracle.block_ilu0_factorize(mcsr, bounds)[1], av[order])[1]
+            else:
+                want = oracle.block_sgs_apply(mcsr, bounds, av[order])[1]
+            np.testing.assert_array_equal(x[order], want)
+            x2 = np.zeros(rows, dtype=dtype)
+            assert M.apply(av, x2) == 0  # the two-launch form on the same A v
+            np.testing.assert_array_equal(x, x2)
+            with pytest.raises(Exception):
+                M.apply_spmv(x, x)
+        J = A.getPreconditioner(P.JACOBI)
+        x = np.zeros(rows, dtype=dtype)
+        assert J.apply_spmv(v, x) == 0
+        x2 = np.zeros(rows, dtype=dtype)
+        assert J.apply(av, x2) == 0
+        np.testing.assert_array_equal(x, x2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bicgstab_loop_with_the_spmv_inside_the_apply_is_the_two_launch_loop(smm, dtype, monkeypatch):
+    """SMM_HIP_BLOCK_FUSE_SPMV=0 (read per solve) runs SpMV and apply as two launches; with the SpMV at one lane per row both loops do
+    the same arithmetic on the same operands -- the dot products ride in the apply's epilogue either way -- so x agrees bit for bit"""
+    P = smm.SolverPreconditioner
+    for csr, block_rows in ((gen.convdiff3d(24, 0.3, dtype=dtype), None), (gen.poisson2d(70, dtype=dtype), 256),
+                            (gen.banded_random_spd(4000, k=12, seed=11, max_offset=90, dtype=dtype), None)):
+        rows = len(csr[0]) - 1
+        A = make(smm, csr)
+        A.set_kernel(smm.SPMV_VECTOR, 1)
+        b = gen.row_sums(csr[0], csr[2])
+        for kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
+            M = A.getPreconditioner(kind, block_rows)
+            got = []
+            for fuse in ("1", "0"):
+                monkeypatch.setenv("SMM_HIP_BLOCK_FUSE_SPMV", fuse)
+                x = np.zeros(rows, dtype=dtype)
+                info = {}
+                st = smm.BiCGStab(A, b, x, 6, dtype(1e-30), M, info=info)
+                got.append((int(st), info["iterations"], x))
+            monkeypatch.delenv("SMM_HIP_BLOCK_FUSE_SPMV")
+            assert got[0][:2] == got[1][:2]
+            np.testing.assert_array_equal(got[0][2], got[1][2])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_level_cut_bounds_every_sweep(smm, oracle, dtype):
     """caps from 2 (every row keeps only entries that point to rows without kept entries of their own) upwards, on matrices whose
     uncut blocks are 30 to 200 levels deep; a tridiagonal matrix (a block is ONE chain, 512 levels) cut to 8"""
