@@ -1301,6 +1301,7 @@ int blockApplySpmvDev(const smm_hip_precond* M, const T* v, T* x, int dotMode, c
 // turn adds the SpMV's three trips to memory in front of a 33 us sweep).  SMM_HIP_BLOCK_FUSE_SPMV=0 / 1 (read per call) forces either.
 bool blockFuseSpmv(const smm_hip_precond* M, bool asked) {
 	if (!M || !M->blk || M->blk->nBlocks > NPART) return false;  // (one workgroup per block: the helper wavefronts leave early)
+	if (M->blk->nBlocks == 0 || !M->a || M->a->nnz <= 0) return false;  // (nothing to multiply: the plain apply knows what to do)
 	const char* env = getenv("SMM_HIP_BLOCK_FUSE_SPMV");
 	if (env && env[0] == '0') return false;
 	if (asked || (env && env[0] == '1')) return true;
