@@ -125,6 +125,14 @@ struct BlkApplyArgs {
 	const int* aPos;
 	const T* aVal;
 	const T* spmvX;
+	// ... or, for a matrix in the constant-diagonal encoding (smm_spmv_pattern.hip: verified bit for bit against every entry at analysis
+	// time), its row masks and the <= 64 offsets / values: nothing of positions[] / values[] is read
+	const unsigned long long* patMasks;
+	const int* patOff;
+	const unsigned long long* patCval;
+	int patK;
+	int cols;
+	int ldsRows;  // elements of the block vector in LDS (the tables of the constant-diagonal form sit behind it)
 	int dotMode;  // 0 none; 1: x.w1 -> partials[0..NPART); 2: x.x -> partials[0..NPART), x.w1 -> partials[NPART..2 NPART)
 	const T* w1;
 	T* partials;
@@ -266,7 +274,7 @@ __device__ __forceinline__ void blkSweep(SweepRing<T, MODE, KREG, D>& sr, long l
 constexpr int BLK_SPMV_TPB = 256;
 template <typename T>
 __device__ __forceinline__ void blkSpmvRows(const BlkApplyArgs<T>& a, int r0, int nb, T* xs) {
-	constexpr int RB = sizeof(T) == 4 ? 4 : 2, KU = 8;  // (registers: the launch keeps as many of these workgroups on a CU as it has blocks there)
+	constexpr int RB = 2, KU = 8;  // (registers: the launch keeps as many of these workgroups on a CU as it has blocks there)
 	const int* __restrict__ start = a.aStart;
 	const int* __restrict__ pos = a.aPos;
 	const T* __restrict__ val = a.aVal;
@@ -316,6 +324,69 @@ __device__ __forceinline__ void blkSpmvRows(const BlkApplyArgs<T>& a, int r0, in
 	}
 }
 
+// the same rows from the constant-diagonal encoding: the row's mask instead of start[] / positions[] / values[] (two trips to memory, 8
+// bytes per row); sOff / sC: the offsets and the diagonals' values in LDS.  Products and order are spmvPatternConstKernel's: the mask's
+// bits ascending = the row's columns ascending (ref:1484-1499), dead slots gather a clamped column and are not added.
+constexpr int BLK_MAXOFF = 64;
+template <typename T>
+__device__ __forceinline__ void blkSpmvRowsConst(const BlkApplyArgs<T>& a, int r0, int nb, T* xs, const int* sOff, const T* sC) {
+	constexpr int RB = 2, KU = 8;
+	const unsigned long long* __restrict__ masks = a.patMasks;
+	const T* __restrict__ v = a.spmvX;
+	for (int i0 = threadIdx.x; i0 < nb; i0 += BLK_SPMV_TPB * RB) {
+		int g[RB];
+		unsigned long long mm[RB];
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+			const int i = i0 + j * BLK_SPMV_TPB;
+			g[j] = -1;
+			if (i < nb) g[j] = a.rowOrder ? a.rowOrder[r0 + i] : r0 + i;
+		}
+#pragma unroll
+		for (int j = 0; j < RB; ++j) mm[j] = g[j] >= 0 ? masks[g[j]] : 0ULL;
+		T dot[RB];
+#pragma unroll
+		for (int j = 0; j < RB; ++j) dot[j] = T(0);
+		bool more;
+		do {
+			int c[RB][KU];
+			T cv[RB][KU], xv[RB][KU];
+			int cnt[RB];  // entries of the row that are still to come: slot u of this pass is live when u < cnt
+#pragma unroll
+			for (int j = 0; j < RB; ++j) {
+				cnt[j] = __popcll(mm[j]);
+#pragma unroll
+				for (int u = 0; u < KU; ++u) {
+					const int jj = mm[j] ? __builtin_ctzll(mm[j]) : 0;
+					mm[j] &= mm[j] - 1;
+					c[j][u] = min(max(max(g[j], 0) + sOff[jj], 0), a.cols - 1);
+					cv[j][u] = sC[jj];
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < RB; ++j) {
+#pragma unroll
+				for (int u = 0; u < KU; ++u) xv[j][u] = v[c[j][u]];
+			}
+			more = false;
+#pragma unroll
+			for (int j = 0; j < RB; ++j) {
+#pragma unroll
+				for (int u = 0; u < KU; ++u) {
+					const T next = smmFma(cv[j][u], xv[j][u], dot[j]);
+					dot[j] = u < cnt[j] ? next : dot[j];
+				}
+				more = more || mm[j] != 0ULL;
+			}
+		} while (more);
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+			const int i = i0 + j * BLK_SPMV_TPB;
+			if (i < nb) xs[i] = dot[j];
+		}
+	}
+}
+
 template <typename T, int KIND, int KREG, bool OV, int D, bool SPMV = false>
 __global__ __launch_bounds__(SPMV ? BLK_SPMV_TPB : WAVE) void blkApplyKernel(const BlkApplyArgs<T> a) {
 	extern __shared__ __align__(16) unsigned char blkLds[];
@@ -341,7 +412,30 @@ __global__ __launch_bounds__(SPMV ? BLK_SPMV_TPB : WAVE) void blkApplyKernel(con
 			ringUp.prologue(a.recUp + rec0 * LU::DW, nc);  // (in flight across the whole lower sweep)
 		}
 		if (SPMV) {
-			blkSpmvRows<T>(a, r0, nb, xs);
+			if (a.patMasks) {
+				// (behind the block's vector: the launch sized the LDS for it)
+				T* sC = xs + a.ldsRows;
+				int* sOff = reinterpret_cast<int*>(sC + BLK_MAXOFF);
+				if (threadIdx.x < BLK_MAXOFF) {
+					const int t = threadIdx.x;
+					sOff[t] = t < a.patK ? a.patOff[t] : 0;
+					T c = T(0);
+					if (t < a.patK) {
+						const unsigned long long bits = a.patCval[t];
+						if (sizeof(T) == 4) {
+							const unsigned lo = static_cast<unsigned>(bits);
+							__builtin_memcpy(&c, &lo, 4);
+						} else {
+							__builtin_memcpy(&c, &bits, sizeof(T));
+						}
+					}
+					sC[t] = c;
+				}
+				__syncthreads();
+				blkSpmvRowsConst<T>(a, r0, nb, xs, sOff, sC);
+			} else {
+				blkSpmvRows<T>(a, r0, nb, xs);
+			}
 			__syncthreads();
 			// the launch has one workgroup per block (launchBlkApply): the three helper wavefronts are done and give their registers back --
 			// a sweep is a chain of LDS round trips, and what a sweep costs is how many blocks of a CU sweep at the same time
@@ -1209,7 +1303,8 @@ static int launchBlkApply(const smm_hip_precond* M, const BlkApplyArgs<T>& args,
 			setError("precond_apply: the fused SpMV serves at most %d blocks", NPART);
 			return SMM_HIP_ERR_INVALID;
 		}
-		blkApplyKernel<T, KIND, KREG, OV, 2, true><<<grid, BLK_SPMV_TPB, lds, s>>>(args);
+		const size_t ldsSpmv = lds + (args.patMasks ? BLK_MAXOFF * (sizeof(T) + sizeof(int)) : 0);
+		blkApplyKernel<T, KIND, KREG, OV, 2, true><<<grid, BLK_SPMV_TPB, ldsSpmv, s>>>(args);
 		SMM_HIP_TRY(hipGetLastError());
 		return SMM_HIP_OK;
 	}
@@ -1238,6 +1333,12 @@ static int launchBlkApplyKind(const smm_hip_precond* M, const BlkApplyArgs<T>& a
 	case 4: return launchBlkApply<T, KIND, 4, false>(M, args, s);
 	default: return launchBlkApply<T, KIND, 8, false>(M, args, s);
 	}
+}
+
+// the matrix is in the constant-diagonal encoding (every pat_* field is final once the state reads 1: smm_internal.h)
+static bool blkConstForm(const smm_hip_csr* A) {
+	return A && A->pat_state.load(std::memory_order_acquire) == 1 && A->pat_encoding == 0 && A->pat_const && !A->pat_const_off && A->d_pat_masks &&
+	       A->d_pat_off && A->d_pat_cval && A->pat_k > 0 && A->pat_k <= BLK_MAXOFF;
 }
 
 // x = M^-1 rhs with the dot products of x fused into the epilogue (dotMode as in launchSpmv; partials: 2 * NPART elements).
@@ -1270,6 +1371,15 @@ static int blockApplyAny(const smm_hip_precond* M, const T* rhs, const T* spmvOf
 	args.aPos = spmvOf ? M->a->d_positions : nullptr;
 	args.aVal = spmvOf ? static_cast<const T*>(M->a->d_values) : nullptr;
 	args.spmvX = spmvOf;
+	// the constant-diagonal encoding, where the matrix is in it (every pat_* field is final once the state reads 1: smm_internal.h)
+	const smm_hip_csr* A = M->a;
+	const bool constForm = spmvOf && blkConstForm(A);
+	args.patMasks = constForm ? A->d_pat_masks : nullptr;
+	args.patOff = constForm ? A->d_pat_off : nullptr;
+	args.patCval = constForm ? A->d_pat_cval : nullptr;
+	args.patK = constForm ? A->pat_k : 0;
+	args.cols = A->cols;
+	args.ldsRows = B->blockRows;
 	args.dotMode = dotMode;
 	args.w1 = w1;
 	args.partials = partials;
@@ -1294,18 +1404,21 @@ int blockApplySpmvDev(const smm_hip_precond* M, const T* v, T* x, int dotMode, c
 }
 
 // Whether x = M^-1 (A v) runs as ONE launch.  asked = true: the caller asked for exactly that operator (smm_hip_precond_apply_spmv):
-// yes wherever the launch exists.  asked = false: a solver loop choosing between one launch and SpMV + apply -- measured
-// (profiles/r06/block_spmv_inside_apply.txt, fp64): one launch wins where every block of a CU starts at once (2-D Poisson 1000^2, 1024
-// blocks = 4 per CU: 122 against 129 us per BiCGStab pass) and loses where they start in turns (108^3, 1372 blocks = 5.4 per CU: 187
-// against 153 -- the four wavefronts a workgroup needs for its SpMV find room only as the helpers of earlier workgroups leave, and every
-// turn adds the SpMV's three trips to memory in front of a 33 us sweep).  SMM_HIP_BLOCK_FUSE_SPMV=0 / 1 (read per call) forces either.
+// yes wherever the launch exists.  asked = false: a solver loop choosing between one launch and SpMV + apply -- measured, fp64, per
+// BiCGStab pass (profiles/r06/block_spmv_inside_apply.txt):
+//   * the matrix in the constant-diagonal encoding (the rows of A v cost a mask and the gathers): always -- 108^3, 1372 blocks: 153 -> 134 us;
+//     2-D Poisson 1000^2, 1024 blocks: 129 -> 104;
+//   * the rows read from start[] / positions[] / values[] (12 bytes per entry more than the SpMV kernels of such a matrix would read,
+//     and a trip to memory more in front of every sweep): where every block of a CU starts at once, i.e. at most 4 blocks per CU
+//     (2-D Poisson 1000^2 with the encoding off: 129 -> 122; 108^3: 153 -> 187, the workgroups of a CU start in turns).
+// SMM_HIP_BLOCK_FUSE_SPMV=0 / 1 (read per call) forces either.
 bool blockFuseSpmv(const smm_hip_precond* M, bool asked) {
 	if (!M || !M->blk || M->blk->nBlocks > NPART) return false;  // (one workgroup per block: the helper wavefronts leave early)
 	if (M->blk->nBlocks == 0 || !M->a || M->a->nnz <= 0) return false;  // (nothing to multiply: the plain apply knows what to do)
 	const char* env = getenv("SMM_HIP_BLOCK_FUSE_SPMV");
 	if (env && env[0] == '0') return false;
 	if (asked || (env && env[0] == '1')) return true;
-	return M->blk->nBlocks <= 4 * numCUs();
+	return blkConstForm(M->a) || M->blk->nBlocks <= 4 * numCUs();
 }
 
 template int blockApplySpmvDev<float>(const smm_hip_precond*, const float*, float*, int, const float*, float*, const int*, hipStream_t);

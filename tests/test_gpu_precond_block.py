@@ -154,28 +154,69 @@ def test_spmv_inside_the_apply_bit_identical_to_oracle(smm, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_spmv_inside_the_apply_from_the_constant_diagonal_encoding(smm, oracle, dtype):
+    """a matrix the PATTERN analysis found constant diagonals in (what the solvers adopt from 2^20 entries; asked for here): the one
+    launch forms A v from the row masks and the diagonals' values -- the same products in the same order, so the bits of the form that
+    reads positions[] / values[] and of the oracle; bricks and contiguous blocks, grids the bricks do not divide, and a matrix whose
+    diagonals are NOT constant (the masks alone: the launch must keep reading the three arrays)"""
+    P = smm.SolverPreconditioner
+    varying = gen.poisson2d(40, dtype=dtype)
+    varying[2][::7] *= dtype(1.5)
+    for csr, block_rows, partition, want_const in (
+        (gen.convdiff3d(24, 0.3, dtype=dtype), None, None, True),
+        (gen.convdiff3d(21, 0.3, dtype=dtype), 512, None, True),
+        (gen.poisson2d(70, dtype=dtype), 256, CONTIGUOUS, True),
+        (varying, None, None, False),
+    ):
+        rows = len(csr[0]) - 1
+        v = np.random.default_rng(23).uniform(-1, 1, rows).astype(dtype)
+        av = oracle.spmv(csr, 0, None, v)
+        plain = make(smm, csr)
+        plain.set_kernel(smm.SPMV_VECTOR, 1)
+        A = make(smm, csr)
+        A.set_kernel(smm.SPMV_PATTERN, 1)
+        y = np.zeros(rows, dtype=dtype)
+        A.rMult(v, y)  # (the analysis runs with the first SpMV of the family)
+        np.testing.assert_array_equal(y, av)
+        assert (A.pattern_info()[0] == 3) == want_const, A.pattern_info()
+        for kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
+            M = A.getPreconditioner(kind, block_rows, None, partition)
+            Mp = plain.getPreconditioner(kind, block_rows, None, partition)
+            x, xp, x2 = (np.zeros(rows, dtype=dtype) for _ in range(3))
+            assert M.apply_spmv(v, x) == 0 and Mp.apply_spmv(v, xp) == 0 and M.apply(av, x2) == 0
+            np.testing.assert_array_equal(x, xp)
+            np.testing.assert_array_equal(x, x2)
+            bounds, order = M.block_bounds(), M.block_rows()[0]
+            mcsr = oracle.level_cut_matrix(permuted(csr, order)[0], bounds, M.level_cap())[0]
+            if kind == P.BLOCK_SGS:
+                np.testing.assert_array_equal(x[order], oracle.block_sgs_apply(mcsr, bounds, av[order])[1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_bicgstab_loop_with_the_spmv_inside_the_apply_is_the_two_launch_loop(smm, dtype, monkeypatch):
     """SMM_HIP_BLOCK_FUSE_SPMV=0 (read per solve) runs SpMV and apply as two launches; with the SpMV at one lane per row both loops do
-    the same arithmetic on the same operands -- the dot products ride in the apply's epilogue either way -- so x agrees bit for bit"""
+    the same arithmetic on the same operands -- the dot products ride in the apply's epilogue either way -- so x agrees bit for bit;
+    also with the matrix in the PATTERN family (the stencils: the one launch then reads their constant diagonals)"""
     P = smm.SolverPreconditioner
     for csr, block_rows in ((gen.convdiff3d(24, 0.3, dtype=dtype), None), (gen.poisson2d(70, dtype=dtype), 256),
                             (gen.banded_random_spd(4000, k=12, seed=11, max_offset=90, dtype=dtype), None)):
         rows = len(csr[0]) - 1
-        A = make(smm, csr)
-        A.set_kernel(smm.SPMV_VECTOR, 1)
         b = gen.row_sums(csr[0], csr[2])
-        for kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
-            M = A.getPreconditioner(kind, block_rows)
-            got = []
-            for fuse in ("1", "0"):
-                monkeypatch.setenv("SMM_HIP_BLOCK_FUSE_SPMV", fuse)
-                x = np.zeros(rows, dtype=dtype)
-                info = {}
-                st = smm.BiCGStab(A, b, x, 6, dtype(1e-30), M, info=info)
-                got.append((int(st), info["iterations"], x))
-            monkeypatch.delenv("SMM_HIP_BLOCK_FUSE_SPMV")
-            assert got[0][:2] == got[1][:2]
-            np.testing.assert_array_equal(got[0][2], got[1][2])
+        for family in (smm.SPMV_VECTOR, smm.SPMV_PATTERN):
+            A = make(smm, csr)
+            A.set_kernel(family, 1)
+            for kind in (P.BLOCK_ILU0, P.BLOCK_SGS):
+                M = A.getPreconditioner(kind, block_rows)
+                got = []
+                for fuse in ("1", "0"):
+                    monkeypatch.setenv("SMM_HIP_BLOCK_FUSE_SPMV", fuse)
+                    x = np.zeros(rows, dtype=dtype)
+                    info = {}
+                    st = smm.BiCGStab(A, b, x, 6, dtype(1e-30), M, info=info)
+                    got.append((int(st), info["iterations"], x))
+                monkeypatch.delenv("SMM_HIP_BLOCK_FUSE_SPMV")
+                assert got[0][:2] == got[1][:2]
+                np.testing.assert_array_equal(got[0][2], got[1][2])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
