@@ -125,8 +125,9 @@ struct BlkApplyArgs {
 	const int* aPos;
 	const T* aVal;
 	const T* spmvX;
-	// ... or, for a matrix in the constant-diagonal encoding (smm_spmv_pattern.hip: verified bit for bit against every entry at analysis
-	// time), its row masks and the <= 64 offsets / values: nothing of positions[] / values[] is read
+	// ... or, for a matrix in the row-mask encoding (smm_spmv_pattern.hip: verified against every entry at analysis time), its row masks and
+	// the <= 64 offsets -- positions[] is not read -- and, with constant diagonals (patCval != nullptr), the diagonals' values: values[] is
+	// not read either
 	const unsigned long long* patMasks;
 	const int* patOff;
 	const unsigned long long* patCval;
@@ -328,11 +329,15 @@ __device__ __forceinline__ void blkSpmvRows(const BlkApplyArgs<T>& a, int r0, in
 // bytes per row); sOff / sC: the offsets and the diagonals' values in LDS.  Products and order are spmvPatternConstKernel's: the mask's
 // bits ascending = the row's columns ascending (ref:1484-1499), dead slots gather a clamped column and are not added.
 constexpr int BLK_MAXOFF = 64;
-template <typename T>
+// VALS: the row-mask encoding of a matrix whose diagonals are NOT constant -- the columns still come from the mask, the values from
+// values[] (the k-th set bit of a row's mask is its k-th stored entry): start[] and the mask are read together, values[] and the gathers
+// together -- a trip to memory and 4 bytes per entry less than the three arrays.
+template <typename T, bool VALS>
 __device__ __forceinline__ void blkSpmvRowsConst(const BlkApplyArgs<T>& a, int r0, int nb, T* xs, const int* sOff, const T* sC) {
 	constexpr int RB = 2, KU = 8;
 	const unsigned long long* __restrict__ masks = a.patMasks;
 	const T* __restrict__ v = a.spmvX;
+	const T* __restrict__ val = a.aVal;
 	for (int i0 = threadIdx.x; i0 < nb; i0 += BLK_SPMV_TPB * RB) {
 		int g[RB];
 		unsigned long long mm[RB];
@@ -344,6 +349,12 @@ __device__ __forceinline__ void blkSpmvRowsConst(const BlkApplyArgs<T>& a, int r
 		}
 #pragma unroll
 		for (int j = 0; j < RB; ++j) mm[j] = g[j] >= 0 ? masks[g[j]] : 0ULL;
+		int kb[RB], klast[RB];  // VALS: the row's next and last stored entry
+#pragma unroll
+		for (int j = 0; j < RB; ++j) {
+			kb[j] = VALS && g[j] >= 0 ? a.aStart[g[j]] : 0;
+			klast[j] = VALS && g[j] >= 0 ? max(a.aStart[g[j] + 1] - 1, 0) : 0;
+		}
 		T dot[RB];
 #pragma unroll
 		for (int j = 0; j < RB; ++j) dot[j] = T(0);
@@ -360,8 +371,10 @@ __device__ __forceinline__ void blkSpmvRowsConst(const BlkApplyArgs<T>& a, int r
 					const int jj = mm[j] ? __builtin_ctzll(mm[j]) : 0;
 					mm[j] &= mm[j] - 1;
 					c[j][u] = min(max(max(g[j], 0) + sOff[jj], 0), a.cols - 1);
-					cv[j][u] = sC[jj];
+					if (VALS) cv[j][u] = val[min(kb[j] + u, klast[j])];  // (dead slots: the row's last entry, not added)
+					else cv[j][u] = sC[jj];
 				}
+				if (VALS) kb[j] += KU;
 			}
 #pragma unroll
 			for (int j = 0; j < RB; ++j) {
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(SPMV ? BLK_SPMV_TPB : WAVE) void blkApplyKernel(con
 					const int t = threadIdx.x;
 					sOff[t] = t < a.patK ? a.patOff[t] : 0;
 					T c = T(0);
-					if (t < a.patK) {
+					if (t < a.patK && a.patCval) {
 						const unsigned long long bits = a.patCval[t];
 						if (sizeof(T) == 4) {
 							const unsigned lo = static_cast<unsigned>(bits);
@@ -432,7 +445,8 @@ __global__ __launch_bounds__(SPMV ? BLK_SPMV_TPB : WAVE) void blkApplyKernel(con
 					sC[t] = c;
 				}
 				__syncthreads();
-				blkSpmvRowsConst<T>(a, r0, nb, xs, sOff, sC);
+				if (a.patCval) blkSpmvRowsConst<T, false>(a, r0, nb, xs, sOff, sC);
+				else blkSpmvRowsConst<T, true>(a, r0, nb, xs, sOff, sC);
 			} else {
 				blkSpmvRows<T>(a, r0, nb, xs);
 			}
@@ -1335,11 +1349,13 @@ static int launchBlkApplyKind(const smm_hip_precond* M, const BlkApplyArgs<T>& a
 	}
 }
 
-// the matrix is in the constant-diagonal encoding (every pat_* field is final once the state reads 1: smm_internal.h)
-static bool blkConstForm(const smm_hip_csr* A) {
-	return A && A->pat_state.load(std::memory_order_acquire) == 1 && A->pat_encoding == 0 && A->pat_const && !A->pat_const_off && A->d_pat_masks &&
-	       A->d_pat_off && A->d_pat_cval && A->pat_k > 0 && A->pat_k <= BLK_MAXOFF;
+// the matrix is in the row-mask encoding (every pat_* field is final once the state reads 1: smm_internal.h) ...
+static bool blkMaskForm(const smm_hip_csr* A) {
+	return A && A->pat_state.load(std::memory_order_acquire) == 1 && A->pat_encoding == 0 && A->d_pat_masks && A->d_pat_off && A->pat_k > 0 &&
+	       A->pat_k <= BLK_MAXOFF;
 }
+// ... with constant diagonals on top
+static bool blkConstForm(const smm_hip_csr* A) { return blkMaskForm(A) && A->pat_const && !A->pat_const_off && A->d_pat_cval; }
 
 // x = M^-1 rhs with the dot products of x fused into the epilogue (dotMode as in launchSpmv; partials: 2 * NPART elements).
 // spmvOf != nullptr: rhs is not read -- the right-hand side is A spmvOf (A = the matrix M was created for), formed inside the launch
@@ -1373,11 +1389,11 @@ static int blockApplyAny(const smm_hip_precond* M, const T* rhs, const T* spmvOf
 	args.spmvX = spmvOf;
 	// the constant-diagonal encoding, where the matrix is in it (every pat_* field is final once the state reads 1: smm_internal.h)
 	const smm_hip_csr* A = M->a;
-	const bool constForm = spmvOf && blkConstForm(A);
-	args.patMasks = constForm ? A->d_pat_masks : nullptr;
-	args.patOff = constForm ? A->d_pat_off : nullptr;
-	args.patCval = constForm ? A->d_pat_cval : nullptr;
-	args.patK = constForm ? A->pat_k : 0;
+	const bool maskForm = spmvOf && blkMaskForm(A);
+	args.patMasks = maskForm ? A->d_pat_masks : nullptr;
+	args.patOff = maskForm ? A->d_pat_off : nullptr;
+	args.patCval = maskForm && blkConstForm(A) ? A->d_pat_cval : nullptr;  // (nullptr with masks: the values are read)
+	args.patK = maskForm ? A->pat_k : 0;
 	args.cols = A->cols;
 	args.ldsRows = B->blockRows;
 	args.dotMode = dotMode;
@@ -1405,12 +1421,12 @@ int blockApplySpmvDev(const smm_hip_precond* M, const T* v, T* x, int dotMode, c
 
 // Whether x = M^-1 (A v) runs as ONE launch.  asked = true: the caller asked for exactly that operator (smm_hip_precond_apply_spmv):
 // yes wherever the launch exists.  asked = false: a solver loop choosing between one launch and SpMV + apply -- measured, fp64, per
-// BiCGStab pass (profiles/r06/block_spmv_inside_apply.txt):
-//   * the matrix in the constant-diagonal encoding (the rows of A v cost a mask and the gathers): always -- 108^3, 1372 blocks: 153 -> 134 us;
-//     2-D Poisson 1000^2, 1024 blocks: 129 -> 104;
-//   * the rows read from start[] / positions[] / values[] (12 bytes per entry more than the SpMV kernels of such a matrix would read,
-//     and a trip to memory more in front of every sweep): where every block of a CU starts at once, i.e. at most 4 blocks per CU
-//     (2-D Poisson 1000^2 with the encoding off: 129 -> 122; 108^3: 153 -> 187, the workgroups of a CU start in turns).
+// BiCGStab pass (profiles/r06/block_spmv_inside_apply*.txt; 108^3: 1372 blocks, 2-D Poisson 1000^2: 1024 blocks):
+//   * the matrix in the row-mask encoding: always.  Constant diagonals (a row of A v costs its mask and the gathers): 153 -> 134 us and
+//     129 -> 104; values read (mask and start[] together, then values[] and the gathers together): 180 -> 175 and 146 -> 118;
+//   * the rows read from start[] / positions[] / values[] (a trip to memory more in front of every sweep, 12 bytes per entry): where
+//     every block of a CU starts at once, i.e. at most 4 blocks per CU (2-D Poisson: 129 -> 122; 108^3: 153 -> 187, the workgroups of a
+//     CU start in turns).
 // SMM_HIP_BLOCK_FUSE_SPMV=0 / 1 (read per call) forces either.
 bool blockFuseSpmv(const smm_hip_precond* M, bool asked) {
 	if (!M || !M->blk || M->blk->nBlocks > NPART) return false;  // (one workgroup per block: the helper wavefronts leave early)
@@ -1418,7 +1434,7 @@ bool blockFuseSpmv(const smm_hip_precond* M, bool asked) {
 	const char* env = getenv("SMM_HIP_BLOCK_FUSE_SPMV");
 	if (env && env[0] == '0') return false;
 	if (asked || (env && env[0] == '1')) return true;
-	return blkConstForm(M->a) || M->blk->nBlocks <= 4 * numCUs();
+	return blkMaskForm(M->a) || M->blk->nBlocks <= 4 * numCUs();
 }
 
 template int blockApplySpmvDev<float>(const smm_hip_precond*, const float*, float*, int, const float*, float*, const int*, hipStream_t);

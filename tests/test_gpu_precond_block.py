@@ -158,7 +158,7 @@ def test_spmv_inside_the_apply_from_the_constant_diagonal_encoding(smm, oracle, 
     """a matrix the PATTERN analysis found constant diagonals in (what the solvers adopt from 2^20 entries; asked for here): the one
     launch forms A v from the row masks and the diagonals' values -- the same products in the same order, so the bits of the form that
     reads positions[] / values[] and of the oracle; bricks and contiguous blocks, grids the bricks do not divide, and a matrix whose
-    diagonals are NOT constant (the masks alone: the launch must keep reading the three arrays)"""
+    diagonals are NOT constant (the masks alone: the launch takes the columns from the masks and reads values[])"""
     P = smm.SolverPreconditioner
     varying = gen.poisson2d(40, dtype=dtype)
     varying[2][::7] *= dtype(1.5)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--skip-global", action="store_true")
     ap.add_argument("--level-caps", default="-1", help="level cuts of the block kinds to time: -1 = the default, 0 = none, 2 .. 4095")
     ap.add_argument("--poisson2d", type=int, default=0, help="also: 2-D Poisson N x N")
+    ap.add_argument("--values-read", action="store_true", help="the constant-diagonal SpMV encoding off: values[] is read (what a stencil with varying coefficients gets)")
     args = ap.parse_args()
     smm.init(0)
     dev = torch.device("cuda:0")
@@ -42,6 +43,9 @@ def main():
         ds, dp, dv = (torch.empty(n + 1, dtype=torch.int32, device=dev), torch.empty(nnz, dtype=torch.int32, device=dev), torch.empty(nnz, dtype=torch.float64, device=dev))
         host.gen_poisson2d_dev(N, N, ds, dp, dv, np.float64, stream)
         mats.append((f"poisson2d {N}^2", smm.CSRMatrix.from_device(n, n, ds, dp, dv, np.float64), n, nnz, (ds, dp, dv)))
+    if args.values_read:
+        for m in mats:
+            m[1].pattern_allow_const(False)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for name, A, n, nnz, _keep in mats:
